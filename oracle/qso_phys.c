@@ -1,0 +1,517 @@
+/* qso_phys.c -- ORACLE (test infrastructure, not product code).
+ *
+ * Restatement of what the reference obtains from pybullet.stepSimulation()
+ * (quadruped_spring/env/quadruped_gym_env.py:218-225, world set-up :299-321, robot set-up
+ * quadruped_spring/env/quadruped.py:454-519, 663-683).  pybullet==3.2.5 is an un-vendored third-party
+ * dependency (setup.py:10) and absent here, so this file restates the published algorithms Bullet's
+ * btMultiBodyDynamicsWorld is built from (SURVEY.md App. D lists the assumed semantics, "parity unpinned"):
+ *   1. forward dynamics: Featherstone articulated-body algorithm, floating base, link coordinates
+ *      (R. Featherstone, Rigid Body Dynamics Algorithms, 2008, Table 9.4), gravity (0,0,-g)
+ *   2. v* = v + dt*a, every generalized velocity clamped to +-vel_cap (maxJointVelocity, quadruped.py:678-683)
+ *   3. collision: foot sphere r=0.02 against the plane z=0; other link primitives only flag invalid contacts
+ *   4. constraint rows: per active foot 1 normal + 2 friction rows (pyramid, |f_t| <= mu*f_n), violated joint
+ *      limits as unilateral rows; projected Gauss-Seidel, `solver_iters` sweeps (gym_env.py:113,302), velocity space
+ *   5. semi-implicit Euler on positions (quaternion by exponential map)
+ */
+#include "qso_internal.h"
+
+/* ------------------------------------------------------------------ spatial algebra */
+typedef struct { real E[3][3]; real r[3]; } xform; /* parent->child coordinates: E = R_child_in_parent^T */
+
+static void xm(const xform* X, const real* v, real* o) { /* motion vector parent -> child */
+    real t[3], w[3];
+    v3cross(X->r, v, t);                 /* r x w */
+    real lin[3] = {v[3] - t[0], v[4] - t[1], v[5] - t[2]};
+    m3v(X->E, v, w);
+    real l2[3]; m3v(X->E, lin, l2);
+    o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = l2[0]; o[4] = l2[1]; o[5] = l2[2];
+}
+static void xft(const xform* X, const real* f, real* o) { /* force vector child -> parent (X^T) */
+    real n[3], l[3], t[3];
+    m3tv(X->E, f, n); m3tv(X->E, f + 3, l);
+    v3cross(X->r, l, t);
+    o[0] = n[0] + t[0]; o[1] = n[1] + t[1]; o[2] = n[2] + t[2]; o[3] = l[0]; o[4] = l[1]; o[5] = l[2];
+}
+static void x6(const xform* X, real M[6][6]) {
+    real rx[3][3] = {{0, -X->r[2], X->r[1]}, {X->r[2], 0, -X->r[0]}, {-X->r[1], X->r[0], 0}};
+    memset(M, 0, 36 * sizeof(real));
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            M[i][j] = X->E[i][j];
+            M[i + 3][j + 3] = X->E[i][j];
+            real s = 0;
+            for (int k = 0; k < 3; k++) s += X->E[i][k] * rx[k][j];
+            M[i + 3][j] = -s;
+        }
+}
+static void crm(const real* v, const real* u, real* o) { /* v x u (motion) */
+    real a[3], b[3], c[3];
+    v3cross(v, u, a); v3cross(v, u + 3, b); v3cross(v + 3, u, c);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+static void crf(const real* v, const real* f, real* o) { /* v x* f (force) */
+    real a[3], b[3], c[3];
+    v3cross(v, f, a); v3cross(v + 3, f + 3, b); v3cross(v, f + 3, c);
+    o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+static void m6v(const real M[6][6], const real* v, real* o) {
+    real t[6];
+    for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s += M[i][j] * v[j]; t[i] = s; }
+    memcpy(o, t, sizeof(t));
+}
+static real dot6(const real* a, const real* b) { real s = 0; for (int i = 0; i < 6; i++) s += a[i] * b[i]; return s; }
+
+static int solve6(const real A[6][6], const real* b, real* x) { /* Gaussian elimination, partial pivoting */
+    real M[6][7];
+    for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) M[i][j] = A[i][j]; M[i][6] = b[i]; }
+    for (int c = 0; c < 6; c++) {
+        int p = c; real best = fabs(M[c][c]);
+        for (int r = c + 1; r < 6; r++) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+        if (best == 0) return -1;
+        if (p != c) for (int j = 0; j < 7; j++) { real t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
+        for (int r = c + 1; r < 6; r++) {
+            real f = M[r][c] / M[c][c];
+            for (int j = c; j < 7; j++) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 5; i >= 0; i--) {
+        real s = M[i][6];
+        for (int j = i + 1; j < 6; j++) s -= M[i][j] * x[j];
+        x[i] = s / M[i][i];
+    }
+    return 0;
+}
+
+void qso_quat_to_mat(const real* q, real R[3][3]) { /* q = (x,y,z,w); row-major like getMatrixFromQuaternion */
+    real x = q[0], y = q[1], z = q[2], w = q[3];
+    real d = x * x + y * y + z * z + w * w;
+    real s = 2 / d;
+    real xs = x * s, ys = y * s, zs = z * s;
+    real wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0][0] = 1 - (yy + zz); R[0][1] = xy - wz; R[0][2] = xz + wy;
+    R[1][0] = xy + wz; R[1][1] = 1 - (xx + zz); R[1][2] = yz - wx;
+    R[2][0] = xz - wy; R[2][1] = yz + wx; R[2][2] = 1 - (xx + yy);
+}
+
+static void joint_xform(const qso_model* M, int i, real q, xform* X) {
+    real c = cos(q), s = sin(q);
+    /* R = rot(axis, q) (child axes in parent); E = R^T */
+    if (M->jaxis[i] == 0) {
+        real E[3][3] = {{1, 0, 0}, {0, c, s}, {0, -s, c}};
+        memcpy(X->E, E, sizeof(E));
+    } else {
+        real E[3][3] = {{c, 0, -s}, {0, 1, 0}, {s, 0, c}};
+        memcpy(X->E, E, sizeof(E));
+    }
+    memcpy(X->r, M->jpos[i], 3 * sizeof(real));
+}
+
+/* ------------------------------------------------------------------ kinematics + ABA with cached factors */
+typedef struct {
+    xform X[NB];
+    real v[NB][6];          /* spatial velocity, body coordinates */
+    real IA[NB][6][6];
+    real U[NB][6], D[NB];
+    real Rw[NB][3][3], ow[NB][3]; /* world pose of each link frame */
+    real R0[3][3];
+} phys_cache;
+
+static void kinematics(const qso_model* M, const qso_dyn* s, phys_cache* C) {
+    qso_quat_to_mat(s->quat, C->R0);
+    memcpy(C->Rw[0], C->R0, sizeof(C->R0));
+    memcpy(C->ow[0], s->pos, 3 * sizeof(real));
+    m3tv(C->R0, s->vang, C->v[0]);
+    m3tv(C->R0, s->vlin, C->v[0] + 3);
+    for (int i = 1; i < NB; i++) {
+        int p = M->parent[i];
+        joint_xform(M, i, s->q[i - 1], &C->X[i]);
+        xm(&C->X[i], C->v[p], C->v[i]);
+        C->v[i][M->jaxis[i]] += s->qd[i - 1];
+        /* world pose: R_i = R_p * E^T ; o_i = o_p + R_p * jpos */
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                real t = 0;
+                for (int k = 0; k < 3; k++) t += C->Rw[p][a][k] * C->X[i].E[b][k];
+                C->Rw[i][a][b] = t;
+            }
+        real t3[3]; m3v(C->Rw[p], M->jpos[i], t3);
+        for (int a = 0; a < 3; a++) C->ow[i][a] = C->ow[p][a] + t3[a];
+    }
+}
+
+/* forward dynamics; acc = [alpha_b a_b qdd] (base part: spatial acceleration in base coordinates) */
+static int aba(const qso_model* M, const qso_dyn* s, const real* tau, real g, phys_cache* C, real* acc) {
+    real c[NB][6], pA[NB][6], u[NB], a[NB][6];
+    for (int i = 0; i < NB; i++) {
+        memcpy(C->IA[i], M->I6[i], sizeof(M->I6[i]));
+        real Iv[6]; m6v(M->I6[i], C->v[i], Iv);
+        crf(C->v[i], Iv, pA[i]);
+        if (i > 0) {
+            real vJ[6] = {0, 0, 0, 0, 0, 0};
+            vJ[M->jaxis[i]] = s->qd[i - 1];
+            crm(C->v[i], vJ, c[i]);
+        }
+    }
+    for (int i = NB - 1; i >= 1; i--) {
+        int p = M->parent[i], ax = M->jaxis[i];
+        for (int k = 0; k < 6; k++) C->U[i][k] = C->IA[i][k][ax];
+        C->D[i] = C->U[i][ax];
+        u[i] = tau[i - 1] - pA[i][ax];
+        real Ia[6][6], pa[6], Iac[6];
+        for (int r = 0; r < 6; r++)
+            for (int q = 0; q < 6; q++) Ia[r][q] = C->IA[i][r][q] - C->U[i][r] * C->U[i][q] / C->D[i];
+        m6v(Ia, c[i], Iac);
+        for (int k = 0; k < 6; k++) pa[k] = pA[i][k] + Iac[k] + C->U[i][k] * u[i] / C->D[i];
+        real X6[6][6], T[6][6];
+        x6(&C->X[i], X6);
+        for (int r = 0; r < 6; r++)
+            for (int q = 0; q < 6; q++) { real t = 0; for (int k = 0; k < 6; k++) t += Ia[r][k] * X6[k][q]; T[r][q] = t; }
+        for (int r = 0; r < 6; r++)
+            for (int q = 0; q < 6; q++) { real t = 0; for (int k = 0; k < 6; k++) t += X6[k][r] * T[k][q]; C->IA[p][r][q] += t; }
+        real pp[6]; xft(&C->X[i], pa, pp);
+        for (int k = 0; k < 6; k++) pA[p][k] += pp[k];
+    }
+    real rhs[6];
+    for (int k = 0; k < 6; k++) rhs[k] = -pA[0][k];
+    if (solve6(C->IA[0], rhs, a[0])) return -1;
+    for (int i = 1; i < NB; i++) {
+        int p = M->parent[i], ax = M->jaxis[i];
+        real ap[6]; xm(&C->X[i], a[p], ap);
+        for (int k = 0; k < 6; k++) ap[k] += c[i][k];
+        real qdd = (u[i] - dot6(C->U[i], ap)) / C->D[i];
+        memcpy(a[i], ap, sizeof(ap));
+        a[i][ax] += qdd;
+        acc[6 + i - 1] = qdd;
+    }
+    real gw[3] = {0, 0, -g}, gb[3];
+    m3tv(C->R0, gw, gb);
+    for (int k = 0; k < 3; k++) { acc[k] = a[0][k]; acc[3 + k] = a[0][3 + k] + gb[k]; }
+    return 0;
+}
+
+/* y = H^-1 x using the factors left in the cache by aba() (Bullet: calcAccelerationDeltasMultiDof) */
+static void minv_apply(const qso_model* M, const phys_cache* C, const real* x, real* y) {
+    real pA[NB][6], u[NB], a[NB][6];
+    memset(pA, 0, sizeof(pA));
+    for (int i = NB - 1; i >= 1; i--) {
+        int p = M->parent[i], ax = M->jaxis[i];
+        u[i] = x[6 + i - 1] - pA[i][ax];
+        real pa[6], pp[6];
+        for (int k = 0; k < 6; k++) pa[k] = pA[i][k] + C->U[i][k] * u[i] / C->D[i];
+        xft(&C->X[i], pa, pp);
+        for (int k = 0; k < 6; k++) pA[p][k] += pp[k];
+    }
+    real rhs[6];
+    for (int k = 0; k < 6; k++) rhs[k] = x[k] - pA[0][k];
+    solve6(C->IA[0], rhs, a[0]);
+    for (int k = 0; k < 6; k++) y[k] = a[0][k];
+    for (int i = 1; i < NB; i++) {
+        int p = M->parent[i], ax = M->jaxis[i];
+        real ap[6]; xm(&C->X[i], a[p], ap);
+        real qdd = (u[i] - dot6(C->U[i], ap)) / C->D[i];
+        memcpy(a[i], ap, sizeof(ap));
+        a[i][ax] += qdd;
+        y[6 + i - 1] = qdd;
+    }
+}
+
+/* ------------------------------------------------------------------ collision geometry */
+/* foot: sphere r=0.02 at calf-frame (0,0,-0.213)  go1.urdf:218-236 */
+#define FOOT_R ((real)0.02)
+static const real FOOT_OFF[3] = {0, 0, -0.213};
+/* Contact breaking thresholds = 0.02 * angular-motion-disc of each link's compound shape
+ * (Bullet CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD; hypothesis, DESIGN.md "contact model"). */
+#define THR_FOOT ((real)0.000727)
+#define THR_TRUNK ((real)0.00407)
+#define THR_HIP ((real)0.00139)
+#define THR_THIGH ((real)0.00433)
+#define THR_CALF ((real)0.00429)
+
+static real box_min_z(const real R[3][3], const real* o, const real* centre, const real* half) {
+    real mn = 1e30;
+    for (int sx = -1; sx <= 1; sx += 2)
+        for (int sy = -1; sy <= 1; sy += 2)
+            for (int sz = -1; sz <= 1; sz += 2) {
+                real p[3] = {centre[0] + sx * half[0], centre[1] + sy * half[1], centre[2] + sz * half[2]};
+                real z = o[2] + R[2][0] * p[0] + R[2][1] * p[1] + R[2][2] * p[2];
+                if (z < mn) mn = z;
+            }
+    return mn;
+}
+
+/* number of non-foot links touching the ground: trunk box :74-79, hip cylinder :128-131,
+ * thigh box :180-183, calf box :207-210 (classification quadruped.py:243-249) */
+static int count_invalid(const phys_cache* C) {
+    int n = 0;
+    static const real zc[3] = {0, 0, 0}, th[3] = {0.1881, 0.04675, 0.057};
+    if (box_min_z(C->Rw[0], C->ow[0], zc, th) < THR_TRUNK) n++;
+    static const real lc[3] = {0, 0, -0.1065}, hh[3] = {0.017, 0.01225, 0.1065}, ch[3] = {0.008, 0.008, 0.1065};
+    for (int L = 0; L < 4; L++) {
+        int ih = 1 + 3 * L;
+        real az = C->Rw[ih][2][1]; /* z component of the cylinder axis (link y) */
+        real s2 = 1 - az * az; if (s2 < 0) s2 = 0;
+        real zmin = C->ow[ih][2] - (real)0.02 * fabs(az) - (real)0.046 * sqrt(s2);
+        if (zmin < THR_HIP) n++;
+        if (box_min_z(C->Rw[ih + 1], C->ow[ih + 1], lc, hh) < THR_THIGH) n++;
+        if (box_min_z(C->Rw[ih + 2], C->ow[ih + 2], lc, ch) < THR_CALF) n++;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ one stepSimulation() */
+typedef struct {
+    real J[NV], W[NV];   /* Jacobian row and H^-1 J^T */
+    real dinv, rhs, lo, hi, lam;
+    int fric_of;         /* index of the normal row bounding this friction row, -1 otherwise */
+    real mu;
+} row;
+
+static void clamp_vel(real* v, real cap) { if (*v > cap) *v = cap; if (*v < -cap) *v = -cap; }
+
+void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, real g) {
+    const qso_model* M = &e->model;
+    qso_dyn* s = &e->s;
+    phys_cache C;
+    real dt = cfg->dt, cap = cfg->vel_cap;
+    kinematics(M, s, &C);
+    real acc[NV];
+    aba(M, s, tau, g, &C, acc);
+
+    /* generalized velocity in base coordinates, predicted */
+    real v[NV];
+    for (int k = 0; k < 6; k++) v[k] = C.v[0][k];
+    for (int j = 0; j < NJ; j++) v[6 + j] = s->qd[j];
+    {
+        /* world-frame semi-implicit update: classical acceleration of the base origin = a_lin + w x v */
+        real wxv[3]; v3cross(C.v[0], C.v[0] + 3, wxv);
+        real al[3] = {acc[3] + wxv[0], acc[4] + wxv[1], acc[5] + wxv[2]};
+        real aw[3], lw[3];
+        m3v(C.R0, acc, aw); m3v(C.R0, al, lw);
+        for (int k = 0; k < 3; k++) { s->vang[k] += dt * aw[k]; s->vlin[k] += dt * lw[k]; }
+        for (int j = 0; j < NJ; j++) { s->qd[j] += dt * acc[6 + j]; clamp_vel(&s->qd[j], cap); }
+        for (int k = 0; k < 3; k++) { clamp_vel(&s->vang[k], cap); clamp_vel(&s->vlin[k], cap); }
+        m3tv(C.R0, s->vang, v); m3tv(C.R0, s->vlin, v + 3);
+        for (int j = 0; j < NJ; j++) v[6 + j] = s->qd[j];
+    }
+
+    /* ---- constraint rows ---- */
+    row rows[12 + 24]; int nlim = 0, nn = 0, nf = 0;
+    row* lim = rows; row* nor = rows + 24; row* fr = rows + 28;
+    int nor_foot[4];
+    /* joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint) */
+    for (int j = 0; j < NJ; j++) {
+        real lo = QSO_JOINT_LO[j % 3], hi = QSO_JOINT_HI[j % 3];
+        for (int side = 0; side < 2; side++) {
+            real pen = side == 0 ? s->q[j] - lo : hi - s->q[j];
+            if (pen > 0) continue;
+            row* r = &lim[nlim++];
+            memset(r, 0, sizeof(*r));
+            r->J[6 + j] = side == 0 ? 1 : -1;
+            minv_apply(M, &C, r->J, r->W);
+            real d = 0; for (int k = 0; k < NV; k++) d += r->J[k] * r->W[k];
+            r->dinv = 1 / d;
+            real rel = 0; for (int k = 0; k < NV; k++) rel += r->J[k] * v[k];
+            r->rhs = (-pen * cfg->joint_erp / dt - rel) * r->dinv;
+            r->lo = 0; r->hi = 1e10; r->fric_of = -1;
+        }
+    }
+    /* foot contacts */
+    for (int L = 0; L < 4; L++) {
+        int ic = 3 + 3 * L;
+        real c3[3]; m3v(C.Rw[ic], FOOT_OFF, c3);
+        real centre[3] = {C.ow[ic][0] + c3[0], C.ow[ic][1] + c3[1], C.ow[ic][2] + c3[2]};
+        real dist = centre[2] - FOOT_R;
+        e->foot_contact[L] = 0; e->foot_force[L] = 0;
+        if (!(dist < THR_FOOT)) { e->warm[L] = 0; continue; }
+        e->foot_contact[L] = 1;
+        real p[3] = {centre[0], centre[1], centre[2] - FOOT_R}; /* contact point on the sphere */
+        /* directions: normal +z; friction t1 = (0,-1,0), t2 = (1,0,0) (btPlaneSpace1 of +z) */
+        static const real dirs[3][3] = {{0, 0, 1}, {0, -1, 0}, {1, 0, 0}};
+        for (int rr = 0; rr < 3; rr++) {
+            row* r = rr == 0 ? &nor[nn] : &fr[nf + rr - 1];
+            memset(r, 0, sizeof(*r));
+            const real* d = dirs[rr];
+            real rb[3], pw[3] = {p[0] - s->pos[0], p[1] - s->pos[1], p[2] - s->pos[2]};
+            m3tv(C.R0, pw, rb);
+            real db[3]; m3tv(C.R0, d, db);
+            real ang[3]; v3cross(rb, db, ang);
+            for (int k = 0; k < 3; k++) { r->J[k] = ang[k]; r->J[3 + k] = db[k]; }
+            for (int j = 0; j < 3; j++) {
+                int b = 1 + 3 * L + j;
+                real ax[3] = {C.Rw[b][0][M->jaxis[b]], C.Rw[b][1][M->jaxis[b]], C.Rw[b][2][M->jaxis[b]]};
+                real rp[3] = {p[0] - C.ow[b][0], p[1] - C.ow[b][1], p[2] - C.ow[b][2]};
+                real t[3]; v3cross(ax, rp, t);
+                r->J[6 + 3 * L + j] = v3dot(d, t);
+            }
+            minv_apply(M, &C, r->J, r->W);
+            real dd = 0; for (int k = 0; k < NV; k++) dd += r->J[k] * r->W[k];
+            r->dinv = 1 / dd;
+            real rel = 0; for (int k = 0; k < NV; k++) rel += r->J[k] * v[k];
+            if (rr == 0) {
+                real pos_err = 0, vel_err = -rel;
+                if (dist > 0) vel_err -= dist / dt; else pos_err = -dist * cfg->contact_erp / dt;
+                r->rhs = (pos_err + vel_err) * r->dinv;
+                r->lo = 0; r->hi = 1e10; r->fric_of = -1;
+                r->lam = e->warm[L] * cfg->warmstart;
+            } else {
+                r->rhs = -rel * r->dinv;
+                r->fric_of = nn; r->mu = e->mu;
+            }
+        }
+        nor_foot[nn] = L;
+        nn++; nf += 2;
+    }
+    e->n_invalid = count_invalid(&C);
+
+    /* ---- projected Gauss-Seidel in velocity space (btMultiBodyConstraintSolver::solveSingleIteration order) ---- */
+    real dv[NV]; memset(dv, 0, sizeof(dv));
+    for (int i = 0; i < nn; i++)
+        if (nor[i].lam != 0) for (int k = 0; k < NV; k++) dv[k] += nor[i].W[k] * nor[i].lam;
+    for (int it = 0; it < cfg->solver_iters; it++) {
+        for (int jj = 0; jj < nlim + nn + nf; jj++) {
+            row* r;
+            if (jj < nlim) r = &lim[(it & 1) ? jj : nlim - 1 - jj];
+            else if (jj < nlim + nn) r = &nor[jj - nlim];
+            else r = &fr[jj - nlim - nn];
+            if (r->fric_of >= 0) {
+                real tot = nor[r->fric_of].lam;
+                if (!(tot > 0)) continue;
+                r->lo = -r->mu * tot; r->hi = r->mu * tot;
+            }
+            real jdv = 0; for (int k = 0; k < NV; k++) jdv += r->J[k] * dv[k];
+            real dl = r->rhs - jdv * r->dinv;
+            real sum = r->lam + dl;
+            if (sum < r->lo) { dl = r->lo - r->lam; sum = r->lo; }
+            else if (sum > r->hi) { dl = r->hi - r->lam; sum = r->hi; }
+            r->lam = sum;
+            for (int k = 0; k < NV; k++) dv[k] += r->W[k] * dl;
+        }
+    }
+    for (int i = 0; i < nn; i++) {
+        e->foot_force[nor_foot[i]] = nor[i].lam / dt;
+        e->warm[nor_foot[i]] = nor[i].lam;
+    }
+    /* apply constraint impulses, clamp, integrate positions */
+    {
+        real dw[3], dl[3];
+        m3v(C.R0, dv, dw); m3v(C.R0, dv + 3, dl);
+        for (int k = 0; k < 3; k++) {
+            s->vang[k] += dw[k]; s->vlin[k] += dl[k];
+            clamp_vel(&s->vang[k], cap); clamp_vel(&s->vlin[k], cap);
+        }
+        for (int j = 0; j < NJ; j++) { s->qd[j] += dv[6 + j]; clamp_vel(&s->qd[j], cap); }
+    }
+    for (int k = 0; k < 3; k++) s->pos[k] += dt * s->vlin[k];
+    {
+        real w[3] = {s->vang[0], s->vang[1], s->vang[2]};
+        real th = sqrt(v3dot(w, w)) * dt, sc;
+        if (th < 1e-6) sc = (real)0.5 * dt * (1 - th * th / 24); else sc = sin((real)0.5 * th) / (th / dt);
+        real dq[4] = {w[0] * sc, w[1] * sc, w[2] * sc, cos((real)0.5 * th)};
+        const real* q = s->quat;
+        real nq[4] = {
+            dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1],
+            dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0],
+            dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3],
+            dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2]};
+        real n = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+        for (int k = 0; k < 4; k++) s->quat[k] = nq[k] / n;
+    }
+    for (int j = 0; j < NJ; j++) s->q[j] += dt * s->qd[j];
+}
+
+/* ------------------------------------------------------------------ independent CRBA + RNEA (KAT K3) */
+static int phys_crba_rnea(const qso_model* M, const qso_dyn* s, real g, real* H, real* Cb) {
+    phys_cache C; kinematics(M, s, &C);
+    /* RNEA with qdd = 0 and base acceleration 0, gravity as a field */
+    real a[NB][6], f[NB][6];
+    real gw[3] = {0, 0, -g}, gb[3];
+    m3tv(C.R0, gw, gb);
+    for (int k = 0; k < 6; k++) a[0][k] = 0;
+    for (int k = 0; k < 3; k++) a[0][3 + k] = -gb[k];
+    for (int i = 0; i < NB; i++) {
+        if (i > 0) {
+            int p = M->parent[i];
+            real vJ[6] = {0, 0, 0, 0, 0, 0}, cc[6];
+            vJ[M->jaxis[i]] = s->qd[i - 1];
+            xm(&C.X[i], a[p], a[i]);
+            crm(C.v[i], vJ, cc);
+            for (int k = 0; k < 6; k++) a[i][k] += cc[k];
+        }
+        real Ia[6], Iv[6], vIv[6];
+        m6v(M->I6[i], a[i], Ia); m6v(M->I6[i], C.v[i], Iv); crf(C.v[i], Iv, vIv);
+        for (int k = 0; k < 6; k++) f[i][k] = Ia[k] + vIv[k];
+    }
+    for (int i = NB - 1; i >= 1; i--) {
+        Cb[6 + i - 1] = f[i][M->jaxis[i]];
+        real pp[6]; xft(&C.X[i], f[i], pp);
+        for (int k = 0; k < 6; k++) f[M->parent[i]][k] += pp[k];
+    }
+    for (int k = 0; k < 6; k++) Cb[k] = f[0][k];
+    /* CRBA */
+    real Ic[NB][6][6];
+    memcpy(Ic, M->I6, sizeof(Ic));
+    for (int i = NB - 1; i >= 1; i--) {
+        real X6[6][6], T[6][6]; x6(&C.X[i], X6);
+        for (int r = 0; r < 6; r++)
+            for (int q = 0; q < 6; q++) { real t = 0; for (int k = 0; k < 6; k++) t += Ic[i][r][k] * X6[k][q]; T[r][q] = t; }
+        for (int r = 0; r < 6; r++)
+            for (int q = 0; q < 6; q++) { real t = 0; for (int k = 0; k < 6; k++) t += X6[k][r] * T[k][q]; Ic[M->parent[i]][r][q] += t; }
+    }
+    memset(H, 0, NV * NV * sizeof(real));
+    for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) H[r * NV + q] = Ic[0][r][q];
+    for (int i = 1; i < NB; i++) {
+        real F[6];
+        for (int k = 0; k < 6; k++) F[k] = Ic[i][k][M->jaxis[i]];
+        H[(6 + i - 1) * NV + 6 + i - 1] = F[M->jaxis[i]];
+        int j = i;
+        while (M->parent[j] > 0) {
+            real Fp[6]; xft(&C.X[j], F, Fp); memcpy(F, Fp, sizeof(Fp));
+            j = M->parent[j];
+            real h = F[M->jaxis[j]];
+            H[(6 + i - 1) * NV + 6 + j - 1] = h; H[(6 + j - 1) * NV + 6 + i - 1] = h;
+        }
+        real Fp[6]; xft(&C.X[j], F, Fp);
+        for (int k = 0; k < 6; k++) { H[k * NV + 6 + i - 1] = Fp[k]; H[(6 + i - 1) * NV + k] = Fp[k]; }
+    }
+    return 0;
+}
+
+int qso_phys_crba_rnea(qso_handle* h, int env, real* H, real* C) {
+    return phys_crba_rnea(&h->env[env].model, &h->env[env].s, h->gravity, H, C);
+}
+int qso_phys_aba(qso_handle* h, int env, const real* tau, real* acc) {
+    phys_cache C; kinematics(&h->env[env].model, &h->env[env].s, &C);
+    return aba(&h->env[env].model, &h->env[env].s, tau, h->gravity, &C, acc);
+}
+int qso_phys_step(qso_handle* h, int env, const real* tau) {
+    qso_physics_substep(&h->cfg, &h->env[env], tau, h->gravity);
+    return 0;
+}
+int qso_phys_set_gravity(qso_handle* h, real g) { h->gravity = g; return 0; }
+
+int qso_phys_energy(qso_handle* h, int env, real* out) {
+    const qso_model* M = &h->env[env].model; const qso_dyn* s = &h->env[env].s;
+    phys_cache C; kinematics(M, s, &C);
+    real KE = 0, PE = 0, p[3] = {0, 0, 0}, Lw[3] = {0, 0, 0}, com[3] = {0, 0, 0};
+    for (int i = 0; i < NB; i++) {
+        real Iv[6]; m6v(M->I6[i], C.v[i], Iv);
+        KE += (real)0.5 * dot6(C.v[i], Iv);
+        real cw[3]; m3v(C.Rw[i], M->com[i], cw);
+        for (int k = 0; k < 3; k++) cw[k] += C.ow[i][k];
+        PE += M->mass[i] * h->gravity * cw[2];
+        /* com velocity in world: R (v + w x c) */
+        real wxc[3]; v3cross(C.v[i], M->com[i], wxc);
+        real vc[3] = {C.v[i][3] + wxc[0], C.v[i][4] + wxc[1], C.v[i][5] + wxc[2]}, vw[3];
+        m3v(C.Rw[i], vc, vw);
+        real Iw[3], Lb[3]; m3v(M->Ic[i], C.v[i], Iw); m3v(C.Rw[i], Iw, Lb);
+        real cxv[3]; v3cross(cw, vw, cxv);
+        for (int k = 0; k < 3; k++) {
+            p[k] += M->mass[i] * vw[k];
+            Lw[k] += Lb[k] + M->mass[i] * cxv[k];
+            com[k] += M->mass[i] * cw[k] / M->total_mass;
+        }
+    }
+    out[0] = KE; out[1] = PE;
+    for (int k = 0; k < 3; k++) { out[2 + k] = p[k]; out[5 + k] = Lw[k]; out[8 + k] = com[k]; }
+    return 0;
+}
