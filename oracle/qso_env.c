@@ -149,9 +149,9 @@ void qso_leg_ik(const float* len, int leg, const real* xyz, real* q) {
 }
 
 /* utils/action_filter.py:110-121; xhist/yhist[0..d) newest, [d..2d) older */
-void qso_filter_step(const float* b, const float* a, int d, const real* x, real* xh, real* yh, real* y) {
+void qso_filter_step(const double* b, const double* a, int d, const real* x, real* xh, real* yh, real* y) {
     for (int i = 0; i < d; i++) {
-        real v = x[i] * b[0] + (xh[i] * b[1] + xh[d + i] * b[2]) - (yh[i] * a[1] + yh[d + i] * a[2]);
+        real v = x[i] * (real)b[0] + (xh[i] * (real)b[1] + xh[d + i] * (real)b[2]) - (yh[i] * (real)a[1] + yh[d + i] * (real)a[2]);
         xh[d + i] = xh[i]; xh[i] = x[i];
         yh[d + i] = yh[i]; yh[i] = v;
         y[i] = v;
@@ -419,6 +419,7 @@ static void apply_and_step(const qso_config* cfg, qso_env* e, const real* cmd, r
 }
 
 static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
+    if ((cfg->randomizer_flags & QSO_RAND_KEEP) && e->episode >= 0) return;
     /* nominal */
     e->mu = 1;
     for (int i = 0; i < 3; i++) { e->k[i] = cfg->spring_k[i]; e->b[i] = cfg->spring_b[i]; e->rest[i] = cfg->spring_rest[i]; e->kp[i] = cfg->kp[i]; e->kd[i] = cfg->kd[i]; e->m_leg[i] = QSO_M_LEG[i]; e->r_pay[i] = 0; }
@@ -579,6 +580,8 @@ int qso_get_info(qso_handle* h, int which, real* out) {
             o[4] = t->pose_to[0]; o[5] = t->pose_to[1]; o[6] = t->pose_to[2]; o[7] = t->yaw_to; o[8] = t->init_h;
             o[9] = t->max_flight; o[10] = t->max_fwd; o[11] = t->max_pitch; o[12] = t->rel_max_h; o[13] = t->max_dx; o[14] = t->max_h;
             o[15] = t->cum_fwd; o[16] = t->cum_ft; o[17] = t->old_fwd; o[18] = t->actual_fwd; o[19] = t->bf_max_pitch;
+            for (int k = 0; k < 3; k++) { o[20 + k] = t->pos[k]; o[23 + k] = t->vel[k]; o[26 + k] = t->rpy[k]; }
+            o[29] = e->n_invalid; o[30] = e->foot_force[0] + e->foot_force[1] + e->foot_force[2] + e->foot_force[3]; o[31] = e->sim_step;
             break; }
         default: FAIL("unknown info id %d", which);
         }
@@ -604,6 +607,28 @@ int qso_set_params(qso_handle* h, int which, const real* v) {
             break; }
         default: FAIL("unknown param id %d", which);
         }
+    }
+    return 0;
+}
+
+int qso_set_task(qso_handle* h, const real* in) {
+    for (int i = 0; i < h->cfg.n_envs; i++) {
+        qso_env* e = &h->env[i]; qso_task* t = &e->task; const real* o = in + 32 * i;
+        t->switched = o[0] != 0; t->all_air = o[1] != 0; t->is_jumping = o[2] != 0; t->t_takeoff = o[3];
+        t->pose_to[0] = o[4]; t->pose_to[1] = o[5]; t->pose_to[2] = o[6]; t->yaw_to = o[7]; t->init_h = o[8];
+        t->max_flight = o[9]; t->max_fwd = o[10]; t->max_pitch = o[11]; t->rel_max_h = o[12]; t->max_dx = o[13]; t->max_h = o[14];
+        t->cum_fwd = o[15]; t->cum_ft = o[16]; t->old_fwd = o[17]; t->actual_fwd = o[18]; t->bf_max_pitch = o[19];
+        for (int k = 0; k < 3; k++) { t->pos[k] = o[20 + k]; t->vel[k] = o[23 + k]; t->rpy[k] = o[26 + k]; }
+        e->n_invalid = (int)o[29];
+        e->foot_force[0] = o[30]; e->foot_force[1] = e->foot_force[2] = e->foot_force[3] = 0;
+        e->sim_step = (int)o[31];
+    }
+    return 0;
+}
+int qso_eval_reward(qso_handle* h, int which, real* out) {
+    for (int i = 0; i < h->cfg.n_envs; i++) {
+        const qso_env* e = &h->env[i];
+        out[i] = which == 0 ? task_reward(&h->cfg, e) : which == 1 ? task_reward_end(&h->cfg, e) : (real)task_terminated(&h->cfg, e);
     }
     return 0;
 }

@@ -1,0 +1,298 @@
+"""Plain-data configuration handed across the C ABI (include/qs_amd.h `qs_config`).
+
+`build_config` turns the reference's constructor keywords (quadruped_spring/env/quadruped_gym_env.py:52-70)
+and string registries (task_collection.py:19-37, sensor_collection.py:92-105, control_interface/collection.py:33,49,
+env_randomizer_collection.py:15-21) into numbers.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import go1_config
+
+MAX_SENSORS = 16
+MAX_OBS = 64
+
+ACTION_SPACE_MODES = {"DEFAULT": (0, 12), "SYMMETRIC": (1, 6), "SYMMETRIC_NO_HIP": (2, 4)}
+MOTOR_CONTROL_MODES = {"PD": 0, "CARTESIAN_PD": 1, "TORQUE": 2}
+TASKS = {
+    "NO_TASK": 0,
+    "JUMPING_IN_PLACE": 1,
+    "JUMPING_FORWARD": 2,
+    "CONTINUOUS_JUMPING_FORWARD": 3,
+    "CONTINUOUS_JUMPING_FORWARD2": 4,
+    "JUMPING_IN_PLACE_PPO": 5,
+    "JUMPING_FORWARD_PPO": 6,
+    "BACKFLIP": 7,
+    "JUMPING_IN_PLACE_PPO_HP": 8,
+    "JUMPING_FORWARD_PPO_HP": 9,
+}
+# registry keys the reference defines but this build does not run: demo tasks need the
+# absent demonstrations/*.npy; the TaskContinuousJumping2 family keeps unbounded per-jump arrays.
+TASKS_UNSUPPORTED = (
+    "JUMPING_IN_PLACE_DEMO", "JUMPING_FORWARD_DEMO", "BACKFLIP_DEMO", "CONTINUOUS_JUMPING_FORWARD_DEMO",
+    "CONTINUOUS_JUMPING_FORWARD_PPO", "BACKFLIP_PPO", "CONTINUOUS_JUMPING_FORWARD3",
+)
+
+# sensor ids (include/qs_amd.h QS_SENS_*): name, dim, (high, low, noise) attribute names, reference obs-dict key
+SENSORS = {
+    "JointPosition": (0, 12, "JOINT_ANGLES", "Encoder"),
+    "JointVelocity": (1, 12, "JOINT_VELOCITIES", "JointVelocity"),
+    "Pitch": (2, 1, "PITCH", "Pitch"),
+    "Height": (3, 1, "HEIGHT", "Height"),
+    "BaseHeightVelocity": (4, 1, "VEL_LIN[2]", "Base Linear Velocity z direction"),
+    "Landing": (5, 1, None, "is landing"),
+    "Jumping": (6, 1, None, "is jumping"),
+    "PitchRate": (7, 1, "PITCH_RATE", "Pitch rate"),
+    "VelocityX": (8, 1, "VEL_LIN[0]", "Base Height Velocity X"),
+    "BooleanContact": (9, 4, "CONTACT_BOOL", "BoolContatc"),
+    "LinearVelocity": (10, 3, "VEL_LIN", "Base Linear Velocity"),
+    "AngularVelocity": (11, 3, "VEL_ANG", "Base Angular Velocity"),
+    "FeetPostion": (12, 12, "FEET_POS", "FeetPosition"),
+    "FeetVelocity": (13, 12, "FEET_VEL", "FeetVelocity"),
+    "PitchBackFlip": (14, 1, "PITCH", "Pitch-BackFlip"),
+    "OrientationRPY": (15, 3, "ORIENT_RPY", "Orientation Roll Pitch Yaw"),
+    "Quaternion": (16, 4, "QUATERNION", "Quaternion"),
+}
+# sensor_collection.py:18-90
+SENSOR_BUNDLES = {
+    "ENCODER": ["JointPosition", "JointVelocity"],
+    "ENCODER_2": ["LinearVelocity", "AngularVelocity", "JointPosition", "JointVelocity"],
+    "CARTESIAN_NO_IMU": ["FeetPostion", "FeetVelocity"],
+    "ARS_BASIC": ["JointPosition", "JointVelocity", "Pitch", "Height", "BaseHeightVelocity"],
+    "ARS_SENSOR": ["JointPosition", "JointVelocity", "Pitch", "PitchRate", "Height", "BaseHeightVelocity"],
+    "LANDING_SENSOR": ["JointPosition", "JointVelocity", "Pitch", "PitchRate", "Height", "BaseHeightVelocity", "Landing"],
+    "PPO_BASIC": ["JointPosition", "JointVelocity", "Pitch", "Height", "BaseHeightVelocity", "Landing"],
+    "PPO_BASIC_X": ["JointPosition", "JointVelocity", "Pitch", "Height", "BaseHeightVelocity", "VelocityX", "Landing"],
+    "PPO_BASIC_CONTACT": ["JointPosition", "JointVelocity", "Pitch", "Height", "BaseHeightVelocity", "Landing", "BooleanContact"],
+    "ARS_BACKFLIP": ["JointPosition", "JointVelocity", "Height", "BaseHeightVelocity", "PitchBackFlip"],
+    "PPO_BACKFLIP": ["JointPosition", "JointVelocity", "Height", "BaseHeightVelocity", "PitchBackFlip", "Landing"],
+    "PPO_CONTINUOUS_JUMPING_FORWARD": ["JointPosition", "JointVelocity", "Height", "BaseHeightVelocity", "Pitch", "Landing", "Jumping"],
+}
+# env_randomizer_collection.py:15-21 (curriculum variant is dead code in the reference)
+RAND_GROUND, RAND_MASSES, RAND_SPRINGS = 1, 2, 4
+RANDOMIZERS = {
+    "GROUND_RANDOMIZER": RAND_GROUND,
+    "MASS_RANDOMIZER": RAND_GROUND | RAND_MASSES,
+    "SPRING_RANDOMIZER": RAND_GROUND | RAND_SPRINGS,
+    "TEST_RANDOMIZER": RAND_GROUND | RAND_MASSES | RAND_SPRINGS,
+    "TEST_RANDOMIZER_CURRICULUM": RAND_GROUND | RAND_MASSES | RAND_SPRINGS,
+    "NONE": 0,  # build extension: BASELINE.json config 2 ("flat ground, mu = 1")
+}
+
+EPISODE_LENGTH = 10  # gym_env.py:35
+OBSERVATION_EPS = 0.01  # gym_env.py:34
+
+
+class QsConfig(C.Structure):
+    """Mirror of `qs_config` (include/qs_amd.h) and `qso_config` (oracle/qso.h)."""
+
+    _fields_ = [
+        ("n_envs", C.c_int32), ("action_dim", C.c_int32), ("action_space_mode", C.c_int32),
+        ("motor_control_mode", C.c_int32), ("symm_idx", C.c_int32), ("rl_interface", C.c_int32),
+        ("task", C.c_int32), ("n_sensors", C.c_int32), ("sensors", C.c_int32 * MAX_SENSORS),
+        ("obs_dim", C.c_int32), ("enable_springs", C.c_int32), ("enable_filter", C.c_int32),
+        ("enable_interp", C.c_int32), ("action_repeat", C.c_int32), ("solver_iters", C.c_int32),
+        ("settle_steps", C.c_int32), ("max_sim_steps", C.c_int32), ("randomizer_flags", C.c_int32),
+        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reserved_i", C.c_int32 * 3),
+        ("seed", C.c_uint64), ("dt", C.c_double), ("filt_b", C.c_double * 3), ("filt_a", C.c_double * 3), ("gravity", C.c_float),
+        ("kp", C.c_float * 3), ("kd", C.c_float * 3), ("tau_max", C.c_float * 3),
+        ("cmd_lo", C.c_float * 12), ("cmd_hi", C.c_float * 12),
+        ("settle_cmd", C.c_float * 12), ("settle_action", C.c_float * 12),
+        ("spring_k", C.c_float * 3), ("spring_b", C.c_float * 3), ("spring_rest", C.c_float * 3),
+        ("fallen_height", C.c_float), ("leg_len", C.c_float * 3),
+        ("contact_erp", C.c_float), ("joint_erp", C.c_float), ("warmstart", C.c_float), ("vel_cap", C.c_float),
+        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("reserved_f", C.c_float * 8),
+    ]
+
+
+def butter2_lowpass(fc, fs):
+    """Coefficients of scipy.signal.butter(2, [fc/(fs/2)]) (utils/action_filter.py:191-213) in closed form
+    (bilinear transform of the 2nd-order Butterworth prototype with pre-warping)."""
+    k = math.tan(math.pi * fc / fs)
+    q = math.sqrt(2.0)
+    norm = 1.0 / (1.0 + q * k + k * k)
+    b0 = k * k * norm
+    return np.array([b0, 2 * b0, b0]), np.array([1.0, 2 * (k * k - 1) * norm, (1 - q * k + k * k) * norm])
+
+
+def _lookup(table, key, what):
+    if key not in table:
+        raise KeyError(f"the {what} {key} is not implemented yet.")  # base_collection.py:8-12 prints the same text
+    return table[key]
+
+
+def _attr(cfg, spec, suffix):
+    if "[" in spec:
+        base, idx = spec[:-1].split("[")
+        return np.atleast_1d(np.asarray(getattr(cfg, f"{base}_{suffix}"))[int(idx)])
+    return np.atleast_1d(np.asarray(getattr(cfg, f"{spec}_{suffix}"), dtype=np.float64))
+
+
+def sensor_layout(robot_config, observation_space_mode):
+    """ids, names, per-element (high, low, noise std) of a bundle (sensor.py:71-136, robot_sensors.py)."""
+    names = _lookup(SENSOR_BUNDLES, observation_space_mode, "sensor package")
+    ids, keys, dims, high, low, std = [], [], [], [], [], []
+    for n in names:
+        sid, dim, spec, key = SENSORS[n]
+        ids.append(sid); keys.append(key); dims.append(dim)
+        if spec is None:  # Landing / Jumping: [0, 1], no noise (robot_sensors.py:141-188)
+            high.append(np.ones(1)); low.append(np.zeros(1)); std.append(np.zeros(1))
+        else:
+            high.append(_attr(robot_config, spec, "HIGH")); low.append(_attr(robot_config, spec, "LOW"))
+            s = _attr(robot_config, spec, "NOISE")
+            std.append(s if np.all(s > 0) else np.zeros_like(s))  # sensor.py:25-32: all-or-nothing
+    return dict(ids=ids, keys=keys, dims=dims, high=np.concatenate(high), low=np.concatenate(low), std=np.concatenate(std))
+
+
+def scale_action_to_command(a12, lo, hi):
+    """interface_base.py:84-90."""
+    a = np.clip(a12, -1, 1)
+    return np.clip(lo + 0.5 * (a + 1) * (hi - lo), lo, hi)
+
+
+def scale_command_to_action(cmd, lo, hi):
+    """interface_base.py:92-100."""
+    c = np.clip(cmd, lo, hi)
+    return np.clip(-1 + 2 * (c - lo) / (hi - lo), -1, 1)
+
+
+def to_default_action_space(a, mode, symm_idx):
+    """action_interface.py:14-15, :29-39, :58-65."""
+    a = np.asarray(a, dtype=np.float64)
+    if mode == "DEFAULT":
+        return a.copy()
+    if mode == "SYMMETRIC":
+        fr, rr = a[0:3].copy(), a[3:6].copy()
+        fl, rl = fr.copy(), rr.copy()
+        fl[symm_idx] = -fr[symm_idx]
+        rl[symm_idx] = -rr[symm_idx]
+        return np.concatenate((fr, fl, rr, rl))
+    fr = np.insert(a[0:2], symm_idx, 0)
+    rr = np.insert(a[2:4], symm_idx, 0)
+    return np.concatenate((fr, fr, rr, rr))
+
+
+def to_actual_action_space(a12, mode, symm_idx):
+    """action_interface.py:17-18, :41-44, :67-74."""
+    if mode == "DEFAULT":
+        return a12.copy()
+    fr, rr = a12[0:3], a12[6:9]
+    if mode == "SYMMETRIC":
+        return np.concatenate((fr, rr))
+    return np.concatenate((np.delete(fr, symm_idx), np.delete(rr, symm_idx)))
+
+
+def build_config(
+    n_envs=1,
+    isRLGymInterface=True,
+    time_step=0.001,
+    action_repeat=10,
+    motor_control_mode="PD",
+    task_env="NO_TASK",
+    observation_space_mode="ENCODER",
+    action_space_mode="SYMMETRIC",
+    enable_springs=False,
+    enable_action_interpolation=False,
+    enable_action_filter=False,
+    env_randomizer_mode="GROUND_RANDOMIZER",
+    seed=0,
+    noise=True,
+    auto_reset=False,
+    settle_steps=2500,
+    robot_config=None,
+    **_ignored,
+):
+    """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
+    if motor_control_mode == "TORQUE" and isRLGymInterface:
+        # gym_env.py:167-168
+        raise ValueError(f"the motor control mode {motor_control_mode} not" "implemented yet for RL Gym interface.")
+    if task_env in TASKS_UNSUPPORTED:
+        raise NotImplementedError(
+            f"task {task_env} exists in the reference registry but is outside this build's scope (see DESIGN.md)")
+    rc = robot_config if robot_config is not None else go1_config.make_config(enable_springs)
+    mode_id, action_dim = _lookup(ACTION_SPACE_MODES, action_space_mode, "action space mode")
+    motor_id = _lookup(MOTOR_CONTROL_MODES, motor_control_mode, "motor control mode")
+    task_id = _lookup(TASKS, task_env, "task")
+    rand = _lookup(RANDOMIZERS, env_randomizer_mode, "env randomizer")
+    lay = sensor_layout(rc, observation_space_mode)
+
+    cfg = QsConfig()
+    cfg.n_envs, cfg.action_dim, cfg.action_space_mode, cfg.motor_control_mode = n_envs, action_dim, mode_id, motor_id
+    cfg.rl_interface, cfg.task = int(bool(isRLGymInterface)), task_id
+    if not isRLGymInterface:
+        cfg.action_dim = action_dim = 12  # raw motor commands (gym_env.py:212-214)
+    # limits and poses (motor_interface.py:9-32, :50-63, :94-100)
+    if motor_control_mode == "PD":
+        if task_env == "BACKFLIP":  # motor_interface.py:17-22 mutates the config arrays in place
+            for i in (7, 10):
+                rc.RL_UPPER_ANGLE_JOINT[i] = math.pi / 2
+        lo, hi, symm = rc.RL_LOWER_ANGLE_JOINT, rc.RL_UPPER_ANGLE_JOINT, 0
+        init_pose, landing_pose = rc.INIT_MOTOR_ANGLES, rc.ANGLE_LANDING_POSE
+    elif motor_control_mode == "CARTESIAN_PD":
+        lo, hi, symm = rc.RL_LOWER_CARTESIAN_POS, rc.RL_UPPER_CARTESIAN_POS, 1
+        init_pose, landing_pose = rc.NOMINAL_FOOT_POS_LEG_FRAME, rc.CARTESIAN_LANDING_POSE
+    else:
+        lo, hi, symm = -rc.TORQUE_LIMITS, rc.TORQUE_LIMITS, 0
+        init_pose, landing_pose = np.zeros(12), np.zeros(12)
+    cfg.symm_idx = symm
+    cfg.n_sensors = len(lay["ids"])
+    for i, s in enumerate(lay["ids"]):
+        cfg.sensors[i] = s
+    cfg.obs_dim = int(sum(lay["dims"]))
+    cfg.enable_springs, cfg.enable_filter = int(bool(enable_springs)), int(bool(enable_action_filter))
+    cfg.enable_interp = int(bool(enable_action_interpolation))
+    cfg.action_repeat = int(action_repeat)
+    cfg.solver_iters = int(300 / action_repeat)  # gym_env.py:113
+    cfg.settle_steps = int(settle_steps) if isRLGymInterface else 1500  # gym_env.py:115 / control_interface/utils.py:31
+    # gym_env.py:245: done when sim_step_counter * dt > 10 (evaluated in python float arithmetic, like the reference)
+    n = max(0, int(EPISODE_LENGTH / time_step) - 2)
+    while n * time_step <= EPISODE_LENGTH:
+        n += 1
+    cfg.max_sim_steps = n - 1
+    cfg.randomizer_flags, cfg.noise_enabled, cfg.auto_reset = rand, int(bool(noise)), int(bool(auto_reset))
+    cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    cfg.dt, cfg.gravity = time_step, 9.8  # gym_env.py:309
+    for i in range(3):
+        cfg.kp[i], cfg.kd[i], cfg.tau_max[i] = rc.MOTOR_KP[i], rc.MOTOR_KD[i], rc.RL_TORQUE_LIMITS[i]
+        cfg.spring_k[i], cfg.spring_b[i], cfg.spring_rest[i] = rc.SPRINGS_STIFFNESS[i], rc.SPRINGS_DAMPING[i], rc.SPRINGS_REST_ANGLE[i]
+    cfg.leg_len[0], cfg.leg_len[1], cfg.leg_len[2] = rc.HIP_LINK_LENGTH, rc.THIGH_LINK_LENGTH, rc.CALF_LINK_LENGTH
+    for i in range(12):
+        cfg.cmd_lo[i], cfg.cmd_hi[i] = lo[i], hi[i]
+    # settle reference -> action -> command round trip (interface_base.py:68-73, 182-200)
+    if isRLGymInterface:
+        aspace = action_space_mode
+        ref_action = to_actual_action_space(scale_command_to_action(np.asarray(init_pose, float), lo, hi), aspace, symm)
+        settle_scaled = scale_action_to_command(to_default_action_space(ref_action, aspace, symm), lo, hi)
+        if motor_control_mode == "CARTESIAN_PD":
+            from .kinematics import leg_ik
+            settle_cmd = np.concatenate([leg_ik(rc, L, settle_scaled[3 * L:3 * L + 3]) for L in range(4)])
+        else:
+            settle_cmd = settle_scaled
+        # interface_base.py:194: the returned "settling action" is the inverse map applied to the *motor command*;
+        # for CARTESIAN_PD that command is joint angles pushed through the Cartesian scaling (reference quirk, kept).
+        settle_action = to_actual_action_space(scale_command_to_action(settle_cmd, lo, hi), aspace, symm)
+    else:  # settle_robot_by_pd: DEFAULT/PD interface, 1500 steps toward INIT_MOTOR_ANGLES (control_interface/utils.py:24-32)
+        plo, phi = rc.RL_LOWER_ANGLE_JOINT, rc.RL_UPPER_ANGLE_JOINT
+        settle_cmd = scale_action_to_command(scale_command_to_action(rc.INIT_MOTOR_ANGLES, plo, phi), plo, phi)
+        settle_action = np.zeros(12)
+    for i in range(12):
+        cfg.settle_cmd[i] = settle_cmd[i]
+        cfg.settle_action[i] = settle_action[i] if i < len(settle_action) else 0.0
+    fb, fa = butter2_lowpass(3.0, 1.0 / (action_repeat * time_step))  # action_filter.py:41-43, gym_env.py:262
+    for i in range(3):
+        cfg.filt_b[i], cfg.filt_a[i] = fb[i], fa[i]
+    cfg.fallen_height = rc.IS_FALLEN_HEIGHT
+    # engine constants assumed for PyBullet defaults (DESIGN.md "contact model")
+    cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = 0.2, 0.2, 0.1, rc.VELOCITY_LIMITS[0]
+    for i, s in enumerate(lay["std"]):
+        cfg.obs_noise_std[i] = s
+    landing_action = to_actual_action_space(scale_command_to_action(np.asarray(landing_pose, float), lo, hi), action_space_mode, symm) \
+        if isRLGymInterface else np.zeros(12)
+    meta = dict(robot_config=rc, layout=lay, lower=np.array(lo, float), upper=np.array(hi, float), symm_idx=symm,
+                init_pose=np.array(init_pose, float), landing_pose=np.array(landing_pose, float),
+                settle_action=np.array(settle_action, float), landing_action=np.array(landing_action, float),
+                action_space_mode=action_space_mode, motor_control_mode=motor_control_mode, task_env=task_env,
+                observation_space_mode=observation_space_mode, env_randomizer_mode=env_randomizer_mode)
+    return cfg, meta

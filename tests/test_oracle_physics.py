@@ -1,0 +1,208 @@
+"""Physics known-answer tests for the oracle's rigid-body step (oracle/qso_phys.c).
+
+PyBullet is absent (parity with the engine is unpinned, see oracle/qso.h); these analytic checks pin the restated
+step instead: K1 free fall, K2 momentum conservation, K3 ABA == CRBA + RNEA, K5 energy drift, K6 static stance,
+K7 Coulomb cone, K8 joint-limit stop, K9 spring gating continuity, K10 velocity cap, K11 determinism."""
+import numpy as np
+import pytest
+
+from oracle.qso import Oracle
+from qs_amd.config import build_config
+
+TOTAL_MASS = 12.01301
+
+
+def make(n=1, springs=True, dt=0.001, **kw):
+    kw.setdefault("task_env", "JUMPING_IN_PLACE")
+    kw.setdefault("observation_space_mode", "PPO_BASIC")
+    kw.setdefault("env_randomizer_mode", "NONE")
+    cfg, meta = build_config(n_envs=n, enable_springs=springs, noise=False, time_step=dt, **kw)
+    return Oracle(cfg), cfg
+
+
+def random_state(o, rng, height=1.0):
+    s = o.get_state()
+    s[0, 3:7] = rng.normal(size=4)
+    s[0, 3:7] /= np.linalg.norm(s[0, 3:7])
+    s[0, 7:13] = rng.normal(size=6)
+    s[0, 13:25] += 0.3 * rng.normal(size=12)
+    s[0, 25:37] = 2 * rng.normal(size=12)
+    s[0, 2] = height
+    return s
+
+
+def test_k3_aba_equals_crba_rnea():
+    o, _ = make()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        o.set_state(random_state(o, rng))
+        tau = 5 * rng.normal(size=12)
+        acc = o.aba(0, tau)
+        H, C = o.crba_rnea(0)
+        assert np.abs(H - H.T).max() < 1e-12
+        assert np.all(np.linalg.eigvalsh(H) > 0)
+        np.testing.assert_allclose(H[3, 3], TOTAL_MASS, rtol=1e-12)
+        res = H @ acc + C - np.concatenate([np.zeros(6), tau])
+        assert np.abs(res).max() < 1e-10
+
+
+def test_k1_free_fall():
+    o, cfg = make()
+    rng = np.random.default_rng(1)
+    o.set_state(random_state(o, rng, height=5.0))
+    e0 = o.energy(0)
+    n = 200
+    for _ in range(n):
+        o.phys_step(0, np.zeros(12))
+    e1 = o.energy(0)
+    dpdt = (e1["p"] - e0["p"]) / (n * cfg.dt)
+    np.testing.assert_allclose(dpdt, [0, 0, -9.8 * TOTAL_MASS], atol=2e-2)  # O(dt) integrator error
+    # com follows the parabola (semi-implicit Euler: z_n = z_0 + v n dt - g dt^2 n(n+1)/2)
+    v0 = e0["p"] / TOTAL_MASS
+    t = n * cfg.dt
+    z_expected = e0["com"][2] + v0[2] * t - 0.5 * 9.8 * cfg.dt ** 2 * n * (n + 1)
+    assert abs(e1["com"][2] - z_expected) < 2e-4
+
+
+def test_k2_zero_gravity_momentum_first_order():
+    """With internal torques only, linear and angular momentum are conserved up to the integrator's O(dt) error."""
+    drift = []
+    for dt, rep in ((1e-3, 1), (1e-4, 10)):
+        o, cfg = make(dt=dt)
+        rng = np.random.default_rng(2)
+        o.set_gravity(0.0)
+        o.set_state(random_state(o, rng))
+        e0 = o.energy(0)
+        for _ in range(100):
+            tau = 3 * rng.normal(size=12)
+            for _ in range(rep):
+                o.phys_step(0, tau)
+        e1 = o.energy(0)
+        drift.append(max(np.abs(e1["p"] - e0["p"]).max(), np.abs(e1["L"] - e0["L"]).max()))
+    assert drift[0] < 1e-2 and drift[1] < drift[0] / 5
+
+
+def test_k5_energy_drift_passive():
+    o, cfg = make(dt=1e-4)
+    rng = np.random.default_rng(3)
+    o.set_gravity(0.0)
+    s = random_state(o, rng)
+    s[0, 25:37] *= 0.5
+    o.set_state(s)
+    e0 = o.energy(0)["KE"]
+    for _ in range(2000):
+        o.phys_step(0, np.zeros(12))
+    e1 = o.energy(0)["KE"]
+    assert abs(e1 - e0) / e0 < 2e-2
+
+
+@pytest.mark.parametrize("springs", [True, False])
+def test_k6_static_stance(springs):
+    o, cfg = make(springs=springs, enable_action_filter=True)
+    o.reset()
+    for _ in range(50):  # a little more settling under the same command
+        o.step(np.array(cfg.settle_action)[None, :6])
+    f = o.get_info(0)[0]
+    assert np.all(o.get_info(1)[0] == 1)
+    np.testing.assert_allclose(f.sum(), TOTAL_MASS * 9.8, rtol=5e-3)
+    np.testing.assert_allclose(f[0], f[1], rtol=2e-2)  # left/right symmetry
+    np.testing.assert_allclose(f[2], f[3], rtol=2e-2)
+    s = o.get_state()[0]
+    assert np.abs(s[7:13]).max() < 2e-2 and np.abs(s[25:]).max() < 0.1
+    assert 0.25 < s[2] < 0.34
+
+
+def test_k7_coulomb_cone():
+    """Sliding feet: the horizontal impulse of every substep equals mu * (sum of normal impulses) exactly."""
+    mu = 0.5
+    o, cfg = make()
+    cfg.randomizer_flags = 8
+    o = Oracle(cfg)
+    o.set_params(0, np.array([mu]))
+    o.reset()
+    s = o.get_state()
+    s[0, 7] = 3.0  # whole robot translating along +x at 3 m/s: all four feet slide
+    o.set_state(s)
+    tau_hold = o.get_info(2)[0] + o.get_info(3)[0]
+    for _ in range(5):
+        p0 = o.energy(0)["p"][0]
+        o.phys_step(0, tau_hold)
+        dp = o.energy(0)["p"][0] - p0
+        fn = o.get_info(0)[0].sum()
+        assert fn > 50
+        assert dp == pytest.approx(-mu * fn * cfg.dt, rel=2e-3)
+    # and a foot at rest on the ground is not dragged: |f_t| stays inside the cone (robot keeps standing still)
+    o.reset()
+    for _ in range(100):
+        o.phys_step(0, tau_hold)
+    assert abs(o.get_state()[0, 7]) < 5e-2
+
+
+def test_k8_joint_limit_stop():
+    o, cfg = make()
+    o.set_gravity(0.0)
+    s = o.get_state()
+    s[0, 2] = 2.0
+    o.set_state(s)
+    tau = np.zeros(12)
+    tau[2] = -33.55  # drive the FR calf into its lower limit
+    for _ in range(400):
+        o.phys_step(0, tau)
+    q = o.get_state()[0, 15]
+    assert q > -2.72271363311 - 0.02 and q < -2.6
+
+
+def test_k9_spring_gating_continuity():
+    o, cfg = make()
+    k, b, rest = np.array(cfg.spring_k, float), np.array(cfg.spring_b, float), np.array(cfg.spring_rest, float)
+    q0 = np.tile(rest, 4)
+    for j in range(12):
+        for eps in (-1e-9, 1e-9):
+            q = q0.copy()
+            q[j] += eps
+            t = o.spring_torque(k, b, rest, q, np.zeros(12))
+            assert abs(t[j]) < 1e-7  # torque is continuous through the rest angle
+    # static deflection under a known load: k * dq = tau
+    q = q0.copy()
+    q[1] += 0.1   # thigh above rest -> spring engaged
+    q[2] -= 0.2   # calf below rest -> engaged
+    t = o.spring_torque(k, b, rest, q, np.zeros(12))
+    np.testing.assert_allclose([t[1], t[2]], [-k[1] * 0.1, k[2] * 0.2], rtol=1e-6)
+
+
+def test_k10_velocity_cap():
+    o, cfg = make()
+    o.set_gravity(0.0)
+    s = o.get_state()
+    s[0, 2] = 2.0
+    s[0, 25:] = 100.0
+    o.set_state(s)
+    o.phys_step(0, np.zeros(12))
+    assert np.abs(o.get_state()[0, 25:]).max() <= cfg.vel_cap + 1e-6
+
+
+def test_k11_determinism_across_batch_size():
+    rng = np.random.default_rng(7)
+    acts = rng.uniform(-1, 1, size=(30, 4, 6)).astype(np.float32)
+    o4, _ = make(n=4, env_randomizer_mode="GROUND_RANDOMIZER", seed=3)
+    o4.reset()
+    out4 = [o4.step(a)[0].copy() for a in acts]
+    o2, _ = make(n=2, env_randomizer_mode="GROUND_RANDOMIZER", seed=3)
+    o2.reset()
+    out2 = [o2.step(a[:2])[0].copy() for a in acts]
+    for a, b in zip(out4, out2):
+        assert np.array_equal(a[:2], b)
+
+
+def test_f32_build_tracks_f64():
+    rng = np.random.default_rng(11)
+    cfg, _ = build_config(n_envs=2, enable_springs=True, noise=False, task_env="JUMPING_IN_PLACE",
+                          observation_space_mode="PPO_BASIC", enable_action_filter=True, env_randomizer_mode="NONE")
+    a, b = Oracle(cfg, "f64"), Oracle(cfg, "f32")
+    a.reset(); b.reset()
+    np.testing.assert_allclose(a.get_state(), b.get_state(), atol=2e-3)
+    for _ in range(5):
+        act = rng.uniform(-1, 1, size=(2, 6))
+        b.set_state(a.get_state())
+        oa, ob = a.step(act)[0], b.step(act)[0]
+        np.testing.assert_allclose(oa, ob, atol=5e-3, rtol=1e-3)

@@ -1,0 +1,48 @@
+"""Oracle full env step vs traces recorded from the REFERENCE's own QuadrupedGymEnv (tools/gen_golden.py, g15).
+
+The reference env ran on a fake BulletClient whose rigid-body step is oracle/qso_phys.c, so every difference found
+here is a difference in the restated caller semantics: action filter, action->command map, PD + PEA torques,
+counters, task state machine, rewards, termination/truncation, sensor layout, reset/settle."""
+import ast
+
+import numpy as np
+import pytest
+
+from oracle.qso import Oracle
+from qs_amd.config import build_config
+
+CASES = ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "cart_s1"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_trace(golden, name):
+    g = golden("traces.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    cfg, meta = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", **kw)
+    cfg.randomizer_flags = 8  # keep parameters across reset; mu of each episode comes from the recorded trace
+    o = Oracle(cfg)
+    assert list(g[f"{name}_keys"]) == meta["layout"]["keys"]
+    acts, obs_ref, rew_ref = g[f"{name}_actions"], g[f"{name}_obs"], g[f"{name}_rew"]
+    done_ref, trunc_ref = g[f"{name}_done"], g[f"{name}_trunc"]
+    reset_obs, reset_at, mus = g[f"{name}_reset_obs"], list(g[f"{name}_reset_at"]), g[f"{name}_mu"]
+    np.testing.assert_allclose(o.command_to_action(meta["landing_pose"] if kw["motor_control_mode"] == "PD" else meta["landing_pose"]),
+                               g[f"{name}_landing_action"], atol=1e-6)
+    ep = 0
+    o.set_params(0, np.array([mus[0]]))
+    ob = o.reset()
+    np.testing.assert_allclose(ob[0], reset_obs[0], atol=2e-5, rtol=1e-5)
+    state_ref = g[f"{name}_state"]
+    for t in range(len(acts)):
+        ob, r, dn, tr = o.step(acts[t][None])
+        np.testing.assert_allclose(o.get_state()[0], state_ref[t], atol=5e-4, rtol=1e-4, err_msg=f"state step {t}")
+        assert bool(dn[0]) == bool(done_ref[t]), f"done mismatch at step {t}"
+        assert bool(tr[0]) == bool(trunc_ref[t]), f"trunc mismatch at step {t}"
+        np.testing.assert_allclose(ob[0], obs_ref[t], atol=5e-4, rtol=1e-4, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r[0], rew_ref[t], atol=2e-4, rtol=1e-4, err_msg=f"reward step {t}")
+        if dn[0]:
+            ep += 1
+            assert reset_at[ep] == t + 1
+            o.set_params(0, np.array([mus[ep]]))
+            ob = o.reset()
+            np.testing.assert_allclose(ob[0], reset_obs[ep], atol=2e-5, rtol=1e-5)
+    assert ep == len(reset_at) - 1

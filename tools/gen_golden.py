@@ -1,0 +1,549 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (this container only: /root/reference never travels).
+
+    python tools/gen_golden.py            # rewrites tests/golden/*.npz
+
+The reference's numpy half is importable with four tiny shims: a `collections.Sequence`
+alias, fake `pybullet` / `pybullet_data` / `pybullet_utils.bullet_client`, fake `gym`, fake `absl.logging`.
+Nothing of the reference is copied into the repository: the fixtures hold inputs and the outputs the
+reference's own functions produced for them.
+
+Two kinds of fixtures:
+  g1..g12  stateless functions of the numpy half, called directly on the reference's classes;
+  g15      the reference's own QuadrupedGymEnv (reset/step, tasks, rewards, sensors, action filter) driven through a
+           FakeBulletClient whose rigid-body step is the build's CPU oracle (oracle/qso_phys.c).  This pins the
+           *caller* semantics around the absent PyBullet engine; it does not pin the engine itself.
+"""
+import collections
+import collections.abc
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "quadruped-springs_amd"))
+sys.path.insert(0, "/root/reference")
+
+
+# --------------------------------------------------------------------------------------------- shims
+def install_shims():
+    collections.Sequence = collections.abc.Sequence
+    pb = types.ModuleType("pybullet")
+    pb.invertTransform = lambda position, orientation: (
+        [-p for p in position], (-orientation[0], -orientation[1], -orientation[2], orientation[3]))
+    pb.GUI = 1
+    sys.modules["pybullet"] = pb
+    pd_ = types.ModuleType("pybullet_data")
+    pd_.getDataPath = lambda: "/nonexistent"
+    sys.modules["pybullet_data"] = pd_
+    pu = types.ModuleType("pybullet_utils")
+    bc = types.ModuleType("pybullet_utils.bullet_client")
+    bc.BulletClient = lambda *a, **k: FakeBulletClient()
+    pu.bullet_client = bc
+    sys.modules["pybullet_utils"] = pu
+    sys.modules["pybullet_utils.bullet_client"] = bc
+
+    gym = types.ModuleType("gym")
+
+    class Env:
+        pass
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            return getattr(self.env, name)
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped if hasattr(self.env, "unwrapped") else self.env
+
+        def step(self, a):
+            return self.env.step(a)
+
+        def reset(self):
+            return self.env.reset()
+
+    class Box:
+        def __init__(self, low, high, dtype=np.float32):
+            self.low, self.high, self.dtype, self.shape = np.asarray(low, dtype), np.asarray(high, dtype), dtype, np.shape(low)
+
+    gym.Env, gym.Wrapper = Env, Wrapper
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box = Box
+    gym.spaces = spaces
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda **k: None
+    envs.registration = reg
+    gym.envs = envs
+    for n, m in (("gym", gym), ("gym.spaces", spaces), ("gym.envs", envs), ("gym.envs.registration", reg)):
+        sys.modules[n] = m
+    absl = types.ModuleType("absl")
+    absl.logging = logging
+    sys.modules["absl"] = absl
+    sys.modules["absl.logging"] = logging
+    cv2 = types.ModuleType("cv2")
+    sys.modules["cv2"] = cv2
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None
+
+
+# --------------------------------------------------------------------------------------------- fake Bullet on oracle physics
+_JOINT_NAMES = ["floating_base", "imu_joint"]
+for leg in ("FR", "FL", "RR", "RL"):
+    _JOINT_NAMES += [f"{leg}_hip_joint", f"{leg}_thigh_joint", f"{leg}_calf_joint", f"{leg}_foot_fixed"]
+_MOTOR_IDS = [2, 3, 4, 6, 7, 8, 10, 11, 12, 14, 15, 16]
+_FOOT_IDS = [5, 9, 13, 17]
+_LINK_MASS = {-1: 1e-5, 0: 5.204, 1: 0.001}
+for k, base in enumerate((2, 6, 10, 14)):
+    _LINK_MASS.update({base: 0.591, base + 1: 0.92, base + 2: 0.131, base + 3: 0.06})
+
+
+class FakeBulletClient:
+    """The 30-odd pybullet methods the reference calls; dynamics = oracle/qso_phys.c."""
+
+    COV_ENABLE_PLANAR_REFLECTION = 0
+    COV_ENABLE_RGB_BUFFER_PREVIEW = COV_ENABLE_DEPTH_BUFFER_PREVIEW = COV_ENABLE_SEGMENTATION_MARK_PREVIEW = COV_ENABLE_GUI = 0
+    TORQUE_CONTROL, VELOCITY_CONTROL, POSITION_CONTROL = 2, 0, 1
+    URDF_USE_SELF_COLLISION = 8
+    JOINT_FIXED = 4
+    LINK_FRAME = 1
+    GUI = 1
+    oracle_factory = None  # set by the generator: callable(dt, solver_iters) -> Oracle
+    log = None
+
+    def __init__(self):
+        self.o = None
+        self.dt = 0.001
+        self.iters = 30
+        self.mu = 1.0
+        self.tau = np.zeros(12)
+        self.mu_log = []
+
+    # world
+    def resetSimulation(self):
+        self.mu = 1.0
+        self.tau[:] = 0
+
+    def setPhysicsEngineParameter(self, numSolverIterations=None, **k):
+        if numSolverIterations is not None:
+            self.iters = int(numSolverIterations)
+
+    def setTimeStep(self, dt):
+        self.dt = dt
+
+    def setGravity(self, x, y, z):
+        self.g = -z
+
+    def loadURDF(self, path, basePosition=None, baseOrientation=None, flags=0, **k):
+        if path.endswith("plane.urdf"):
+            return 0
+        self.o = FakeBulletClient.oracle_factory(self.dt, self.iters)
+        s = self.o.get_state()
+        s[0, :3] = basePosition
+        s[0, 3:7] = baseOrientation
+        s[0, 7:] = 0
+        self.o.set_state(s)
+        self.o.set_gravity(self.g)
+        return 1
+
+    def changeVisualShape(self, *a, **k):
+        pass
+
+    def configureDebugVisualizer(self, *a, **k):
+        pass
+
+    def disconnect(self):
+        pass
+
+    def resetDebugVisualizerCamera(self, *a, **k):
+        pass
+
+    # model queries
+    def getNumJoints(self, body):
+        return 18
+
+    def getJointInfo(self, body, i):
+        return (i, _JOINT_NAMES[i].encode("UTF-8"))
+
+    def getDynamicsInfo(self, body, link):
+        return (_LINK_MASS[link], 1.0, (0.0, 0.0, 0.0))
+
+    def changeDynamics(self, body, link, lateralFriction=None, **k):
+        if body == 0 and link == -1 and lateralFriction is not None:
+            self.mu = float(lateralFriction)
+            self.mu_log.append(self.mu)
+            if self.o is not None:
+                self.o.set_params(0, np.array([self.mu]))
+
+    # state
+    def _state(self):
+        return self.o.get_state()[0]
+
+    def resetJointState(self, body, jid, angle, targetVelocity=0):
+        s = self.o.get_state()
+        k = _MOTOR_IDS.index(jid)
+        s[0, 13 + k] = angle
+        s[0, 25 + k] = targetVelocity
+        self.o.set_state(s)
+
+    def resetBasePositionAndOrientation(self, body, pos, orn):
+        s = self.o.get_state()
+        s[0, :3] = pos
+        s[0, 3:7] = orn
+        self.o.set_state(s)
+
+    def resetBaseVelocity(self, body, lin, ang):
+        s = self.o.get_state()
+        s[0, 7:10] = lin
+        s[0, 10:13] = ang
+        self.o.set_state(s)
+
+    def setJointMotorControl2(self, bodyIndex=None, jointIndex=None, controlMode=None, force=0, **k):
+        if controlMode == self.TORQUE_CONTROL and jointIndex in _MOTOR_IDS:
+            self.tau[_MOTOR_IDS.index(jointIndex)] += force  # App. D-1: torques accumulate within a step
+
+    def stepSimulation(self):
+        self.o.set_params(0, np.array([self.mu]))
+        self.o.phys_step(0, self.tau)
+        self.tau[:] = 0
+
+    def getJointState(self, body, jid):
+        s = self._state()
+        k = _MOTOR_IDS.index(jid)
+        return (s[13 + k], s[25 + k], (0,) * 6, 0.0)
+
+    def getBasePositionAndOrientation(self, body):
+        s = self._state()
+        return tuple(s[:3]), tuple(s[3:7])
+
+    def getBaseVelocity(self, body):
+        s = self._state()
+        return tuple(s[7:10]), tuple(s[10:13])
+
+    def getContactPoints(self, *a, **k):
+        pts = []
+        force = self.o.get_info(0)[0]
+        flag = self.o.get_info(1)[0]
+        for f in range(4):
+            if flag[f]:
+                pts.append((0, 1, 0, _FOOT_IDS[f], -1, (0, 0, 0), (0, 0, 0), (0, 0, 1), 0.0, float(force[f])))
+        for _ in range(int(self.o.get_info(5)[0, 0])):
+            pts.append((0, 1, 0, 0, -1, (0, 0, 0), (0, 0, 0), (0, 0, 1), 0.0, 0.0))  # trunk-ground: invalid
+        return pts
+
+    # maths helpers (independent of the oracle's C versions: scipy)
+    def getEulerFromQuaternion(self, q):
+        from scipy.spatial.transform import Rotation as R
+        return tuple(R.from_quat(q).as_euler("xyz"))
+
+    def getQuaternionFromEuler(self, e):
+        from scipy.spatial.transform import Rotation as R
+        return tuple(R.from_euler("xyz", e).as_quat())
+
+    def getMatrixFromQuaternion(self, q):
+        from scipy.spatial.transform import Rotation as R
+        return tuple(R.from_quat(q).as_matrix().flatten())
+
+    def multiplyTransforms(self, positionA, orientationA, positionB, orientationB):
+        from scipy.spatial.transform import Rotation as R
+        ra, rb = R.from_quat(orientationA), R.from_quat(orientationB)
+        return tuple(np.asarray(positionA) + ra.apply(positionB)), tuple((ra * rb).as_quat())
+
+    def invertTransform(self, position, orientation):
+        from scipy.spatial.transform import Rotation as R
+        r = R.from_quat(orientation).inv()
+        return tuple(-r.apply(position)), tuple(r.as_quat())
+
+
+# --------------------------------------------------------------------------------------------- stateless goldens
+def stub_env(cfg_mod, task_env="NO_TASK"):
+    e = types.SimpleNamespace()
+    e._robot_config = cfg_mod
+    e.task_env = task_env
+    return e
+
+
+def stub_robot(cfg_mod):
+    from quadruped_spring.env.quadruped import Quadruped
+    r = object.__new__(Quadruped)
+    r._robot_config = cfg_mod
+    return r
+
+
+def gen_stateless():
+    import importlib
+    from quadruped_spring.env.control_interface import action_interface as ai
+    from quadruped_spring.env.control_interface import motor_interface as mi
+    from quadruped_spring.env.quadruped_motor import QuadrupedMotorModel
+    from quadruped_spring.utils.action_filter import ActionFilterButter
+    rng = np.random.default_rng(0)
+    out = {}
+    for springs in (True, False):
+        tag = "s1" if springs else "s0"
+        mod = importlib.import_module(
+            "quadruped_spring.go1.configs_go1_with_springs" if springs else "quadruped_spring.go1.configs_go1_without_springs")
+        robot = stub_robot(mod)
+        # G1/G2 action map + inverse
+        for mname, mcls in (("PD", mi.MotorInterfacePD), ("CARTESIAN_PD", mi.MotorInterfaceCARTESIAN_PD)):
+            for aname, acls in (("DEFAULT", ai.DefaultActionWrapper), ("SYMMETRIC", ai.SymmetricActionWrapper),
+                                ("SYMMETRIC_NO_HIP", ai.SymmetricNoHipActionWrapper)):
+                iface = acls(mcls(stub_env(mod)))
+                iface._reset(robot)
+                d = iface.get_action_space_dim()
+                a = rng.uniform(-1.5, 1.5, size=(64, d))
+                a[0] = 0
+                cmd = np.array([iface._transform_action_to_motor_command(x) for x in a])
+                ref = rng.uniform(-3, 3, size=(64, 12)) if mname == "PD" else rng.uniform(-0.5, 0.5, size=(64, 12))
+                inv = np.array([iface._transform_motor_command_to_action(x) for x in ref])
+                key = f"g1_{tag}_{mname}_{aname}"
+                out[key + "_a"], out[key + "_cmd"], out[key + "_ref"], out[key + "_inv"] = a, cmd, ref, inv
+                out[key + "_init_action"] = iface.get_init_action()
+                out[key + "_landing_action"] = iface.get_landing_action()
+                out[key + "_settle_cmd"] = iface._convert_reference_to_command(iface.get_init_pose())
+        # G4 PD torques, G5 spring torques
+        mm = QuadrupedMotorModel(robot_config=mod, enable_springs=springs, kp=mod.MOTOR_KP, kd=mod.MOTOR_KD,
+                                 torque_limits=mod.RL_TORQUE_LIMITS, motor_control_mode="PD")
+        q = rng.uniform(mod.REAL_LOWER_ANGLE_JOINT, mod.REAL_UPPER_ANGLE_JOINT, size=(128, 12))
+        qd = rng.uniform(-30, 30, size=(128, 12))
+        cmd = rng.uniform(mod.RL_LOWER_ANGLE_JOINT, mod.RL_UPPER_ANGLE_JOINT, size=(128, 12))
+        out[f"g4_{tag}_q"], out[f"g4_{tag}_qd"], out[f"g4_{tag}_cmd"] = q, qd, cmd
+        out[f"g4_{tag}_tau"] = np.array([mm.convert_to_torque(c, a, b)[0] for c, a, b in zip(cmd, q, qd)])
+        out[f"g4_{tag}_tau_torque_mode"] = np.array([mm.convert_to_torque(c * 20, a, b, "TORQUE")[0] for c, a, b in zip(cmd, q, qd)])
+        out[f"g4_{tag}_kp"], out[f"g4_{tag}_kd"] = np.array(mod.MOTOR_KP[:3], float), np.array(mod.MOTOR_KD[:3], float)
+        if springs:
+            qs = q.copy()
+            qs[:16] = np.array(mod.SPRINGS_REST_ANGLE * 4) + rng.uniform(-1e-3, 1e-3, size=(16, 12))  # around the gates
+            out["g5_q"], out["g5_qd"] = qs, qd
+            out["g5_tau"] = np.array([mm.compute_spring_torques(a, b) for a, b in zip(qs, qd)])
+            k2, b2 = [22.0, 18.5, 31.0], [0.33, 0.27, 0.31]
+            mm._setSpringStiffness(k2); mm._setSpringDumping(b2)
+            out["g5_k2"], out["g5_b2"] = np.array(k2), np.array(b2)
+            out["g5_tau2"] = np.array([mm.compute_spring_torques(a, b) for a, b in zip(qs, qd)])
+            out["g5_k"], out["g5_b"], out["g5_rest"] = (np.array(mod.SPRINGS_STIFFNESS, float), np.array(mod.SPRINGS_DAMPING, float),
+                                                        np.array(mod.SPRINGS_REST_ANGLE, float))
+        # G6 FK/J, G7 IK
+        qq = rng.uniform(mod.REAL_LOWER_ANGLE_JOINT, mod.REAL_UPPER_ANGLE_JOINT, size=(128, 12))
+        J = np.zeros((128, 4, 3, 3)); P = np.zeros((128, 4, 3))
+        for i, x in enumerate(qq):
+            for leg in range(4):
+                J[i, leg], P[i, leg] = robot._compute_jacobian_and_position(x, leg)
+        out[f"g6_{tag}_q"], out[f"g6_{tag}_J"], out[f"g6_{tag}_p"] = qq, J, P
+        xyz = rng.uniform([-0.3, -0.25, -0.45], [0.3, 0.25, -0.02], size=(128, 4, 3))
+        xyz[:8] *= 3.0  # out of reach -> clamps
+        out[f"g7_{tag}_xyz"] = xyz
+        out[f"g7_{tag}_q"] = np.array([[robot.ComputeInverseKinematics(leg, x[leg]) for leg in range(4)] for x in xyz])
+        # G10 sensor bundles
+        from quadruped_spring.env.sensors.sensor import SensorList
+        from quadruped_spring.env.sensors.sensor_collection import SensorCollection
+        for mode in SensorCollection()._dict:
+            sl = SensorList(list(SensorCollection().get_el(mode)), stub_env(mod))
+            sl._init(mod)
+            out[f"g10_{tag}_{mode}_high"] = sl._get_high_limits()
+            out[f"g10_{tag}_{mode}_low"] = sl._get_low_limits()
+            out[f"g10_{tag}_{mode}_std"] = np.concatenate([np.atleast_1d(np.asarray(s._noise_std, float)).flatten() for s in sl._sensor_list])
+            out[f"g10_{tag}_{mode}_names"] = np.array([s._name for s in sl._sensor_list])
+        out[f"g10_{tag}_fallen_height"] = np.array(mod.IS_FALLEN_HEIGHT)
+    # G3 Butterworth filter
+    for fs in (100, 250, 500):
+        f = ActionFilterButter(sampling_rate=fs, num_joints=6)
+        out[f"g3_{fs}_b"], out[f"g3_{fs}_a"] = f.b[0].copy(), f.a[0].copy()
+        f.reset()
+        x0 = rng.uniform(-1, 1, size=6)
+        f.init_history(x0)
+        xs = rng.uniform(-1, 1, size=(200, 6))
+        out[f"g3_{fs}_x0"], out[f"g3_{fs}_x"] = x0, xs
+        out[f"g3_{fs}_y"] = np.array([f.filter(x) for x in xs])
+    f = ActionFilterButter(sampling_rate=100, num_joints=1)
+    f.reset()
+    out["g3_step_response"] = np.array([f.filter(np.ones(1)) for _ in range(5)]).flatten()
+    # G12 euler / backflip pitch on a quaternion sweep (reference uses scipy + Bullet's getEulerFromQuaternion)
+    from scipy.spatial.transform import Rotation as R
+    from quadruped_spring.env.sensors.robot_sensors import PitchBackFlip
+    quats = np.concatenate([R.from_euler("y", np.linspace(-3.1, 3.1, 63)).as_quat(), R.random(96, random_state=1).as_quat()])
+    pbf = []
+    for sw in (False, True):
+        for qv in quats:
+            env = types.SimpleNamespace(robot=types.SimpleNamespace(GetBaseOrientation=lambda qv=qv: qv),
+                                        task=types.SimpleNamespace(_switched_controller=sw))
+            pbf.append(PitchBackFlip._get_pitch(env))
+    out["g12_quat"] = quats
+    out["g12_rpy_scipy_xyz"] = R.from_quat(quats).as_euler("xyz")
+    out["g12_pitch_backflip"] = np.array(pbf).reshape(2, -1)
+    out["g12_matrix"] = R.from_quat(quats).as_matrix()
+    np.savez_compressed(os.path.join(OUT, "stateless.npz"), **out)
+    print("stateless.npz:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------------------------- G9 rewards as pure functions
+def gen_rewards():
+    import importlib
+    from quadruped_spring.env.tasks import robot_tasks as rt
+    rng = np.random.default_rng(9)
+    out = {}
+    classes = {"JUMPING_IN_PLACE": rt.JumpingInPlace, "JUMPING_FORWARD": rt.JumpingForward,
+               "CONTINUOUS_JUMPING_FORWARD": rt.JumpingForwardContinuous, "CONTINUOUS_JUMPING_FORWARD2": rt.JumpingForwardContinuous2,
+               "JUMPING_IN_PLACE_PPO": rt.JumpingInPlacePPO, "JUMPING_FORWARD_PPO": rt.JumpingForwardPPO,
+               "JUMPING_IN_PLACE_PPO_HP": rt.JumpingInPlacePPOHP, "JUMPING_FORWARD_PPO_HP": rt.JumpingForwardPPOHP,
+               "BACKFLIP": rt.BackFlip}
+    mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs")
+    n = 96
+    for name, cls in classes.items():
+        rows, rew_step, rew_end, old_tau, new_tau = [], [], [], [], []
+        for i in range(n):
+            term = bool(i % 2)
+            env = types.SimpleNamespace()
+            env._robot_config = mod
+            env._MAX_EP_LEN = 10
+            sim_step = int(rng.integers(0, 10000))
+            env.get_sim_time = lambda s=sim_step: s * 0.001
+            env.get_ac_interface = lambda: None
+            ff = [float(rng.uniform(0, 600)), 0, 0, 0] if rng.uniform() < 0.5 else [float(rng.uniform(700, 1500)), 0, 0, 0]
+            env.robot = types.SimpleNamespace(GetContactInfo=lambda ff=ff: (0, 0, ff, [1, 0, 0, 0]))
+            t = cls(env)
+            t._terminated = lambda term=term: term
+            t._switched_controller = bool(rng.integers(0, 2))
+            t._relative_max_height = float(rng.uniform(0, 1.2)) if i % 3 else float(rng.uniform(0, 0.25))
+            t._max_pitch = float(rng.uniform(0, 0.6))
+            t._max_delta_x = float(rng.uniform(0, 0.5))
+            t._max_forward_distance = float(rng.uniform(0, 1.6))
+            t._max_flight_time = float(rng.uniform(0, 0.6))
+            t._max_height = float(rng.uniform(0.2, 1.0))
+            t._pos_abs = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.1, 0.1), rng.uniform(0.1, 1.3)])
+            t._orient_rpy = np.array([0.0, rng.uniform(-0.5, 0.5), 0.0])
+            t._old_torque, t._new_torque = rng.uniform(-30, 30, 12), rng.uniform(-30, 30, 12)
+            t.cumulative_fwd, t.cumulative_flight_time = float(rng.uniform(0, 2)), float(rng.uniform(0, 1))
+            t.old_fwd = float(rng.uniform(0, 1.5))
+            t.actual_fwd = t.old_fwd if i % 5 == 0 else float(rng.uniform(0, 1.5))
+            t.max_pitch = float(rng.uniform(0, 6.5))
+            row = np.zeros(32)
+            row[0] = t._switched_controller; row[9] = t._max_flight_time; row[10] = t._max_forward_distance
+            row[11] = t._max_pitch; row[12] = t._relative_max_height; row[13] = t._max_delta_x; row[14] = t._max_height
+            row[15] = t.cumulative_fwd; row[16] = t.cumulative_flight_time; row[17] = t.old_fwd; row[18] = t.actual_fwd
+            row[19] = t.max_pitch; row[20:23] = t._pos_abs; row[26:29] = t._orient_rpy
+            row[29] = 1 if term else 0; row[30] = sum(ff); row[31] = sim_step
+            if not term:
+                row[22] = max(row[22], 0.2)  # keep "not fallen" consistent with the forced _terminated()
+                t._pos_abs[2] = row[22]
+            rows.append(row); old_tau.append(t._old_torque); new_tau.append(t._new_torque)
+            rew_step.append(float(t._reward())); rew_end.append(float(t._reward_end_episode()))
+        out[f"g9_{name}_task"], out[f"g9_{name}_old_tau"], out[f"g9_{name}_new_tau"] = np.array(rows), np.array(old_tau), np.array(new_tau)
+        out[f"g9_{name}_rew_step"], out[f"g9_{name}_rew_end"] = np.array(rew_step), np.array(rew_end)
+    np.savez_compressed(os.path.join(OUT, "rewards.npz"), **out)
+    print("rewards.npz:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------------------------- G15 differential traces
+def scripted_actions(rng, n, d, jump_at):
+    """crouch, explosive extension, then smooth random actions: produces flight phases and landings."""
+    a = np.zeros((n, d))
+    for t in range(n):
+        ph = t % jump_at
+        if ph < jump_at * 0.5:
+            base = np.array([0.0, 0.9, -0.9])
+        elif ph < jump_at * 0.62:
+            base = np.array([0.0, -0.8, 1.0])
+        else:
+            base = np.array([0.0, 0.1, 0.2])
+        full = np.tile(base, d // 3) if d % 3 == 0 else np.tile(base[1:], d // 2)
+        a[t] = full + 0.15 * rng.standard_normal(d)
+    return a
+
+
+def gen_traces():
+    import importlib
+    from qs_amd.config import build_config
+    from oracle.qso import Oracle
+    from quadruped_spring.env.quadruped_gym_env import QuadrupedGymEnv
+
+    cases = [
+        dict(name="jip_s1", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=260, jump_at=90),
+        dict(name="jip_s0", task_env="JUMPING_IN_PLACE", observation_space_mode="ARS_BASIC", enable_springs=False,
+             enable_action_filter=False, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=70),
+        dict(name="jf_s1", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT", enable_springs=True,
+             enable_action_filter=True, action_space_mode="DEFAULT", motor_control_mode="PD", steps=220, jump_at=80),
+        dict(name="cjf_s1", task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+             enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=260, jump_at=60),
+        dict(name="cjf2_s1", task_env="CONTINUOUS_JUMPING_FORWARD2", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+             enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC_NO_HIP", motor_control_mode="PD", steps=200, jump_at=60),
+        dict(name="jipppo_s1", task_env="JUMPING_IN_PLACE_PPO", observation_space_mode="PPO_BASIC_X", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="jfppo_s1", task_env="JUMPING_FORWARD_PPO", observation_space_mode="LANDING_SENSOR", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="bf_s1", task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="cart_s1", task_env="JUMPING_IN_PLACE", observation_space_mode="CARTESIAN_NO_IMU", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="CARTESIAN_PD", steps=150, jump_at=70),
+    ]
+    out = {}
+    for case in cases:
+        name = case["name"]
+        kw = {k: v for k, v in case.items() if k not in ("name", "steps", "jump_at")}
+        mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs" if kw["enable_springs"]
+                                      else "quadruped_spring.go1.configs_go1_without_springs")
+        saved = {}
+        for attr in dir(mod):  # deterministic traces: switch the i.i.d. sensor noise off in the reference's config
+            if attr.endswith("_NOISE"):
+                saved[attr] = getattr(mod, attr)
+                setattr(mod, attr, np.zeros_like(np.asarray(saved[attr], float)))
+        saved_upper = mod.RL_UPPER_ANGLE_JOINT.copy()
+
+        def factory(dt, iters, kw=kw):
+            cfg, _ = build_config(n_envs=1, time_step=dt, noise=False, env_randomizer_mode="NONE", **kw)
+            cfg.solver_iters = iters
+            cfg.randomizer_flags = 8
+            return Oracle(cfg)
+
+        FakeBulletClient.oracle_factory = factory
+        np.random.seed(1234)
+        rng = np.random.default_rng(5)
+        env = QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", **kw)
+        client = env._pybullet_client
+        d = env.action_dim
+        acts = scripted_actions(rng, case["steps"], d, case["jump_at"])
+        keys = None
+        obs_l, rew_l, done_l, trunc_l, reset_obs, reset_at, mu_at_reset, state_l = [], [], [], [], [], [], [], []
+        o = env.reset()
+        keys = list(o.keys())
+        flat = lambda ob: np.concatenate([np.atleast_1d(np.asarray(ob[k], float)).flatten() for k in keys])
+        reset_obs.append(flat(o)); reset_at.append(0); mu_at_reset.append(client.mu)
+        for t in range(case["steps"]):
+            ob, r, dn, info = env.step(acts[t])
+            obs_l.append(flat(ob)); rew_l.append(r); done_l.append(dn)
+            trunc_l.append(bool(info.get("TimeLimit.truncated", False)))
+            state_l.append(client.o.get_state()[0].copy())
+            if dn:
+                o = env.reset()
+                client = env._pybullet_client
+                reset_obs.append(flat(o)); reset_at.append(t + 1); mu_at_reset.append(client.mu)
+        out[f"{name}_actions"], out[f"{name}_obs"], out[f"{name}_rew"] = acts, np.array(obs_l), np.array(rew_l, float)
+        out[f"{name}_done"], out[f"{name}_trunc"] = np.array(done_l), np.array(trunc_l)
+        out[f"{name}_reset_obs"], out[f"{name}_reset_at"], out[f"{name}_mu"] = np.array(reset_obs), np.array(reset_at), np.array(mu_at_reset)
+        out[f"{name}_state"] = np.array(state_l)
+        out[f"{name}_keys"] = np.array(keys)
+        out[f"{name}_kwargs"] = np.array(repr(kw))
+        out[f"{name}_landing_action"] = np.asarray(env.get_landing_action(), float)
+        print(f"trace {name}: steps={case['steps']} episodes={len(reset_at)} dones={int(np.sum(done_l))} obs_dim={len(obs_l[0])} "
+              f"max_h={np.max(np.array(state_l)[:, 2]):.3f}")
+        for attr, v in saved.items():
+            setattr(mod, attr, v)
+        mod.RL_UPPER_ANGLE_JOINT[:] = saved_upper
+    np.savez_compressed(os.path.join(OUT, "traces.npz"), **out)
+    print("traces.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    install_shims()
+    logging.disable(logging.CRITICAL)
+    gen_stateless()
+    gen_rewards()
+    gen_traces()
