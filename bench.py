@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the batched Go1 + PEA step (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one QuadrupedGymEnv.step() of every environment (10 physics substeps x 30 solver sweeps + task / reward /
+observation epilogue) with actions already resident in HBM.  Environments shard over ranks with no data-path collective
+(weak scaling: 8192 environments per GPU); the only collective is the max-over-ranks of the elapsed time."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "quadruped-springs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+ALGO_BYTES_PER_ENV_STEP = 1112  # SURVEY.md 8(d), d = 6, o = 28
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def workload(name):
+    base = dict(enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD")
+    if name == "jump_in_place_8192":   # the configuration BASELINE.json's metric is quoted on
+        return 8192, dict(base, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="GROUND_RANDOMIZER",
+                          time_step=0.001, action_repeat=10)
+    if name == "config2_4096":         # BASELINE.json configs[1]: dt = 1/500 s, flat ground
+        return 4096, dict(base, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="NONE",
+                          time_step=0.002, action_repeat=5)
+    if name == "config3_8192":         # configs[2]
+        return 8192, dict(base, task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+                          env_randomizer_mode="SPRING_RANDOMIZER", time_step=0.001, action_repeat=10)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(cfg_kwargs, budget_s=12.0):
+    """The oracle (CPU restatement, float64, scalar C, one thread) timed on this box's host cores on a bounded sample."""
+    import numpy as np
+    from oracle.qso import Oracle
+    from qs_amd.config import build_config
+    n = 8
+    cfg, _ = build_config(n_envs=n, auto_reset=True, seed=1234, **cfg_kwargs)
+    o = Oracle(cfg)
+    o.reset()
+    rng = np.random.default_rng(0)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(20):
+            o.step(rng.uniform(-1, 1, size=(n, cfg.action_dim)).astype(np.float32))
+        steps += 20
+    dt = time.perf_counter() - t0
+    return dict(value=n * steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample=f"{n} envs x {steps} env-steps of the same workload on 1 host thread, auto-reset incl. 2500-substep settles ({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="jump_in_place_8192")
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--reset-pool", type=int, default=4096, help="pre-settled reset states per GPU (0 = settle inside the step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the simulation step has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from qs_amd.vec_env import QuadrupedVecEnv
+    n_default, kw = workload(args.workload)
+    n = args.envs_per_gpu or n_default
+    env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, seed=1234 + 7919 * rank, **kw)
+    env.reset_tensor()
+    d = env.action_dim
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_act = 64  # a ring of pre-generated U(-1,1) action batches, resident in HBM
+    acts = torch.rand((n_act, n, d), generator=gen, device=dev) * 2 - 1
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        env.step_tensor(acts[i % n_act])
+    stats0 = env.stats()
+    env.enable_timing(True)
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step_tensor(acts[i % n_act])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-launch duration of the step kernel from HIP events on the kernel's own stream (separate short loop so that
+    # the event synchronisation does not sit inside the timed region)
+    for i in range(min(args.steps, 50)):
+        env.step_tensor(acts[i % n_act])
+        kernel_ms.append(env.last_step_kernel_ms())
+    env.enable_timing(False)
+    stats1 = env.stats()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_steps = n * world * args.steps
+    if rank == 0:
+        kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
+        achieved = n * ALGO_BYTES_PER_ENV_STEP / kavg / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), Go1+PEA jump-in-place, N=8192 envs",
+            "value": total_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
+                       "solver_sweeps": int(300 / kw["action_repeat"]), "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
+                       "auto_reset": True, "reset": (f"pre-settled pool of {args.reset_pool} states per GPU" if args.reset_pool else "2500-substep settle inside the step"),
+                       "resets_in_timed_region": int((stats1["resets"] - stats0["resets"]) * args.steps / (args.steps + min(args.steps, 50))),
+                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_step", "kernel_ms": kavg * 1e3,
+                         "note": "1112 algorithmic bytes per env-step (SURVEY 8d); the step is ~0.6 MFLOP of dependent fp32 work per env-step, latency-bound, not HBM-bound"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kw)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/*
+ * qs_amd.h -- C ABI of the MI355X-native batched Go1 + PEA simulation step.
+ *
+ * This is the drop-in boundary for the hot path of francescovezzi/quadruped-springs.  The reference has no FFI:
+ * the path sits behind the Python class QuadrupedGymEnv, so every entry point names the Python-level interface
+ * it replaces (paths relative to the reference's quadruped_spring/ package):
+ *
+ *   qs_create      QuadrupedGymEnv.__init__                      env/quadruped_gym_env.py:52-155
+ *   qs_reset       QuadrupedGymEnv.reset (+ randomizers, settle)  env/quadruped_gym_env.py:278-329,
+ *                                                                 env/env_randomizers/env_randomizer.py:19-122,279-291
+ *   qs_step        QuadrupedGymEnv.step for N environments        env/quadruped_gym_env.py:227-256
+ *                  (filter, action map, ApplyAction = PD + PEA,   utils/action_filter.py:110-121,
+ *                   stepSimulation x action_repeat, task,          env/quadruped.py:288-320, env/quadruped_motor.py:45-104,
+ *                   reward, termination, sensors)                  env/springs.py:28-74, env/tasks/, env/sensors/
+ *   qs_get_obs     QuadrupedGymEnv.get_observation                env/quadruped_gym_env.py:343-345
+ *   qs_get_state / qs_set_state    Quadruped state getters / reset_desired_state   env/quadruped.py:107-207, 521-525
+ *   qs_get_info    GetContactInfo, GetMotorTorques, task scalars  env/quadruped.py:209-258, env/tasks/task_base.py:44-59
+ *   qs_set_params  set_spring_stiffness/damping, changeDynamics(lateralFriction), kp/kd swaps of the landing wrappers
+ *                                                                 env/quadruped.py:732-742, env/wrappers/landing_wrapper.py:22-30
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all array arguments are DEVICE pointers (HIP) owned by the caller, row-major,
+ *     float32 unless stated; the handle owns the persistent per-environment records.
+ *   - returns 0 on success, a negative code on failure with text in qs_last_error(); never throws.
+ *   - a handle is driven by one host thread; work is enqueued on the stream given to qs_set_stream (default: the
+ *     null stream) and is asynchronous with respect to the host.  Handles are independent (one per GPU rank).
+ *   - there is no CPU fallback: qs_create fails if no HIP device is usable.
+ */
+#ifndef QS_AMD_H
+#define QS_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { QS_ACT_DEFAULT = 0, QS_ACT_SYMMETRIC = 1, QS_ACT_SYMMETRIC_NO_HIP = 2 };  /* control_interface/collection.py:49 */
+enum { QS_MOTOR_PD = 0, QS_MOTOR_CARTESIAN_PD = 1, QS_MOTOR_TORQUE = 2 };       /* control_interface/collection.py:33 */
+enum {                                                                          /* tasks/task_collection.py:19-37 */
+    QS_TASK_NO_TASK = 0, QS_TASK_JUMPING_IN_PLACE = 1, QS_TASK_JUMPING_FORWARD = 2,
+    QS_TASK_CONT_JUMPING_FORWARD = 3, QS_TASK_CONT_JUMPING_FORWARD2 = 4,
+    QS_TASK_JUMPING_IN_PLACE_PPO = 5, QS_TASK_JUMPING_FORWARD_PPO = 6, QS_TASK_BACKFLIP = 7,
+    QS_TASK_JUMPING_IN_PLACE_PPO_HP = 8, QS_TASK_JUMPING_FORWARD_PPO_HP = 9,
+};
+enum {                                                                          /* sensors/robot_sensors.py */
+    QS_SENS_JOINT_POS = 0, QS_SENS_JOINT_VEL = 1, QS_SENS_PITCH = 2, QS_SENS_HEIGHT = 3, QS_SENS_VEL_Z = 4,
+    QS_SENS_LANDING = 5, QS_SENS_JUMPING = 6, QS_SENS_PITCH_RATE = 7, QS_SENS_VEL_X = 8, QS_SENS_BOOL_CONTACT = 9,
+    QS_SENS_LIN_VEL = 10, QS_SENS_ANG_VEL = 11, QS_SENS_FEET_POS = 12, QS_SENS_FEET_VEL = 13,
+    QS_SENS_PITCH_BACKFLIP = 14, QS_SENS_RPY = 15, QS_SENS_QUAT = 16,
+};
+#define QS_RAND_GROUND 1   /* env_randomizer.py:279-291 */
+#define QS_RAND_MASSES 2   /* env_randomizer.py:19-83 */
+#define QS_RAND_SPRINGS 4  /* env_randomizer.py:86-122 */
+#define QS_RAND_KEEP 8     /* reset keeps the parameters last written by qs_set_params */
+
+#define QS_MAX_SENSORS 16
+#define QS_MAX_OBS 64
+#define QS_STATE_DIM 37    /* pos3 quat4(xyzw) vlin3 vang3 q12 qd12 */
+#define QS_PARAM_DIM 24    /* mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_payload, r_payload3 */
+#define QS_TASK_DIM 32
+
+/* Keyword arguments of QuadrupedGymEnv.__init__ (gym_env.py:52-70) resolved to numbers by the host
+ * (quadruped-springs_amd/qs_amd/config.py); constants come from go1/configs_go1_*.py. */
+typedef struct qs_config {
+    int32_t n_envs;
+    int32_t action_dim;          /* 12 / 6 / 4 (action_interface.py:12,27,56) */
+    int32_t action_space_mode;
+    int32_t motor_control_mode;
+    int32_t symm_idx;            /* motor_interface.py:15,56 */
+    int32_t rl_interface;        /* isRLGymInterface */
+    int32_t task;
+    int32_t n_sensors;
+    int32_t sensors[QS_MAX_SENSORS];
+    int32_t obs_dim;
+    int32_t enable_springs;
+    int32_t enable_filter;
+    int32_t enable_interp;
+    int32_t action_repeat;
+    int32_t solver_iters;        /* int(300 / action_repeat), gym_env.py:113 */
+    int32_t settle_steps;        /* 2500, gym_env.py:115 */
+    int32_t max_sim_steps;       /* truncation when sim_step_counter > max_sim_steps (sim time > 10 s, gym_env.py:245) */
+    int32_t randomizer_flags;
+    int32_t noise_enabled;
+    int32_t auto_reset;          /* SB3 VecEnv convention: finished environments are reset inside qs_step */
+    int32_t reset_pool;          /* 0: every reset runs the 2500-substep settle; P > 0: resets draw from P pre-settled states */
+    int32_t reserved_i[2];
+    uint64_t seed;
+    double dt;
+    double filt_b[3], filt_a[3]; /* scipy.signal.butter(2, 3 Hz) at 1/env_dt, action_filter.py:191-213 */
+    float gravity;
+    float kp[3], kd[3], tau_max[3];
+    float cmd_lo[12], cmd_hi[12];
+    float settle_cmd[12];
+    float settle_action[12];
+    float spring_k[3], spring_b[3], spring_rest[3];
+    float fallen_height;
+    float leg_len[3];
+    float contact_erp, joint_erp, warmstart, vel_cap;
+    float obs_noise_std[QS_MAX_OBS];
+    float task_p[16];
+    float reserved_f[8];
+} qs_config;
+
+typedef struct qs_handle qs_handle;
+
+int qs_create(const qs_config* cfg, int device, qs_handle** out);
+void qs_destroy(qs_handle* h);
+int qs_set_stream(qs_handle* h, void* hip_stream);
+/* mask: device pointer to n_envs bytes, or NULL for all environments */
+int qs_reset(qs_handle* h, const uint8_t* mask);
+int qs_get_obs(qs_handle* h, float* obs /*[N,obs_dim]*/);
+int qs_step(qs_handle* h, const float* actions /*[N,action_dim]*/, float* obs /*[N,obs_dim]*/, float* rew /*[N]*/,
+            uint8_t* done /*[N]*/, uint8_t* truncated /*[N]*/);
+int qs_get_state(qs_handle* h, float* state /*[N,37]*/);
+int qs_set_state(qs_handle* h, const float* state /*[N,37]*/);
+enum {
+    QS_INFO_FOOT_FORCE = 0, QS_INFO_FOOT_CONTACT = 1, QS_INFO_TORQUE = 2, QS_INFO_SPRING_TORQUE = 3, QS_INFO_TASK = 4,
+    QS_INFO_N_INVALID = 5, QS_INFO_PARAMS = 6, QS_INFO_COUNTERS = 7, QS_INFO_LAST_ACTION = 8, QS_INFO_TERMINAL_OBS = 9,
+};
+int qs_info_dim(const qs_handle* h, int which);
+int qs_get_info(qs_handle* h, int which, float* out /*[N, qs_info_dim]*/);
+enum { QS_PARAM_MU = 0, QS_PARAM_SPRING_K = 1, QS_PARAM_SPRING_B = 2, QS_PARAM_KP = 3, QS_PARAM_KD = 4, QS_PARAM_ALL = 5 };
+int qs_set_params(qs_handle* h, int which, const float* vals);
+/* number of env-steps' worth of settle substeps executed so far (reset cost accounting) */
+int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets);
+/* HIP events bracketing the step kernel of the most recent qs_step (on the handle's stream): elapsed milliseconds, for
+ * bench.py's roofline leg.  Recording is off by default (qs_enable_timing). */
+int qs_enable_timing(qs_handle* h, int on);
+int qs_last_step_kernel_ms(qs_handle* h, float* ms);
+/* redraw the pool of pre-settled reset states (cfg.reset_pool > 0): new parameter draws, 2500 settle substeps each */
+int qs_refresh_pool(qs_handle* h);
+const char* qs_last_error(void);
+const char* qs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

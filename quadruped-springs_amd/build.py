@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Build the gfx950 shared library of the batched simulation step (hipcc cross-compiles without a GPU).
+
+    python quadruped-springs_amd/build.py            # -> quadruped-springs_amd/qs_amd/libqs_hip.so
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "qs_hip.hip")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h")] + \
+       [os.path.join(REPO, "include", "qs_amd.h")]
+OUT = os.path.join(HERE, "qs_amd", "libqs_hip.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I" + os.path.join(REPO, "include"), "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

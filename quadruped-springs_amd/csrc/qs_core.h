@@ -1,0 +1,615 @@
+// qs_core.h -- the batched Go1 + PEA simulation step, written once against the lane abstraction of qs_lane.h.
+//
+// What the reference obtains from 49 PyBullet C-API calls per 1 ms substep (quadruped.py:288-320 + stepSimulation,
+// gym_env.py:207-225) is one call of Sim<T>::substep here; one QuadrupedGymEnv.step() (gym_env.py:227-256) is
+// Env<T>::step.  Formulation (MI355X-first, not Bullet's):
+//   * one lane per leg, everything expressed in BASE-frame coordinates, so composite inertias are plain sums and the
+//     only cross-lane traffic is 4-lane sums (DPP): the floating-base mass matrix has the arrow structure
+//         H = [ Hbb  B1 B2 B3 B4 ]      Hbb 6x6 (replicated), B_L 6x3 and D_L 3x3 private to leg L
+//             [ B_L^T     D_L    ]
+//     and is eliminated leg-locally:  S = Hbb - sum_L B_L D_L^-1 B_L^T  (one 21-value quad sum), S = L L^T.
+//   * forward dynamics = CRBA + RNEA + that block solve (mathematically the ABA the oracle uses; tests compare them)
+//   * contact: foot sphere vs plane, rows (normal, t1, t2) per foot; Delassus columns A[:, own rows] stay in registers;
+//     projected Gauss-Seidel in impulse space in Bullet's row order (limits, normals, frictions), `solver_iters` sweeps
+//   * semi-implicit Euler, quaternion exponential map.
+// Numerical contract: float32; compared with oracle/ (float64 ABA) in tests/ within the tolerances stated there.
+#pragma once
+#include "qs_lane.h"
+#include "qs_layout.h"
+#include "../../include/qs_amd.h"
+
+namespace qs {
+
+// ------------------------------------------------------------------ Go1 model constants (go1.urdf)
+namespace go1 {
+constexpr float HIP_X = 0.1881f, HIP_Y = 0.04675f, THIGH_Y = 0.08f, LEG_Z = -0.213f, FOOT_R = 0.02f;
+constexpr float BASE_M = 0.00001f, BASE_I = 1e-5f;                                        // :55-59
+constexpr float TRUNK_M = 5.204f, TRUNK_CX = 0.0223f, TRUNK_CZ = -0.0005f;                // :80-85
+constexpr float TRUNK_I[6] = {0.0168352186f, 0.0004636141f, 0.0002367952f, 0.0656071082f, 3.6671e-05f, 0.0742720659f};
+constexpr float IMU_M = 0.001f, IMU_I = 0.0001f, IMU_X = -0.01592f, IMU_Y = -0.06659f, IMU_Z = -0.00617f;  // :87-97
+constexpr float HIP_M = 0.591f, HIP_C[3] = {0.00541f, 0.00074f, 6e-06f};                   // :134-136 and mirrors
+constexpr float HIP_I[6] = {0.000374268192f, 3.6844422e-05f, 9.86754e-07f, 0.000635923669f, 1.172894e-06f, 0.000457647394f};
+constexpr float THIGH_M = 0.92f, THIGH_C[3] = {-0.003468f, 0.018947f, -0.032736f};         // :186-188
+constexpr float THIGH_I[6] = {0.005851561134f, 1.783284e-06f, 0.000328291374f, 0.005596155105f, 2.1430713e-05f, 0.00107157026f};
+constexpr float CALF_M = 0.131f, CALF_C[3] = {0.006286f, 0.001307f, -0.122269f};           // :212-216
+constexpr float CALF_I[6] = {0.002939186297f, 1.440899e-06f, -0.00010535955f, 0.00295576935f, -2.4397752e-05f, 3.0273372e-05f};
+constexpr float FOOT_M = 0.06f, FOOT_I = 9.6e-06f;                                         // :237-240
+constexpr float JLO[3] = {-1.0471975512f, -0.663225115758f, -2.72271363311f};              // :117 :169 :196
+constexpr float JHI[3] = {1.0471975512f, 2.96705972839f, -0.837758040957f};
+// contact breaking thresholds = 0.02 x angular-motion-disc of each link's collision compound (DESIGN.md "contact model")
+constexpr float THR_FOOT = 0.000727f, THR_TRUNK = 0.00407f, THR_HIP = 0.00139f, THR_THIGH = 0.00433f, THR_CALF = 0.00429f;
+constexpr float TRUNK_HALF[3] = {0.1881f, 0.04675f, 0.057f};                               // box :74-79
+constexpr float HIP_CYL_HALF_LEN = 0.02f, HIP_CYL_R = 0.046f;                              // cylinder :128-131
+constexpr float LINK_BOX_Z = -0.1065f, THIGH_HALF[3] = {0.017f, 0.01225f, 0.1065f}, CALF_HALF[3] = {0.008f, 0.008f, 0.1065f};
+constexpr float PAYLOAD_I = 0.1f * 0.1f / 6.0f;                                            // cube of half extent 0.05, quadruped.py:793
+}  // namespace go1
+
+// ------------------------------------------------------------------ small linear algebra on lane values
+template <class V> struct V3 { V x, y, z; };
+template <class V> QS_FN V3<V> mk3(V x, V y, V z) { V3<V> r; r.x = x; r.y = y; r.z = z; return r; }
+template <class V> QS_FN V3<V> operator+(V3<V> a, V3<V> b) { return mk3<V>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class V> QS_FN V3<V> operator-(V3<V> a, V3<V> b) { return mk3<V>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class V> QS_FN V3<V> operator*(V3<V> a, V s) { return mk3<V>(a.x * s, a.y * s, a.z * s); }
+template <class V> QS_FN V dot(V3<V> a, V3<V> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class V> QS_FN V3<V> cross(V3<V> a, V3<V> b) { return mk3<V>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <class V> struct S3 { V xx, xy, xz, yy, yz, zz; };
+template <class V> QS_FN V3<V> mul(S3<V> I, V3<V> w) {
+    return mk3<V>(I.xx * w.x + I.xy * w.y + I.xz * w.z, I.xy * w.x + I.yy * w.y + I.yz * w.z, I.xz * w.x + I.yz * w.y + I.zz * w.z);
+}
+template <class V> struct Sp { V3<V> a, l; };  // spatial vector: (angular; linear) for motion, (moment; force) for force
+template <class V> QS_FN Sp<V> operator+(Sp<V> p, Sp<V> q) { Sp<V> r; r.a = p.a + q.a; r.l = p.l + q.l; return r; }
+template <class V> QS_FN V dot(Sp<V> p, Sp<V> q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+template <class V> QS_FN Sp<V> crm(Sp<V> v, Sp<V> u) { Sp<V> r; r.a = cross(v.a, u.a); r.l = cross(v.a, u.l) + cross(v.l, u.a); return r; }
+template <class V> QS_FN Sp<V> crf(Sp<V> v, Sp<V> f) { Sp<V> r; r.a = cross(v.a, f.a) + cross(v.l, f.l); r.l = cross(v.a, f.l); return r; }
+// spatial inertia about the base origin, base coordinates
+template <class V> struct SI { V m; V3<V> h; S3<V> I; };
+template <class V> QS_FN SI<V> operator+(SI<V> p, SI<V> q) {
+    SI<V> r; r.m = p.m + q.m; r.h = p.h + q.h;
+    r.I.xx = p.I.xx + q.I.xx; r.I.xy = p.I.xy + q.I.xy; r.I.xz = p.I.xz + q.I.xz; r.I.yy = p.I.yy + q.I.yy; r.I.yz = p.I.yz + q.I.yz; r.I.zz = p.I.zz + q.I.zz;
+    return r;
+}
+template <class V> QS_FN Sp<V> apply(SI<V> I, Sp<V> v) { Sp<V> f; f.a = mul(I.I, v.a) + cross(I.h, v.l); f.l = v.l * I.m - cross(I.h, v.a); return f; }
+// rigid part with mass m, COM cl and inertia Il (6 unique, about the COM) given in a link frame whose origin is p and whose
+// axes are X, Y, Z (all in base coordinates)
+template <class V> QS_FN SI<V> part_inertia(V m, V3<V> cl, S3<V> Il, V3<V> p, V3<V> X, V3<V> Y, V3<V> Z) {
+    V3<V> c = p + X * cl.x + Y * cl.y + Z * cl.z;
+    V3<V> Tx = X * Il.xx + Y * Il.xy + Z * Il.xz;
+    V3<V> Ty = X * Il.xy + Y * Il.yy + Z * Il.yz;
+    V3<V> Tz = X * Il.xz + Y * Il.yz + Z * Il.zz;
+    SI<V> r; r.m = m; r.h = c * m;
+    V cc = dot(c, c);
+    r.I.xx = Tx.x * X.x + Ty.x * Y.x + Tz.x * Z.x + m * (cc - c.x * c.x);
+    r.I.xy = Tx.x * X.y + Ty.x * Y.y + Tz.x * Z.y - m * c.x * c.y;
+    r.I.xz = Tx.x * X.z + Ty.x * Y.z + Tz.x * Z.z - m * c.x * c.z;
+    r.I.yy = Tx.y * X.y + Ty.y * Y.y + Tz.y * Z.y + m * (cc - c.y * c.y);
+    r.I.yz = Tx.y * X.z + Ty.y * Y.z + Tz.y * Z.z - m * c.y * c.z;
+    r.I.zz = Tx.z * X.z + Ty.z * Y.z + Tz.z * Z.z + m * (cc - c.z * c.z);
+    return r;
+}
+template <class V> QS_FN SI<V> point_inertia(V m, V iso, V3<V> c) {  // isotropic inertia `iso` about its COM c
+    SI<V> r; r.m = m; r.h = c * m;
+    V cc = dot(c, c);
+    r.I.xx = iso + m * (cc - c.x * c.x); r.I.xy = -(m * c.x * c.y); r.I.xz = -(m * c.x * c.z);
+    r.I.yy = iso + m * (cc - c.y * c.y); r.I.yz = -(m * c.y * c.z); r.I.zz = iso + m * (cc - c.z * c.z);
+    return r;
+}
+// symmetric 6x6 in packed lower-triangular storage, idx(i,j) = i(i+1)/2 + j for j <= i
+QS_FN constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+template <class V> QS_FN void chol6(V* s) {  // in place: s <- L with S = L L^T
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        V d = s[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) d = d - s[tri(j, k)] * s[tri(j, k)];
+        d = qsqrt(d);
+        s[tri(j, j)] = d;
+        V inv = V(1.0f) / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            V t = s[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) t = t - s[tri(i, k)] * s[tri(j, k)];
+            s[tri(i, j)] = t * inv;
+        }
+    }
+}
+template <class V> QS_FN void lsolve6(const V* L, const V* dinv, V* b) {  // b <- L^-1 b   (dinv[i] = 1/L_ii)
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        V t = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t = t - L[tri(i, k)] * b[k];
+        b[i] = t * dinv[i];
+    }
+}
+template <class V> QS_FN void ltsolve6(const V* L, const V* dinv, V* b) {  // b <- L^-T b
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        V t = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) t = t - L[tri(k, i)] * b[k];
+        b[i] = t * dinv[i];
+    }
+}
+template <class V> QS_FN V clampv(V x, V lo, V hi) { return qmin(qmax(x, lo), hi); }
+
+// ------------------------------------------------------------------ Philox4x32-10 (same stream definition as oracle/qso_env.c)
+QS_FN void philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+QS_FN float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+QS_FN void normal4_scalar(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr, uint32_t blk, float z[4]) {
+    uint32_t r[4]; philox4x32(seed, env, stream, ctr, blk, r);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        float u1 = u01(r[2 * h]), u2 = u01(r[2 * h + 1]);
+        float rad = sqrtf(-2.0f * logf(u1)), th = 6.283185307179586f * u2;
+        z[2 * h] = rad * cosf(th); z[2 * h + 1] = rad * sinf(th);
+    }
+}
+template <class T> struct Rng;
+#if defined(__HIPCC__)
+template <> struct Rng<LaneDev> {  // lane `leg` draws block blk0 + leg
+    static QS_DEV void normal4(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr, uint32_t blk0, float z[4]) {
+        normal4_scalar(seed, env, stream, ctr, blk0 + (uint32_t)(threadIdx.x & 3u), z);
+    }
+};
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+template <> struct Rng<LaneEmu> {
+    static void normal4(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr, uint32_t blk0, V4 z[4]) {
+        for (int l = 0; l < 4; l++) { float t[4]; normal4_scalar(seed, env, stream, ctr, blk0 + l, t); for (int k = 0; k < 4; k++) z[k].v[l] = t[k]; }
+    }
+};
+#endif
+
+// ------------------------------------------------------------------ rigid-body substep
+template <class T> struct Sim {
+    using V = typename T::V;
+    using M = typename T::M;
+    using V3v = V3<V>;
+    using Spv = Sp<V>;
+
+    struct State {          // registers carried through the substeps of one env step
+        V3v pos; V qx, qy, qz, qw; V3v vlin, vang;  // replicated over the quad
+        V q[3], qd[3];                              // own leg
+        V warm;                                     // own foot
+    };
+    struct Par {            // per-environment parameters (replicated) + own-leg model constants
+        V mu, k[3], b[3], rest[3], kp[3], kd[3];
+        SI<V> I0;                                   // base + trunk + imu (+ payload) about the base origin
+        V m_hip, m_thigh, m_calf;
+        V3v c_hip, c_thigh; S3<V> I_hip, I_thigh, I_calf;
+        V mtot;
+    };
+    struct Out {            // results of the last substep
+        V tau_pd[3], tau_spring[3], foot_force, foot_contact, n_invalid;
+    };
+
+    // per-env model from the randomizable masses (env_randomizer.py:56-83); link inertias scale with link mass
+    static QS_FN void build_par(Par& P, V m_trunk, const V* m_leg, V m_pay, V3v r_pay) {
+        using namespace go1;
+        V fx = T::fx(), sy = T::sy();
+        V st = m_trunk * (1.0f / TRUNK_M);
+        SI<V> I0 = point_inertia<V>(V(BASE_M), V(BASE_I), mk3<V>(V(0.0f), V(0.0f), V(0.0f)));
+        S3<V> It; It.xx = st * TRUNK_I[0]; It.xy = st * TRUNK_I[1]; It.xz = st * TRUNK_I[2]; It.yy = st * TRUNK_I[3]; It.yz = st * TRUNK_I[4]; It.zz = st * TRUNK_I[5];
+        V3v ex = mk3<V>(V(1.0f), V(0.0f), V(0.0f)), ey = mk3<V>(V(0.0f), V(1.0f), V(0.0f)), ez = mk3<V>(V(0.0f), V(0.0f), V(1.0f));
+        V3v zero = mk3<V>(V(0.0f), V(0.0f), V(0.0f));
+        I0 = I0 + part_inertia<V>(m_trunk, mk3<V>(V(TRUNK_CX), V(0.0f), V(TRUNK_CZ)), It, zero, ex, ey, ez);
+        I0 = I0 + point_inertia<V>(V(IMU_M), V(IMU_I), mk3<V>(V(IMU_X), V(IMU_Y), V(IMU_Z)));
+        I0 = I0 + point_inertia<V>(m_pay, m_pay * PAYLOAD_I, r_pay);
+        P.I0 = I0;
+        V s1 = m_leg[0] * (1.0f / HIP_M), s2 = m_leg[1] * (1.0f / THIGH_M), s3 = m_leg[2] * (1.0f / CALF_M);
+        P.m_hip = m_leg[0]; P.m_thigh = m_leg[1]; P.m_calf = m_leg[2];
+        P.c_hip = mk3<V>(fx * (-HIP_C[0]), sy * (-HIP_C[1]), V(HIP_C[2]));
+        P.I_hip.xx = s1 * HIP_I[0]; P.I_hip.xy = s1 * (fx * sy) * HIP_I[1]; P.I_hip.xz = s1 * fx * (-HIP_I[2]);
+        P.I_hip.yy = s1 * HIP_I[3]; P.I_hip.yz = s1 * sy * (-HIP_I[4]); P.I_hip.zz = s1 * HIP_I[5];
+        P.c_thigh = mk3<V>(V(THIGH_C[0]), sy * (-THIGH_C[1]), V(THIGH_C[2]));
+        P.I_thigh.xx = s2 * THIGH_I[0]; P.I_thigh.xy = s2 * sy * THIGH_I[1]; P.I_thigh.xz = s2 * THIGH_I[2];
+        P.I_thigh.yy = s2 * THIGH_I[3]; P.I_thigh.yz = s2 * sy * THIGH_I[4]; P.I_thigh.zz = s2 * THIGH_I[5];
+        P.I_calf.xx = s3 * CALF_I[0]; P.I_calf.xy = s3 * CALF_I[1]; P.I_calf.xz = s3 * CALF_I[2];
+        P.I_calf.yy = s3 * CALF_I[3]; P.I_calf.yz = s3 * CALF_I[4]; P.I_calf.zz = s3 * CALF_I[5];
+        P.mtot = I0.m + 4.0f * (m_leg[0] + m_leg[1] + m_leg[2] + FOOT_M);
+    }
+
+    // PD law + torque clip (quadruped_motor.py:45-99) and unilateral PEA (quadruped_motor.py:101-104, springs.py:34-74)
+    static QS_FN void actuate(const qs_config& cfg, const Par& P, const State& s, const V* cmd, Out& o, V* tau) {
+        V sy = T::sy();
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            V lim = V(cfg.tau_max[j]);
+            V t = cfg.motor_control_mode == QS_MOTOR_TORQUE ? cmd[j] : (V(0.0f) - (P.kp[j] * (s.q[j] - cmd[j])) - P.kd[j] * s.qd[j]);
+            o.tau_pd[j] = clampv<V>(t, V(0.0f) - lim, lim);
+            V ts = V(0.0f);
+            if (cfg.enable_springs) {
+                V dq = s.q[j] - P.rest[j];
+                M off = j == 0 ? qlt(sy * dq, V(0.0f)) : (j == 1 ? qlt(dq, V(0.0f)) : qgt(dq, V(0.0f)));
+                ts = qsel(off, V(0.0f), V(0.0f) - P.k[j] * dq - P.b[j] * s.qd[j]);
+            }
+            o.tau_spring[j] = ts;
+            tau[j] = o.tau_pd[j] + ts;
+        }
+    }
+
+    struct Row { V jq[3], u[3], w[6], rhs, dinv, act; };
+
+    // One stepSimulation() (gym_env.py:218-219) under joint torques tau[3] per leg.
+    template <int NR> static QS_FN void solve_and_integrate(const qs_config& cfg, const Par& P, State& s, Out& o, Row* rows,
+                                                            const V* Lc, const V* Ld, const V (*BK)[6], const V* R, V dist, V active) {
+        constexpr int NT = 4 * NR;
+        const float dt = (float)cfg.dt;
+        // Delassus columns of the own rows: A[(k,r)][(own,c)] = w_kr . w_c + [k == own] jq_r . u_c
+        V A[NT][NR];
+        V rhs_all[NT], dinv_all[NT], lam_all[NT], act_all[NT];
+        V lam_own[NR];
+        V loc[NR][NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int c = 0; c < NR; c++) loc[r][c] = rows[r].jq[0] * rows[c].u[0] + rows[r].jq[1] * rows[c].u[1] + rows[r].jq[2] * rows[c].u[2];
+#define QS_GATHER(K)                                                                                                   \
+    {                                                                                                                  \
+        M own = T::is_leg(K);                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                               \
+            V wk[6];                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 6; i++) wk[i] = T::template bcast<K>(rows[r].w[i]);                  \
+            _Pragma("unroll") for (int c = 0; c < NR; c++) {                                                           \
+                V d = wk[0] * rows[c].w[0] + wk[1] * rows[c].w[1] + wk[2] * rows[c].w[2] + wk[3] * rows[c].w[3] +      \
+                      wk[4] * rows[c].w[4] + wk[5] * rows[c].w[5];                                                     \
+                A[NR * K + r][c] = d + qsel(own, loc[r][c], V(0.0f));                                                  \
+            }                                                                                                          \
+            rhs_all[NR * K + r] = T::template bcast<K>(rows[r].rhs);                                                   \
+            dinv_all[NR * K + r] = T::template bcast<K>(rows[r].dinv);                                                 \
+            act_all[NR * K + r] = T::template bcast<K>(rows[r].act);                                                   \
+        }                                                                                                              \
+    }
+        QS_GATHER(0) QS_GATHER(1) QS_GATHER(2) QS_GATHER(3)
+#undef QS_GATHER
+        // warm start: normal rows only, factor cfg.warmstart (btMultiBodyConstraintSolver, SOLVER_USE_WARMSTARTING)
+#pragma unroll
+        for (int r = 0; r < NR; r++) lam_own[r] = V(0.0f);
+        lam_own[0] = s.warm * cfg.warmstart * rows[0].act;
+#pragma unroll
+        for (int i = 0; i < NT; i++) lam_all[i] = V(0.0f);
+        lam_all[NR * 0] = T::template bcast<0>(lam_own[0]); lam_all[NR * 1] = T::template bcast<1>(lam_own[0]);
+        lam_all[NR * 2] = T::template bcast<2>(lam_own[0]); lam_all[NR * 3] = T::template bcast<3>(lam_own[0]);
+
+        const V big = V(1e10f), zero = V(0.0f);
+        for (int it = 0; it < cfg.solver_iters; it++) {
+#define QS_ROW_UPDATE(K, RR, KIND)                                                                                    \
+    {                                                                                                                  \
+        constexpr int i_ = NR * (K) + (RR);                                                                            \
+        V part = A[i_][0] * lam_own[0];                                                                                \
+        _Pragma("unroll") for (int c = 1; c < NR; c++) part = part + A[i_][c] * lam_own[c];                            \
+        V sdot = T::quad_sum(part);                                                                                    \
+        V sum = lam_all[i_] + (rhs_all[i_] - sdot * dinv_all[i_]);                                                     \
+        if (KIND == 0) { /* unilateral row: [0, 1e10] */                                                               \
+            sum = qmin(qmax(sum, zero), big);                                                                          \
+            sum = qsel(qgt(act_all[i_], zero), sum, zero);                                                             \
+        } else { /* friction row bounded by mu * current normal impulse; skipped while that impulse is not positive */ \
+            V tot = lam_all[NR * (K)];                                                                                 \
+            V lim = P.mu * tot;                                                                                        \
+            V cl = qmin(qmax(sum, zero - lim), lim);                                                                   \
+            sum = qsel(qand(qgt(tot, zero), qgt(act_all[i_], zero)), cl, lam_all[i_]);                                 \
+        }                                                                                                              \
+        lam_all[i_] = sum;                                                                                             \
+        lam_own[RR] = qsel(T::is_leg(K), sum, lam_own[RR]);                                                            \
+    }
+            if (NR == 6) {  // joint-limit rows first; Bullet walks them backwards on even sweeps
+                if (it & 1) {
+                    QS_ROW_UPDATE(0, NR - 3, 0) QS_ROW_UPDATE(0, NR - 2, 0) QS_ROW_UPDATE(0, NR - 1, 0)
+                    QS_ROW_UPDATE(1, NR - 3, 0) QS_ROW_UPDATE(1, NR - 2, 0) QS_ROW_UPDATE(1, NR - 1, 0)
+                    QS_ROW_UPDATE(2, NR - 3, 0) QS_ROW_UPDATE(2, NR - 2, 0) QS_ROW_UPDATE(2, NR - 1, 0)
+                    QS_ROW_UPDATE(3, NR - 3, 0) QS_ROW_UPDATE(3, NR - 2, 0) QS_ROW_UPDATE(3, NR - 1, 0)
+                } else {
+                    QS_ROW_UPDATE(3, NR - 1, 0) QS_ROW_UPDATE(3, NR - 2, 0) QS_ROW_UPDATE(3, NR - 3, 0)
+                    QS_ROW_UPDATE(2, NR - 1, 0) QS_ROW_UPDATE(2, NR - 2, 0) QS_ROW_UPDATE(2, NR - 3, 0)
+                    QS_ROW_UPDATE(1, NR - 1, 0) QS_ROW_UPDATE(1, NR - 2, 0) QS_ROW_UPDATE(1, NR - 3, 0)
+                    QS_ROW_UPDATE(0, NR - 1, 0) QS_ROW_UPDATE(0, NR - 2, 0) QS_ROW_UPDATE(0, NR - 3, 0)
+                }
+            }
+            QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
+            QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
+            QS_ROW_UPDATE(2, 1, 1) QS_ROW_UPDATE(2, 2, 1) QS_ROW_UPDATE(3, 1, 1) QS_ROW_UPDATE(3, 2, 1)
+#undef QS_ROW_UPDATE
+        }
+        o.foot_force = lam_own[0] * (1.0f / dt);   // getContactPoints()[9] = normal impulse / dt
+        s.warm = lam_own[0];
+
+        // delta v = H^-1 J^T lambda :  dv_b = L^-T sum_i w_i lam_i ;  dqd = sum_own u_r lam_r - (B K)^T dv_b
+        V z[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            V t = rows[0].w[i] * lam_own[0];
+#pragma unroll
+            for (int r = 1; r < NR; r++) t = t + rows[r].w[i] * lam_own[r];
+            z[i] = T::quad_sum(t);
+        }
+        ltsolve6<V>(Lc, Ld, z);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            V t = rows[0].u[j] * lam_own[0];
+#pragma unroll
+            for (int r = 1; r < NR; r++) t = t + rows[r].u[j] * lam_own[r];
+#pragma unroll
+            for (int i = 0; i < 6; i++) t = t - BK[j][i] * z[i];
+            s.qd[j] = clampv<V>(s.qd[j] + t, V(-cfg.vel_cap), V(cfg.vel_cap));
+        }
+        const V cap = V(cfg.vel_cap);
+        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), zero - cap, cap);
+        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), zero - cap, cap);
+        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), zero - cap, cap);
+        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), zero - cap, cap);
+        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), zero - cap, cap);
+        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), zero - cap, cap);
+        (void)dist; (void)active;
+    }
+
+    static QS_FN void substep(const qs_config& cfg, const Par& P, State& s, const V* tau, Out& o) {
+        using namespace go1;
+        const float dt = (float)cfg.dt;
+        const V zero = V(0.0f), one = V(1.0f);
+        V fx = T::fx(), sy = T::sy();
+        // ---- base rotation (row-major, base -> world), velocities in base coordinates
+        V R[9];
+        {
+            V x = s.qx, y = s.qy, z = s.qz, w = s.qw;
+            V d = x * x + y * y + z * z + w * w;
+            V sc = V(2.0f) / d;
+            V xs = x * sc, ys = y * sc, zs = z * sc;
+            V wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+            R[0] = one - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+            R[3] = xy + wz; R[4] = one - (xx + zz); R[5] = yz - wx;
+            R[6] = xz - wy; R[7] = yz + wx; R[8] = one - (xx + yy);
+        }
+        V3v Rx = mk3<V>(R[0], R[1], R[2]), Ry = mk3<V>(R[3], R[4], R[5]), Rz = mk3<V>(R[6], R[7], R[8]);  // R^T e_x, R^T e_y, R^T e_z
+        Spv v0;
+        v0.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
+        v0.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
+
+        // ---- leg kinematics in base coordinates
+        V s1 = qsin(s.q[0]), c1 = qcos(s.q[0]), s2 = qsin(s.q[1]), c2 = qcos(s.q[1]);
+        V q23 = s.q[1] + s.q[2];
+        V s23 = qsin(q23), c23 = qcos(q23);
+        V3v p1 = mk3<V>(fx * HIP_X, sy * HIP_Y, zero);
+        V3v ax1 = mk3<V>(one, zero, zero);
+        V3v Y = mk3<V>(zero, c1, s1);                       // joint axis of thigh and calf
+        V3v Z1 = mk3<V>(zero, zero - s1, c1);
+        V3v p2 = p1 + Y * (sy * THIGH_Y);
+        V3v X2 = mk3<V>(c2, s1 * s2, zero - c1 * s2), Z2 = mk3<V>(s2, zero - s1 * c2, c1 * c2);
+        V3v p3 = p2 + Z2 * V(LEG_Z);
+        V3v X3 = mk3<V>(c23, s1 * s23, zero - c1 * s23), Z3 = mk3<V>(s23, zero - s1 * c23, c1 * c23);
+        V3v rf = p3 + Z3 * V(LEG_Z);                        // foot centre
+
+        // ---- link inertias about the base origin
+        SI<V> I1 = part_inertia<V>(P.m_hip, P.c_hip, P.I_hip, p1, ax1, Y, Z1);
+        SI<V> I2 = part_inertia<V>(P.m_thigh, P.c_thigh, P.I_thigh, p2, X2, Y, Z2);
+        SI<V> I3 = part_inertia<V>(P.m_calf, mk3<V>(V(CALF_C[0]), V(CALF_C[1]), V(CALF_C[2])), P.I_calf, p3, X3, Y, Z3) +
+                   point_inertia<V>(V(FOOT_M), V(FOOT_I), rf);
+        SI<V> Ic2 = I2 + I3, Ic1 = I1 + Ic2;
+        // motion subspaces S_j = (a_j ; p_j x a_j)
+        Spv S1, S2, S3j;
+        S1.a = ax1; S1.l = cross(p1, ax1);
+        S2.a = Y; S2.l = cross(p2, Y);
+        S3j.a = Y; S3j.l = cross(p3, Y);
+        // ---- CRBA: B = [F1 F2 F3] (6x3), D (3x3 symmetric)
+        Spv F1 = apply(Ic1, S1), F2 = apply(Ic2, S2), F3 = apply(I3, S3j);
+        V D11 = dot(S1, F1), D12 = dot(S1, F2), D13 = dot(S1, F3), D22 = dot(S2, F2), D23 = dot(S2, F3), D33 = dot(S3j, F3);
+        // K = D^-1 (symmetric cofactor inverse)
+        V K11, K12, K13, K22, K23, K33;
+        {
+            V c11 = D22 * D33 - D23 * D23, c12 = D13 * D23 - D12 * D33, c13 = D12 * D23 - D13 * D22;
+            V det = D11 * c11 + D12 * c12 + D13 * c13;
+            V id = one / det;
+            K11 = c11 * id; K12 = c12 * id; K13 = c13 * id;
+            K22 = (D11 * D33 - D13 * D13) * id; K23 = (D12 * D13 - D11 * D23) * id; K33 = (D11 * D22 - D12 * D12) * id;
+        }
+        V Bm[3][6] = {{F1.a.x, F1.a.y, F1.a.z, F1.l.x, F1.l.y, F1.l.z}, {F2.a.x, F2.a.y, F2.a.z, F2.l.x, F2.l.y, F2.l.z}, {F3.a.x, F3.a.y, F3.a.z, F3.l.x, F3.l.y, F3.l.z}};
+        V BK[3][6];   // BK[j] = column j of B K
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            BK[0][i] = Bm[0][i] * K11 + Bm[1][i] * K12 + Bm[2][i] * K13;
+            BK[1][i] = Bm[0][i] * K12 + Bm[1][i] * K22 + Bm[2][i] * K23;
+            BK[2][i] = Bm[0][i] * K13 + Bm[1][i] * K23 + Bm[2][i] * K33;
+        }
+        // ---- S = Hbb - sum_legs B K B^T, then Cholesky (replicated)
+        SI<V> Itot;
+        Itot.m = P.mtot;
+        {
+            SI<V> Il = Ic1;
+            Itot.h = mk3<V>(T::quad_sum(Il.h.x), T::quad_sum(Il.h.y), T::quad_sum(Il.h.z)) + P.I0.h;
+            Itot.I.xx = T::quad_sum(Il.I.xx) + P.I0.I.xx; Itot.I.xy = T::quad_sum(Il.I.xy) + P.I0.I.xy; Itot.I.xz = T::quad_sum(Il.I.xz) + P.I0.I.xz;
+            Itot.I.yy = T::quad_sum(Il.I.yy) + P.I0.I.yy; Itot.I.yz = T::quad_sum(Il.I.yz) + P.I0.I.yz; Itot.I.zz = T::quad_sum(Il.I.zz) + P.I0.I.zz;
+        }
+        V Sm[21];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) Sm[tri(i, j)] = T::quad_sum(BK[0][i] * Bm[0][j] + BK[1][i] * Bm[1][j] + BK[2][i] * Bm[2][j]);
+        {
+            V H[21];
+            H[tri(0, 0)] = Itot.I.xx; H[tri(1, 0)] = Itot.I.xy; H[tri(1, 1)] = Itot.I.yy; H[tri(2, 0)] = Itot.I.xz; H[tri(2, 1)] = Itot.I.yz; H[tri(2, 2)] = Itot.I.zz;
+            // rows 3..5 (linear) x cols 0..2 (angular): -[h]x  ; diagonal block m
+            H[tri(3, 0)] = zero; H[tri(3, 1)] = Itot.h.z; H[tri(3, 2)] = zero - Itot.h.y;
+            H[tri(4, 0)] = zero - Itot.h.z; H[tri(4, 1)] = zero; H[tri(4, 2)] = Itot.h.x;
+            H[tri(5, 0)] = Itot.h.y; H[tri(5, 1)] = zero - Itot.h.x; H[tri(5, 2)] = zero;
+            H[tri(3, 3)] = Itot.m; H[tri(4, 3)] = zero; H[tri(4, 4)] = Itot.m; H[tri(5, 3)] = zero; H[tri(5, 4)] = zero; H[tri(5, 5)] = Itot.m;
+#pragma unroll
+            for (int i = 0; i < 21; i++) Sm[i] = H[i] - Sm[i];
+        }
+        chol6<V>(Sm);
+        V Ld[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Ld[i] = one / Sm[tri(i, i)];
+
+        // ---- RNEA bias with qdd = 0, base acceleration 0, gravity as the fictitious base acceleration -g
+        Spv a0; a0.a = mk3<V>(zero, zero, zero); a0.l = Rz * V(cfg.gravity);
+        Spv vj1, vj2, vj3;
+        vj1.a = S1.a * s.qd[0]; vj1.l = S1.l * s.qd[0];
+        vj2.a = S2.a * s.qd[1]; vj2.l = S2.l * s.qd[1];
+        vj3.a = S3j.a * s.qd[2]; vj3.l = S3j.l * s.qd[2];
+        Spv v1 = v0 + vj1, v2 = v1 + vj2, v3 = v2 + vj3;
+        Spv a1 = a0 + crm(v0, vj1), a2 = a1 + crm(v1, vj2), a3 = a2 + crm(v2, vj3);
+        Spv f1 = apply(I1, a1) + crf(v1, apply(I1, v1));
+        Spv f2 = apply(I2, a2) + crf(v2, apply(I2, v2));
+        Spv f3 = apply(I3, a3) + crf(v3, apply(I3, v3));
+        Spv fs2 = f2 + f3, fs1 = f1 + fs2;
+        V C1 = dot(S1, fs1), C2 = dot(S2, fs2), C3 = dot(S3j, f3);
+        Spv f0 = apply(P.I0, a0) + crf(v0, apply(P.I0, v0));
+        V Cb[6] = {T::quad_sum(fs1.a.x) + f0.a.x, T::quad_sum(fs1.a.y) + f0.a.y, T::quad_sum(fs1.a.z) + f0.a.z,
+                   T::quad_sum(fs1.l.x) + f0.l.x, T::quad_sum(fs1.l.y) + f0.l.y, T::quad_sum(fs1.l.z) + f0.l.z};
+        // ---- unconstrained accelerations
+        V t1 = tau[0] - C1, t2 = tau[1] - C2, t3 = tau[2] - C3;
+        V y1 = K11 * t1 + K12 * t2 + K13 * t3, y2 = K12 * t1 + K22 * t2 + K23 * t3, y3 = K13 * t1 + K23 * t2 + K33 * t3;
+        V ab[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) ab[i] = zero - Cb[i] - T::quad_sum(Bm[0][i] * y1 + Bm[1][i] * y2 + Bm[2][i] * y3);
+        lsolve6<V>(Sm, Ld, ab);
+        ltsolve6<V>(Sm, Ld, ab);
+        V qdd[3] = {y1, y2, y3};
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 6; i++) qdd[j] = qdd[j] - BK[j][i] * ab[i];
+        // ---- v* = v + dt a (world frame for the base; classical acceleration of the origin = a_lin + w x v)
+        const V cap = V(cfg.vel_cap);
+        {
+            V3v wxv = cross(v0.a, v0.l);
+            V3v al = mk3<V>(ab[3] + wxv.x, ab[4] + wxv.y, ab[5] + wxv.z);
+            s.vang.x = clampv<V>(s.vang.x + dt * (R[0] * ab[0] + R[1] * ab[1] + R[2] * ab[2]), zero - cap, cap);
+            s.vang.y = clampv<V>(s.vang.y + dt * (R[3] * ab[0] + R[4] * ab[1] + R[5] * ab[2]), zero - cap, cap);
+            s.vang.z = clampv<V>(s.vang.z + dt * (R[6] * ab[0] + R[7] * ab[1] + R[8] * ab[2]), zero - cap, cap);
+            s.vlin.x = clampv<V>(s.vlin.x + dt * (R[0] * al.x + R[1] * al.y + R[2] * al.z), zero - cap, cap);
+            s.vlin.y = clampv<V>(s.vlin.y + dt * (R[3] * al.x + R[4] * al.y + R[5] * al.z), zero - cap, cap);
+            s.vlin.z = clampv<V>(s.vlin.z + dt * (R[6] * al.x + R[7] * al.y + R[8] * al.z), zero - cap, cap);
+#pragma unroll
+            for (int j = 0; j < 3; j++) s.qd[j] = clampv<V>(s.qd[j] + dt * qdd[j], zero - cap, cap);
+        }
+        Spv vs;  // predicted base velocity in base coordinates
+        vs.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
+        vs.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
+
+        // ---- collision: foot sphere vs plane z = 0 ; other link primitives only flag invalid contacts (quadruped.py:243-249)
+        V dist = s.pos.z + dot(Rz, rf) - FOOT_R;
+        M act_m = qlt(dist, V(THR_FOOT));
+        V active = qflag(act_m);
+        o.foot_contact = active;
+        {
+            V zc = s.pos.z;
+            // trunk box: this lane tests the two corners on its own side
+            V tz = zc + Rz.x * (fx * TRUNK_HALF[0]) + Rz.y * (sy * TRUNK_HALF[1]) - qabs(Rz.z) * TRUNK_HALF[2];
+            V trunk = qflag(qgt(T::quad_sum(qflag(qlt(tz, V(THR_TRUNK)))), zero));
+            // hip cylinder, axis = link y
+            V az = dot(Rz, Y);
+            V hz = zc + dot(Rz, p1) - HIP_CYL_HALF_LEN * qabs(az) - HIP_CYL_R * qsqrt(qmax(one - az * az, zero));
+            V n = qflag(qlt(hz, V(THR_HIP)));
+            // thigh / calf boxes centred at (0,0,-0.1065) of their frames
+            V3v ct = p2 + Z2 * V(LINK_BOX_Z), cc = p3 + Z3 * V(LINK_BOX_Z);
+            V tzm = zc + dot(Rz, ct) - qabs(dot(Rz, X2)) * THIGH_HALF[0] - qabs(az) * THIGH_HALF[1] - qabs(dot(Rz, Z2)) * THIGH_HALF[2];
+            V czm = zc + dot(Rz, cc) - qabs(dot(Rz, X3)) * CALF_HALF[0] - qabs(az) * CALF_HALF[1] - qabs(dot(Rz, Z3)) * CALF_HALF[2];
+            n = n + qflag(qlt(tzm, V(THR_THIGH))) + qflag(qlt(czm, V(THR_CALF)));
+            o.n_invalid = T::quad_sum(n) + trunk;
+        }
+
+        // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
+        Row rows[6];
+        V3v rc = rf - Rz * V(FOOT_R);                   // contact point on the sphere, base coordinates
+        V3v d1 = rc - p1, d2 = rc - p2, d3 = rc - p3;
+        V3v g1 = cross(ax1, d1), g2 = cross(Y, d2), g3 = cross(Y, d3);  // d(point)/dq_j
+        const V inv_dt = V(1.0f / dt);
+#define QS_CONTACT_ROW(IDX, DIR, NORMAL)                                                                               \
+    {                                                                                                                  \
+        Row& r_ = rows[IDX];                                                                                           \
+        V3v d_ = DIR;                                                                                                  \
+        V3v ja = cross(rc, d_);                                                                                        \
+        r_.jq[0] = dot(d_, g1); r_.jq[1] = dot(d_, g2); r_.jq[2] = dot(d_, g3);                                        \
+        r_.u[0] = K11 * r_.jq[0] + K12 * r_.jq[1] + K13 * r_.jq[2];                                                    \
+        r_.u[1] = K12 * r_.jq[0] + K22 * r_.jq[1] + K23 * r_.jq[2];                                                    \
+        r_.u[2] = K13 * r_.jq[0] + K23 * r_.jq[1] + K33 * r_.jq[2];                                                    \
+        V jb[6] = {ja.x, ja.y, ja.z, d_.x, d_.y, d_.z};                                                                \
+        _Pragma("unroll") for (int i = 0; i < 6; i++)                                                                  \
+            r_.w[i] = (jb[i] - (Bm[0][i] * r_.u[0] + Bm[1][i] * r_.u[1] + Bm[2][i] * r_.u[2])) * active;               \
+        lsolve6<V>(Sm, Ld, r_.w);                                                                                      \
+        V diag = r_.jq[0] * r_.u[0] + r_.jq[1] * r_.u[1] + r_.jq[2] * r_.u[2];                                         \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
+        r_.dinv = one / diag;                                                                                          \
+        V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
+        if (NORMAL) {                                                                                                  \
+            V pos_err = qsel(qgt(dist, zero), zero, (zero - dist) * (cfg.contact_erp * inv_dt));                       \
+            V vel_err = (zero - rel) - qsel(qgt(dist, zero), dist * inv_dt, zero);                                     \
+            r_.rhs = (pos_err + vel_err) * r_.dinv * active;                                                           \
+        } else {                                                                                                       \
+            r_.rhs = (zero - rel) * r_.dinv * active;                                                                  \
+        }                                                                                                              \
+        r_.act = active;                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) { r_.jq[j] = r_.jq[j] * active; r_.u[j] = r_.u[j] * active; }    \
+    }
+        QS_CONTACT_ROW(0, Rz, true)
+        QS_CONTACT_ROW(1, (mk3<V>(zero - Ry.x, zero - Ry.y, zero - Ry.z)), false)
+        QS_CONTACT_ROW(2, Rx, false)
+#undef QS_CONTACT_ROW
+        // joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint)
+        V lim_pen[3], lim_sgn[3];
+        M any_lim = qlt(one, zero);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            V plo = s.q[j] - JLO[j], phi = V(JHI[j]) - s.q[j];
+            M vlo = qle(plo, zero), vhi = qle(phi, zero);
+            lim_pen[j] = qsel(vlo, plo, phi);
+            lim_sgn[j] = qsel(vlo, one, zero - one);
+            M v = qor(vlo, vhi);
+            rows[3 + j].act = qflag(v);
+            any_lim = qor(any_lim, v);
+        }
+        V Kc[3][3] = {{K11, K12, K13}, {K12, K22, K23}, {K13, K23, K33}};
+        if (T::any(any_lim)) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                Row& r_ = rows[3 + j];
+                V a_ = r_.act * lim_sgn[j];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { r_.jq[c] = c == j ? a_ : zero; r_.u[c] = Kc[c][j] * a_; }
+#pragma unroll
+                for (int i = 0; i < 6; i++) r_.w[i] = zero - BK[j][i] * a_;
+                lsolve6<V>(Sm, Ld, r_.w);
+                V diag = Kc[j][j];
+#pragma unroll
+                for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];
+                r_.dinv = one / diag;
+                V rel = lim_sgn[j] * s.qd[j];
+                r_.rhs = ((zero - lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
+            }
+            solve_and_integrate<6>(cfg, P, s, o, rows, Sm, Ld, BK, R, dist, active);
+        } else {
+            solve_and_integrate<3>(cfg, P, s, o, rows, Sm, Ld, BK, R, dist, active);
+        }
+        // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
+        s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;
+        {
+            V wn = qsqrt(dot(s.vang, s.vang));
+            V th = wn * dt;
+            V small = V(0.5f * dt) * (one - th * th * (1.0f / 24.0f));
+            V big = qsin(V(0.5f) * th) / qmax(wn, V(1e-12f));
+            V sc = qsel(qlt(th, V(1e-6f)), small, big);
+            V dx = s.vang.x * sc, dy = s.vang.y * sc, dz = s.vang.z * sc, dw = qcos(V(0.5f) * th);
+            V nx = dw * s.qx + dx * s.qw + dy * s.qz - dz * s.qy;
+            V ny = dw * s.qy - dx * s.qz + dy * s.qw + dz * s.qx;
+            V nz = dw * s.qz + dx * s.qy - dy * s.qx + dz * s.qw;
+            V nw = dw * s.qw - dx * s.qx - dy * s.qy - dz * s.qz;
+            V inv = one / qsqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+            s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw * inv;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) s.q[j] = s.q[j] + dt * s.qd[j];
+    }
+};
+
+}  // namespace qs

@@ -1,0 +1,492 @@
+// qs_env.h -- one QuadrupedGymEnv.step() / reset() per environment record, on top of Sim<T>::substep.
+// Reference lines are relative to quadruped_spring/ ; the same restatement in float64 lives in oracle/qso_env.c.
+#pragma once
+#include "qs_core.h"
+
+namespace qs {
+
+QS_FN float i2f(int v) { union { int i; float f; } u; u.i = v; return u.f; }
+QS_FN int f2i(float v) { union { int i; float f; } u; u.f = v; return u.i; }
+
+template <class T> struct Env {
+    using V = typename T::V;
+    using M = typename T::M;
+    using S = Sim<T>;
+    using V3v = V3<V>;
+    static constexpr float PI = 3.14159265358979323846f;
+
+    // ---- analytic leg IK (quadruped.py:399-438), side sign -1 for right legs = T::sy()
+    static QS_FN void leg_ik(const qs_config& cfg, V x, V y, V z, V* q) {
+        const float sh = cfg.leg_len[0], el = cfg.leg_len[1], wr = cfg.leg_len[2];
+        V D = (y * y + z * z - sh * sh + x * x - el * el - wr * wr) * (1.0f / (2.0f * wr * el));
+        D = clampv<V>(D, V(-1.0f), V(1.0f));
+        V wrist = qatan2(V(0.0f) - qsqrt(V(1.0f) - D * D), D);
+        V sc = qmax(y * y + z * z - sh * sh, V(0.0f));
+        V rt = qsqrt(sc);
+        V shoulder = V(0.0f) - qatan2(z, y) - qatan2(rt, T::sy() * sh);
+        V elbow = qatan2(V(0.0f) - x, rt) - qatan2(qsin(wrist) * wr, qcos(wrist) * wr + el);
+        q[0] = V(0.0f) - shoulder; q[1] = elbow; q[2] = wrist;
+    }
+    // ---- analytic leg FK + Jacobian (quadruped.py:348-392)
+    static QS_FN void leg_fk(const qs_config& cfg, const V* q, V* J, V* p) {
+        const float l1 = cfg.leg_len[0], l2 = cfg.leg_len[1], l3 = cfg.leg_len[2];
+        V sg = T::sy();
+        V s1 = qsin(q[0]), s2 = qsin(q[1]), s3 = qsin(q[2]), c1 = qcos(q[0]), c2 = qcos(q[1]), c3 = qcos(q[2]);
+        V c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
+        V zero = V(0.0f);
+        J[0] = zero; J[3] = zero - sg * l1 * s1 + c2 * c1 * l2 + c23 * c1 * l3; J[6] = sg * l1 * c1 + c2 * s1 * l2 + c23 * s1 * l3;
+        J[1] = zero - c23 * l3 - c2 * l2; J[4] = zero - s2 * s1 * l2 - s23 * s1 * l3; J[7] = s2 * c1 * l2 + s23 * c1 * l3;
+        J[2] = zero - c23 * l3; J[5] = zero - s23 * s1 * l3; J[8] = s23 * c1 * l3;
+        p[0] = zero - s23 * l3 - s2 * l2;
+        p[1] = sg * c1 * l1 + (s1 * c23) * l3 + c2 * s1 * l2;
+        p[2] = sg * s1 * l1 - (c1 * c23) * l3 - c1 * c2 * l2;
+    }
+    // ---- pybullet getEulerFromQuaternion (quadruped.py:131-139)
+    static QS_FN void quat_to_rpy(V x, V y, V z, V w, V& roll, V& pitch, V& yaw) {
+        V sarg = V(-2.0f) * (x * z - w * y);
+        M lo = qle(sarg, V(-0.99999f)), hi = qge(sarg, V(0.99999f));
+        V p = qasin(clampv<V>(sarg, V(-1.0f), V(1.0f)));
+        V r = qatan2(V(2.0f) * (y * z + w * x), w * w - x * x - y * y + z * z);
+        V yw = qatan2(V(2.0f) * (x * y + w * z), w * w + x * x - y * y - z * z);
+        pitch = qsel(lo, V(-0.5f * PI), qsel(hi, V(0.5f * PI), p));
+        roll = qsel(qor(lo, hi), V(0.0f), r);
+        yaw = qsel(lo, V(2.0f) * qatan2(x, V(0.0f) - y), qsel(hi, V(2.0f) * qatan2(V(0.0f) - x, y), yw));
+    }
+    // ---- PitchBackFlip sensor (robot_sensors.py:333-340)
+    static QS_FN V pitch_backflip(V x, V y, V z, V w, V switched) {
+        V d = x * x + y * y + z * z + w * w, sc = V(2.0f) / d;
+        V r20 = (x * z - w * y) * sc, r22 = V(1.0f) - (x * x + y * y) * sc;
+        V pitch = V(0.0f) - qatan2(V(0.0f) - r20, r22);
+        return qsel(qand(qlt(pitch, V(0.0f)), qgt(switched, V(0.5f))), pitch + 2.0f * PI, pitch);
+    }
+
+    // ---- action -> own-leg motor command (action_interface.py:14-65, interface_base.py:84-90, motor_interface.py:70-80)
+    static QS_FN void action_to_command(const qs_config& cfg, const V* act, V* cmd) {
+        V a[3];
+        if (!cfg.rl_interface) {  // raw motor commands (gym_env.py:212-214)
+#pragma unroll
+            for (int j = 0; j < 3; j++) cmd[j] = act[12 + j];
+            return;
+        }
+        M front = qgt(T::fx(), V(0.0f));
+        if (cfg.action_space_mode == QS_ACT_DEFAULT) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) a[j] = act[12 + j];
+        } else if (cfg.action_space_mode == QS_ACT_SYMMETRIC) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                V t = qsel(front, act[j], act[3 + j]);
+                a[j] = j == cfg.symm_idx ? t * (V(0.0f) - T::sy()) : t;  // left legs mirror index symm_idx
+            }
+        } else {
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j == cfg.symm_idx) a[j] = V(0.0f);
+                else { a[j] = qsel(front, act[k], act[2 + k]); k++; }
+            }
+        }
+        V s[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            V lo = T::ld_leg(cfg.cmd_lo, j, 3), hi = T::ld_leg(cfg.cmd_hi, j, 3);
+            V c = clampv<V>(a[j], V(-1.0f), V(1.0f));
+            s[j] = clampv<V>(lo + V(0.5f) * (c + 1.0f) * (hi - lo), lo, hi);
+        }
+        if (cfg.motor_control_mode == QS_MOTOR_CARTESIAN_PD) leg_ik(cfg, s[0], s[1], s[2], cmd);
+        else { cmd[0] = s[0]; cmd[1] = s[1]; cmd[2] = s[2]; }
+    }
+
+    // ---- record <-> registers
+    static QS_FN void load_state(const float* rec, typename S::State& s) {
+        s.pos = mk3<V>(T::ld(rec, R_POS), T::ld(rec, R_POS + 1), T::ld(rec, R_POS + 2));
+        s.qx = T::ld(rec, R_QUAT); s.qy = T::ld(rec, R_QUAT + 1); s.qz = T::ld(rec, R_QUAT + 2); s.qw = T::ld(rec, R_QUAT + 3);
+        s.vlin = mk3<V>(T::ld(rec, R_VLIN), T::ld(rec, R_VLIN + 1), T::ld(rec, R_VLIN + 2));
+        s.vang = mk3<V>(T::ld(rec, R_VANG), T::ld(rec, R_VANG + 1), T::ld(rec, R_VANG + 2));
+#pragma unroll
+        for (int j = 0; j < 3; j++) { s.q[j] = T::ld_leg(rec, R_Q + j, 3); s.qd[j] = T::ld_leg(rec, R_QD + j, 3); }
+        s.warm = T::ld_leg(rec, R_WARM, 1);
+    }
+    static QS_FN void store_state(float* rec, const typename S::State& s, const typename S::Out& o) {
+        T::st(rec, R_POS, s.pos.x); T::st(rec, R_POS + 1, s.pos.y); T::st(rec, R_POS + 2, s.pos.z);
+        T::st(rec, R_QUAT, s.qx); T::st(rec, R_QUAT + 1, s.qy); T::st(rec, R_QUAT + 2, s.qz); T::st(rec, R_QUAT + 3, s.qw);
+        T::st(rec, R_VLIN, s.vlin.x); T::st(rec, R_VLIN + 1, s.vlin.y); T::st(rec, R_VLIN + 2, s.vlin.z);
+        T::st(rec, R_VANG, s.vang.x); T::st(rec, R_VANG + 1, s.vang.y); T::st(rec, R_VANG + 2, s.vang.z);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T::st_leg(rec, R_Q + j, 3, s.q[j]); T::st_leg(rec, R_QD + j, 3, s.qd[j]);
+            T::st_leg(rec, R_TAU_PD + j, 3, o.tau_pd[j]); T::st_leg(rec, R_TAU_SPRING + j, 3, o.tau_spring[j]);
+        }
+        T::st_leg(rec, R_WARM, 1, s.warm);
+        T::st_leg(rec, R_FOOT_FORCE, 1, o.foot_force); T::st_leg(rec, R_FOOT_CONTACT, 1, o.foot_contact);
+        T::st(rec, R_N_INVALID, o.n_invalid);
+    }
+    static QS_FN void load_par(const float* rec, typename S::Par& P) {
+        const float* p = rec + R_PARAMS;
+        P.mu = T::ld(p, P_MU);
+        V ml[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            P.k[j] = T::ld(p, P_K + j); P.b[j] = T::ld(p, P_B + j); P.rest[j] = T::ld(p, P_REST + j);
+            P.kp[j] = T::ld(p, P_KP + j); P.kd[j] = T::ld(p, P_KD + j); ml[j] = T::ld(p, P_M_LEG + j);
+        }
+        S::build_par(P, T::ld(p, P_M_TRUNK), ml, T::ld(p, P_M_PAY), mk3<V>(T::ld(p, P_R_PAY), T::ld(p, P_R_PAY + 1), T::ld(p, P_R_PAY + 2)));
+    }
+
+    // ---- task state machine (tasks/task_base.py:61-166, 222-280) on replicated values
+    struct Task {
+        V switched, all_air, is_jumping, t_takeoff, pose_to[3], yaw_to, init_h, max_flight, max_fwd, max_pitch, rel_max_h, max_dx,
+            max_h, cum_fwd, cum_ft, old_fwd, actual_fwd, bf_max_pitch;
+        V pos[3], vel[3], rpy[3];
+        V dtau2;  // |old_torque - new_torque|^2
+    };
+    static QS_FN void load_task(const float* rec, Task& t) {
+        const float* p = rec + R_TASK;
+        t.switched = T::ld(p, T_SWITCHED); t.all_air = T::ld(p, T_ALL_AIR); t.is_jumping = T::ld(p, T_IS_JUMPING); t.t_takeoff = T::ld(p, T_TAKEOFF);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { t.pose_to[k] = T::ld(p, T_POSE_TO + k); t.pos[k] = T::ld(rec, R_POSE_CACHE + k); t.vel[k] = T::ld(rec, R_POSE_CACHE + 3 + k); t.rpy[k] = T::ld(rec, R_POSE_CACHE + 6 + k); }
+        t.yaw_to = T::ld(p, T_YAW_TO); t.init_h = T::ld(p, T_INIT_H); t.max_flight = T::ld(p, T_MAX_FLIGHT); t.max_fwd = T::ld(p, T_MAX_FWD);
+        t.max_pitch = T::ld(p, T_MAX_PITCH); t.rel_max_h = T::ld(p, T_REL_MAX_H); t.max_dx = T::ld(p, T_MAX_DX); t.max_h = T::ld(p, T_MAX_H);
+        t.cum_fwd = T::ld(p, T_CUM_FWD); t.cum_ft = T::ld(p, T_CUM_FT); t.old_fwd = T::ld(p, T_OLD_FWD); t.actual_fwd = T::ld(p, T_ACTUAL_FWD);
+        t.bf_max_pitch = T::ld(p, T_BF_MAX_PITCH);
+        t.dtau2 = V(0.0f);
+    }
+    static QS_FN void store_task(float* rec, const Task& t) {
+        float* p = rec + R_TASK;
+        T::st(p, T_SWITCHED, t.switched); T::st(p, T_ALL_AIR, t.all_air); T::st(p, T_IS_JUMPING, t.is_jumping); T::st(p, T_TAKEOFF, t.t_takeoff);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { T::st(p, T_POSE_TO + k, t.pose_to[k]); T::st(rec, R_POSE_CACHE + k, t.pos[k]); T::st(rec, R_POSE_CACHE + 3 + k, t.vel[k]); T::st(rec, R_POSE_CACHE + 6 + k, t.rpy[k]); }
+        T::st(p, T_YAW_TO, t.yaw_to); T::st(p, T_INIT_H, t.init_h); T::st(p, T_MAX_FLIGHT, t.max_flight); T::st(p, T_MAX_FWD, t.max_fwd);
+        T::st(p, T_MAX_PITCH, t.max_pitch); T::st(p, T_REL_MAX_H, t.rel_max_h); T::st(p, T_MAX_DX, t.max_dx); T::st(p, T_MAX_H, t.max_h);
+        T::st(p, T_CUM_FWD, t.cum_fwd); T::st(p, T_CUM_FT, t.cum_ft); T::st(p, T_OLD_FWD, t.old_fwd); T::st(p, T_ACTUAL_FWD, t.actual_fwd);
+        T::st(p, T_BF_MAX_PITCH, t.bf_max_pitch);
+    }
+    static QS_FN bool continuous(int task) { return task == QS_TASK_CONT_JUMPING_FORWARD || task == QS_TASK_CONT_JUMPING_FORWARD2; }
+    static QS_FN V jump_distance(const Task& t) {  // task_base.py:108-116
+        V dx = t.pos[0] - t.pose_to[0], dy = t.pos[1] - t.pose_to[1];
+        return qmax(qcos(t.yaw_to) * dx - qsin(t.yaw_to) * dy, V(0.0f));
+    }
+    // `old_tau` is the record's R_NEW_TAU (own leg), `o.tau_pd` the torque of the last substep
+    static QS_FN void task_on_step(const qs_config& cfg, Task& t, const typename S::State& s, const typename S::Out& o, const V* old_tau, V now) {
+        if (cfg.task == QS_TASK_NO_TASK) return;
+        const V zero = V(0.0f), one = V(1.0f);
+        M flying = qlt(T::quad_sum(o.foot_contact), V(0.5f));                     // quadruped.py:260-262
+        M takeoff_v = qgt(s.vlin.z * (1.0f / 9.81f), V(0.06f));                   // task_base.py:157-160 (g = 9.81 here)
+        t.switched = qsel(qand(qand(qlt(t.switched, V(0.5f)), flying), takeoff_v), one, t.switched);  // :152-155
+        V d2 = zero;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { V d = old_tau[j] - o.tau_pd[j]; d2 = d2 + d * d; }
+        t.dtau2 = T::quad_sum(d2);                                                 // :68-70, :149-150
+        t.pos[0] = s.pos.x; t.pos[1] = s.pos.y; t.pos[2] = s.pos.z; t.vel[0] = s.vlin.x; t.vel[1] = s.vlin.y; t.vel[2] = s.vlin.z;
+        quat_to_rpy(s.qx, s.qy, s.qz, s.qw, t.rpy[0], t.rpy[1], t.rpy[2]);        // :72-75
+        V z = t.pos[2];
+        t.rel_max_h = qmax(t.rel_max_h, qmax(z - t.init_h, zero));                 // :81-86
+        t.max_h = qmax(qabs(z), t.max_h);
+        t.max_dx = qmax(qabs(t.pos[0]), t.max_dx);
+        t.max_pitch = qmax(qabs(t.rpy[1]), t.max_pitch);                           // :88-90
+        M air = qgt(t.all_air, V(0.5f));
+        M take = qand(flying, qnot(air)), land = qand(qnot(flying), air);
+        // at take-off: remember time / pose / yaw
+        V t_takeoff0 = t.t_takeoff;
+        t.t_takeoff = qsel(take, now, t.t_takeoff);
+#pragma unroll
+        for (int k = 0; k < 3; k++) t.pose_to[k] = qsel(take, t.pos[k], t.pose_to[k]);
+        t.yaw_to = qsel(take, t.rpy[2], t.yaw_to);
+        V dist = jump_distance(t);
+        V fwd_upd = qmax(dist, t.max_fwd);
+        V flight_upd = qmax(now - t_takeoff0, t.max_flight);
+        if (!continuous(cfg.task)) {  // task_base.py:92-106
+            M in_flight = qand(flying, air);
+            t.max_flight = qsel(land, flight_upd, t.max_flight);
+            t.max_fwd = qsel(qor(in_flight, land), fwd_upd, qsel(qand(qnot(flying), qnot(air)), zero, t.max_fwd));
+        } else {                      // task_base.py:244-280
+            const float jump_limit = 0.5f, time_limit = cfg.task == QS_TASK_CONT_JUMPING_FORWARD ? 0.15f : 0.35f;
+            t.is_jumping = qsel(take, qflag(takeoff_v), qsel(land, zero, t.is_jumping));
+            t.max_flight = qsel(land, flight_upd, t.max_flight);
+            t.max_fwd = qsel(land, fwd_upd, t.max_fwd);
+            t.cum_fwd = qsel(land, t.cum_fwd + qmin(t.max_fwd, V(jump_limit)), t.cum_fwd);
+            t.cum_ft = qsel(land, t.cum_ft + qmin(t.max_flight, V(time_limit)), t.cum_ft);
+        }
+        t.all_air = qsel(take, one, qsel(land, zero, t.all_air));
+        if (cfg.task == QS_TASK_JUMPING_FORWARD_PPO || cfg.task == QS_TASK_JUMPING_FORWARD_PPO_HP) { t.old_fwd = t.actual_fwd; t.actual_fwd = t.max_fwd; }  // robot_tasks.py:418-425
+        if (cfg.task == QS_TASK_BACKFLIP) t.bf_max_pitch = qmax(t.bf_max_pitch, pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched));   // :527-530
+    }
+    static QS_FN V task_terminated(const qs_config& cfg, const Task& t, const typename S::State& s, V n_invalid) {
+        if (cfg.task == QS_TASK_NO_TASK) return V(0.0f);
+        M low = qlt(t.pos[2], V(cfg.fallen_height));                              // task_base.py:123-124
+        M bad = qgt(n_invalid, V(0.5f));                                          // :137-147
+        if (cfg.task == QS_TASK_BACKFLIP) return qflag(qor(low, bad));            // robot_tasks.py:532-533
+        V d = s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw;
+        V r22 = V(1.0f) - (s.qx * s.qx + s.qy * s.qy) * (V(2.0f) / d);
+        return qflag(qor(qand(qlt(r22, V(0.85f)), low), bad));                    // task_base.py:126-135
+    }
+    static QS_FN V task_reward(const qs_config& cfg, const Task& t, V contact_force) {
+        const bool ip = cfg.task == QS_TASK_JUMPING_IN_PLACE_PPO || cfg.task == QS_TASK_JUMPING_IN_PLACE_PPO_HP;
+        const bool fw = cfg.task == QS_TASK_JUMPING_FORWARD_PPO || cfg.task == QS_TASK_JUMPING_FORWARD_PPO_HP;
+        if (!ip && !fw) return V(0.0f);
+        // robot_tasks.py:258-344 / :369-472
+        const float max_h = ip ? (cfg.task == QS_TASK_JUMPING_IN_PLACE_PPO ? 1.0f : 1.25f) : (cfg.task == QS_TASK_JUMPING_FORWARD_PPO ? 0.9f : 1.1f);
+        const float k_h = ip ? 0.023f : 0.026f;
+        V z = t.pos[2];
+        V rew_h = qsel(qor(qlt(z, V(0.29f)), qgt(z, V(max_h))), V(0.0f), z) * k_h;
+        V rew_smooth = qexp(qsqrt(t.dtau2) * (-0.1f)) * 0.015f;
+        V rew_contact = qsel(qgt(contact_force, V(800.0f)), contact_force, V(0.0f)) * (-3e-4f);
+        V rew_pitch = qexp(qabs(t.rpy[1]) * (-26.0f)) * 0.014f;
+        if (ip) {
+            V rew_pos = qexp(qabs(t.pos[0]) * (-40.0f)) * 0.013f;
+            return rew_pos * 0.05f + rew_contact * 0.5f + rew_smooth * 0.2f + rew_h * 0.45f + rew_pitch * 0.3f;
+        }
+        const float max_fwd = cfg.task == QS_TASK_JUMPING_FORWARD_PPO ? 1.3f : 1.4f;
+        V fwd = t.actual_fwd;
+        M drop = qor(qgt(fwd, V(max_fwd)), qand(qle(fwd, t.old_fwd), qge(fwd, t.old_fwd)));
+        V rew_fwd = qsel(drop, V(0.0f), fwd) * 0.038f;
+        return rew_contact * 0.4f + rew_smooth * 0.2f + rew_h * 0.25f + rew_pitch * 0.3f + rew_fwd * 0.4f;
+    }
+    static QS_FN V task_reward_end(const qs_config& cfg, const Task& t, V term, V now) {
+        const V zero = V(0.0f), one = V(1.0f);
+        M alive = qlt(term, V(0.5f));
+        V g = qexp(zero - t.max_pitch * t.max_pitch * (1.0f / (0.15f * 0.15f)));
+        switch (cfg.task) {
+        case QS_TASK_JUMPING_IN_PLACE: {  // robot_tasks.py:31-57
+            V hn = qsel(qgt(t.rel_max_h, V(0.9f)), one, t.rel_max_h * (1.0f / 0.9f));
+            V r = hn * 0.7f + hn * 0.3f * g + hn * 0.05f * qexp(zero - t.max_dx * t.max_dx * (1.0f / 0.05f));
+            return r + qsel(alive, hn * 0.1f, zero - (one + hn * 0.8f) * 0.08f);
+        }
+        case QS_TASK_JUMPING_FORWARD: {   // :70-99
+            V hn = qsel(qgt(t.rel_max_h, V(0.3f)), one, t.rel_max_h * (1.0f / 0.3f));
+            V fn = qsel(qgt(t.max_fwd, V(1.3f)), one, t.max_fwd * (1.0f / 1.3f));
+            V bm = (hn + fn) * 0.5f;
+            V r = hn * 0.25f + fn * hn * 0.5f + hn * 0.25f * g;
+            return r + qsel(alive, bm * 0.1f, zero - (one + bm * 1.2f) * 0.08f);
+        }
+        case QS_TASK_CONT_JUMPING_FORWARD: {  // :112-131
+            V tn = t.cum_ft * (1.0f / 0.15f), dn = t.cum_fwd * (1.0f / 0.5f), bm = (tn + dn) * 0.5f;
+            return tn * 0.25f + dn * 0.5f + tn * 0.25f * g + qsel(alive, bm * 0.1f, zero);
+        }
+        case QS_TASK_CONT_JUMPING_FORWARD2: { // :144-165
+            V tn = qmin(t.max_flight, V(0.35f)) * (1.0f / 0.35f), dn = qmin(t.max_fwd, V(0.5f)) * (1.0f / 0.5f), bm = (tn + dn) * 0.5f;
+            return tn * 0.25f + dn * 0.5f + dn * 0.15f * g + (now * 0.1f) * bm * 0.4f + qsel(alive, bm * 0.2f, zero);
+        }
+        case QS_TASK_JUMPING_IN_PLACE_PPO: case QS_TASK_JUMPING_IN_PLACE_PPO_HP:  // :348-358
+            return qsel(alive, zero, zero - t.max_h * 0.25f);
+        case QS_TASK_JUMPING_FORWARD_PPO: case QS_TASK_JUMPING_FORWARD_PPO_HP:    // :475-485
+            return qsel(alive, (t.max_fwd + t.max_h) * 0.025f, zero);
+        case QS_TASK_BACKFLIP: {              // :535-550
+            V h = clampv<V>(t.max_h - 0.3f, zero, V(0.4f)) * (1.0f / 0.4f);
+            V pm = t.bf_max_pitch * (1.0f / (2.0f * PI));
+            return pm * 0.4f + h * 0.4f + h * pm + qsel(qand(qgt(t.switched, V(0.5f)), alive), V(0.2f), zero);
+        }
+        default: return zero;
+        }
+    }
+    static QS_FN void task_reset(const qs_config& cfg, Task& t, const typename S::State& s, const typename S::Out& o, V now) {  // task_base.py:40-59
+        const V zero = V(0.0f);
+        V keep = t.bf_max_pitch;  // BackFlip.max_pitch is initialised in __init__ only (robot_tasks.py:524)
+        t.switched = zero; t.all_air = zero; t.is_jumping = zero; t.t_takeoff = now;
+        t.pose_to[0] = s.pos.x; t.pose_to[1] = s.pos.y; t.pose_to[2] = s.pos.z; t.init_h = s.pos.z;
+        V r, p, y; quat_to_rpy(s.qx, s.qy, s.qz, s.qw, r, p, y); t.yaw_to = y;
+        t.max_flight = zero; t.max_fwd = zero; t.max_pitch = zero; t.rel_max_h = zero; t.max_dx = zero; t.max_h = zero;
+        t.cum_fwd = zero; t.cum_ft = zero; t.old_fwd = zero; t.actual_fwd = zero; t.bf_max_pitch = keep;
+        task_on_step(cfg, t, s, o, o.tau_pd, now);  // old == new torque at reset
+    }
+
+    // ---- sensors (sensors/robot_sensors.py, sensor.py:46-60) into obs[QS_MAX_OBS] of this environment
+    static QS_FN void write_obs(const qs_config& cfg, float* obs, const typename S::State& s, const typename S::Out& o, const Task& t,
+                                uint32_t env_id, uint32_t total_steps) {
+        int n = 0;
+        V roll, pitch, yaw; quat_to_rpy(s.qx, s.qy, s.qz, s.qw, roll, pitch, yaw);
+        for (int si = 0; si < cfg.n_sensors; si++) {
+            switch (cfg.sensors[si]) {
+            case QS_SENS_JOINT_POS: for (int j = 0; j < 3; j++) T::st_leg(obs, n + j, 3, s.q[j]); n += 12; break;
+            case QS_SENS_JOINT_VEL: for (int j = 0; j < 3; j++) T::st_leg(obs, n + j, 3, s.qd[j]); n += 12; break;
+            case QS_SENS_PITCH: T::st(obs, n++, pitch); break;
+            case QS_SENS_HEIGHT: T::st(obs, n++, s.pos.z); break;
+            case QS_SENS_VEL_Z: T::st(obs, n++, s.vlin.z); break;
+            case QS_SENS_VEL_X: T::st(obs, n++, s.vlin.x); break;
+            case QS_SENS_LANDING: T::st(obs, n++, t.switched); break;
+            case QS_SENS_JUMPING: T::st(obs, n++, t.is_jumping); break;
+            case QS_SENS_PITCH_RATE: {  // quadruped.py:141-170: (R^T w_world)[1]
+                V d = s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw, sc = V(2.0f) / d;
+                V r01 = (s.qx * s.qy - s.qw * s.qz) * sc, r11 = V(1.0f) - (s.qx * s.qx + s.qz * s.qz) * sc, r21 = (s.qy * s.qz + s.qw * s.qx) * sc;
+                T::st(obs, n++, r01 * s.vang.x + r11 * s.vang.y + r21 * s.vang.z);
+                break;
+            }
+            case QS_SENS_BOOL_CONTACT: T::st_leg(obs, n, 1, o.foot_contact); n += 4; break;
+            case QS_SENS_LIN_VEL: T::st(obs, n, s.vlin.x); T::st(obs, n + 1, s.vlin.y); T::st(obs, n + 2, s.vlin.z); n += 3; break;
+            case QS_SENS_ANG_VEL: T::st(obs, n, s.vang.x); T::st(obs, n + 1, s.vang.y); T::st(obs, n + 2, s.vang.z); n += 3; break;
+            case QS_SENS_RPY: T::st(obs, n, roll); T::st(obs, n + 1, pitch); T::st(obs, n + 2, yaw); n += 3; break;
+            case QS_SENS_QUAT: T::st(obs, n, s.qx); T::st(obs, n + 1, s.qy); T::st(obs, n + 2, s.qz); T::st(obs, n + 3, s.qw); n += 4; break;
+            case QS_SENS_FEET_POS: case QS_SENS_FEET_VEL: {  // quadruped.py:440-449
+                V J[9], p[3]; leg_fk(cfg, s.q, J, p);
+                for (int i = 0; i < 3; i++) {
+                    V v = cfg.sensors[si] == QS_SENS_FEET_POS ? p[i] : J[3 * i] * s.qd[0] + J[3 * i + 1] * s.qd[1] + J[3 * i + 2] * s.qd[2];
+                    T::st_leg(obs, n + i, 3, v);
+                }
+                n += 12; break;
+            }
+            case QS_SENS_PITCH_BACKFLIP: T::st(obs, n++, pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched)); break;
+            default: break;
+            }
+        }
+        T::sync();  // the noise pass reads observation entries written by other lanes of the quad
+        if (cfg.noise_enabled) {  // sensor.py:25-32, 46-52: i.i.d. N(0, sigma) resampled at every read
+            for (int blk0 = 0; blk0 * 4 < cfg.obs_dim; blk0 += 4) {
+                V z[4]; Rng<T>::normal4(cfg.seed, env_id, 0u, total_steps, (uint32_t)blk0, z);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {  // element index = 4 * (blk0 + leg) + k ; sigma is zero-padded beyond obs_dim
+                    V sd = T::ld_leg(cfg.obs_noise_std, 4 * blk0 + k, 4);
+                    V cur = T::ld_leg(obs, 4 * blk0 + k, 4);
+                    T::st_leg(obs, 4 * blk0 + k, 4, qsel(qgt(sd, V(0.0f)), cur + sd * z[k], cur));
+                }
+            }
+        }
+    }
+
+    // ---- Butterworth action filter (action_filter.py:110-121) in a form whose DC gain is exactly 1 in float32:
+    //      y = y1 + a2 (y1 - y2) + b0 (x - y1) + b1 (x1 - y1) + b2 (x2 - y1)     [uses 1 + a1 + a2 = b0 + b1 + b2]
+    static QS_FN V filter(const qs_config& cfg, V x, V x1, V x2, V y1, V y2) {
+        const float a2 = (float)cfg.filt_a[2], b0 = (float)cfg.filt_b[0], b1 = (float)cfg.filt_b[1], b2 = (float)cfg.filt_b[2];
+        return y1 + (y1 - y2) * a2 + (x - y1) * b0 + (x1 - y1) * b1 + (x2 - y1) * b2;
+    }
+
+    struct StepOut { V reward, done, trunc; };
+
+    // One env.step(action) (gym_env.py:227-256).  `rec` = this environment's record, `act` = its action row,
+    // `obs` = QS_MAX_OBS floats of staging for its observation.
+    static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id) {
+        typename S::State s; typename S::Par P; typename S::Out o; Task t;
+        load_state(rec, s); load_par(rec, P); load_task(rec, t);
+        const int d = cfg.action_dim;
+        // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
+        V act[15];
+        for (int k = 0; k < 15; k++) act[k] = V(0.0f);
+        if (d == 12) {  // DEFAULT space / raw commands: every lane handles the 3 entries of its own leg
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                V a = T::ld_leg(act_row, j, 3);
+                T::st_leg(rec, R_LAST_ACTION + j, 3, a);
+                if (cfg.enable_filter) {
+                    V x1 = T::ld_leg(rec, R_XHIST + j, 3), x2 = T::ld_leg(rec, R_XHIST + 12 + j, 3), y1 = T::ld_leg(rec, R_YHIST + j, 3), y2 = T::ld_leg(rec, R_YHIST + 12 + j, 3);
+                    V y = filter(cfg, a, x1, x2, y1, y2);
+                    T::st_leg(rec, R_XHIST + 12 + j, 3, x1); T::st_leg(rec, R_XHIST + j, 3, a); T::st_leg(rec, R_YHIST + 12 + j, 3, y1); T::st_leg(rec, R_YHIST + j, 3, y);
+                    a = y;
+                }
+                act[12 + j] = a;
+            }
+        } else {        // SYMMETRIC (6) / SYMMETRIC_NO_HIP (4): the few values are replicated over the quad
+            for (int k = 0; k < d; k++) {
+                V a = T::ld(act_row, k);
+                T::st(rec, R_LAST_ACTION + k, a);
+                if (cfg.enable_filter) {
+                    V x1 = T::ld(rec, R_XHIST + k), x2 = T::ld(rec, R_XHIST + 12 + k), y1 = T::ld(rec, R_YHIST + k), y2 = T::ld(rec, R_YHIST + 12 + k);
+                    V y = filter(cfg, a, x1, x2, y1, y2);
+                    T::st(rec, R_XHIST + 12 + k, x1); T::st(rec, R_XHIST + k, a); T::st(rec, R_YHIST + 12 + k, y1); T::st(rec, R_YHIST + k, y);
+                    a = y;
+                }
+                act[k] = a;
+            }
+        }
+        // _interpolate_actions (gym_env.py:187-205) is the identity in the reference (both "last" actions are overwritten
+        // with the current one at :230/:234 before the substeps run), so there is nothing to do for enable_interp.
+        V cmd[3];
+        action_to_command(cfg, act, cmd);
+        int sim_step = f2i(rec[R_SIM_STEP]), env_step = f2i(rec[R_ENV_STEP]), total = f2i(rec[R_TOTAL_STEPS]);
+        V old_tau[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) old_tau[j] = T::ld_leg(rec, R_NEW_TAU + j, 3);
+        for (int k = 0; k < cfg.action_repeat; k++) {  // gym_env.py:236-237, 207-216
+            V tau[3];
+            S::actuate(cfg, P, s, cmd, o, tau);
+            S::substep(cfg, P, s, tau, o);
+        }
+        sim_step += cfg.action_repeat; env_step += 1; total += 1;
+        V now = V((float)((double)sim_step * cfg.dt));
+        task_on_step(cfg, t, s, o, old_tau, now);
+        V force = T::quad_sum(o.foot_force);
+        V reward = task_reward(cfg, t, force);
+        V term = task_terminated(cfg, t, s, o.n_invalid);
+        bool timeout = sim_step > cfg.max_sim_steps;   // gym_env.py:245
+        V done = timeout ? V(1.0f) : term;
+        reward = reward + qsel(qgt(done, V(0.5f)), task_reward_end(cfg, t, term, now), V(0.0f));  // :250-251
+        StepOut r; r.reward = reward; r.done = done; r.trunc = qsel(qgt(term, V(0.5f)), V(0.0f), done);  // :246
+        store_state(rec, s, o); store_task(rec, t);
+#pragma unroll
+        for (int j = 0; j < 3; j++) T::st_leg(rec, R_NEW_TAU + j, 3, o.tau_pd[j]);
+        T::st(rec, R_SIM_STEP, V(i2f(sim_step))); T::st(rec, R_ENV_STEP, V(i2f(env_step))); T::st(rec, R_TOTAL_STEPS, V(i2f(total)));
+        write_obs(cfg, obs, s, o, t, env_id, (uint32_t)total);
+        return r;
+    }
+
+    // Per-reset parameter draws (env_randomizers/env_randomizer.py), Philox(seed; env, stream 1, episode, block)
+    static QS_FN void randomize(const qs_config& cfg, float* rec, uint32_t env_id, int episode, bool force) {
+        float* p = rec + R_PARAMS;
+        if ((cfg.randomizer_flags & QS_RAND_KEEP) && !force) return;
+        float mu = 1.0f, k[3], b[3], ml[3] = {go1::HIP_M, go1::THIGH_M, go1::CALF_M}, mt = go1::TRUNK_M, mp = 0.0f, rp[3] = {0, 0, 0};
+        for (int j = 0; j < 3; j++) { k[j] = cfg.spring_k[j]; b[j] = cfg.spring_b[j]; }
+        uint32_t r[16];
+        for (int blk = 0; blk < 4; blk++) philox4x32(cfg.seed, env_id, 1u, (uint32_t)episode, (uint32_t)blk, r + 4 * blk);
+        if (cfg.randomizer_flags & QS_RAND_GROUND) mu = 0.5f + 0.5f * u01(r[0]);                       // :287-289
+        if ((cfg.randomizer_flags & QS_RAND_SPRINGS) && cfg.enable_springs)                           // :100-122
+            for (int j = 0; j < 3; j++) {
+                float lo = cfg.spring_k[j] * 0.9f, hi = cfg.spring_k[j] * 1.1f; k[j] = lo + (hi - lo) * u01(r[1 + j]);
+                lo = cfg.spring_b[j] * 0.9f; hi = cfg.spring_b[j] * 1.1f; b[j] = lo + (hi - lo) * u01(r[4 + j]);
+            }
+        if (cfg.randomizer_flags & QS_RAND_MASSES) {                                                  // :56-83
+            float legs = 0, legs0 = 0;
+            for (int j = 0; j < 3; j++) { float m0 = ml[j]; ml[j] = m0 * 0.9f + (m0 * 1.1f - m0 * 0.9f) * u01(r[8 + j]); legs += 4 * ml[j]; legs0 += 4 * m0; }
+            mp = u01(r[7]); rp[0] = -0.1f + 0.2f * u01(r[11]); rp[2] = -0.1f + 0.2f * u01(r[13]);
+            mt = go1::TRUNK_M + legs0 - legs - mp;
+        }
+        T::st(p, P_MU, V(mu));
+        for (int j = 0; j < 3; j++) {
+            T::st(p, P_K + j, V(k[j])); T::st(p, P_B + j, V(b[j])); T::st(p, P_REST + j, V(cfg.spring_rest[j]));
+            T::st(p, P_KP + j, V(cfg.kp[j])); T::st(p, P_KD + j, V(cfg.kd[j])); T::st(p, P_M_LEG + j, V(ml[j])); T::st(p, P_R_PAY + j, V(rp[j]));
+        }
+        T::st(p, P_M_TRUNK, V(mt)); T::st(p, P_M_PAY, V(mp));
+    }
+
+    // env.reset() (gym_env.py:278-297): randomize, spawn (quadruped.py:487-519), settle 2500 substeps toward the init pose
+    // with the sim counter frozen (interface_base.py:182-200), task / sensor / filter reset.
+    static QS_FN void reset(const qs_config& cfg, float* rec, float* obs, uint32_t env_id, bool settle) {
+        int episode = f2i(rec[R_EPISODE]) + 1;
+        int total = f2i(rec[R_TOTAL_STEPS]);
+        typename S::State s; typename S::Out o; Task t;
+        const V zero = V(0.0f);
+        if (settle) {
+            randomize(cfg, rec, env_id, episode, false);
+            T::sync();  // parameters were written by lane 0 of the quad
+            s.pos = mk3<V>(zero, zero, V(0.32f)); s.qx = zero; s.qy = zero; s.qz = zero; s.qw = V(1.0f);
+            s.vlin = mk3<V>(zero, zero, zero); s.vang = mk3<V>(zero, zero, zero);
+            s.q[0] = zero; s.q[1] = V(0.25f * PI); s.q[2] = V(-0.5f * PI);
+            s.qd[0] = zero; s.qd[1] = zero; s.qd[2] = zero; s.warm = zero;
+            typename S::Par P;
+            o.foot_force = zero; o.foot_contact = zero; o.n_invalid = zero;
+            for (int j = 0; j < 3; j++) { o.tau_pd[j] = zero; o.tau_spring[j] = zero; }
+            load_par(rec, P);
+            V cmd[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
+            for (int n = 0; n < cfg.settle_steps; n++) { V tau[3]; S::actuate(cfg, P, s, cmd, o, tau); S::substep(cfg, P, s, tau, o); }
+            store_state(rec, s, o);
+        } else {  // the record already holds a settled state (copied from the pre-settled pool)
+            load_state(rec, s);
+            o.foot_force = T::ld_leg(rec, R_FOOT_FORCE, 1); o.foot_contact = T::ld_leg(rec, R_FOOT_CONTACT, 1); o.n_invalid = T::ld(rec, R_N_INVALID);
+#pragma unroll
+            for (int j = 0; j < 3; j++) { o.tau_pd[j] = T::ld_leg(rec, R_TAU_PD + j, 3); o.tau_spring[j] = T::ld_leg(rec, R_TAU_SPRING + j, 3); }
+        }
+        load_task(rec, t);
+        T::st(rec, R_SIM_STEP, V(i2f(0))); T::st(rec, R_ENV_STEP, V(i2f(0))); T::st(rec, R_EPISODE, V(i2f(episode)));
+        for (int k = 0; k < 12; k++) {  // gym_env.py:325-327, 267-269
+            V a = V(k < cfg.action_dim ? cfg.settle_action[k] : 0.0f);
+            T::st(rec, R_LAST_ACTION + k, a);
+            T::st(rec, R_XHIST + k, a); T::st(rec, R_XHIST + 12 + k, a); T::st(rec, R_YHIST + k, a); T::st(rec, R_YHIST + 12 + k, a);
+        }
+        task_reset(cfg, t, s, o, V(0.0f));
+        store_task(rec, t);
+#pragma unroll
+        for (int j = 0; j < 3; j++) T::st_leg(rec, R_NEW_TAU + j, 3, o.tau_pd[j]);
+        write_obs(cfg, obs, s, o, t, env_id, (uint32_t)total);
+    }
+};
+
+}  // namespace qs

@@ -1,0 +1,402 @@
+// qs_hip.hip -- gfx950 kernels and the C ABI (include/qs_amd.h) of the batched Go1 + PEA simulation step.
+//
+// Launch geometry: one 64-lane wavefront per workgroup = 16 environments (a quad of lanes per environment, one lane
+// per leg).  N = 8192 environments -> 512 single-wave workgroups spread over the 256 CUs; the kernel is a long chain of
+// dependent fp32 VALU work per lane, so the design goal is the shortest per-lane instruction stream, registers instead of
+// memory (everything between the tile load and the tile store lives in VGPRs), and DPP for the 4-lane reductions.
+// HBM traffic: each wave moves its 16 contiguous records (16 x 832 B) HBM -> LDS -> HBM with 16-byte-per-lane coalesced
+// accesses, plus the action / observation / reward rows.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "qs_env.h"
+
+using qs::Env;
+using E = Env<LaneDev>;
+
+#define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC)
+
+// ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
+__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs) {
+    const float4* src = reinterpret_cast<const float4*>(g + (size_t)first_env * QS_REC);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    int nvalid = min(QS_ENVS_PER_WAVE, n_envs - first_env) * (QS_REC / 4);
+    for (int i = threadIdx.x; i < QS_TILE_FLOATS / 4; i += QS_WAVE)
+        dst[i] = i < nvalid ? src[i] : src[i % (QS_REC / 4)];  // tail quads replay the tile's first record (never stored)
+}
+__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs) {
+    float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
+    const float4* src = reinterpret_cast<const float4*>(lds);
+    int nvalid = min(QS_ENVS_PER_WAVE, n_envs - first_env) * (QS_REC / 4);
+    for (int i = threadIdx.x; i < nvalid; i += QS_WAVE) dst[i] = src[i];
+}
+
+struct PoolView { const float* pool; int size; };
+
+// settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
+__device__ __forceinline__ void copy_settled(float* rec, const float* src) {
+    const int lane = threadIdx.x & 3;
+    for (int i = lane; i < R_LAST_ACTION; i += 4) rec[i] = src[i];                       // rigid-body state + warm start
+    for (int i = R_PARAMS + lane; i < R_POSE_CACHE; i += 4) rec[i] = src[i];             // params, contact results, torques
+}
+
+// ------------------------------------------------------------------ kernels
+__global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict__ cfgp, float* __restrict__ recs) {
+    const qs_config& cfg = *cfgp;
+    int env = blockIdx.x * QS_ENVS_PER_WAVE + (threadIdx.x >> 2);
+    if (env >= cfg.n_envs) return;
+    float* r = recs + (size_t)env * QS_REC;
+    for (int i = threadIdx.x & 3; i < QS_REC; i += 4) r[i] = 0.0f;
+    LaneDev::sync();
+    if ((threadIdx.x & 3) == 0) {
+        r[R_EPISODE] = qs::i2f(-1);
+        r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f;
+        for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
+    }
+    E::randomize(cfg, r, (uint32_t)env, -1, true);
+}
+
+// QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
+__global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+                                                     const float* __restrict__ actions, float* __restrict__ obs_out,
+                                                     float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                                     uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
+                                                     float* __restrict__ term_obs, PoolView pool,
+                                                     unsigned long long* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
+    __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
+    const qs_config& cfg = *cfgp;
+    const int first = blockIdx.x * QS_ENVS_PER_WAVE;
+    const int slot = threadIdx.x >> 2;
+    const int env = first + slot;
+    const bool valid = env < cfg.n_envs;
+    const int d = cfg.action_dim, od = cfg.obs_dim;
+    tile_load(s_rec, recs, first, cfg.n_envs);
+    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * d; i += QS_WAVE) {
+        int e = first + i / d;
+        s_act[(i / d) * 12 + (i % d)] = e < cfg.n_envs ? actions[(size_t)first * d + i] : 0.0f;
+    }
+    __syncthreads();
+    float* rec = s_rec + slot * QS_REC;
+    float* ob = s_obs + slot * QS_MAX_OBS;
+    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, (uint32_t)env);
+    const bool dn = r.done > 0.5f;
+    if (valid && (threadIdx.x & 3) == 0) {
+        rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0;
+    }
+    if (cfg.auto_reset) {
+        const bool do_reset = dn && valid;
+        if (__any(do_reset)) {
+            LaneDev::sync();
+            if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
+                for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
+                if ((threadIdx.x & 3) == 0) atomicAdd(&stats[1], 1ull);
+            }
+            if (pool.size > 0) {
+                if (do_reset) {
+                    uint32_t rr[4];
+                    qs::philox4x32(cfg.seed, (uint32_t)env, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
+                    copy_settled(rec, pool.pool + (size_t)(rr[0] % (uint32_t)pool.size) * QS_REC);
+                }
+                LaneDev::sync();
+                if (do_reset) E::reset(cfg, rec, ob, (uint32_t)env, false);
+            } else {
+                // exact mode: the whole wave walks through the 2500-substep settle (lanes of running environments idle)
+                if (do_reset) {
+                    E::reset(cfg, rec, ob, (uint32_t)env, true);
+                    if ((threadIdx.x & 3) == 0) atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    tile_store(s_rec, recs, first, cfg.n_envs);
+    const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
+    for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
+        float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
+        obs_out[(size_t)first * od + i] = v;
+        obs_keep[(size_t)first * od + i] = v;
+    }
+}
+
+// QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297); all settles run side by side.
+__global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ obs_keep,
+                                                      unsigned long long* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
+    const qs_config& cfg = *cfgp;
+    const int first = blockIdx.x * QS_ENVS_PER_WAVE;
+    const int slot = threadIdx.x >> 2, env = first + slot;
+    const bool valid = env < cfg.n_envs;
+    const bool sel = valid && (mask == nullptr || mask[env] != 0);
+    if (!__any(sel)) return;
+    tile_load(s_rec, recs, first, cfg.n_envs);
+    const int od = cfg.obs_dim;
+    __syncthreads();
+    float* rec = s_rec + slot * QS_REC;
+    float* ob = s_obs + slot * QS_MAX_OBS;
+    // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);
+    // quads that are not selected work on their LDS copy and simply do not write it back
+    E::reset(cfg, rec, ob, (uint32_t)(valid ? env : 0), true);
+    if (sel && (threadIdx.x & 3) == 0) { atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps); atomicAdd(&stats[1], 1ull); }
+    __syncthreads();
+    if (sel) {
+        float* g = recs + (size_t)env * QS_REC;
+        for (int i = threadIdx.x & 3; i < QS_REC; i += 4) g[i] = rec[i];
+        for (int i = threadIdx.x & 3; i < od; i += 4) obs_keep[(size_t)env * od + i] = ob[i];
+    }
+}
+
+// Pre-settled reset states: entry p = reset of a virtual environment id 0x40000000 + p (its own parameter draw).
+__global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(const qs_config* __restrict__ cfgp, float* __restrict__ pool, int size, int generation) {
+    __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
+    const qs_config& cfg = *cfgp;
+    const int slot = threadIdx.x >> 2, p = blockIdx.x * QS_ENVS_PER_WAVE + slot;
+    float* rec = s_rec + slot * QS_REC;
+    for (int i = threadIdx.x & 3; i < QS_REC; i += 4) rec[i] = 0.0f;
+    LaneDev::sync();
+    if ((threadIdx.x & 3) == 0) rec[R_EPISODE] = qs::i2f(generation - 1);
+    LaneDev::sync();
+    E::reset(cfg, rec, s_obs + slot * QS_MAX_OBS, 0x40000000u + (uint32_t)p, true);
+    LaneDev::sync();
+    if (p < size) {
+        float* g = pool + (size_t)p * QS_REC;
+        for (int i = threadIdx.x & 3; i < QS_REC; i += 4) g[i] = rec[i];
+    }
+}
+
+__global__ void k_gather(const float* __restrict__ recs, int n, int off, int dim, float* __restrict__ out, int as_int) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    float v = recs[(size_t)(i / dim) * QS_REC + off + i % dim];
+    out[i] = as_int ? (float)qs::f2i(v) : v;
+}
+__global__ void k_scatter(float* __restrict__ recs, int n, int off, int dim, const float* __restrict__ in, int zero_warm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    recs[(size_t)(i / dim) * QS_REC + off + i % dim] = in[i];
+    if (zero_warm && i % dim < 4) recs[(size_t)(i / dim) * QS_REC + R_WARM + i % dim] = 0.0f;
+}
+__global__ void k_task_info(const float* __restrict__ recs, int n, float* __restrict__ out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* r = recs + (size_t)e * QS_REC;
+    float* o = out + (size_t)e * QS_TASK_DIM;
+    for (int k = 0; k < 20; k++) o[k] = r[R_TASK + k];
+    for (int k = 0; k < 9; k++) o[20 + k] = r[R_POSE_CACHE + k];
+    o[29] = r[R_N_INVALID];
+    o[30] = r[R_FOOT_FORCE] + r[R_FOOT_FORCE + 1] + r[R_FOOT_FORCE + 2] + r[R_FOOT_FORCE + 3];
+    o[31] = (float)qs::f2i(r[R_SIM_STEP]);
+}
+
+// ------------------------------------------------------------------ host side of the C ABI
+static thread_local char g_err[512] = "";
+#define QS_FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+#define QS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) QS_FAIL(-2, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+struct qs_handle {
+    qs_config cfg;
+    int device;
+    hipStream_t stream;
+    qs_config* d_cfg;
+    float* d_rec;
+    float* d_obs;       // last observation of every environment [N, obs_dim]
+    float* d_term_obs;  // [N, obs_dim]
+    float* d_pool;
+    int pool_size, pool_generation;
+    unsigned long long* d_stats;
+    hipEvent_t ev0, ev1;
+    int timing;
+};
+
+static int sensor_dim(int s) {
+    switch (s) {
+    case QS_SENS_JOINT_POS: case QS_SENS_JOINT_VEL: case QS_SENS_FEET_POS: case QS_SENS_FEET_VEL: return 12;
+    case QS_SENS_BOOL_CONTACT: case QS_SENS_QUAT: return 4;
+    case QS_SENS_LIN_VEL: case QS_SENS_ANG_VEL: case QS_SENS_RPY: return 3;
+    default: return 1;
+    }
+}
+static int n_waves(int n) { return (n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE; }
+
+extern "C" {
+
+const char* qs_last_error(void) { return g_err; }
+const char* qs_version(void) { return "qs_amd 0.1 (gfx950, quad-per-env)"; }
+
+int qs_create(const qs_config* cfg, int device, qs_handle** out) {
+    if (!cfg || !out) QS_FAIL(-1, "null argument");
+    if (cfg->n_envs <= 0) QS_FAIL(-1, "n_envs must be positive");
+    if (cfg->obs_dim <= 0 || cfg->obs_dim > QS_MAX_OBS || cfg->n_sensors > QS_MAX_SENSORS) QS_FAIL(-1, "observation bundle too large");
+    if (cfg->action_dim != 12 && cfg->action_dim != 6 && cfg->action_dim != 4) QS_FAIL(-1, "action_dim must be 12, 6 or 4");
+    if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
+        QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
+    int od = 0;
+    for (int i = 0; i < cfg->n_sensors; i++) od += sensor_dim(cfg->sensors[i]);
+    if (od != cfg->obs_dim) QS_FAIL(-1, "obs_dim %d does not match the sensor bundle (%d)", cfg->obs_dim, od);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) QS_FAIL(-3, "no HIP device available: this library has no CPU path");
+    if (device < 0 || device >= ndev) QS_FAIL(-3, "HIP device %d out of range (%d visible)", device, ndev);
+    QS_HIP(hipSetDevice(device));
+    qs_handle* h = new (std::nothrow) qs_handle();
+    if (!h) QS_FAIL(-4, "out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg; h->device = device; h->stream = nullptr;
+    const size_t n = (size_t)cfg->n_envs;
+    QS_HIP(hipMalloc(&h->d_cfg, sizeof(qs_config)));
+    QS_HIP(hipMalloc(&h->d_rec, n * QS_REC * sizeof(float)));
+    QS_HIP(hipMalloc(&h->d_obs, n * cfg->obs_dim * sizeof(float)));
+    QS_HIP(hipMalloc(&h->d_term_obs, n * cfg->obs_dim * sizeof(float)));
+    QS_HIP(hipMalloc(&h->d_stats, 2 * sizeof(unsigned long long)));
+    QS_HIP(hipMemcpy(h->d_cfg, &h->cfg, sizeof(qs_config), hipMemcpyHostToDevice));
+    QS_HIP(hipMemset(h->d_obs, 0, n * cfg->obs_dim * sizeof(float)));
+    QS_HIP(hipMemset(h->d_term_obs, 0, n * cfg->obs_dim * sizeof(float)));
+    QS_HIP(hipMemset(h->d_stats, 0, 2 * sizeof(unsigned long long)));
+    QS_HIP(hipEventCreate(&h->ev0));
+    QS_HIP(hipEventCreate(&h->ev1));
+    hipLaunchKernelGGL(k_init, dim3(n_waves(cfg->n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec);
+    QS_HIP(hipGetLastError());
+    h->pool_size = 0;
+    if (cfg->reset_pool > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
+        h->pool_size = cfg->reset_pool;
+        QS_HIP(hipMalloc(&h->d_pool, (size_t)h->pool_size * QS_REC * sizeof(float)));
+        hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, h->pool_size, 0);
+        QS_HIP(hipGetLastError());
+    }
+    QS_HIP(hipStreamSynchronize(h->stream));
+    *out = h;
+    return 0;
+}
+
+void qs_destroy(qs_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
+    if (h->d_pool) hipFree(h->d_pool);
+    hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int qs_set_stream(qs_handle* h, void* s) { if (!h) QS_FAIL(-1, "null handle"); h->stream = (hipStream_t)s; return 0; }
+int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle"); h->timing = on; return 0; }
+
+int qs_reset(qs_handle* h, const uint8_t* mask) {
+    if (!h) QS_FAIL(-1, "null handle");
+    hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
+int qs_get_obs(qs_handle* h, float* obs) {
+    if (!h || !obs) QS_FAIL(-1, "null argument");
+    QS_HIP(hipMemcpyAsync(obs, h->d_obs, (size_t)h->cfg.n_envs * h->cfg.obs_dim * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
+    if (!h || !actions || !obs || !rew || !done || !trunc) QS_FAIL(-1, "null argument");
+    PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
+    if (h->timing) hipEventRecord(h->ev0, h->stream);
+    hipLaunchKernelGGL(k_step, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
+                       h->d_obs, h->d_term_obs, pv, h->d_stats);
+    if (h->timing) hipEventRecord(h->ev1, h->stream);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
+int qs_last_step_kernel_ms(qs_handle* h, float* ms) {
+    if (!h || !ms) QS_FAIL(-1, "null argument");
+    if (!h->timing) QS_FAIL(-1, "timing is off (qs_enable_timing)");
+    QS_HIP(hipEventSynchronize(h->ev1));
+    QS_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+int qs_refresh_pool(qs_handle* h) {  // redraw the pre-settled reset states (new parameter draws)
+    if (!h) QS_FAIL(-1, "null handle");
+    if (h->pool_size <= 0) return 0;
+    h->pool_generation++;
+    hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, h->pool_size, h->pool_generation);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
+static int gather(qs_handle* h, int off, int dim, float* out, int as_int) {
+    int total = h->cfg.n_envs * dim;
+    hipLaunchKernelGGL(k_gather, dim3((total + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, off, dim, out, as_int);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+static int scatter(qs_handle* h, int off, int dim, const float* in, int zero_warm) {
+    int total = h->cfg.n_envs * dim;
+    hipLaunchKernelGGL(k_scatter, dim3((total + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, off, dim, in, zero_warm);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
+int qs_get_state(qs_handle* h, float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); return gather(h, R_POS, QS_STATE_DIM, st, 0); }
+int qs_set_state(qs_handle* h, const float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); return scatter(h, R_POS, QS_STATE_DIM, st, 1); }
+
+int qs_info_dim(const qs_handle* h, int which) {
+    switch (which) {
+    case QS_INFO_FOOT_FORCE: case QS_INFO_FOOT_CONTACT: case QS_INFO_COUNTERS: return 4;
+    case QS_INFO_TORQUE: case QS_INFO_SPRING_TORQUE: case QS_INFO_LAST_ACTION: return 12;
+    case QS_INFO_TASK: return QS_TASK_DIM;
+    case QS_INFO_N_INVALID: return 1;
+    case QS_INFO_PARAMS: return QS_PARAM_DIM;
+    case QS_INFO_TERMINAL_OBS: return h ? h->cfg.obs_dim : -1;
+    default: return -1;
+    }
+}
+
+int qs_get_info(qs_handle* h, int which, float* out) {
+    if (!h || !out) QS_FAIL(-1, "null argument");
+    switch (which) {
+    case QS_INFO_FOOT_FORCE: return gather(h, R_FOOT_FORCE, 4, out, 0);
+    case QS_INFO_FOOT_CONTACT: return gather(h, R_FOOT_CONTACT, 4, out, 0);
+    case QS_INFO_TORQUE: return gather(h, R_TAU_PD, 12, out, 0);
+    case QS_INFO_SPRING_TORQUE: return gather(h, R_TAU_SPRING, 12, out, 0);
+    case QS_INFO_N_INVALID: return gather(h, R_N_INVALID, 1, out, 0);
+    case QS_INFO_PARAMS: return gather(h, R_PARAMS, QS_PARAM_DIM, out, 0);
+    case QS_INFO_COUNTERS: return gather(h, R_SIM_STEP, 4, out, 1);
+    case QS_INFO_LAST_ACTION: return gather(h, R_LAST_ACTION, 12, out, 0);
+    case QS_INFO_TASK:
+        hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out);
+        QS_HIP(hipGetLastError());
+        return 0;
+    case QS_INFO_TERMINAL_OBS:
+        QS_HIP(hipMemcpyAsync(out, h->d_term_obs, (size_t)h->cfg.n_envs * h->cfg.obs_dim * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        return 0;
+    default: QS_FAIL(-1, "unknown info id %d", which);
+    }
+}
+
+int qs_set_params(qs_handle* h, int which, const float* v) {
+    if (!h || !v) QS_FAIL(-1, "null argument");
+    switch (which) {
+    case QS_PARAM_MU: return scatter(h, R_PARAMS + P_MU, 1, v, 0);
+    case QS_PARAM_SPRING_K: return scatter(h, R_PARAMS + P_K, 3, v, 0);
+    case QS_PARAM_SPRING_B: return scatter(h, R_PARAMS + P_B, 3, v, 0);
+    case QS_PARAM_KP: return scatter(h, R_PARAMS + P_KP, 3, v, 0);
+    case QS_PARAM_KD: return scatter(h, R_PARAMS + P_KD, 3, v, 0);
+    case QS_PARAM_ALL: return scatter(h, R_PARAMS, QS_PARAM_DIM, v, 0);
+    default: QS_FAIL(-1, "unknown param id %d", which);
+    }
+}
+
+int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets) {
+    if (!h) QS_FAIL(-1, "null handle");
+    unsigned long long v[2];
+    QS_HIP(hipStreamSynchronize(h->stream));
+    QS_HIP(hipMemcpy(v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+    if (settle_substeps) *settle_substeps = v[0];
+    if (resets) *resets = v[1];
+    return 0;
+}
+
+}  // extern "C"

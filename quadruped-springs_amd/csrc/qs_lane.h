@@ -1,0 +1,130 @@
+// qs_lane.h -- lane abstraction for the quad-per-environment kernels.
+//
+// One environment is simulated by a QUAD of four adjacent lanes of a wavefront, one lane per leg
+// (FR, FL, RR, RL = PyBullet motor order, quadruped.py:586-596); a 64-wide wavefront carries 16 environments.
+// Per-leg quantities are lane-private, base quantities are replicated over the quad, and the only cross-lane
+// traffic is a 4-lane sum / broadcast, which maps onto DPP quad_perm moves (no LDS, no ds_bpermute).
+//
+// The arithmetic in qs_core.h is written once against this abstraction:
+//   LaneDev  : V = float, the real thing (HIP device code)
+//   LaneEmu  : V = V4, a 4-wide value type evaluated on the host in lockstep; used ONLY by tests/ to exercise the
+//              kernel arithmetic without a GPU.  The product library never instantiates it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define QS_FN __host__ __device__ __forceinline__
+#define QS_DEV __device__ __forceinline__
+#else
+#define QS_FN inline
+#endif
+
+// ------------------------------------------------------------------ scalar (device) flavour
+QS_FN float qsqrt(float x) { return sqrtf(x); }
+QS_FN float qabs(float x) { return fabsf(x); }
+QS_FN float qmin(float a, float b) { return fminf(a, b); }
+QS_FN float qmax(float a, float b) { return fmaxf(a, b); }
+QS_FN float qsin(float x) { return sinf(x); }
+QS_FN float qcos(float x) { return cosf(x); }
+QS_FN float qatan2(float y, float x) { return atan2f(y, x); }
+QS_FN float qasin(float x) { return asinf(x); }
+QS_FN float qexp(float x) { return expf(x); }
+QS_FN float qlog(float x) { return logf(x); }
+QS_FN float qsel(bool m, float a, float b) { return m ? a : b; }
+QS_FN bool qlt(float a, float b) { return a < b; }
+QS_FN bool qgt(float a, float b) { return a > b; }
+QS_FN bool qle(float a, float b) { return a <= b; }
+QS_FN bool qge(float a, float b) { return a >= b; }
+QS_FN bool qand(bool a, bool b) { return a && b; }
+QS_FN bool qor(bool a, bool b) { return a || b; }
+QS_FN bool qnot(bool a) { return !a; }
+QS_FN float qflag(bool m) { return m ? 1.0f : 0.0f; }
+
+#if defined(__HIPCC__)
+struct LaneDev {
+    using V = float;
+    using M = bool;
+    // quad_perm DPP controls: xor1 = [1,0,3,2] = 0xB1, xor2 = [2,3,0,1] = 0x4E, broadcast k = k*0x55
+    template <int CTRL> static QS_DEV float dpp(float x) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+    }
+    static QS_DEV float quad_sum(float x) {
+        x += dpp<0xB1>(x);
+        x += dpp<0x4E>(x);
+        return x;
+    }
+    template <int K> static QS_DEV float bcast(float x) { return dpp<K * 0x55>(x); }
+    static QS_DEV int leg() { return (int)(threadIdx.x & 3u); }
+    static QS_DEV float fx() { return (threadIdx.x & 2u) ? -1.0f : 1.0f; }  // front +, rear -
+    static QS_DEV float sy() { return (threadIdx.x & 1u) ? 1.0f : -1.0f; }  // right -, left +
+    static QS_DEV bool is_leg(int k) { return (int)(threadIdx.x & 3u) == k; }
+    static QS_DEV bool any(bool m) { return __any(m); }                     // wave-uniform vote (16 environments)
+    static QS_DEV float ld_leg(const float* rec, int base, int stride) { return rec[base + stride * (int)(threadIdx.x & 3u)]; }
+    static QS_DEV void st_leg(float* rec, int base, int stride, float v) { rec[base + stride * (int)(threadIdx.x & 3u)] = v; }
+    static QS_DEV float ld(const float* rec, int i) { return rec[i]; }
+    static QS_DEV void st(float* rec, int i, float v) { if ((threadIdx.x & 3u) == 0) rec[i] = v; }
+    static QS_DEV float first(float x) { return x; }
+    // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
+    static QS_DEV void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+#endif
+
+// ------------------------------------------------------------------ 4-wide host emulation (tests only)
+#if !defined(__HIP_DEVICE_COMPILE__)
+struct V4 {
+    float v[4];
+    V4() : v{0, 0, 0, 0} {}
+    V4(float a) : v{a, a, a, a} {}
+    V4(float a, float b, float c, float d) : v{a, b, c, d} {}
+};
+struct M4 { bool v[4]; };
+#define QS_V4_BIN(op)                                                                                          \
+    inline V4 operator op(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; } \
+    inline V4 operator op(V4 a, float b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b; return r; }   \
+    inline V4 operator op(float a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = a op b.v[i]; return r; }
+QS_V4_BIN(+) QS_V4_BIN(-) QS_V4_BIN(*) QS_V4_BIN(/)
+inline V4 operator-(V4 a) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = -a.v[i]; return r; }
+inline V4& operator+=(V4& a, V4 b) { a = a + b; return a; }
+inline V4& operator-=(V4& a, V4 b) { a = a - b; return a; }
+inline V4& operator*=(V4& a, V4 b) { a = a * b; return a; }
+#define QS_V4_FN1(name, f) inline V4 name(V4 a) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = f(a.v[i]); return r; }
+QS_V4_FN1(qsqrt, sqrtf) QS_V4_FN1(qabs, fabsf) QS_V4_FN1(qsin, sinf) QS_V4_FN1(qcos, cosf) QS_V4_FN1(qasin, asinf)
+QS_V4_FN1(qexp, expf) QS_V4_FN1(qlog, logf)
+inline V4 qmin(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
+inline V4 qmax(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }
+inline V4 qatan2(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = atan2f(a.v[i], b.v[i]); return r; }
+inline V4 qsel(M4 m, V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+#define QS_V4_CMP(name, op) inline M4 name(V4 a, V4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
+QS_V4_CMP(qlt, <) QS_V4_CMP(qgt, >) QS_V4_CMP(qle, <=) QS_V4_CMP(qge, >=)
+inline M4 qand(M4 a, M4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline M4 qor(M4 a, M4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline M4 qnot(M4 a) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
+inline V4 qflag(M4 m) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? 1.0f : 0.0f; return r; }
+
+struct LaneEmu {
+    using V = V4;
+    using M = M4;
+    static V4 quad_sum(V4 x) {  // same association as the DPP butterfly: (l ^ 1) first, then (l ^ 2)
+        V4 t, r;
+        for (int i = 0; i < 4; i++) t.v[i] = x.v[i] + x.v[i ^ 1];
+        for (int i = 0; i < 4; i++) r.v[i] = t.v[i] + t.v[i ^ 2];
+        return r;
+    }
+    template <int K> static V4 bcast(V4 x) { return V4(x.v[K]); }
+    static V4 fx() { return V4(1, 1, -1, -1); }
+    static V4 sy() { return V4(-1, 1, -1, 1); }
+    static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
+    static bool any(M4 m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
+    static V4 ld_leg(const float* rec, int base, int stride) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = rec[base + stride * i]; return r; }
+    static void st_leg(float* rec, int base, int stride, V4 v) { for (int i = 0; i < 4; i++) rec[base + stride * i] = v.v[i]; }
+    static V4 ld(const float* rec, int i) { return V4(rec[i]); }
+    static void st(float* rec, int i, V4 v) { rec[i] = v.v[0]; }
+    static float first(V4 x) { return x.v[0]; }
+    static void sync() {}
+};
+#endif

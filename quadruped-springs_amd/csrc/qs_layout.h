@@ -1,0 +1,36 @@
+// qs_layout.h -- persistent per-environment record (env-major: records[N][QS_REC] float32 in HBM).
+//
+// A wavefront owns 16 consecutive environments = 16*QS_REC contiguous floats (12 KiB), which it moves HBM <-> LDS with
+// fully coalesced 16-byte-per-lane loads/stores at kernel entry/exit; the lanes then pick their fields out of LDS.
+// Fields mirror the state the reference carries between env.step() calls.
+#pragma once
+
+enum {
+    // rigid-body state, same order as qs_get_state rows (quadruped.py:107-207)
+    R_POS = 0, R_QUAT = 3, R_VLIN = 7, R_VANG = 10, R_Q = 13, R_QD = 25,
+    R_WARM = 37,          // 4: normal impulse of each foot at the previous substep (contact warm start)
+    R_LAST_ACTION = 41,   // 12: gym_env.py:230,284
+    R_XHIST = 53,         // 2 x 12: action_filter.py:98-108 (row 0 newest)
+    R_YHIST = 77,         // 2 x 12
+    R_SIM_STEP = 101, R_ENV_STEP = 102, R_EPISODE = 103, R_TOTAL_STEPS = 104,  // integers stored as float bit patterns
+    // task scalars (task_base.py:44-59, 228-233; robot_tasks.py:418-425, 524-530), order of QS_INFO_TASK
+    R_TASK = 105,         // 20: switched, all_air, is_jumping, t_takeoff, pose_to[3], yaw_to, init_h, max_flight, max_fwd,
+                          //     max_pitch, rel_max_h, max_dx, max_h, cum_fwd, cum_ft, old_fwd, actual_fwd, bf_max_pitch
+    R_NEW_TAU = 125,      // 12: task._new_torque
+    R_PARAMS = 137,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
+    R_FOOT_FORCE = 161,   // 4
+    R_FOOT_CONTACT = 165, // 4
+    R_N_INVALID = 169,
+    R_TAU_PD = 170,       // 12: observed motor torque of the last substep (quadruped.py:299)
+    R_TAU_SPRING = 182,   // 12
+    R_POSE_CACHE = 194,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
+    R_FLAGS = 203,        // bit 0: needs reset
+    QS_REC = 208,         // multiple of 4 (16-byte vector moves)
+};
+enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };
+enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO = 4, T_YAW_TO = 7, T_INIT_H = 8, T_MAX_FLIGHT = 9,
+       T_MAX_FWD = 10, T_MAX_PITCH = 11, T_REL_MAX_H = 12, T_MAX_DX = 13, T_MAX_H = 14, T_CUM_FWD = 15, T_CUM_FT = 16,
+       T_OLD_FWD = 17, T_ACTUAL_FWD = 18, T_BF_MAX_PITCH = 19 };
+
+#define QS_ENVS_PER_WAVE 16
+#define QS_WAVE 64

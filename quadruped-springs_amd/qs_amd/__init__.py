@@ -1,1 +1,14 @@
-"""MI355X-native batched Go1 + PEA simulation step behind the QuadrupedGymEnv / VecEnv API."""
+"""MI355X-native batched Go1 + PEA simulation step behind the QuadrupedGymEnv / VecEnv API of
+francescovezzi/quadruped-springs.  The step itself is hand-written HIP (csrc/), reached through the C ABI of
+include/qs_amd.h; there is no CPU path."""
+from .config import build_config  # noqa: F401
+
+
+def __getattr__(name):  # lazy: importing the package must not need torch / a GPU
+    if name == "QuadrupedVecEnv":
+        from .vec_env import QuadrupedVecEnv
+        return QuadrupedVecEnv
+    if name == "QuadrupedGymEnv":
+        from .env.quadruped_gym_env import QuadrupedGymEnv
+        return QuadrupedGymEnv
+    raise AttributeError(name)

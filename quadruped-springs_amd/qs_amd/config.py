@@ -95,7 +95,7 @@ class QsConfig(C.Structure):
         ("obs_dim", C.c_int32), ("enable_springs", C.c_int32), ("enable_filter", C.c_int32),
         ("enable_interp", C.c_int32), ("action_repeat", C.c_int32), ("solver_iters", C.c_int32),
         ("settle_steps", C.c_int32), ("max_sim_steps", C.c_int32), ("randomizer_flags", C.c_int32),
-        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reserved_i", C.c_int32 * 3),
+        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_pool", C.c_int32), ("reserved_i", C.c_int32 * 2),
         ("seed", C.c_uint64), ("dt", C.c_double), ("filt_b", C.c_double * 3), ("filt_a", C.c_double * 3), ("gravity", C.c_float),
         ("kp", C.c_float * 3), ("kd", C.c_float * 3), ("tau_max", C.c_float * 3),
         ("cmd_lo", C.c_float * 12), ("cmd_hi", C.c_float * 12),
@@ -216,6 +216,11 @@ def build_config(
     motor_id = _lookup(MOTOR_CONTROL_MODES, motor_control_mode, "motor control mode")
     task_id = _lookup(TASKS, task_env, "task")
     rand = _lookup(RANDOMIZERS, env_randomizer_mode, "env randomizer")
+    if motor_control_mode == "PD" and task_env == "BACKFLIP":
+        # motor_interface.py:17-22 mutates the config arrays in place BEFORE the sensors read their limits
+        # (gym_env.py:119 precedes :127), so the JointPosition limits widen as well
+        for i in (7, 10):
+            rc.RL_UPPER_ANGLE_JOINT[i] = math.pi / 2
     lay = sensor_layout(rc, observation_space_mode)
 
     cfg = QsConfig()
@@ -225,9 +230,6 @@ def build_config(
         cfg.action_dim = action_dim = 12  # raw motor commands (gym_env.py:212-214)
     # limits and poses (motor_interface.py:9-32, :50-63, :94-100)
     if motor_control_mode == "PD":
-        if task_env == "BACKFLIP":  # motor_interface.py:17-22 mutates the config arrays in place
-            for i in (7, 10):
-                rc.RL_UPPER_ANGLE_JOINT[i] = math.pi / 2
         lo, hi, symm = rc.RL_LOWER_ANGLE_JOINT, rc.RL_UPPER_ANGLE_JOINT, 0
         init_pose, landing_pose = rc.INIT_MOTOR_ANGLES, rc.ANGLE_LANDING_POSE
     elif motor_control_mode == "CARTESIAN_PD":

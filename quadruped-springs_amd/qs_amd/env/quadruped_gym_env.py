@@ -1,0 +1,251 @@
+"""QuadrupedGymEnv: the reference's gym.Env surface (quadruped_spring/env/quadruped_gym_env.py:41-436) as an N = 1
+view over the batched device step.  Same constructor keywords, same 4-tuple step / old-gym reset, same getters."""
+import numpy as np
+
+from ..config import EPISODE_LENGTH
+from ..kinematics import leg_fk_jacobian, leg_ik
+from ..spaces import GymEnv
+from ..vec_env import QuadrupedVecEnv
+
+ACTION_EPS = 0.01
+OBSERVATION_EPS = 0.01
+
+
+class _RobotView:
+    """State getters of quadruped.py:107-262, 348-449 on the single environment."""
+
+    def __init__(self, env):
+        self._env = env
+        self._robot_config = env._robot_config
+
+    def _state(self):
+        return self._env._vec.get_state()[0].cpu().numpy().astype(np.float64)
+
+    def GetBasePosition(self):
+        return tuple(self._state()[0:3])
+
+    def GetBaseOrientation(self):
+        return tuple(self._state()[3:7])
+
+    def GetBaseLinearVelocity(self):
+        return self._state()[7:10]
+
+    def GetBaseAngularVelocity(self):
+        return self._state()[10:13]
+
+    def GetMotorAngles(self):
+        return self._state()[13:25]
+
+    def GetMotorVelocities(self):
+        return self._state()[25:37]
+
+    def GetMotorTorques(self):
+        return self._env._vec.get_info("torque")[0].cpu().numpy().astype(np.float64)
+
+    def GetBaseOrientationRollPitchYaw(self):
+        return self._env._vec.get_info("task")[0, 26:29].cpu().numpy().astype(np.float64)
+
+    def GetContactInfo(self):
+        force = self._env._vec.get_info("foot_force")[0].cpu().numpy()
+        flag = self._env._vec.get_info("foot_contact")[0].cpu().numpy()
+        n_invalid = int(self._env._vec.get_info("n_invalid")[0, 0].item())
+        return int(flag.sum()), n_invalid, list(force.astype(float)), [int(f) for f in flag]
+
+    def _is_flying(self):
+        return not any(self.GetContactInfo()[3])
+
+    def ComputeJacobianAndPosition(self, legID):
+        return leg_fk_jacobian(self._robot_config, self.GetMotorAngles(), legID)
+
+    def ComputeInverseKinematics(self, legID, xyz_coord):
+        return leg_ik(self._robot_config, legID, xyz_coord)
+
+    def ComputeFeetPosAndVel(self):
+        q, dq = self.GetMotorAngles(), self.GetMotorVelocities()
+        pos, vel = np.zeros(12), np.zeros(12)
+        for i in range(4):
+            J, xyz = leg_fk_jacobian(self._robot_config, q, i)
+            pos[3 * i:3 * i + 3] = xyz
+            vel[3 * i:3 * i + 3] = J @ dq[3 * i:3 * i + 3]
+        return pos, vel
+
+    def get_spring_nominal_params(self):
+        c = self._robot_config
+        return c.SPRINGS_STIFFNESS, c.SPRINGS_DAMPING, c.SPRINGS_REST_ANGLE
+
+    def set_spring_stiffness(self, k):
+        self._env._vec.set_params("spring_k", np.asarray(k, np.float32)[None])
+
+    def set_spring_damping(self, b):
+        self._env._vec.set_params("spring_b", np.asarray(b, np.float32)[None])
+
+
+class _TaskView:
+    def __init__(self, env):
+        self._env = env
+
+    def _scalars(self):
+        return self._env._vec.get_info("task")[0].cpu().numpy()
+
+    @property
+    def _switched_controller(self):
+        return bool(self._scalars()[0] > 0.5)
+
+    def is_switched_controller(self):
+        return self._switched_controller
+
+    @property
+    def _max_height(self):
+        return float(self._scalars()[14])
+
+    @property
+    def _relative_max_height(self):
+        return float(self._scalars()[12])
+
+    @property
+    def _max_forward_distance(self):
+        return float(self._scalars()[10])
+
+
+class QuadrupedGymEnv(GymEnv):
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(
+        self,
+        isRLGymInterface=True,
+        time_step=0.001,
+        action_repeat=10,
+        motor_control_mode="PD",
+        task_env="NO_TASK",
+        observation_space_mode="ENCODER",
+        action_space_mode="SYMMETRIC",
+        on_rack=False,
+        render=False,
+        enable_springs=False,
+        enable_action_interpolation=False,
+        enable_action_filter=False,
+        env_randomizer_mode="GROUND_RANDOMIZER",
+        camera_mode="CLASSIC",
+        curriculum_level=0.0,
+        verbose=0,
+        device=0,
+        seed=0,
+    ):
+        if on_rack or render:
+            raise NotImplementedError("on_rack / render need the PyBullet GUI path, which this build does not provide")
+        self.verbose = verbose
+        self._vec = QuadrupedVecEnv(
+            num_envs=1, device=device, auto_reset=False, isRLGymInterface=isRLGymInterface, time_step=time_step,
+            action_repeat=action_repeat, motor_control_mode=motor_control_mode, task_env=task_env,
+            observation_space_mode=observation_space_mode, action_space_mode=action_space_mode, enable_springs=enable_springs,
+            enable_action_interpolation=enable_action_interpolation, enable_action_filter=enable_action_filter,
+            env_randomizer_mode=env_randomizer_mode, seed=seed)
+        meta = self._vec.meta
+        self._robot_config = meta["robot_config"]
+        self._enable_springs = enable_springs
+        self._isRLGymInterface = isRLGymInterface
+        self.sim_time_step = time_step
+        self._action_repeat = action_repeat
+        self.env_time_step = action_repeat * time_step
+        self._enable_action_filter = enable_action_filter
+        self._enable_action_interpolation = enable_action_interpolation
+        self._num_bullet_solver_iterations = int(300 / action_repeat)
+        self._MAX_EP_LEN = EPISODE_LENGTH
+        self._settling_steps = 2500
+        self.task_env = task_env
+        self._motor_control_mode = motor_control_mode
+        self._action_space_mode = action_space_mode
+        self._observation_space_mode = observation_space_mode
+        self._env_randomizer_mode = env_randomizer_mode
+        self.curriculum_level = curriculum_level
+        self.action_dim = self._vec.action_dim
+        self.action_space = self._vec.action_space
+        self.observation_space = self._vec.observation_space
+        self.robot = _RobotView(self)
+        self.task = _TaskView(self)
+        self._keys, self._dims = meta["layout"]["keys"], meta["layout"]["dims"]
+        self._last_action = np.zeros(self.action_dim)
+        self._settling_action = meta["settle_action"]
+        self.sub_step_callback = None
+        if self.verbose > 0:
+            self.print_info()
+
+    def _as_dict(self, flat):
+        obs, n = {}, 0
+        for k, d in zip(self._keys, self._dims):  # sensor.py:107-111
+            obs[k] = flat[n:n + d].astype(np.float64)
+            n += d
+        return obs
+
+    def reset(self):
+        flat = self._vec.reset()[0]
+        self._last_action = np.asarray(self._settling_action, float)
+        return self._as_dict(flat)
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32).reshape(1, self.action_dim)
+        self._last_action = a[0].astype(np.float64).copy()
+        obs, rew, done, infos = self._vec.step(a)
+        info = {}
+        if done[0]:
+            info["TimeLimit.truncated"] = infos[0]["TimeLimit.truncated"]
+        return self._as_dict(obs[0]), float(rew[0]), bool(done[0]), info
+
+    def render(self, mode="rgb_array"):
+        return None
+
+    def close(self):
+        self._vec.close()
+
+    # ---- getters used by the reference's wrappers (gym_env.py:343-426)
+    def get_observation(self):
+        import ctypes as C
+        from .. import lib as _lib
+        out = self._vec.torch.empty((1, self._vec.obs_dim), dtype=self._vec.torch.float32, device=self._vec.device)
+        _lib.check(self._vec.lib.qs_get_obs(self._vec.h, C.c_void_p(out.data_ptr())))
+        return self._as_dict(out[0].cpu().numpy())
+
+    def get_sim_time(self):
+        return float(self._vec.get_info("counters")[0, 0].item()) * self.sim_time_step
+
+    def get_motor_control_mode(self):
+        return self._motor_control_mode
+
+    def get_robot_config(self):
+        return self._robot_config
+
+    def are_springs_enabled(self):
+        return self._enable_springs
+
+    def get_init_pose(self):
+        return self._vec.meta["init_pose"]
+
+    def get_settling_action(self):
+        return self._settling_action
+
+    def get_landing_action(self):
+        return self._vec.meta["landing_action"]
+
+    def get_last_action(self):
+        return self._last_action
+
+    def get_observation_space_mode(self):
+        return self._observation_space_mode
+
+    def get_curriculum_level(self):
+        return self.curriculum_level
+
+    def get_randomizer_mode(self):
+        return self._env_randomizer_mode
+
+    def set_sub_step_callback(self, callback):
+        self.sub_step_callback = callback  # substeps are fused on the device; the callback is kept but never fired
+
+    def print_info(self):
+        print("\n*** Environment Info ***")
+        print(f"task environment -> {self.task_env}")
+        print(f"spring enabled -> {self._enable_springs}")
+        print(f"low-pass action filter > {self._enable_action_filter}")
+        print(f"sensors -> {self._observation_space_mode}")
+        print(f"env randomizer -> {self._env_randomizer_mode}")
+        print("")

@@ -1,0 +1,54 @@
+"""ctypes binding of the C ABI declared in include/qs_amd.h (libqs_hip.so, built by quadruped-springs_amd/build.py).
+
+There is no CPU path: if the library is missing or no HIP device is usable this module raises."""
+import ctypes as C
+import os
+
+from .config import QsConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqs_hip.so")
+
+EXPORTS = (
+    "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_get_obs", "qs_step", "qs_get_state", "qs_set_state",
+    "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
+    "qs_refresh_pool", "qs_last_error", "qs_version",
+)
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python quadruped-springs_amd/build.py` (needs hipcc). "
+                           "The simulation step has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    lib.qs_create.argtypes = [C.POINTER(QsConfig), i32, C.POINTER(vp)]
+    lib.qs_destroy.argtypes = [vp]
+    lib.qs_destroy.restype = None
+    lib.qs_set_stream.argtypes = [vp, vp]
+    lib.qs_reset.argtypes = [vp, vp]
+    lib.qs_get_obs.argtypes = [vp, vp]
+    lib.qs_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.qs_get_state.argtypes = [vp, vp]
+    lib.qs_set_state.argtypes = [vp, vp]
+    lib.qs_info_dim.argtypes = [vp, i32]
+    lib.qs_get_info.argtypes = [vp, i32, vp]
+    lib.qs_set_params.argtypes = [vp, i32, vp]
+    lib.qs_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.qs_enable_timing.argtypes = [vp, i32]
+    lib.qs_last_step_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.qs_refresh_pool.argtypes = [vp]
+    lib.qs_last_error.restype = C.c_char_p
+    lib.qs_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("qs_amd: " + load().qs_last_error().decode())

@@ -1,0 +1,181 @@
+"""QuadrupedVecEnv: N Go1 environments advanced by one HIP kernel launch per step.
+
+Duck-types stable_baselines3.common.vec_env.VecEnv as the reference's consumer uses it (load_model.py:109-137:
+num_envs, observation_space, action_space, reset, step_async/step_wait/step, auto-reset with
+infos[i]["terminal_observation"] and infos[i]["TimeLimit.truncated"], get_attr/set_attr/env_method/env_is_wrapped, seed).
+State lives on the GPU; `step_tensor` keeps actions / observations there for on-device learners."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .config import OBSERVATION_EPS, build_config
+from .spaces import Box, SB3VecEnv
+
+INFO = dict(foot_force=0, foot_contact=1, torque=2, spring_torque=3, task=4, n_invalid=5, params=6, counters=7,
+            last_action=8, terminal_obs=9)
+PARAM = dict(mu=0, spring_k=1, spring_b=2, kp=3, kd=4, all=5)
+
+
+class QuadrupedVecEnv(SB3VecEnv):
+    def __init__(self, num_envs=1, device=0, auto_reset=True, reset_pool=0, **env_kwargs):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("QuadrupedVecEnv needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.torch = torch
+        self.lib = _lib.load()
+        self.cfg, self.meta = build_config(n_envs=num_envs, auto_reset=auto_reset, **env_kwargs)
+        self.cfg.reset_pool = int(reset_pool)
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", device)
+        lay = self.meta["layout"]
+        self.observation_space = Box(lay["low"] - OBSERVATION_EPS, lay["high"] + OBSERVATION_EPS, dtype=np.float32)  # gym_env.py:160-164
+        d = self.cfg.action_dim
+        self.action_space = Box(-np.ones(d), np.ones(d), dtype=np.float32)                                       # gym_env.py:179-182
+        self.action_dim, self.obs_dim = d, self.cfg.obs_dim
+        self.h = C.c_void_p()
+        _lib.check(self.lib.qs_create(C.byref(self.cfg), device, C.byref(self.h)))
+        n, o = self.num_envs, self.obs_dim
+        with torch.cuda.device(self.device):
+            self._obs = torch.zeros((n, o), dtype=torch.float32, device=self.device)
+            self._rew = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._trunc = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._act = torch.zeros((n, d), dtype=torch.float32, device=self.device)
+        self._actions = None
+        self._closed = False
+        self.render_mode = None
+
+    # ---- plumbing
+    def _stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.qs_set_stream(self.h, C.c_void_p(s)))
+
+    def _ptr(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def close(self):
+        if not self._closed and self.h:
+            self.lib.qs_destroy(self.h)
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- device-resident API
+    def reset_tensor(self, mask=None):
+        self._stream()
+        m = None
+        if mask is not None:
+            m = self.torch.as_tensor(mask, device=self.device).to(self.torch.uint8).contiguous()
+        _lib.check(self.lib.qs_reset(self.h, None if m is None else self._ptr(m)))
+        _lib.check(self.lib.qs_get_obs(self.h, self._ptr(self._obs)))
+        return self._obs
+
+    def step_tensor(self, actions):
+        """actions: float32 CUDA tensor [N, action_dim] -> (obs, rew, done, truncated) CUDA tensors (reused buffers)."""
+        a = actions
+        if a.dtype != self.torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=self.torch.float32).contiguous()
+        if a.shape != (self.num_envs, self.action_dim):
+            raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
+        self._stream()
+        _lib.check(self.lib.qs_step(self.h, self._ptr(a), self._ptr(self._obs), self._ptr(self._rew), self._ptr(self._done), self._ptr(self._trunc)))
+        return self._obs, self._rew, self._done, self._trunc
+
+    def get_state(self):
+        out = self.torch.empty((self.num_envs, 37), dtype=self.torch.float32, device=self.device)
+        self._stream()
+        _lib.check(self.lib.qs_get_state(self.h, self._ptr(out)))
+        return out
+
+    def set_state(self, state):
+        s = self.torch.as_tensor(state, dtype=self.torch.float32, device=self.device).contiguous().reshape(self.num_envs, 37)
+        self._stream()
+        _lib.check(self.lib.qs_set_state(self.h, self._ptr(s)))
+
+    def get_info(self, which):
+        k = INFO[which] if isinstance(which, str) else int(which)
+        dim = self.lib.qs_info_dim(self.h, k)
+        out = self.torch.empty((self.num_envs, dim), dtype=self.torch.float32, device=self.device)
+        self._stream()
+        _lib.check(self.lib.qs_get_info(self.h, k, self._ptr(out)))
+        return out
+
+    def set_params(self, which, values):
+        k = PARAM[which] if isinstance(which, str) else int(which)
+        v = self.torch.as_tensor(values, dtype=self.torch.float32, device=self.device).contiguous()
+        self._stream()
+        _lib.check(self.lib.qs_set_params(self.h, k, self._ptr(v)))
+        self.torch.cuda.current_stream(self.device).synchronize()  # `v` may be a temporary
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.qs_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(settle_substeps=a.value, resets=b.value)
+
+    def enable_timing(self, on=True):
+        _lib.check(self.lib.qs_enable_timing(self.h, int(on)))
+
+    def last_step_kernel_ms(self):
+        ms = C.c_float()
+        _lib.check(self.lib.qs_last_step_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def refresh_pool(self):
+        self._stream()
+        _lib.check(self.lib.qs_refresh_pool(self.h))
+
+    # ---- SB3 VecEnv surface (numpy)
+    def reset(self):
+        return self.reset_tensor().cpu().numpy().copy()
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.action_dim)
+
+    def step_wait(self):
+        self._act.copy_(self.torch.from_numpy(self._actions))
+        obs, rew, done, trunc = self.step_tensor(self._act)
+        obs, rew = obs.cpu().numpy().copy(), rew.cpu().numpy().copy()
+        done, trunc = done.cpu().numpy().astype(bool), trunc.cpu().numpy().astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        if done.any():
+            term = self.get_info("terminal_obs").cpu().numpy() if self.cfg.auto_reset else obs
+            for i in np.nonzero(done)[0]:
+                infos[i]["TimeLimit.truncated"] = bool(trunc[i])  # gym_env.py:246
+                infos[i]["terminal_observation"] = term[i].copy()
+        return obs, rew, done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def seed(self, seed=None):
+        return [None] * self.num_envs  # randomness is counter based: fixed by the `seed` keyword at construction
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self, attr_name)] * len(self._indices(indices))
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self, method_name)(*args, **kwargs)] * len(self._indices(indices))
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(self._indices(indices))
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode="rgb_array"):
+        return None
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        return [indices] if isinstance(indices, int) else list(indices)

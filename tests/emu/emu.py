@@ -1,0 +1,79 @@
+"""ctypes driver for the TEST-ONLY host emulation of the kernel arithmetic (tests/emu/qs_emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(os.path.dirname(_HERE))
+_SO = os.path.join(_HERE, "libqs_emu.so")
+_SRC = [os.path.join(_HERE, "qs_emu.cpp")] + [os.path.join(_REPO, "quadruped-springs_amd", "csrc", f)
+                                             for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h")] + \
+       [os.path.join(_REPO, "include", "qs_amd.h")]
+
+
+def build():
+    if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRC):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-ffp-contract=off",
+                               "-I" + os.path.join(_REPO, "include"), "-o", _SO, _SRC[0]])
+    return _SO
+
+
+class Emu:
+    def __init__(self, cfg):
+        self.lib = C.CDLL(build())
+        self.lib.qse_create.restype = C.c_void_p
+        self.lib.qse_records.restype = C.POINTER(C.c_float)
+        self.cfg = cfg
+        self.n, self.d, self.o = cfg.n_envs, cfg.action_dim, cfg.obs_dim
+        self.h = C.c_void_p(self.lib.qse_create(C.byref(cfg)))
+        self.rec_size = self.lib.qse_rec_size()
+
+    def _p(self, a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def field(self, name):
+        return self.lib.qse_field(name.encode())
+
+    def records(self):
+        return np.ctypeslib.as_array(self.lib.qse_records(self.h), shape=(self.n, self.rec_size))
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.lib.qse_reset(self.h, None if m is None else self._p(m))
+        return self.get_obs()
+
+    def get_obs(self):
+        obs = np.zeros((self.n, self.o), np.float32)
+        self.lib.qse_get_obs(self.h, self._p(obs))
+        return obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.n, self.d)
+        obs = np.zeros((self.n, self.o), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        done = np.zeros(self.n, np.uint8)
+        trunc = np.zeros(self.n, np.uint8)
+        self.lib.qse_step(self.h, self._p(a), self._p(obs), self._p(rew), self._p(done), self._p(trunc))
+        return obs, rew, done.astype(bool), trunc.astype(bool)
+
+    def get_state(self):
+        s = np.zeros((self.n, 37), np.float32)
+        self.lib.qse_get_state(self.h, self._p(s))
+        return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, np.float32).reshape(self.n, 37)
+        self.lib.qse_set_state(self.h, self._p(s))
+
+    def phys_step(self, env, tau):
+        t = np.ascontiguousarray(tau, np.float32)
+        self.lib.qse_phys_step(self.h, env, self._p(t))
+
+    def get(self, name, dim):
+        f = self.field(name)
+        return self.records()[:, f:f + dim].copy()
+
+    def set_mu(self, mu):
+        self.records()[:, self.field("R_PARAMS")] = mu

@@ -1,0 +1,98 @@
+// qs_emu.cpp -- TEST-ONLY host emulation of the quad-per-environment kernels.
+// Instantiates the kernel arithmetic of quadruped-springs_amd/csrc/qs_env.h with the 4-wide LaneEmu type so that the
+// CPU test-suite (no GPU in the build container) can compare it with the oracle.  Never linked into the product.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../quadruped-springs_amd/csrc/qs_env.h"
+
+using E = qs::Env<LaneEmu>;
+
+struct Emu {
+    qs_config cfg;
+    std::vector<float> rec, obs, term_obs;
+};
+
+static void init_record(const qs_config& cfg, float* r, int env) {
+    memset(r, 0, QS_REC * sizeof(float));
+    r[R_EPISODE] = qs::i2f(-1);
+    r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f;
+    for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
+    E::randomize(cfg, r, (uint32_t)env, -1, true);
+}
+
+extern "C" {
+void* qse_create(const qs_config* cfg) {
+    Emu* e = new Emu();
+    e->cfg = *cfg;
+    e->rec.assign((size_t)cfg->n_envs * QS_REC, 0.0f);
+    e->obs.assign((size_t)cfg->n_envs * QS_MAX_OBS, 0.0f);
+    e->term_obs.assign((size_t)cfg->n_envs * QS_MAX_OBS, 0.0f);
+    for (int i = 0; i < cfg->n_envs; i++) init_record(e->cfg, &e->rec[(size_t)i * QS_REC], i);
+    return e;
+}
+void qse_destroy(void* h) { delete (Emu*)h; }
+int qse_reset(void* h, const uint8_t* mask) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++)
+        if (!mask || mask[i]) E::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)i, true);
+    return 0;
+}
+int qse_get_obs(void* h, float* obs) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++) memcpy(obs + (size_t)i * e->cfg.obs_dim, &e->obs[(size_t)i * QS_MAX_OBS], e->cfg.obs_dim * sizeof(float));
+    return 0;
+}
+int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
+    Emu* e = (Emu*)h;
+    const int d = e->cfg.action_dim;
+    for (int i = 0; i < e->cfg.n_envs; i++) {
+        float* rec = &e->rec[(size_t)i * QS_REC];
+        float* ob = &e->obs[(size_t)i * QS_MAX_OBS];
+        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)i);
+        rew[i] = r.reward.v[0]; done[i] = r.done.v[0] > 0.5f; trunc[i] = r.trunc.v[0] > 0.5f;
+        if (done[i] && e->cfg.auto_reset) {
+            memcpy(&e->term_obs[(size_t)i * QS_MAX_OBS], ob, QS_MAX_OBS * sizeof(float));
+            E::reset(e->cfg, rec, ob, (uint32_t)i, true);
+        }
+        memcpy(obs + (size_t)i * e->cfg.obs_dim, ob, e->cfg.obs_dim * sizeof(float));
+    }
+    return 0;
+}
+int qse_get_state(void* h, float* st) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++) memcpy(st + (size_t)i * 37, &e->rec[(size_t)i * QS_REC], 37 * sizeof(float));
+    return 0;
+}
+int qse_set_state(void* h, const float* st) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++) {
+        float* r = &e->rec[(size_t)i * QS_REC];
+        memcpy(r, st + (size_t)i * 37, 37 * sizeof(float));
+        for (int k = 0; k < 4; k++) r[R_WARM + k] = 0.0f;
+    }
+    return 0;
+}
+float* qse_records(void* h) { return ((Emu*)h)->rec.data(); }
+int qse_rec_size(void) { return QS_REC; }
+int qse_field(const char* name) {
+#define F(n) if (!strcmp(name, #n)) return n;
+    F(R_POS) F(R_QUAT) F(R_VLIN) F(R_VANG) F(R_Q) F(R_QD) F(R_WARM) F(R_LAST_ACTION) F(R_XHIST) F(R_YHIST) F(R_SIM_STEP) F(R_ENV_STEP)
+    F(R_EPISODE) F(R_TOTAL_STEPS) F(R_TASK) F(R_NEW_TAU) F(R_PARAMS) F(R_FOOT_FORCE) F(R_FOOT_CONTACT) F(R_N_INVALID) F(R_TAU_PD)
+    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_FLAGS)
+#undef F
+    return -1;
+}
+// one physics substep of env `i` under given joint torques (KATs on the kernel arithmetic)
+int qse_phys_step(void* h, int i, const float* tau12) {
+    Emu* e = (Emu*)h;
+    float* rec = &e->rec[(size_t)i * QS_REC];
+    typename E::S::State s; typename E::S::Par P; typename E::S::Out o;
+    E::load_state(rec, s); E::load_par(rec, P);
+    V4 tau[3];
+    for (int j = 0; j < 3; j++) { tau[j] = LaneEmu::ld_leg(tau12, j, 3); o.tau_pd[j] = V4(0.0f); o.tau_spring[j] = V4(0.0f); }
+    E::S::substep(e->cfg, P, s, tau, o);
+    E::store_state(rec, s, o);
+    return 0;
+}
+}

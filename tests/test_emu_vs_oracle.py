@@ -1,0 +1,134 @@
+"""Kernel arithmetic (quadruped-springs_amd/csrc/qs_core.h + qs_env.h, float32, base-frame CRBA + block elimination,
+impulse-space PGS) evaluated on the HOST through the test-only 4-wide lane emulation, compared with the oracle
+(float64, link-frame articulated-body algorithm, velocity-space PGS).  The two share no code.
+
+Tolerances (one env.step = 10 substeps x 30 PGS sweeps from an identical state): the float32 build of the oracle
+itself differs from its float64 build by the same amounts, see test_oracle_physics.py::test_f32_build_tracks_f64."""
+import numpy as np
+import pytest
+
+from emu.emu import Emu
+from oracle.qso import Oracle
+from qs_amd.config import build_config
+
+TOL_Q, TOL_QD, TOL_BASE_V, TOL_POS = 2e-5, 5e-3, 5e-4, 5e-6
+
+
+def pair(n=1, **kw):
+    kw.setdefault("task_env", "JUMPING_IN_PLACE")
+    kw.setdefault("observation_space_mode", "PPO_BASIC")
+    kw.setdefault("enable_springs", True)
+    kw.setdefault("enable_action_filter", True)
+    kw.setdefault("env_randomizer_mode", "NONE")
+    cfg, meta = build_config(n_envs=n, noise=False, **kw)
+    return Oracle(cfg), Emu(cfg), cfg
+
+
+def random_state(o, rng):
+    s = o.get_state()
+    s[:, 3:7] = rng.normal(size=(len(s), 4))
+    s[:, 3:7] /= np.linalg.norm(s[:, 3:7], axis=1, keepdims=True)
+    s[:, 7:13] = rng.normal(size=(len(s), 6))
+    s[:, 13:25] += 0.3 * rng.normal(size=(len(s), 12))
+    s[:, 25:37] = 2 * rng.normal(size=(len(s), 12))
+    s[:, 2] = 1.0
+    return s
+
+
+def test_free_flight_substep_matches_aba():
+    o, e, cfg = pair()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        s = random_state(o, rng)
+        o.set_state(s); e.set_state(s)
+        tau = 5 * rng.normal(size=12)
+        o.phys_step(0, tau); e.phys_step(0, tau)
+        np.testing.assert_allclose(e.get_state()[0], o.get_state()[0], atol=5e-5, rtol=1e-5)  # accelerations are O(1e3): fp32 eps * a * dt
+
+
+def test_reset_settle_matches():
+    o, e, cfg = pair()
+    oo, eo = o.reset(), e.reset()
+    np.testing.assert_allclose(eo, oo, atol=5e-4)
+    np.testing.assert_allclose(e.get("R_FOOT_FORCE", 4)[0], o.get_info(0)[0], rtol=2e-3)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(enable_springs=False, enable_action_filter=False, observation_space_mode="ARS_BASIC"),
+    dict(action_space_mode="DEFAULT", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT"),
+    dict(motor_control_mode="CARTESIAN_PD", observation_space_mode="CARTESIAN_NO_IMU"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", action_space_mode="SYMMETRIC_NO_HIP"),
+    dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="LANDING_SENSOR"),
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP"),
+])
+def test_env_step_parity_resynced(kw):
+    """Every step starts from the oracle's state, so chaotic divergence cannot accumulate."""
+    o, e, cfg = pair(**kw)
+    o.reset(); e.reset()
+    rng = np.random.default_rng(1)
+    d = cfg.action_dim
+    for i in range(120):
+        a = rng.uniform(-1, 1, size=(1, d)).astype(np.float32)
+        if i % 40 > 25:  # periodic explosive extension: flight phases, landings, falls
+            a[:] = np.tile([0.0, -1.0, 1.0], 4)[:d] if d != 4 else np.tile([-1.0, 1.0], 2)
+        s = o.get_state()
+        o.set_state(s); e.set_state(s)
+        oo, ro, do, to = o.step(a)
+        eo, re, de, te = e.step(a)
+        so, se = o.get_state()[0], e.get_state()[0]
+        np.testing.assert_allclose(se[:7], so[:7], atol=TOL_POS, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(se[7:13], so[7:13], atol=TOL_BASE_V, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(se[13:25], so[13:25], atol=TOL_Q, err_msg=f"q step {i}")
+        np.testing.assert_allclose(se[25:], so[25:], atol=TOL_QD, err_msg=f"qd step {i}")
+        assert do[0] == de[0] and to[0] == te[0], f"done/trunc step {i}"
+        np.testing.assert_allclose(re, ro, atol=2e-4, rtol=1e-3, err_msg=f"reward step {i}")
+        np.testing.assert_allclose(eo, oo, atol=TOL_QD, err_msg=f"obs step {i}")
+        np.testing.assert_allclose(e.get("R_FOOT_FORCE", 4)[0], o.get_info(0)[0], rtol=2e-2, atol=0.5, err_msg=f"contact force step {i}")
+        np.testing.assert_array_equal(e.get("R_FOOT_CONTACT", 4)[0], o.get_info(1)[0])
+        if do[0]:
+            o.reset(); e.reset()
+
+
+def test_joint_limit_path():
+    """Drive the calves into their lower stop: exercises the rare 6-rows-per-leg solver path."""
+    o, e, cfg = pair(isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                     enable_action_filter=False)
+    s = o.get_state()
+    s[0, 2] = 2.0
+    o.set_state(s); e.set_state(s)
+    tau = np.zeros(12); tau[2::3] = -33.55
+    for i in range(300):
+        o.phys_step(0, tau); e.phys_step(0, tau)
+        if i % 20 == 0:
+            e.set_state(o.get_state())
+    so, se = o.get_state()[0], e.get_state()[0]
+    assert so[15] < -2.7
+    np.testing.assert_allclose(se[13:25], so[13:25], atol=2e-4)
+    np.testing.assert_allclose(se[25:], so[25:], atol=2e-2)
+
+
+def test_short_trajectory_without_resync():
+    o, e, cfg = pair()
+    o.reset(); e.reset()
+    rng = np.random.default_rng(5)
+    for i in range(30):
+        a = rng.uniform(-0.3, 0.3, size=(1, 6)).astype(np.float32)
+        oo = o.step(a)[0]; eo = e.step(a)[0]
+    np.testing.assert_allclose(eo, oo, atol=2e-2)
+
+
+def test_noise_stream_matches_oracle():
+    cfg, _ = build_config(n_envs=2, noise=True, seed=42, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                          enable_springs=True, env_randomizer_mode="GROUND_RANDOMIZER")
+    o, e = Oracle(cfg), Emu(cfg)
+    oo, eo = o.reset(), e.reset()
+    np.testing.assert_allclose(eo, oo, atol=1e-3)
+    cfg0, _ = build_config(n_envs=2, noise=False, seed=42, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                           enable_springs=True, env_randomizer_mode="GROUND_RANDOMIZER")
+    clean = Oracle(cfg0).reset()
+    assert np.abs(oo - clean)[:, :24].max() > 1e-4      # noise really is applied to the noisy sensors
+    assert np.all(oo[:, 27] == clean[:, 27])            # and never to the "is landing" flag
+    # randomised friction (Philox stream 1) is identical on both sides
+    np.testing.assert_allclose(e.get("R_PARAMS", 1)[:, 0], o.get_info(6)[:, 0], rtol=1e-6)
+    assert np.all((o.get_info(6)[:, 0] >= 0.5) & (o.get_info(6)[:, 0] <= 1.0))

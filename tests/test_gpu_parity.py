@@ -1,0 +1,238 @@
+"""Parity of the HIP path (through the C ABI of include/qs_amd.h) against the CPU oracle, on a real MI355X.
+
+Bar (restated): float32 kernel vs float64 oracle, one env.step (10 substeps x 30 PGS sweeps) from an
+identical state: |dq| <= 2e-5 rad, |dqd| <= 5e-3 rad/s, base velocity 5e-4, pose 5e-6, contact force 2 % (+0.5 N),
+identical contact flags / done / truncated.  The oracle's own float32 build shows the same spread against float64
+(tests/test_oracle_physics.py::test_f32_build_tracks_f64), i.e. these are rounding, not algorithm, differences."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_Q, TOL_QD, TOL_BASE_V, TOL_POS = 2e-5, 5e-3, 5e-4, 5e-6
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch
+
+
+def make_pair(n, torch, oracle=True, **kw):
+    from oracle.qso import Oracle
+    from qs_amd.vec_env import QuadrupedVecEnv
+    kw.setdefault("task_env", "JUMPING_IN_PLACE")
+    kw.setdefault("observation_space_mode", "PPO_BASIC")
+    kw.setdefault("enable_springs", True)
+    kw.setdefault("enable_action_filter", True)
+    kw.setdefault("env_randomizer_mode", "NONE")
+    kw.setdefault("noise", False)
+    auto_reset = kw.pop("auto_reset", False)
+    keep = kw.pop("keep_params", False)
+    v = QuadrupedVecEnv.__new__(QuadrupedVecEnv)
+    # build by hand so that cfg can be edited before qs_create
+    import ctypes as C
+    from qs_amd import lib as L
+    from qs_amd.config import build_config, OBSERVATION_EPS
+    from qs_amd.spaces import Box
+    cfg, meta = build_config(n_envs=n, auto_reset=auto_reset, **kw)
+    if keep:
+        cfg.randomizer_flags |= 8
+    v.torch, v.lib, v.cfg, v.meta, v.num_envs = torch, L.load(), cfg, meta, n
+    v.device = torch.device("cuda", 0)
+    v.action_dim, v.obs_dim = cfg.action_dim, cfg.obs_dim
+    v.observation_space = Box(meta["layout"]["low"] - OBSERVATION_EPS, meta["layout"]["high"] + OBSERVATION_EPS)
+    v.action_space = Box(-np.ones(cfg.action_dim), np.ones(cfg.action_dim))
+    v.h = C.c_void_p()
+    L.check(v.lib.qs_create(C.byref(cfg), 0, C.byref(v.h)))
+    v._obs = torch.zeros((n, cfg.obs_dim), dtype=torch.float32, device=v.device)
+    v._rew = torch.zeros(n, dtype=torch.float32, device=v.device)
+    v._done = torch.zeros(n, dtype=torch.uint8, device=v.device)
+    v._trunc = torch.zeros(n, dtype=torch.uint8, device=v.device)
+    v._act = torch.zeros((n, cfg.action_dim), dtype=torch.float32, device=v.device)
+    v._actions, v._closed, v.render_mode = None, False, None
+    return (Oracle(cfg) if oracle else None), v, cfg
+
+
+def test_native_library_is_the_path():
+    from qs_amd import lib
+    assert os.path.exists(lib.LIB_PATH)
+    assert b"gfx950" in lib.load().qs_version()
+
+
+def test_reset_settle_and_static_stance(torch_cuda):
+    o, v, cfg = make_pair(8, torch_cuda)
+    oo, vo = o.reset(), v.reset()
+    np.testing.assert_allclose(vo, oo, atol=5e-4)
+    f = v.get_info("foot_force").cpu().numpy()
+    np.testing.assert_allclose(f, o.get_info(0), rtol=2e-3)
+    np.testing.assert_allclose(f.sum(axis=1), 12.01301 * 9.8, rtol=5e-3)   # K6: the feet carry the robot's weight
+    assert np.all(v.get_info("foot_contact").cpu().numpy() == 1)
+
+
+CASES = [
+    dict(),
+    dict(enable_springs=False, enable_action_filter=False, observation_space_mode="ARS_BASIC"),
+    dict(action_space_mode="DEFAULT", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT"),
+    dict(motor_control_mode="CARTESIAN_PD", observation_space_mode="CARTESIAN_NO_IMU"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", action_space_mode="SYMMETRIC_NO_HIP"),
+    dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="LANDING_SENSOR"),
+    dict(task_env="JUMPING_IN_PLACE_PPO", observation_space_mode="PPO_BASIC_X"),
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP"),
+    dict(time_step=0.002, action_repeat=5),   # BASELINE.json config 2: dt = 1/500 s, 60 solver sweeps
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_env_step_parity_resynced(torch_cuda, kw):
+    n = 16
+    o, v, cfg = make_pair(n, torch_cuda, **kw)
+    o.reset(); v.reset()
+    rng = np.random.default_rng(1)
+    d = cfg.action_dim
+    for i in range(100):
+        a = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+        if i % 40 > 25:
+            a[: n // 2] = np.tile([0.0, -1.0, 1.0], 4)[:d] if d != 4 else np.tile([-1.0, 1.0], 2)
+        s = o.get_state()
+        o.set_state(s); v.set_state(s.astype(np.float32))
+        oo, ro, do, to = o.step(a)
+        vo, rv, dv, infos = v.step(a)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        np.testing.assert_allclose(sv[:, :7], so[:, :7], atol=TOL_POS, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(sv[:, 7:13], so[:, 7:13], atol=TOL_BASE_V, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=TOL_Q, err_msg=f"q step {i}")
+        np.testing.assert_allclose(sv[:, 25:], so[:, 25:], atol=TOL_QD, err_msg=f"qd step {i}")
+        np.testing.assert_array_equal(dv, do)
+        tv = np.array([inf.get("TimeLimit.truncated", False) for inf in infos])
+        np.testing.assert_array_equal(tv, to)
+        np.testing.assert_allclose(rv, ro, atol=2e-4, rtol=1e-3, err_msg=f"reward step {i}")
+        np.testing.assert_allclose(vo, oo, atol=TOL_QD, err_msg=f"obs step {i}")
+        np.testing.assert_allclose(v.get_info("foot_force").cpu().numpy(), o.get_info(0), rtol=2e-2, atol=0.5)
+        np.testing.assert_array_equal(v.get_info("foot_contact").cpu().numpy(), o.get_info(1))
+        np.testing.assert_allclose(v.get_info("torque").cpu().numpy(), o.get_info(2), atol=5e-3)
+        if do.any():
+            o.reset(do.astype(np.uint8)); v.reset_tensor(do.astype(np.uint8))
+
+
+@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "cart_s1"])
+def test_reference_traces(torch_cuda, golden, name):
+    """Traces recorded from the REFERENCE's QuadrupedGymEnv (tests/golden/traces.npz).  Trajectories are chaotic, so the
+    device state is re-synchronised to the recorded state before every step; what is compared is one full env.step."""
+    g = golden("traces.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    _, v, cfg = make_pair(1, torch_cuda, oracle=False, keep_params=True, **kw)
+    acts, obs_ref, rew_ref = g[f"{name}_actions"], g[f"{name}_obs"], g[f"{name}_rew"]
+    done_ref, trunc_ref, state_ref = g[f"{name}_done"], g[f"{name}_trunc"], g[f"{name}_state"]
+    reset_obs, reset_at, mus = g[f"{name}_reset_obs"], list(g[f"{name}_reset_at"]), g[f"{name}_mu"]
+    ep = 0
+    v.set_params("mu", np.array([[mus[0]]], np.float32))
+    np.testing.assert_allclose(v.reset()[0], reset_obs[0], atol=1e-3)
+    for t in range(len(acts)):
+        if t > 0 and t not in reset_at:
+            v.set_state(state_ref[t - 1][None].astype(np.float32))
+        ob, r, dn, infos = v.step(acts[t][None].astype(np.float32))
+        assert bool(dn[0]) == bool(done_ref[t]), f"done mismatch at step {t}"
+        assert bool(infos[0].get("TimeLimit.truncated", False)) == bool(trunc_ref[t])
+        sv = v.get_state().cpu().numpy()[0]
+        np.testing.assert_allclose(sv[13:25], state_ref[t][13:25], atol=1e-4, err_msg=f"q step {t}")
+        np.testing.assert_allclose(sv[25:], state_ref[t][25:], atol=2e-2, err_msg=f"qd step {t}")
+        if t == 0 or (t - 1) not in [x - 1 for x in reset_at[1:]]:
+            np.testing.assert_allclose(ob[0], obs_ref[t], atol=2e-2, rtol=1e-3, err_msg=f"obs step {t}")
+        if dn[0]:
+            ep += 1
+            v.set_params("mu", np.array([[mus[ep]]], np.float32))
+            np.testing.assert_allclose(v.reset()[0], reset_obs[ep], atol=1e-3)
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE.json size (N = 8192): size-independent properties instead of the (slow) oracle."""
+    torch = torch_cuda
+    n = 8192
+    _, v, cfg = make_pair(n, torch, oracle=False, env_randomizer_mode="GROUND_RANDOMIZER", seed=7, noise=True)
+    _, w, _ = make_pair(64, torch, oracle=False, env_randomizer_mode="GROUND_RANDOMIZER", seed=7, noise=True)
+    ov, ow = v.reset(), w.reset()
+    assert np.array_equal(ov[:64], ow)                       # batch-size invariance (counter-based RNG, no cross-env state)
+    f = v.get_info("foot_force").cpu().numpy()
+    np.testing.assert_allclose(f.sum(axis=1), 12.01301 * 9.8, rtol=1e-2)
+    mu = v.get_info("params").cpu().numpy()[:, 0]
+    assert mu.min() >= 0.5 and mu.max() <= 1.0 and 0.70 < mu.mean() < 0.80   # env_randomizer.py:287-289
+    g = torch.Generator(device="cpu").manual_seed(0)
+    outs = []
+    for rep in range(2):
+        if rep == 1:
+            v.reset_tensor()
+        acc = []
+        gg = torch.Generator(device="cpu").manual_seed(0)
+        for i in range(20):
+            a = (torch.rand((n, 6), generator=gg) * 2 - 1).to(v.device)
+            o, r, d, t = v.step_tensor(a)
+            acc.append((o.clone(), r.clone(), d.clone()))
+            if i < 5:
+                o64 = w.step_tensor(a[:64].contiguous())[0]
+                assert torch.equal(o[:64], o64)
+        outs.append(acc)
+    for (o1, r1, d1), (o2, r2, d2) in zip(*outs):            # determinism: same inputs -> bitwise same outputs
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    s = v.get_state()
+    assert torch.isfinite(s).all()
+    np.testing.assert_allclose(torch.linalg.norm(s[:, 3:7], dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    assert float(s[:, 25:].abs().max()) <= cfg.vel_cap + 1e-4   # K10
+
+
+def test_auto_reset_and_terminal_observation(torch_cuda):
+    o, v, cfg = make_pair(32, torch_cuda, auto_reset=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=3)
+    oo, vo = o.reset(), v.reset()
+    np.testing.assert_allclose(vo, oo, atol=5e-4)
+    rng = np.random.default_rng(2)
+    seen = 0
+    for i in range(60):
+        a = rng.uniform(-1, 1, size=(32, 6)).astype(np.float32)
+        s = o.get_state(); o.set_state(s); v.set_state(s.astype(np.float32))
+        oo, ro, do, to = o.step(a)
+        vo, rv, dv, infos = v.step(a)
+        np.testing.assert_array_equal(dv, do)
+        np.testing.assert_allclose(vo, oo, atol=TOL_QD)     # rows of finished envs already hold the post-reset observation
+        for k in np.nonzero(dv)[0]:
+            seen += 1
+            np.testing.assert_allclose(infos[k]["terminal_observation"], o.get_info(9)[k], atol=TOL_QD)
+            assert infos[k]["TimeLimit.truncated"] == bool(to[k])
+    assert seen > 0
+    assert v.stats()["resets"] == seen + 32
+
+
+def test_pooled_reset_states_are_settled(torch_cuda):
+    _, v, cfg = make_pair(256, torch_cuda, oracle=False, auto_reset=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5)
+    v.close()
+    from qs_amd.vec_env import QuadrupedVecEnv
+    v = QuadrupedVecEnv(num_envs=256, auto_reset=True, reset_pool=128, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                        enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=False)
+    v.reset()
+    rng = np.random.default_rng(3)
+    n_done = 0
+    for i in range(80):
+        obs, rew, done, infos = v.step(rng.uniform(-1, 1, size=(256, 6)).astype(np.float32))
+        if done.any():
+            n_done += int(done.sum())
+            st = v.get_state().cpu().numpy()[done]
+            assert np.all(np.abs(st[:, 2] - 0.328) < 0.01)          # settled standing height
+            assert np.abs(st[:, 7:13]).max() < 0.05                 # at rest
+            assert np.all(obs[done][:, 27] == 0)
+    assert n_done > 0
+
+
+def test_create_rejects_bad_config(torch_cuda):
+    import ctypes as C
+    from qs_amd import lib as L
+    from qs_amd.config import build_config
+    cfg, _ = build_config(n_envs=4, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC")
+    cfg.obs_dim = 27
+    h = C.c_void_p()
+    assert L.load().qs_create(C.byref(cfg), 0, C.byref(h)) != 0
+    assert b"obs_dim" in L.load().qs_last_error()
+    with pytest.raises(ValueError):   # gym_env.py:167-168
+        build_config(motor_control_mode="TORQUE", isRLGymInterface=True)

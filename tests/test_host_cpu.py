@@ -1,0 +1,97 @@
+"""CPU-side checks of the product: the C-ABI library builds, loads and exports every symbol include/qs_amd.h declares
+(no compute calls without a GPU), the config struct matches the header, the host registries mirror the reference."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from qs_amd import config as qcfg
+from qs_amd.config import QsConfig, build_config
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from qs_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("qs_build", os.path.join(REPO, "quadruped-springs_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    header = open(os.path.join(REPO, "include", "qs_amd.h")).read()
+    declared = set(re.findall(r"\b(qs_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    l = lib.load()
+    for name in declared:
+        assert hasattr(l, name), f"{name} declared in include/qs_amd.h but not exported"
+    assert set(lib.EXPORTS) == declared
+
+
+def test_config_struct_layout_matches_header():
+    """Compile a tiny C program that prints sizeof/offsetof of qs_config and compare with the ctypes mirror."""
+    import subprocess
+    import tempfile
+    fields = [f[0] for f in QsConfig._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "qs_amd.h"\nint main(){printf("%zu\\n", sizeof(qs_config));\n'
+    for f in fields:
+        src += f'printf("%zu\\n", offsetof(qs_config, {f}));\n'
+    src += "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I" + os.path.join(REPO, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert int(out[0]) == C.sizeof(QsConfig)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(QsConfig, f).offset == int(off), f
+    # the oracle's qso_config has the same layout
+    src2 = src.replace("qs_amd.h", "qso.h").replace("qs_config", "qso_config").replace("reset_pool", "reserved_i").replace(
+        'offsetof(qso_config, reserved_i));\nprintf("%zu\\n", offsetof(qso_config, reserved_i));', 'offsetof(qso_config, reserved_i));\nprintf("%zu\\n", offsetof(qso_config, reserved_i) + 4);')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src2)
+        subprocess.check_call(["gcc", "-I" + os.path.join(REPO, "oracle"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        out2 = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert out2 == out
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from qs_amd.vec_env import QuadrupedVecEnv
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        QuadrupedVecEnv(num_envs=2)
+    from qs_amd import lib
+    cfg, _ = build_config(n_envs=2)
+    h = C.c_void_p()
+    assert lib.load().qs_create(C.byref(cfg), 0, C.byref(h)) != 0   # the C ABI refuses as well
+    assert b"no HIP device" in lib.load().qs_last_error() or b"failed" in lib.load().qs_last_error()
+
+
+def test_registries_and_errors_mirror_the_reference():
+    cfg, meta = build_config(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True)
+    assert cfg.action_dim == 6 and cfg.obs_dim == 28 and cfg.solver_iters == 30 and cfg.settle_steps == 2500
+    assert cfg.max_sim_steps == 10000   # sim_time > 10 s first holds at step 10001 (gym_env.py:245)
+    assert meta["layout"]["keys"] == ["Encoder", "JointVelocity", "Pitch", "Height", "Base Linear Velocity z direction", "is landing"]
+    with pytest.raises(ValueError):
+        build_config(motor_control_mode="TORQUE")            # gym_env.py:167-168
+    with pytest.raises(KeyError):
+        build_config(observation_space_mode="ARS_HEIGHT")    # the reference's broken gym default (quadruped_spring/__init__.py:9)
+    with pytest.raises(NotImplementedError):
+        build_config(task_env="JUMPING_IN_PLACE_DEMO")
+    c2, _ = build_config(time_step=0.002, action_repeat=5, enable_springs=True)
+    assert c2.solver_iters == 60 and c2.max_sim_steps == 5000
+    # BACKFLIP widens two joint limits in place (motor_interface.py:17-22)
+    c3, m3 = build_config(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", enable_springs=True)
+    assert abs(c3.cmd_hi[7] - np.pi / 2) < 1e-6 and abs(c3.cmd_hi[10] - np.pi / 2) < 1e-6 and abs(c3.cmd_hi[1] - (np.pi / 4 + 0.5)) < 1e-6
+    assert m3["layout"]["high"][7] == pytest.approx(np.pi / 2)
+
+
+def test_symmetric_action_kat_from_survey():
+    """symmetric action [0.3,-0.5,0.9,-1,1,0.1] -> command."""
+    from oracle.qso import Oracle
+    cfg, _ = build_config(enable_springs=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC")
+    cmd = Oracle(cfg).action_to_command([0.3, -0.5, 0.9, -1, 1, 0.1])
+    np.testing.assert_allclose(cmd, [0.06, 0.535398, -1.0275, -0.06, 0.535398, -1.0275, -0.2, 1.285398, -1.6475, 0.2, 1.285398, -1.6475], atol=1e-6)
