@@ -83,7 +83,8 @@ typedef struct qs_config {
     int32_t noise_enabled;
     int32_t auto_reset;          /* SB3 VecEnv convention: finished environments are reset inside qs_step */
     int32_t reset_pool;          /* 0: every reset runs the 2500-substep settle; P > 0: resets draw from P pre-settled states */
-    int32_t reserved_i[2];
+    int32_t env_id_offset;       /* global id of environment 0 (sharded runs): RNG streams are keyed by the global id */
+    int32_t reserved_i[1];
     uint64_t seed;
     double dt;
     double filt_b[3], filt_a[3]; /* scipy.signal.butter(2, 3 Hz) at 1/env_dt, action_filter.py:191-213 */

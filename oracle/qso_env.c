@@ -399,7 +399,7 @@ static void read_sensors(const qso_config* cfg, qso_env* e, float* obs) {
 static void add_noise(const qso_config* cfg, qso_env* e, int env_id, float* obs) {
     if (!cfg->noise_enabled) return;
     for (int blk = 0; blk * 4 < cfg->obs_dim; blk++) {
-        real z[4]; normal4(cfg->seed, (uint32_t)env_id, 0, e->total_steps, (uint32_t)blk, z);
+        real z[4]; normal4(cfg->seed, (uint32_t)(env_id + cfg->env_id_offset), 0, e->total_steps, (uint32_t)blk, z);
         for (int k = 0; k < 4 && blk * 4 + k < cfg->obs_dim; k++) {
             float sd = cfg->obs_noise_std[blk * 4 + k];
             if (sd > 0) obs[blk * 4 + k] = (float)((real)obs[blk * 4 + k] + (real)sd * z[k]);
@@ -425,7 +425,7 @@ static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
     for (int i = 0; i < 3; i++) { e->k[i] = cfg->spring_k[i]; e->b[i] = cfg->spring_b[i]; e->rest[i] = cfg->spring_rest[i]; e->kp[i] = cfg->kp[i]; e->kd[i] = cfg->kd[i]; e->m_leg[i] = QSO_M_LEG[i]; e->r_pay[i] = 0; }
     e->m_trunk = QSO_M_TRUNK; e->m_pay = 0;
     uint32_t r[16];
-    for (int b = 0; b < 4; b++) qso_philox(cfg->seed, (uint32_t)env_id, 1, (uint32_t)e->episode, (uint32_t)b, r + 4 * b);
+    for (int b = 0; b < 4; b++) qso_philox(cfg->seed, (uint32_t)(env_id + cfg->env_id_offset), 1, (uint32_t)e->episode, (uint32_t)b, r + 4 * b);
     if (cfg->randomizer_flags & QSO_RAND_GROUND) /* env_randomizer.py:287-289 */
         e->mu = (real)0.5 + (real)0.5 * qso_u01(r[0]);
     if ((cfg->randomizer_flags & QSO_RAND_SPRINGS) && cfg->enable_springs) { /* :100-122 */

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
         r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f;
         for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
     }
-    E::randomize(cfg, r, (uint32_t)env, -1, true);
+    E::randomize(cfg, r, (uint32_t)(env + cfg.env_id_offset), -1, true);
 }
 
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
     __syncthreads();
     float* rec = s_rec + slot * QS_REC;
     float* ob = s_obs + slot * QS_MAX_OBS;
-    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, (uint32_t)env);
+    const uint32_t gid = (uint32_t)(env + cfg.env_id_offset);
+    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid);
     const bool dn = r.done > 0.5f;
     if (valid && (threadIdx.x & 3) == 0) {
         rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0;
@@ -97,15 +98,15 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
             if (pool.size > 0) {
                 if (do_reset) {
                     uint32_t rr[4];
-                    qs::philox4x32(cfg.seed, (uint32_t)env, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
+                    qs::philox4x32(cfg.seed, gid, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
                     copy_settled(rec, pool.pool + (size_t)(rr[0] % (uint32_t)pool.size) * QS_REC);
                 }
                 LaneDev::sync();
-                if (do_reset) E::reset(cfg, rec, ob, (uint32_t)env, false);
+                if (do_reset) E::reset(cfg, rec, ob, gid, false);
             } else {
                 // exact mode: the whole wave walks through the 2500-substep settle (lanes of running environments idle)
                 if (do_reset) {
-                    E::reset(cfg, rec, ob, (uint32_t)env, true);
+                    E::reset(cfg, rec, ob, gid, true);
                     if ((threadIdx.x & 3) == 0) atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps);
                 }
             }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restric
     float* ob = s_obs + slot * QS_MAX_OBS;
     // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);
     // quads that are not selected work on their LDS copy and simply do not write it back
-    E::reset(cfg, rec, ob, (uint32_t)(valid ? env : 0), true);
+    E::reset(cfg, rec, ob, (uint32_t)((valid ? env : 0) + cfg.env_id_offset), true);
     if (sel && (threadIdx.x & 3) == 0) { atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps); atomicAdd(&stats[1], 1ull); }
     __syncthreads();
     if (sel) {
@@ -239,7 +240,9 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     for (int i = 0; i < cfg->n_sensors; i++) od += sensor_dim(cfg->sensors[i]);
     if (od != cfg->obs_dim) QS_FAIL(-1, "obs_dim %d does not match the sensor bundle (%d)", cfg->obs_dim, od);
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) QS_FAIL(-3, "no HIP device available: this library has no CPU path");
+    hipError_t derr = hipGetDeviceCount(&ndev);
+    if (derr != hipSuccess || ndev <= 0)
+        QS_FAIL(-3, "no HIP device available (hipGetDeviceCount: %s, %d devices): this library has no CPU path", hipGetErrorString(derr), ndev);
     if (device < 0 || device >= ndev) QS_FAIL(-3, "HIP device %d out of range (%d visible)", device, ndev);
     QS_HIP(hipSetDevice(device));
     qs_handle* h = new (std::nothrow) qs_handle();

@@ -95,7 +95,7 @@ class QsConfig(C.Structure):
         ("obs_dim", C.c_int32), ("enable_springs", C.c_int32), ("enable_filter", C.c_int32),
         ("enable_interp", C.c_int32), ("action_repeat", C.c_int32), ("solver_iters", C.c_int32),
         ("settle_steps", C.c_int32), ("max_sim_steps", C.c_int32), ("randomizer_flags", C.c_int32),
-        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_pool", C.c_int32), ("reserved_i", C.c_int32 * 2),
+        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_pool", C.c_int32), ("env_id_offset", C.c_int32), ("reserved_i", C.c_int32 * 1),
         ("seed", C.c_uint64), ("dt", C.c_double), ("filt_b", C.c_double * 3), ("filt_a", C.c_double * 3), ("gravity", C.c_float),
         ("kp", C.c_float * 3), ("kd", C.c_float * 3), ("tau_max", C.c_float * 3),
         ("cmd_lo", C.c_float * 12), ("cmd_hi", C.c_float * 12),
@@ -201,6 +201,7 @@ def build_config(
     noise=True,
     auto_reset=False,
     settle_steps=2500,
+    env_id_offset=0,
     robot_config=None,
     **_ignored,
 ):
@@ -255,6 +256,7 @@ def build_config(
     cfg.max_sim_steps = n - 1
     cfg.randomizer_flags, cfg.noise_enabled, cfg.auto_reset = rand, int(bool(noise)), int(bool(auto_reset))
     cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    cfg.env_id_offset = int(env_id_offset)
     cfg.dt, cfg.gravity = time_step, 9.8  # gym_env.py:309
     for i in range(3):
         cfg.kp[i], cfg.kd[i], cfg.tau_max[i] = rc.MOTOR_KP[i], rc.MOTOR_KD[i], rc.RL_TORQUE_LIMITS[i]

@@ -25,6 +25,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python quadruped-springs_amd/build.py` (needs hipcc). "
                            "The simulation step has no CPU fallback.")
+    # The library must share ONE HIP runtime with PyTorch (device pointers and streams cross the boundary).  torch
+    # wheels bundle their own libamdhip64 / libhsa-runtime64; importing torch first makes the loader satisfy this
+    # library's DT_NEEDED entry with the runtime torch already mapped.  Loaded the other way round the process ends up
+    # with two HSA runtimes and the second one sees no device (measured on the MI355X box, tools/diag_hip_runtime.py).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int
     lib.qs_create.argtypes = [C.POINTER(QsConfig), i32, C.POINTER(vp)]

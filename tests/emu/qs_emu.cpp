@@ -18,7 +18,7 @@ static void init_record(const qs_config& cfg, float* r, int env) {
     r[R_EPISODE] = qs::i2f(-1);
     r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f;
     for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
-    E::randomize(cfg, r, (uint32_t)env, -1, true);
+    E::randomize(cfg, r, (uint32_t)(env + cfg.env_id_offset), -1, true);
 }
 
 extern "C" {
@@ -35,7 +35,7 @@ void qse_destroy(void* h) { delete (Emu*)h; }
 int qse_reset(void* h, const uint8_t* mask) {
     Emu* e = (Emu*)h;
     for (int i = 0; i < e->cfg.n_envs; i++)
-        if (!mask || mask[i]) E::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)i, true);
+        if (!mask || mask[i]) E::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)(i + e->cfg.env_id_offset), true);
     return 0;
 }
 int qse_get_obs(void* h, float* obs) {
@@ -49,11 +49,11 @@ int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* don
     for (int i = 0; i < e->cfg.n_envs; i++) {
         float* rec = &e->rec[(size_t)i * QS_REC];
         float* ob = &e->obs[(size_t)i * QS_MAX_OBS];
-        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)i);
+        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset));
         rew[i] = r.reward.v[0]; done[i] = r.done.v[0] > 0.5f; trunc[i] = r.trunc.v[0] > 0.5f;
         if (done[i] && e->cfg.auto_reset) {
             memcpy(&e->term_obs[(size_t)i * QS_MAX_OBS], ob, QS_MAX_OBS * sizeof(float));
-            E::reset(e->cfg, rec, ob, (uint32_t)i, true);
+            E::reset(e->cfg, rec, ob, (uint32_t)(i + e->cfg.env_id_offset), true);
         }
         memcpy(obs + (size_t)i * e->cfg.obs_dim, ob, e->cfg.obs_dim * sizeof(float));
     }

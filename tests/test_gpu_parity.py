@@ -190,8 +190,10 @@ def test_auto_reset_and_terminal_observation(torch_cuda):
     np.testing.assert_allclose(vo, oo, atol=5e-4)
     rng = np.random.default_rng(2)
     seen = 0
-    for i in range(60):
+    for i in range(160):
         a = rng.uniform(-1, 1, size=(32, 6)).astype(np.float32)
+        if i % 40 > 25:   # explosive extension -> flight, bad landings, terminations
+            a[:16] = [0.0, -1.0, 1.0, 0.0, -1.0, 1.0]
         s = o.get_state(); o.set_state(s); v.set_state(s.astype(np.float32))
         oo, ro, do, to = o.step(a)
         vo, rv, dv, infos = v.step(a)

@@ -47,8 +47,7 @@ def test_config_struct_layout_matches_header():
     for f, off in zip(fields, out[1:]):
         assert getattr(QsConfig, f).offset == int(off), f
     # the oracle's qso_config has the same layout
-    src2 = src.replace("qs_amd.h", "qso.h").replace("qs_config", "qso_config").replace("reset_pool", "reserved_i").replace(
-        'offsetof(qso_config, reserved_i));\nprintf("%zu\\n", offsetof(qso_config, reserved_i));', 'offsetof(qso_config, reserved_i));\nprintf("%zu\\n", offsetof(qso_config, reserved_i) + 4);')
+    src2 = src.replace("qs_amd.h", "qso.h").replace("qs_config", "qso_config")
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src2)
         subprocess.check_call(["gcc", "-I" + os.path.join(REPO, "oracle"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
