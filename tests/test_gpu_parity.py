@@ -172,7 +172,7 @@ def test_full_size_properties(torch_cuda):
             a = (torch.rand((n, 6), generator=gg) * 2 - 1).to(v.device)
             o, r, d, t = v.step_tensor(a)
             acc.append((o.clone(), r.clone(), d.clone()))
-            if i < 5:
+            if rep == 0 and i < 5:
                 o64 = w.step_tensor(a[:64].contiguous())[0]
                 assert torch.equal(o[:64], o64)
         outs.append(acc)
