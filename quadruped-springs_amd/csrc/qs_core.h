@@ -95,15 +95,15 @@ template <class V> QS_FN SI<V> point_inertia(V m, V iso, V3<V> c) {  // isotropi
 }
 // symmetric 6x6 in packed lower-triangular storage, idx(i,j) = i(i+1)/2 + j for j <= i
 QS_FN constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-template <class V> QS_FN void chol6(V* s) {  // in place: s <- L with S = L L^T
+template <class V> QS_FN void chol6(V* s, V* dinv) {  // in place: s <- L with S = L L^T ; dinv[j] = 1 / L_jj
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         V d = s[tri(j, j)];
 #pragma unroll
         for (int k = 0; k < j; k++) d = d - s[tri(j, k)] * s[tri(j, k)];
-        d = qsqrt(d);
-        s[tri(j, j)] = d;
-        V inv = V(1.0f) / d;
+        V inv = qrsqrt(d);
+        s[tri(j, j)] = d * inv;
+        dinv[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             V t = s[tri(i, j)];
@@ -246,10 +246,13 @@ template <class T> struct Sim {
                                                             const V* Lc, const V* Ld, const V (*BK)[6], const V* R, V dist, V active) {
         constexpr int NT = 4 * NR;
         const float dt = (float)cfg.dt;
-        // Delassus columns of the own rows: A[(k,r)][(own,c)] = w_kr . w_c + [k == own] jq_r . u_c
-        V A[NT][NR];
-        V rhs_all[NT], dinv_all[NT], lam_all[NT], act_all[NT];
-        V lam_own[NR];
+        // Delassus columns of the own rows, pre-scaled by the own row's 1/diag:
+        //   Ap[(k,r)][c] = (w_kr . w_c + [k == own] jq_r . u_c) * dinv_c
+        // Projected Gauss-Seidel then runs on the lane-private residual  res_c = rhs_c - dinv_c * sum_j A_cj lam_j :
+        //   candidate lam_i = lam_i + res_i, clamp, delta broadcast over the quad (one DPP move), res_c -= Ap[i][c] * delta.
+        // Rows of inactive contacts / limits have w = jq = u = rhs = 0, so their residual stays 0 and lam stays 0.
+        V Ap[NT][NR];
+        V lam_own[NR], res[NR];
         V loc[NR][NR];
 #pragma unroll
         for (int r = 0; r < NR; r++)
@@ -264,44 +267,37 @@ template <class T> struct Sim {
             _Pragma("unroll") for (int c = 0; c < NR; c++) {                                                           \
                 V d = wk[0] * rows[c].w[0] + wk[1] * rows[c].w[1] + wk[2] * rows[c].w[2] + wk[3] * rows[c].w[3] +      \
                       wk[4] * rows[c].w[4] + wk[5] * rows[c].w[5];                                                     \
-                A[NR * K + r][c] = d + qsel(own, loc[r][c], V(0.0f));                                                  \
+                Ap[NR * K + r][c] = (d + qsel(own, loc[r][c], V(0.0f))) * rows[c].dinv;                                \
             }                                                                                                          \
-            rhs_all[NR * K + r] = T::template bcast<K>(rows[r].rhs);                                                   \
-            dinv_all[NR * K + r] = T::template bcast<K>(rows[r].dinv);                                                 \
-            act_all[NR * K + r] = T::template bcast<K>(rows[r].act);                                                   \
         }                                                                                                              \
     }
         QS_GATHER(0) QS_GATHER(1) QS_GATHER(2) QS_GATHER(3)
 #undef QS_GATHER
         // warm start: normal rows only, factor cfg.warmstart (btMultiBodyConstraintSolver, SOLVER_USE_WARMSTARTING)
 #pragma unroll
-        for (int r = 0; r < NR; r++) lam_own[r] = V(0.0f);
+        for (int r = 0; r < NR; r++) { lam_own[r] = V(0.0f); res[r] = rows[r].rhs; }
         lam_own[0] = s.warm * cfg.warmstart * rows[0].act;
+        {
+            V l0 = T::template bcast<0>(lam_own[0]), l1 = T::template bcast<1>(lam_own[0]), l2 = T::template bcast<2>(lam_own[0]), l3 = T::template bcast<3>(lam_own[0]);
 #pragma unroll
-        for (int i = 0; i < NT; i++) lam_all[i] = V(0.0f);
-        lam_all[NR * 0] = T::template bcast<0>(lam_own[0]); lam_all[NR * 1] = T::template bcast<1>(lam_own[0]);
-        lam_all[NR * 2] = T::template bcast<2>(lam_own[0]); lam_all[NR * 3] = T::template bcast<3>(lam_own[0]);
-
+            for (int c = 0; c < NR; c++) res[c] = res[c] - (Ap[NR * 0][c] * l0 + Ap[NR * 1][c] * l1 + Ap[NR * 2][c] * l2 + Ap[NR * 3][c] * l3);
+        }
         const V big = V(1e10f), zero = V(0.0f);
         for (int it = 0; it < cfg.solver_iters; it++) {
 #define QS_ROW_UPDATE(K, RR, KIND)                                                                                    \
     {                                                                                                                  \
         constexpr int i_ = NR * (K) + (RR);                                                                            \
-        V part = A[i_][0] * lam_own[0];                                                                                \
-        _Pragma("unroll") for (int c = 1; c < NR; c++) part = part + A[i_][c] * lam_own[c];                            \
-        V sdot = T::quad_sum(part);                                                                                    \
-        V sum = lam_all[i_] + (rhs_all[i_] - sdot * dinv_all[i_]);                                                     \
+        V cand = lam_own[RR] + res[RR];                                                                                \
         if (KIND == 0) { /* unilateral row: [0, 1e10] */                                                               \
-            sum = qmin(qmax(sum, zero), big);                                                                          \
-            sum = qsel(qgt(act_all[i_], zero), sum, zero);                                                             \
+            cand = qmin(qmax(cand, zero), big);                                                                        \
         } else { /* friction row bounded by mu * current normal impulse; skipped while that impulse is not positive */ \
-            V tot = lam_all[NR * (K)];                                                                                 \
+            V tot = lam_own[0];                                                                                        \
             V lim = P.mu * tot;                                                                                        \
-            V cl = qmin(qmax(sum, zero - lim), lim);                                                                   \
-            sum = qsel(qand(qgt(tot, zero), qgt(act_all[i_], zero)), cl, lam_all[i_]);                                 \
+            cand = qsel(qgt(tot, zero), qmin(qmax(cand, zero - lim), lim), lam_own[RR]);                               \
         }                                                                                                              \
-        lam_all[i_] = sum;                                                                                             \
-        lam_own[RR] = qsel(T::is_leg(K), sum, lam_own[RR]);                                                            \
+        V dk = T::template bcast<K>(cand - lam_own[RR]);                                                               \
+        lam_own[RR] = qsel(T::is_leg(K), cand, lam_own[RR]);                                                           \
+        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] - Ap[i_][c] * dk;                               \
     }
             if (NR == 6) {  // joint-limit rows first; Bullet walks them backwards on even sweeps
                 if (it & 1) {
@@ -363,7 +359,7 @@ template <class T> struct Sim {
         {
             V x = s.qx, y = s.qy, z = s.qz, w = s.qw;
             V d = x * x + y * y + z * z + w * w;
-            V sc = V(2.0f) / d;
+            V sc = V(2.0f) * qrcp(d);
             V xs = x * sc, ys = y * sc, zs = z * sc;
             V wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
             R[0] = one - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
@@ -376,9 +372,8 @@ template <class T> struct Sim {
         v0.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
 
         // ---- leg kinematics in base coordinates
-        V s1 = qsin(s.q[0]), c1 = qcos(s.q[0]), s2 = qsin(s.q[1]), c2 = qcos(s.q[1]);
-        V q23 = s.q[1] + s.q[2];
-        V s23 = qsin(q23), c23 = qcos(q23);
+        V s1, c1, s2, c2, s23, c23;
+        qsincos(s.q[0], s1, c1); qsincos(s.q[1], s2, c2); qsincos(s.q[1] + s.q[2], s23, c23);
         V3v p1 = mk3<V>(fx * HIP_X, sy * HIP_Y, zero);
         V3v ax1 = mk3<V>(one, zero, zero);
         V3v Y = mk3<V>(zero, c1, s1);                       // joint axis of thigh and calf
@@ -408,7 +403,7 @@ template <class T> struct Sim {
         {
             V c11 = D22 * D33 - D23 * D23, c12 = D13 * D23 - D12 * D33, c13 = D12 * D23 - D13 * D22;
             V det = D11 * c11 + D12 * c12 + D13 * c13;
-            V id = one / det;
+            V id = qrcp(det);
             K11 = c11 * id; K12 = c12 * id; K13 = c13 * id;
             K22 = (D11 * D33 - D13 * D13) * id; K23 = (D12 * D13 - D11 * D23) * id; K33 = (D11 * D22 - D12 * D12) * id;
         }
@@ -445,10 +440,8 @@ template <class T> struct Sim {
 #pragma unroll
             for (int i = 0; i < 21; i++) Sm[i] = H[i] - Sm[i];
         }
-        chol6<V>(Sm);
         V Ld[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) Ld[i] = one / Sm[tri(i, i)];
+        chol6<V>(Sm, Ld);
 
         // ---- RNEA bias with qdd = 0, base acceleration 0, gravity as the fictitious base acceleration -g
         Spv a0; a0.a = mk3<V>(zero, zero, zero); a0.l = Rz * V(cfg.gravity);
@@ -540,7 +533,7 @@ template <class T> struct Sim {
         lsolve6<V>(Sm, Ld, r_.w);                                                                                      \
         V diag = r_.jq[0] * r_.u[0] + r_.jq[1] * r_.u[1] + r_.jq[2] * r_.u[2];                                         \
         _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
-        r_.dinv = one / diag;                                                                                          \
+        r_.dinv = qrcp(diag);                                                                                          \
         V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
         if (NORMAL) {                                                                                                  \
             V pos_err = qsel(qgt(dist, zero), zero, (zero - dist) * (cfg.contact_erp * inv_dt));                       \
@@ -583,7 +576,7 @@ template <class T> struct Sim {
                 V diag = Kc[j][j];
 #pragma unroll
                 for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];
-                r_.dinv = one / diag;
+                r_.dinv = qrcp(diag);
                 V rel = lim_sgn[j] * s.qd[j];
                 r_.rhs = ((zero - lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
             }
@@ -594,17 +587,16 @@ template <class T> struct Sim {
         // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
         s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;
         {
-            V wn = qsqrt(dot(s.vang, s.vang));
-            V th = wn * dt;
-            V small = V(0.5f * dt) * (one - th * th * (1.0f / 24.0f));
-            V big = qsin(V(0.5f) * th) / qmax(wn, V(1e-12f));
-            V sc = qsel(qlt(th, V(1e-6f)), small, big);
-            V dx = s.vang.x * sc, dy = s.vang.y * sc, dz = s.vang.z * sc, dw = qcos(V(0.5f) * th);
+            // exp map of w*dt: (w * sin(th/2)/|w|, cos(th/2)), th = |w| dt <= vel_cap*sqrt(3)*dt: series in th^2
+            V th2 = dot(s.vang, s.vang) * (dt * dt);
+            V sc = V(0.5f * dt) * (one - th2 * (1.0f / 24.0f) * (one - th2 * (1.0f / 80.0f)));
+            V dw = one - th2 * 0.125f * (one - th2 * (1.0f / 48.0f));
+            V dx = s.vang.x * sc, dy = s.vang.y * sc, dz = s.vang.z * sc;
             V nx = dw * s.qx + dx * s.qw + dy * s.qz - dz * s.qy;
             V ny = dw * s.qy - dx * s.qz + dy * s.qw + dz * s.qx;
             V nz = dw * s.qz + dx * s.qy - dy * s.qx + dz * s.qw;
             V nw = dw * s.qw - dx * s.qx - dy * s.qy - dz * s.qz;
-            V inv = one / qsqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+            V inv = qrsqrt(nx * nx + ny * ny + nz * nz + nw * nw);
             s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw * inv;
         }
 #pragma unroll
