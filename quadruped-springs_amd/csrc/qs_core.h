@@ -242,8 +242,8 @@ template <class T> struct Sim {
     struct Row { V jq[3], u[3], w[6], rhs, dinv, act; };
 
     // One stepSimulation() (gym_env.py:218-219) under joint torques tau[3] per leg.
-    template <int NR> static QS_FN void solve_and_integrate(const qs_config& cfg, const Par& P, State& s, Out& o, Row* rows,
-                                                            const V* Lc, const V* Ld, const V (*BK)[6], const V* R, V dist, V active) {
+    template <int NR> static QS_FN void solve_and_integrate(const qs_config& cfg, V mu, State& s, Out& o, const Row* rows,
+                                                            const V* Lc, const V* Ld, const V (*BK)[6], const V* R) {
         constexpr int NT = 4 * NR;
         const float dt = (float)cfg.dt;
         // Delassus columns of the own rows, pre-scaled by the own row's 1/diag:
@@ -292,26 +292,13 @@ template <class T> struct Sim {
             cand = qmin(qmax(cand, zero), big);                                                                        \
         } else { /* friction row bounded by mu * current normal impulse; skipped while that impulse is not positive */ \
             V tot = lam_own[0];                                                                                        \
-            V lim = P.mu * tot;                                                                                        \
+            V lim = mu * tot;                                                                                          \
             cand = qsel(qgt(tot, zero), qmin(qmax(cand, zero - lim), lim), lam_own[RR]);                               \
         }                                                                                                              \
         V dk = T::template bcast<K>(cand - lam_own[RR]);                                                               \
         lam_own[RR] = qsel(T::is_leg(K), cand, lam_own[RR]);                                                           \
         _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] - Ap[i_][c] * dk;                               \
     }
-            if (NR == 6) {  // joint-limit rows first; Bullet walks them backwards on even sweeps
-                if (it & 1) {
-                    QS_ROW_UPDATE(0, NR - 3, 0) QS_ROW_UPDATE(0, NR - 2, 0) QS_ROW_UPDATE(0, NR - 1, 0)
-                    QS_ROW_UPDATE(1, NR - 3, 0) QS_ROW_UPDATE(1, NR - 2, 0) QS_ROW_UPDATE(1, NR - 1, 0)
-                    QS_ROW_UPDATE(2, NR - 3, 0) QS_ROW_UPDATE(2, NR - 2, 0) QS_ROW_UPDATE(2, NR - 1, 0)
-                    QS_ROW_UPDATE(3, NR - 3, 0) QS_ROW_UPDATE(3, NR - 2, 0) QS_ROW_UPDATE(3, NR - 1, 0)
-                } else {
-                    QS_ROW_UPDATE(3, NR - 1, 0) QS_ROW_UPDATE(3, NR - 2, 0) QS_ROW_UPDATE(3, NR - 3, 0)
-                    QS_ROW_UPDATE(2, NR - 1, 0) QS_ROW_UPDATE(2, NR - 2, 0) QS_ROW_UPDATE(2, NR - 3, 0)
-                    QS_ROW_UPDATE(1, NR - 1, 0) QS_ROW_UPDATE(1, NR - 2, 0) QS_ROW_UPDATE(1, NR - 3, 0)
-                    QS_ROW_UPDATE(0, NR - 1, 0) QS_ROW_UPDATE(0, NR - 2, 0) QS_ROW_UPDATE(0, NR - 3, 0)
-                }
-            }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
             QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
             QS_ROW_UPDATE(2, 1, 1) QS_ROW_UPDATE(2, 2, 1) QS_ROW_UPDATE(3, 1, 1) QS_ROW_UPDATE(3, 2, 1)
@@ -346,7 +333,87 @@ template <class T> struct Sim {
         s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), zero - cap, cap);
         s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), zero - cap, cap);
         s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), zero - cap, cap);
-        (void)dist; (void)active;
+    }
+
+    // The joint-limit path (6 rows per leg: contact rows + one row per violated limit) is rare (falls).  It is written
+    // with ROLLED loops over dynamically indexed arrays, so the compiler keeps its 24 x 6 Delassus block and row data in
+    // private (scratch) memory instead of ~300 extra registers: the common path then needs no spills at all, and the
+    // scratch traffic exists only in waves that actually take this branch.  Same arithmetic as solve_and_integrate<3>.
+    struct RareArgs { Row rows[6]; V Sm[21], Ld[6], BK[3][6], R[9]; };
+    static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs& a) {
+        const float dt = (float)cfg.dt;
+        const V zero = V(0.0f), big = V(1e10f);
+        V Ap[24][6], lam[6], res[6], loc[6][6];
+#pragma clang loop unroll(disable)
+        for (int r = 0; r < 6; r++)
+#pragma clang loop unroll(disable)
+            for (int c = 0; c < 6; c++) loc[r][c] = a.rows[r].jq[0] * a.rows[c].u[0] + a.rows[r].jq[1] * a.rows[c].u[1] + a.rows[r].jq[2] * a.rows[c].u[2];
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < 4; k++) {
+            M own = T::is_leg(k);
+#pragma clang loop unroll(disable)
+            for (int r = 0; r < 6; r++) {
+                V wk[6];
+                for (int i = 0; i < 6; i++) wk[i] = T::bcast_dyn(a.rows[r].w[i], k);
+#pragma clang loop unroll(disable)
+                for (int c = 0; c < 6; c++) {
+                    V d = wk[0] * a.rows[c].w[0] + wk[1] * a.rows[c].w[1] + wk[2] * a.rows[c].w[2] + wk[3] * a.rows[c].w[3] +
+                          wk[4] * a.rows[c].w[4] + wk[5] * a.rows[c].w[5];
+                    Ap[6 * k + r][c] = (d + qsel(own, loc[r][c], zero)) * a.rows[c].dinv;
+                }
+            }
+        }
+#pragma clang loop unroll(disable)
+        for (int r = 0; r < 6; r++) { lam[r] = zero; res[r] = a.rows[r].rhs; }
+        lam[0] = s.warm * cfg.warmstart * a.rows[0].act;
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < 4; k++) {
+            V lk = T::bcast_dyn(lam[0], k);
+#pragma clang loop unroll(disable)
+            for (int c = 0; c < 6; c++) res[c] = res[c] - Ap[6 * k][c] * lk;
+        }
+        for (int it = 0; it < cfg.solver_iters; it++) {
+            // 36 row updates per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), 4 normals, 8 frictions
+#pragma clang loop unroll(disable)
+            for (int n = 0; n < 24; n++) {
+                int k, r, kind = 0;
+                if (n < 12) { int m = (it & 1) ? n : 11 - n; k = m / 3; r = 3 + m % 3; }
+                else if (n < 16) { k = n - 12; r = 0; }
+                else { k = (n - 16) >> 1; r = 1 + ((n - 16) & 1); kind = 1; }
+                V cand = lam[r] + res[r];
+                if (kind == 0) cand = qmin(qmax(cand, zero), big);
+                else { V tot = lam[0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, zero - lim), lim), lam[r]); }
+                V dk = T::bcast_dyn(cand - lam[r], k);
+                lam[r] = qsel(T::is_leg(k), cand, lam[r]);
+#pragma clang loop unroll(disable)
+                for (int c = 0; c < 6; c++) res[c] = res[c] - Ap[6 * k + r][c] * dk;
+            }
+        }
+        o.foot_force = lam[0] * (1.0f / dt);
+        s.warm = lam[0];
+        V z[6];
+        for (int i = 0; i < 6; i++) {
+            V t = zero;
+#pragma clang loop unroll(disable)
+            for (int r = 0; r < 6; r++) t = t + a.rows[r].w[i] * lam[r];
+            z[i] = T::quad_sum(t);
+        }
+        ltsolve6<V>(a.Sm, a.Ld, z);
+        const V cap = V(cfg.vel_cap);
+        for (int j = 0; j < 3; j++) {
+            V t = zero;
+#pragma clang loop unroll(disable)
+            for (int r = 0; r < 6; r++) t = t + a.rows[r].u[j] * lam[r];
+            for (int i = 0; i < 6; i++) t = t - a.BK[j][i] * z[i];
+            s.qd[j] = clampv<V>(s.qd[j] + t, zero - cap, cap);
+        }
+        const V* R = a.R;
+        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), zero - cap, cap);
+        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), zero - cap, cap);
+        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), zero - cap, cap);
+        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), zero - cap, cap);
+        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), zero - cap, cap);
+        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), zero - cap, cap);
     }
 
     static QS_FN void substep(const qs_config& cfg, const Par& P, State& s, const V* tau, Out& o) {
@@ -580,9 +647,22 @@ template <class T> struct Sim {
                 V rel = lim_sgn[j] * s.qd[j];
                 r_.rhs = ((zero - lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
             }
-            solve_and_integrate<6>(cfg, P, s, o, rows, Sm, Ld, BK, R, dist, active);
+            RareArgs a;
+#pragma unroll
+            for (int r = 0; r < 6; r++) a.rows[r] = rows[r];
+#pragma unroll
+            for (int i = 0; i < 21; i++) a.Sm[i] = Sm[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.Ld[i] = Ld[i];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) a.BK[j][i] = BK[j][i];
+#pragma unroll
+            for (int i = 0; i < 9; i++) a.R[i] = R[i];
+            solve_with_limits(cfg, P.mu, s, o, a);
         } else {
-            solve_and_integrate<3>(cfg, P, s, o, rows, Sm, Ld, BK, R, dist, active);
+            solve_and_integrate<3>(cfg, P.mu, s, o, rows, Sm, Ld, BK, R);
         }
         // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
         s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;

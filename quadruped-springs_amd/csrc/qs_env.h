@@ -354,8 +354,8 @@ template <class T> struct Env {
     // One env.step(action) (gym_env.py:227-256).  `rec` = this environment's record, `act` = its action row,
     // `obs` = QS_MAX_OBS floats of staging for its observation.
     static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id) {
-        typename S::State s; typename S::Par P; typename S::Out o; Task t;
-        load_state(rec, s); load_par(rec, P); load_task(rec, t);
+        typename S::State s; typename S::Par P; typename S::Out o;
+        load_state(rec, s); load_par(rec, P);
         const int d = cfg.action_dim;
         // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
         V act[15];
@@ -400,6 +400,8 @@ template <class T> struct Env {
             S::substep(cfg, P, s, tau, o);
         }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;
+        Task t;
+        load_task(rec, t);
         V now = V((float)((double)sim_step * cfg.dt));
         task_on_step(cfg, t, s, o, old_tau, now);
         V force = T::quad_sum(o.foot_force);

@@ -16,8 +16,10 @@
 #if defined(__HIPCC__)
 #define QS_FN __host__ __device__ __forceinline__
 #define QS_DEV __device__ __forceinline__
+#define QS_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define QS_FN inline
+#define QS_NOINLINE inline
 #endif
 
 // ------------------------------------------------------------------ scalar (device) flavour
@@ -76,6 +78,7 @@ struct LaneDev {
         return x;
     }
     template <int K> static QS_DEV float bcast(float x) { return dpp<K * 0x55>(x); }
+    static QS_DEV float bcast_dyn(float x, int k) { return __shfl(x, (int)((threadIdx.x & 60u) | (unsigned)k), 64); }  // rare path only
     static QS_DEV int leg() { return (int)(threadIdx.x & 3u); }
     static QS_DEV float fx() { return (threadIdx.x & 2u) ? -1.0f : 1.0f; }  // front +, rear -
     static QS_DEV float sy() { return (threadIdx.x & 1u) ? 1.0f : -1.0f; }  // right -, left +
@@ -138,6 +141,7 @@ struct LaneEmu {
         return r;
     }
     template <int K> static V4 bcast(V4 x) { return V4(x.v[K]); }
+    static V4 bcast_dyn(V4 x, int k) { return V4(x.v[k]); }
     static V4 fx() { return V4(1, 1, -1, -1); }
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }

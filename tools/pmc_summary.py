@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output directories (kernel stats + one directory per --pmc pass) for one kernel.
+usage: python tools/pmc_summary.py gpurun_out/prof3 k_step"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+root, kernel = sys.argv[1], sys.argv[2]
+for f in glob.glob(os.path.join(root, "*", "*_kernel_stats.csv")):
+    print("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
+    for r in csv.DictReader(open(f)):
+        n = r["Name"].split("(")[0]
+        if n.startswith("k_") or float(r["Percentage"]) > 1:
+            print(f"| {n[:50]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {r['Percentage']} |")
+print()
+print("| counter | per-launch avg | min | max | launches |\n|---|---|---|---|---|")
+for f in sorted(glob.glob(os.path.join(root, "*", "*_counter_collection.csv"))):
+    d = collections.defaultdict(list)
+    meta = None
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].split("(")[0] == kernel:
+            d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = r
+    for c, v in d.items():
+        print(f"| {c} | {sum(v) / len(v):.6g} | {min(v):.6g} | {max(v):.6g} | {len(v)} |")
+if meta:
+    print(f"\n{kernel}: grid {meta['Grid_Size']}, workgroup {meta['Workgroup_Size']}, LDS {meta['LDS_Block_Size']} B, scratch {meta['Scratch_Size']} B/lane, "
+          f"VGPR {meta['VGPR_Count']}, AGPR {meta['Accum_VGPR_Count']}, SGPR {meta['SGPR_Count']}")
