@@ -33,6 +33,9 @@ def workload(name):
     if name == "config3_8192":         # configs[2]
         return 8192, dict(base, task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
                           env_randomizer_mode="SPRING_RANDOMIZER", time_step=0.001, action_repeat=10)
+    if name == "config5_8192":         # configs[4]: backflip task, Hopf CPG action layer, masses + payload + springs + friction randomised
+        return 8192, dict(base, task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", env_randomizer_mode="TEST_RANDOMIZER",
+                          action_space_mode="CPG", time_step=0.001, action_repeat=10)
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-enum { QS_ACT_DEFAULT = 0, QS_ACT_SYMMETRIC = 1, QS_ACT_SYMMETRIC_NO_HIP = 2 };  /* control_interface/collection.py:49 */
+enum { QS_ACT_DEFAULT = 0, QS_ACT_SYMMETRIC = 1, QS_ACT_SYMMETRIC_NO_HIP = 2, QS_ACT_CPG = 3 /* build extension */ };  /* control_interface/collection.py:49 */
 enum { QS_MOTOR_PD = 0, QS_MOTOR_CARTESIAN_PD = 1, QS_MOTOR_TORQUE = 2 };       /* control_interface/collection.py:33 */
 enum {                                                                          /* tasks/task_collection.py:19-37 */
     QS_TASK_NO_TASK = 0, QS_TASK_JUMPING_IN_PLACE = 1, QS_TASK_JUMPING_FORWARD = 2,
@@ -63,7 +63,7 @@ enum {                                                                          
  * (quadruped-springs_amd/qs_amd/config.py); constants come from go1/configs_go1_*.py. */
 typedef struct qs_config {
     int32_t n_envs;
-    int32_t action_dim;          /* 12 / 6 / 4 (action_interface.py:12,27,56) */
+    int32_t action_dim;          /* 12 / 6 / 4 (action_interface.py:12,27,56); 5 for the CPG layer */
     int32_t action_space_mode;
     int32_t motor_control_mode;
     int32_t symm_idx;            /* motor_interface.py:15,56 */
@@ -100,6 +100,11 @@ typedef struct qs_config {
     float obs_noise_std[QS_MAX_OBS];
     float task_p[16];
     float reserved_f[8];
+    /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
+    float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
+    float cpg_lo[5], cpg_hi[5];/* action -> (omega_swing, omega_stance, mu, des_step_len, robot_height) */
+    float cpg_clearance, cpg_penetration, cpg_coupling, cpg_alpha;  /* :42-43, :35, :142 */
+    float reserved_g[2];
 } qs_config;
 
 typedef struct qs_handle qs_handle;

@@ -173,6 +173,13 @@ class Oracle:
         q = np.ascontiguousarray(q, self.real)
         return float(self.lib.qso_pitch_backflip(self._p(q), int(switched)))
 
+    def cpg_update(self, p5, dt, X8):
+        """one HopfNetwork.update(): X8 (r[4], theta[4]) is advanced in place; returns (x[4], z[4])"""
+        p = np.ascontiguousarray(p5, self.real)
+        x, z = np.zeros(4, self.real), np.zeros(4, self.real)
+        self.lib.qso_cpg_update(C.byref(self.cfg), self._p(p), self._creal(dt), self._p(X8), self._p(x), self._p(z))
+        return x, z
+
     def philox(self, seed, env, stream, ctr, blk):
         out = (C.c_uint32 * 4)()
         self.lib.qso_philox(C.c_uint64(seed), C.c_uint32(env), C.c_uint32(stream), C.c_uint32(ctr), C.c_uint32(blk), out)

@@ -180,6 +180,45 @@ real qso_pitch_backflip(const real* q, int switched) {
     return pitch;
 }
 
+/* ------------------------------------------------------------------ Hopf CPG (hopf_network.py:117-173) */
+void qso_cpg_update(const qso_config* cfg, const real* p, real dt, real* X, real* x, real* z) {
+    real w_swing = p[0], w_stance = p[1], mu = p[2], d_step = p[3], h = p[4];
+    real rd[4], td[4];
+    for (int i = 0; i < 4; i++) {
+        real r = X[i], th = X[4 + i];
+        rd[i] = (real)cfg->cpg_alpha * (mu - r * r) * r;                                    /* :149 */
+        td[i] = sin(th) > 0 ? w_swing : w_stance;                                           /* :152-156 */
+        for (int j = 0; j < 4; j++)                                                         /* :159-162 */
+            if (j != i) td[i] += X[j] * (real)cfg->cpg_coupling * sin(X[4 + j] - th - (real)cfg->cpg_phi[4 * i + j]);
+    }
+    for (int i = 0; i < 4; i++) {
+        X[i] += dt * rd[i];
+        real th = X[4 + i] + dt * td[i];
+        X[4 + i] = th - 2 * PI * floor(th / (2 * PI));                                      /* :170 python % */
+    }
+    for (int i = 0; i < 4; i++) {                                                           /* :124-133 */
+        real r = X[i], th = X[4 + i], s = sin(th);
+        x[i] = -d_step * r * cos(th);
+        z[i] = s > 0 ? -h + (real)cfg->cpg_clearance * s : -h + (real)cfg->cpg_penetration * s;
+    }
+}
+
+/* CPG action layer (BASELINE.json configs[4]): action in [-1,1]^5 -> CPG parameters; feet at (x, side * hip_len, z) -> IK */
+static void cpg_params(const qso_config* cfg, const real* act, real* p) {
+    for (int i = 0; i < 5; i++) {
+        real a = clampr(act[i], -1, 1);
+        p[i] = (real)cfg->cpg_lo[i] + (real)0.5 * (a + 1) * ((real)cfg->cpg_hi[i] - (real)cfg->cpg_lo[i]);
+    }
+}
+static void cpg_command(const qso_config* cfg, qso_env* e, const real* p, real* cmd) {
+    real x[4], z[4];
+    qso_cpg_update(cfg, p, (real)cfg->dt, e->cpg, x, z);
+    for (int L = 0; L < 4; L++) {
+        real xyz[3] = {x[L], ((L & 1) ? 1 : -1) * (real)cfg->leg_len[0], z[L]};
+        qso_leg_ik(cfg->leg_len, L, xyz, cmd + 3 * L);
+    }
+}
+
 /* ------------------------------------------------------------------ task state machine */
 static real sim_time(const qso_config* cfg, const qso_env* e) { return (real)e->sim_step * (real)cfg->dt; }
 static int is_flying(const qso_env* e) { /* quadruped.py:260-262 */
@@ -470,6 +509,10 @@ static void reset_env(qso_handle* h, int i) {
     real cmd[12]; for (int k = 0; k < 12; k++) cmd[k] = cfg->settle_cmd[k];
     for (int n = 0; n < cfg->settle_steps; n++) apply_and_step(cfg, e, cmd, h->gravity);
     for (int k = 0; k < 12; k++) e->last_action[k] = k < cfg->action_dim ? (real)cfg->settle_action[k] : 0;
+    if (cfg->action_space_mode == QSO_ACT_CPG) { /* hopf_network.py:62-63: r ~ 0.1 U(0,1), theta = PHI[0,:] */
+        uint32_t rr[4]; qso_philox(cfg->seed, (uint32_t)(i + cfg->env_id_offset), 3, (uint32_t)e->episode, 0, rr);
+        for (int L = 0; L < 4; L++) { e->cpg[L] = (real)0.1 * qso_u01(rr[L]); e->cpg[4 + L] = cfg->cpg_phi[L]; }
+    }
     task_reset(cfg, e);
     read_sensors(cfg, e, e->obs);
     add_noise(cfg, e, i, e->obs);
@@ -519,9 +562,15 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         if (cfg->enable_filter) { qso_filter_step(cfg->filt_b, cfg->filt_a, d, act, e->xhist, e->yhist, act); memcpy(e->last_filtered, act, d * sizeof(real)); }
         /* _interpolate_actions (:187-205) is an identity in the reference: _last_action/_last_filtered_action
            were overwritten with the current action at :230/:234 before the substeps run. */
-        real cmd[12];
-        if (cfg->rl_interface) qso_action_to_command(cfg, act, cmd); else for (int k = 0; k < 12; k++) cmd[k] = act[k];
-        for (int s = 0; s < cfg->action_repeat; s++) { apply_and_step(cfg, e, cmd, h->gravity); e->sim_step++; }
+        real cmd[12], cpgp[5];
+        const int cpg = cfg->action_space_mode == QSO_ACT_CPG;
+        if (cpg) cpg_params(cfg, act, cpgp);
+        else if (cfg->rl_interface) qso_action_to_command(cfg, act, cmd);
+        else for (int k = 0; k < 12; k++) cmd[k] = act[k];
+        for (int s = 0; s < cfg->action_repeat; s++) {
+            if (cpg) cpg_command(cfg, e, cpgp, cmd);   /* the oscillators tick at the physics rate (hopf_network.py:241-289) */
+            apply_and_step(cfg, e, cmd, h->gravity); e->sim_step++;
+        }
         e->env_step++; e->total_steps++;
         task_on_step(cfg, e);
         real r = task_reward(cfg, e);

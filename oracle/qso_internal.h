@@ -55,6 +55,7 @@ typedef struct {
     int sim_step, env_step, episode;
     uint32_t total_steps;
     qso_task task;
+    real cpg[8];            /* Hopf oscillators: r[4], theta[4] */
     float obs[QSO_MAX_OBS], term_obs[QSO_MAX_OBS];
 } qso_env;
 

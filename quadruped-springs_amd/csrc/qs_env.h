@@ -97,6 +97,30 @@ template <class T> struct Env {
         else { cmd[0] = s[0]; cmd[1] = s[1]; cmd[2] = s[2]; }
     }
 
+    // ---- Hopf CPG action layer (hopf_network.py:117-173, 241-289): one oscillator per lane
+    static QS_FN void cpg_command(const qs_config& cfg, const V* p, V& r, V& th, V* cmd) {
+        const float dt = (float)cfg.dt;
+        const V zero = V(0.0f);
+        V s_th, c_th; qsincos(th, s_th, c_th);
+        V rd = (p[2] - r * r) * r * cfg.cpg_alpha;                                                   // :149
+        V td = qsel(qgt(s_th, zero), p[0], p[1]);                                                   // :152-156
+#define QS_CPG_COUPLE(J)                                                                             \
+    {                                                                                                \
+        V rj = T::template bcast<J>(r), tj = T::template bcast<J>(th);                               \
+        V sj, cj; qsincos(tj - th - T::ld_leg(cfg.cpg_phi, J, 4), sj, cj);                           \
+        td = td + qsel(T::is_leg(J), zero, rj * cfg.cpg_coupling * sj);                              \
+    }
+        QS_CPG_COUPLE(0) QS_CPG_COUPLE(1) QS_CPG_COUPLE(2) QS_CPG_COUPLE(3)                          // :159-162
+#undef QS_CPG_COUPLE
+        r = r + rd * dt;
+        V t2 = th + td * dt;
+        th = t2 - qfloor(t2 * (1.0f / (2.0f * PI))) * (2.0f * PI);                                   // :170
+        qsincos(th, s_th, c_th);
+        V x = zero - p[3] * r * c_th;                                                                // :128
+        V z = qsel(qgt(s_th, zero), s_th * cfg.cpg_clearance, s_th * cfg.cpg_penetration) - p[4];    // :129-132
+        leg_ik(cfg, x, T::sy() * cfg.leg_len[0], z, cmd);
+    }
+
     // ---- record <-> registers
     static QS_FN void load_state(const float* rec, typename S::State& s) {
         s.pos = mk3<V>(T::ld(rec, R_POS), T::ld(rec, R_POS + 1), T::ld(rec, R_POS + 2));
@@ -389,16 +413,26 @@ template <class T> struct Env {
         // _interpolate_actions (gym_env.py:187-205) is the identity in the reference (both "last" actions are overwritten
         // with the current one at :230/:234 before the substeps run), so there is nothing to do for enable_interp.
         V cmd[3];
-        action_to_command(cfg, act, cmd);
+        const bool cpg = cfg.action_space_mode == QS_ACT_CPG;
+        V cpg_p[5], cpg_r = V(0.0f), cpg_th = V(0.0f);
+        if (cpg) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) cpg_p[k] = clampv<V>(act[k], V(-1.0f), V(1.0f)) * (0.5f * (cfg.cpg_hi[k] - cfg.cpg_lo[k])) + 0.5f * (cfg.cpg_hi[k] + cfg.cpg_lo[k]);
+            cpg_r = T::ld_leg(rec, R_CPG, 1); cpg_th = T::ld_leg(rec, R_CPG + 4, 1);
+        } else {
+            action_to_command(cfg, act, cmd);
+        }
         int sim_step = f2i(rec[R_SIM_STEP]), env_step = f2i(rec[R_ENV_STEP]), total = f2i(rec[R_TOTAL_STEPS]);
         V old_tau[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) old_tau[j] = T::ld_leg(rec, R_NEW_TAU + j, 3);
         for (int k = 0; k < cfg.action_repeat; k++) {  // gym_env.py:236-237, 207-216
             V tau[3];
+            if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             S::actuate(cfg, P, s, cmd, o, tau);
             S::substep(cfg, P, s, tau, o);
         }
+        if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;
         Task t;
         load_task(rec, t);
@@ -482,6 +516,10 @@ template <class T> struct Env {
             V a = V(k < cfg.action_dim ? cfg.settle_action[k] : 0.0f);
             T::st(rec, R_LAST_ACTION + k, a);
             T::st(rec, R_XHIST + k, a); T::st(rec, R_XHIST + 12 + k, a); T::st(rec, R_YHIST + k, a); T::st(rec, R_YHIST + 12 + k, a);
+        }
+        if (cfg.action_space_mode == QS_ACT_CPG) {  // hopf_network.py:62-63: r ~ 0.1 U(0,1), theta = PHI[0,:]
+            uint32_t rr[4]; philox4x32(cfg.seed, env_id, 3u, (uint32_t)episode, 0u, rr);
+            for (int L = 0; L < 4; L++) { T::st(rec, R_CPG + L, V(0.1f * u01(rr[L]))); T::st(rec, R_CPG + 4 + L, V(cfg.cpg_phi[L])); }
         }
         task_reset(cfg, t, s, o, V(0.0f));
         store_task(rec, t);

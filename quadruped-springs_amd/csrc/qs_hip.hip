@@ -233,7 +233,7 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (!cfg || !out) QS_FAIL(-1, "null argument");
     if (cfg->n_envs <= 0) QS_FAIL(-1, "n_envs must be positive");
     if (cfg->obs_dim <= 0 || cfg->obs_dim > QS_MAX_OBS || cfg->n_sensors > QS_MAX_SENSORS) QS_FAIL(-1, "observation bundle too large");
-    if (cfg->action_dim != 12 && cfg->action_dim != 6 && cfg->action_dim != 4) QS_FAIL(-1, "action_dim must be 12, 6 or 4");
+    if (cfg->action_dim != 12 && cfg->action_dim != 6 && cfg->action_dim != 4 && cfg->action_dim != 5) QS_FAIL(-1, "action_dim must be 12, 6, 4 or 5 (CPG)");
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
     int od = 0;

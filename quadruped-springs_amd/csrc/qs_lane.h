@@ -25,6 +25,7 @@
 // ------------------------------------------------------------------ scalar (device) flavour
 QS_FN float qsqrt(float x) { return sqrtf(x); }
 QS_FN float qabs(float x) { return fabsf(x); }
+QS_FN float qfloor(float x) { return floorf(x); }
 QS_FN float qmin(float a, float b) { return fminf(a, b); }
 QS_FN float qmax(float a, float b) { return fmaxf(a, b); }
 QS_FN float qsin(float x) { return sinf(x); }
@@ -117,7 +118,7 @@ inline V4& operator+=(V4& a, V4 b) { a = a + b; return a; }
 inline V4& operator-=(V4& a, V4 b) { a = a - b; return a; }
 inline V4& operator*=(V4& a, V4 b) { a = a * b; return a; }
 #define QS_V4_FN1(name, f) inline V4 name(V4 a) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = f(a.v[i]); return r; }
-QS_V4_FN1(qsqrt, sqrtf) QS_V4_FN1(qabs, fabsf) QS_V4_FN1(qsin, sinf) QS_V4_FN1(qcos, cosf) QS_V4_FN1(qasin, asinf)
+QS_V4_FN1(qsqrt, sqrtf) QS_V4_FN1(qabs, fabsf) QS_V4_FN1(qfloor, floorf) QS_V4_FN1(qsin, sinf) QS_V4_FN1(qcos, cosf) QS_V4_FN1(qasin, asinf)
 QS_V4_FN1(qexp, expf) QS_V4_FN1(qlog, logf) QS_V4_FN1(qrcp, qrcp) QS_V4_FN1(qrsqrt, qrsqrt)
 inline void qsincos(V4 x, V4& s, V4& c) { for (int i = 0; i < 4; i++) qsincos(x.v[i], s.v[i], c.v[i]); }
 inline V4 qmin(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }

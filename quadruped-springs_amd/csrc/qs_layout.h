@@ -25,7 +25,8 @@ enum {
     R_TAU_SPRING = 182,   // 12
     R_POSE_CACHE = 194,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
     R_FLAGS = 203,        // bit 0: needs reset
-    QS_REC = 208,         // multiple of 4 (16-byte vector moves)
+    R_CPG = 204,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
+    QS_REC = 212,         // multiple of 4 (16-byte vector moves)
 };
 enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };
 enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO = 4, T_YAW_TO = 7, T_INIT_H = 8, T_MAX_FLIGHT = 9,

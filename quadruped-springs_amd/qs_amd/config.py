@@ -14,7 +14,21 @@ from . import go1_config
 MAX_SENSORS = 16
 MAX_OBS = 64
 
-ACTION_SPACE_MODES = {"DEFAULT": (0, 12), "SYMMETRIC": (1, 6), "SYMMETRIC_NO_HIP": (2, 4)}
+ACTION_SPACE_MODES = {"DEFAULT": (0, 12), "SYMMETRIC": (1, 6), "SYMMETRIC_NO_HIP": (2, 4),
+                      "CPG": (3, 5)}  # build extension for BASELINE.json configs[4]: the policy drives a Hopf CPG
+
+# hopf_network.py:74-115
+_PI = math.pi
+CPG_GAITS = {
+    "TROT": [[0, -_PI, -_PI, 0], [_PI, 0, 0, _PI], [_PI, 0, 0, _PI], [0, -_PI, -_PI, 0]],
+    "WALK": [[0, -_PI, -_PI / 2, _PI / 2], [_PI, 0, _PI / 2, 3 * _PI / 2], [_PI / 2, -_PI / 2, 0, _PI], [-_PI / 2, -3 * _PI / 2, -_PI, 0]],
+    "BOUND": [[0, 0, -_PI, -_PI], [0, 0, -_PI, -_PI], [_PI, _PI, 0, 0], [_PI, _PI, 0, 0]],
+    "PACE": [[0, -_PI, 0, -_PI], [_PI, 0, _PI, 0], [0, -_PI, 0, -_PI], [_PI, 0, _PI, 0]],
+}
+# action in [-1, 1]^5 -> (omega_swing, omega_stance, mu, des_step_len, robot_height); ranges chosen around the values the
+# reference's CPG driver uses (hopf_network.py:36-45, 195-206)
+CPG_LO = [2 * _PI, 2 * _PI, 0.5, 0.0, 0.15]
+CPG_HI = [40 * _PI, 40 * _PI, 2.5, 0.10, 0.30]
 MOTOR_CONTROL_MODES = {"PD": 0, "CARTESIAN_PD": 1, "TORQUE": 2}
 TASKS = {
     "NO_TASK": 0,
@@ -104,6 +118,9 @@ class QsConfig(C.Structure):
         ("fallen_height", C.c_float), ("leg_len", C.c_float * 3),
         ("contact_erp", C.c_float), ("joint_erp", C.c_float), ("warmstart", C.c_float), ("vel_cap", C.c_float),
         ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("reserved_f", C.c_float * 8),
+        ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
+        ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
+        ("reserved_g", C.c_float * 2),
     ]
 
 
@@ -202,6 +219,7 @@ def build_config(
     auto_reset=False,
     settle_steps=2500,
     env_id_offset=0,
+    cpg_gait="BOUND",
     robot_config=None,
     **_ignored,
 ):
@@ -230,6 +248,8 @@ def build_config(
     if not isRLGymInterface:
         cfg.action_dim = action_dim = 12  # raw motor commands (gym_env.py:212-214)
     # limits and poses (motor_interface.py:9-32, :50-63, :94-100)
+    if action_space_mode == "CPG" and motor_control_mode != "PD":
+        raise ValueError("the CPG action layer drives joint PD targets: motor_control_mode must be PD")
     if motor_control_mode == "PD":
         lo, hi, symm = rc.RL_LOWER_ANGLE_JOINT, rc.RL_UPPER_ANGLE_JOINT, 0
         init_pose, landing_pose = rc.INIT_MOTOR_ANGLES, rc.ANGLE_LANDING_POSE
@@ -265,7 +285,16 @@ def build_config(
     for i in range(12):
         cfg.cmd_lo[i], cfg.cmd_hi[i] = lo[i], hi[i]
     # settle reference -> action -> command round trip (interface_base.py:68-73, 182-200)
-    if isRLGymInterface:
+    for i, row in enumerate(CPG_GAITS[cpg_gait]):
+        for j, v in enumerate(row):
+            cfg.cpg_phi[4 * i + j] = v
+    for i in range(5):
+        cfg.cpg_lo[i], cfg.cpg_hi[i] = CPG_LO[i], CPG_HI[i]
+    cfg.cpg_clearance, cfg.cpg_penetration, cfg.cpg_coupling, cfg.cpg_alpha = 0.05, 0.01, 1.0, 50.0  # hopf_network.py:42-43, 35, 142
+    if isRLGymInterface and action_space_mode == "CPG":
+        settle_cmd = scale_action_to_command(scale_command_to_action(np.asarray(init_pose, float), lo, hi), lo, hi)
+        settle_action = np.zeros(5)
+    elif isRLGymInterface:
         aspace = action_space_mode
         ref_action = to_actual_action_space(scale_command_to_action(np.asarray(init_pose, float), lo, hi), aspace, symm)
         settle_scaled = scale_action_to_command(to_default_action_space(ref_action, aspace, symm), lo, hi)
@@ -292,8 +321,12 @@ def build_config(
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = 0.2, 0.2, 0.1, rc.VELOCITY_LIMITS[0]
     for i, s in enumerate(lay["std"]):
         cfg.obs_noise_std[i] = s
-    landing_action = to_actual_action_space(scale_command_to_action(np.asarray(landing_pose, float), lo, hi), action_space_mode, symm) \
-        if isRLGymInterface else np.zeros(12)
+    if not isRLGymInterface:
+        landing_action = np.zeros(12)
+    elif action_space_mode == "CPG":
+        landing_action = np.zeros(5)
+    else:
+        landing_action = to_actual_action_space(scale_command_to_action(np.asarray(landing_pose, float), lo, hi), action_space_mode, symm)
     meta = dict(robot_config=rc, layout=lay, lower=np.array(lo, float), upper=np.array(hi, float), symm_idx=symm,
                 init_pose=np.array(init_pose, float), landing_pose=np.array(landing_pose, float),
                 settle_action=np.array(settle_action, float), landing_action=np.array(landing_action, float),

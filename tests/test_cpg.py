@@ -1,0 +1,54 @@
+"""Hopf CPG (hopf_network.py:26-173): the oracle's restatement against the reference's HopfNetwork (golden G13), and the
+CPG action layer of BASELINE.json configs[4] (kernel arithmetic on the host emulation vs the oracle)."""
+import numpy as np
+import pytest
+
+from emu.emu import Emu
+from oracle.qso import Oracle
+from qs_amd import config as qcfg
+from qs_amd.config import build_config
+
+
+@pytest.mark.parametrize("gait", ["TROT", "WALK", "PACE", "BOUND"])
+def test_g13_hopf_network(golden, gait):
+    g = golden("cpg.npz")
+    cfg, _ = build_config(action_space_mode="CPG", cpg_gait=gait, enable_springs=True, task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP")
+    np.testing.assert_allclose(np.array(cfg.cpg_phi).reshape(4, 4), g[f"g13_{gait}_phi"], atol=1e-6)
+    np.testing.assert_allclose([cfg.cpg_clearance, cfg.cpg_penetration, cfg.cpg_coupling, cfg.cpg_alpha], g[f"g13_{gait}_shape"], rtol=1e-6)
+    o = Oracle(cfg)
+    X = g[f"g13_{gait}_X0"].astype(np.float64).reshape(8).copy()
+    p = g[f"g13_{gait}_params"]
+    worst = 0.0
+    for k in range(2000):
+        x, z = o.cpg_update(p, 0.001, X)
+        ref = g[f"g13_{gait}_X"][k].reshape(8)
+        d = np.abs(X - ref)
+        d[4:] = np.minimum(d[4:], 2 * np.pi - d[4:])   # a phase that wraps one step earlier/later is the same phase
+        worst = max(worst, d.max())
+        X[:] = ref                                      # float32 PHI constants: re-synchronise, compare one update at a time
+        np.testing.assert_allclose(x, g[f"g13_{gait}_x"][k], atol=2e-6)
+        np.testing.assert_allclose(z, g[f"g13_{gait}_z"][k], atol=2e-6)
+    assert worst < 5e-6
+
+
+def test_cpg_action_layer_emu_vs_oracle():
+    cfg, meta = build_config(n_envs=1, task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", enable_springs=True,
+                             enable_action_filter=True, noise=False, env_randomizer_mode="TEST_RANDOMIZER", action_space_mode="CPG", seed=5)
+    assert cfg.action_dim == 5
+    o, e = Oracle(cfg), Emu(cfg)
+    np.testing.assert_allclose(e.reset(), o.reset(), atol=5e-4)
+    np.testing.assert_allclose(e.get("R_PARAMS", 24)[0], o.get_info(6)[0], rtol=1e-6)   # masses, payload, springs, friction
+    par = o.get_info(6)[0]
+    assert 0.5 <= par[0] <= 1.0 and 0 <= par[20] <= 1.0 and abs(par[21]) <= 0.1 and par[22] == 0 and abs(par[23]) <= 0.1
+    assert abs(par[16] + 4 * par[17:20].sum() + par[20] + 4 * 0.06 + 0.00101 - 12.01301) < 1e-5   # total mass is kept (env_randomizer.py:61-65)
+    rng = np.random.default_rng(0)
+    for i in range(80):
+        a = rng.uniform(-1, 1, size=(1, 5)).astype(np.float32)
+        s = o.get_state(); o.set_state(s); e.set_state(s)
+        oo, ro, do, to = o.step(a)
+        eo, re, de, te = e.step(a)
+        np.testing.assert_allclose(eo, oo, atol=5e-3, err_msg=f"obs step {i}")
+        np.testing.assert_allclose(re, ro, atol=2e-4)
+        assert do[0] == de[0]
+        if do[0]:
+            o.reset(); e.reset()

@@ -84,6 +84,8 @@ CASES = [
     dict(task_env="JUMPING_IN_PLACE_PPO", observation_space_mode="PPO_BASIC_X"),
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP"),
     dict(time_step=0.002, action_repeat=5),   # BASELINE.json config 2: dt = 1/500 s, 60 solver sweeps
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", env_randomizer_mode="SPRING_RANDOMIZER", seed=9),  # config 3
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER", seed=4),  # config 5
 ]
 
 
@@ -97,7 +99,10 @@ def test_env_step_parity_resynced(torch_cuda, kw):
     for i in range(100):
         a = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
         if i % 40 > 25:
-            a[: n // 2] = np.tile([0.0, -1.0, 1.0], 4)[:d] if d != 4 else np.tile([-1.0, 1.0], 2)
+            if d == 5:
+                a[: n // 2] = [1.0, 1.0, 1.0, 1.0, -1.0]
+            else:
+                a[: n // 2] = np.tile([0.0, -1.0, 1.0], 4)[:d] if d != 4 else np.tile([-1.0, 1.0], 2)
         s = o.get_state()
         o.set_state(s); v.set_state(s.astype(np.float32))
         oo, ro, do, to = o.step(a)

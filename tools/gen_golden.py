@@ -540,10 +540,34 @@ def gen_traces():
     print("traces.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- G13 Hopf CPG
+def gen_cpg():
+    from quadruped_spring.hopf_network import HopfNetwork
+    out = {}
+    import contextlib
+    import io
+    for gait, (ws, wst) in {"TROT": (16.0, 4.0), "WALK": (24.0, 25.0), "PACE": (20.0, 20.0), "BOUND": (10.0, 40.0)}.items():
+        np.random.seed(7)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cpg = HopfNetwork(gait=gait, omega_swing=ws * np.pi, omega_stance=wst * np.pi, time_step=0.001)
+        X0 = cpg.X.copy()
+        xs, zs, Xs = [], [], []
+        for _ in range(2000):
+            x, z = cpg.update()
+            xs.append(x); zs.append(z); Xs.append(cpg.X.copy())
+        out[f"g13_{gait}_X0"], out[f"g13_{gait}_X"] = X0, np.array(Xs)
+        out[f"g13_{gait}_x"], out[f"g13_{gait}_z"] = np.array(xs), np.array(zs)
+        out[f"g13_{gait}_params"] = np.array([ws * np.pi, wst * np.pi, cpg._mu, cpg._des_step_len, cpg._robot_height])
+        out[f"g13_{gait}_phi"] = cpg.PHI.copy()
+        out[f"g13_{gait}_shape"] = np.array([cpg._ground_clearance, cpg._ground_penetration, cpg._coupling_strength, 50.0])
+    np.savez_compressed(os.path.join(OUT, "cpg.npz"), **out)
+    print("cpg.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    gen_stateless()
-    gen_rewards()
-    gen_traces()
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg"]
+    for w in which:
+        {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg}[w]()
