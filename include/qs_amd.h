@@ -40,7 +40,8 @@ enum {                                                                          
     QS_TASK_NO_TASK = 0, QS_TASK_JUMPING_IN_PLACE = 1, QS_TASK_JUMPING_FORWARD = 2,
     QS_TASK_CONT_JUMPING_FORWARD = 3, QS_TASK_CONT_JUMPING_FORWARD2 = 4,
     QS_TASK_JUMPING_IN_PLACE_PPO = 5, QS_TASK_JUMPING_FORWARD_PPO = 6, QS_TASK_BACKFLIP = 7,
-    QS_TASK_JUMPING_IN_PLACE_PPO_HP = 8, QS_TASK_JUMPING_FORWARD_PPO_HP = 9,
+    QS_TASK_JUMPING_IN_PLACE_PPO_HP = 8, QS_TASK_JUMPING_FORWARD_PPO_HP = 9, QS_TASK_BACKFLIP_PPO = 10,
+    QS_TASK_CONT_JUMPING_FORWARD3 = 11, QS_TASK_CONT_JUMPING_FORWARD_PPO = 12,
 };
 enum {                                                                          /* sensors/robot_sensors.py */
     QS_SENS_JOINT_POS = 0, QS_SENS_JOINT_VEL = 1, QS_SENS_PITCH = 2, QS_SENS_HEIGHT = 3, QS_SENS_VEL_Z = 4,
@@ -57,7 +58,7 @@ enum {                                                                          
 #define QS_MAX_OBS 64
 #define QS_STATE_DIM 37    /* pos3 quat4(xyzw) vlin3 vang3 q12 qd12 */
 #define QS_PARAM_DIM 24    /* mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_payload, r_payload3 */
-#define QS_TASK_DIM 32
+#define QS_TASK_DIM 48    /* 32 task scalars, pose cache 9 (pos, vel, rpy), n_invalid, foot-force sum, sim_step, 4 spare */
 
 /* Keyword arguments of QuadrupedGymEnv.__init__ (gym_env.py:52-70) resolved to numbers by the host
  * (quadruped-springs_amd/qs_amd/config.py); constants come from go1/configs_go1_*.py. */

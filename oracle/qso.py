@@ -72,7 +72,7 @@ class Oracle:
         s = np.ascontiguousarray(s, self.real).reshape(self.n, 37)
         self._check(self.lib.qso_set_state(self.h, self._p(s)))
 
-    _INFO_DIM = {0: 4, 1: 4, 2: 12, 3: 12, 4: 32, 5: 1, 6: 24, 7: 4, 8: 12}
+    _INFO_DIM = {0: 4, 1: 4, 2: 12, 3: 12, 4: 48, 5: 1, 6: 24, 7: 4, 8: 12}
 
     def get_info(self, which):
         dim = self.o if which == 9 else self._INFO_DIM[which]
@@ -85,7 +85,7 @@ class Oracle:
         self._check(self.lib.qso_set_params(self.h, which, self._p(v)))
 
     def set_task(self, task):
-        t = np.ascontiguousarray(task, self.real).reshape(self.n, 32)
+        t = np.ascontiguousarray(task, self.real).reshape(self.n, 48)
         self._check(self.lib.qso_set_task(self.h, self._p(t)))
 
     def eval_reward(self, which):

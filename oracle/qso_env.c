@@ -231,6 +231,18 @@ static real jump_distance(const qso_task* t) { /* task_base.py:108-116: (pos - p
 }
 static void max_fwd_update(qso_task* t) { real d = jump_distance(t); if (d > t->max_fwd) t->max_fwd = d; }
 static int task_family_continuous(int task) { return task == QSO_TASK_CONT_JUMPING_FORWARD || task == QSO_TASK_CONT_JUMPING_FORWARD2; }
+static int task_family_continuous2(int task) { return task == QSO_TASK_CONT_JUMPING_FORWARD3 || task == QSO_TASK_CONT_JUMPING_FORWARD_PPO; }
+/* TaskContinuousJumping2 constants (task_base.py:286-290; robot_tasks.py:171-175, 559-561) */
+static void cj2_constants(int task, real* jump_limit, real* height_limit, real* bound) {
+    if (task == QSO_TASK_CONT_JUMPING_FORWARD3) { *jump_limit = (real)0.6; *height_limit = (real)0.45; *bound = (real)0.7; }
+    else { *jump_limit = (real)0.6; *height_limit = (real)0.5; *bound = (real)0.85; }
+}
+/* get_entropy_fwd (task_base.py:376-383) from the sums: -sum p log2 p = log2 S - (sum f log2 f) / S, over max(n, 3) entries */
+static real cj2_entropy(const qso_task* t) {
+    if (t->jump_count == 0 || t->sum_fwd < (real)0.05) return 0;
+    real n = t->jump_count < 3 ? 3 : t->jump_count;
+    return (log2(t->sum_fwd) - t->sum_flogf / t->sum_fwd) / log2(n);
+}
 
 static void task_on_step(const qso_config* cfg, qso_env* e) {
     qso_task* t = &e->task;
@@ -252,7 +264,29 @@ static void task_on_step(const qso_config* cfg, qso_env* e) {
     if (fabs(t->pos[0]) > t->max_dx) t->max_dx = fabs(t->pos[0]);
     if (fabs(t->rpy[1]) > t->max_pitch) t->max_pitch = fabs(t->rpy[1]);
     real now = sim_time(cfg, e);
-    if (!task_family_continuous(cfg->task)) { /* :92-106 */
+    if (task_family_continuous2(cfg->task)) { /* task_base.py:321-355 */
+        real jump_limit, height_limit, bound; cj2_constants(cfg->task, &jump_limit, &height_limit, &bound);
+        t->end_jump = 0;
+        if (flying) {
+            if (!t->all_air) {
+                t->all_air = 1; t->t_takeoff = now; memcpy(t->pose_to, t->pos, sizeof(t->pos)); t->yaw_to = t->rpy[2];
+                t->is_jumping = flying && vz / (real)9.81 > (real)0.06;
+                t->max_jump_h = 0; /* restart_jump_performance_variables() right after max_jump_height = z (:327-330) */
+            } else if (t->pos[2] > t->max_jump_h) t->max_jump_h = t->pos[2];
+        } else if (t->all_air) {
+            if (now - t->t_takeoff > t->max_flight) t->max_flight = now - t->t_takeoff;
+            if (t->first_jump == 0) { /* :342-353; the first jump is ignored */
+                real d = jump_distance(t);
+                real fwd = d < jump_limit ? d : jump_limit, hgt = t->max_jump_h < height_limit ? t->max_jump_h : height_limit;
+                real perf = (real)0.7 * fwd / jump_limit + (real)0.3 * hgt / height_limit;
+                t->jump_count += 1; t->sum_fwd += fwd; t->sum_flogf += fwd > 0 ? fwd * log2(fwd) : 0; t->sum_height += hgt;
+                t->sum_perf += perf; if (perf > t->max_perf) t->max_perf = perf; t->last_perf = perf;
+                if (perf >= bound) t->good_jumps += 1;
+                t->end_jump = 1;
+            } else t->first_jump = 0;
+            t->all_air = 0; t->is_jumping = 0;
+        }
+    } else if (!task_family_continuous(cfg->task)) { /* :92-106 */
         if (flying) {
             if (!t->all_air) { t->all_air = 1; t->t_takeoff = now; memcpy(t->pose_to, t->pos, sizeof(t->pos)); t->yaw_to = t->rpy[2]; }
             else max_fwd_update(t);
@@ -282,6 +316,10 @@ static void task_on_step(const qso_config* cfg, qso_env* e) {
         real p = qso_pitch_backflip(e->s.quat, t->switched);
         if (p > t->bf_max_pitch) t->bf_max_pitch = p;
     }
+    if (cfg->task == QSO_TASK_BACKFLIP_PPO) { /* robot_tasks.py:752-754: reuses TaskJumping._max_pitch */
+        real p = qso_pitch_backflip(e->s.quat, t->switched);
+        if (p > t->max_pitch) t->max_pitch = p;
+    }
 }
 
 static void task_reset(const qso_config* cfg, qso_env* e) { /* task_base.py:40-59 */
@@ -289,6 +327,7 @@ static void task_reset(const qso_config* cfg, qso_env* e) { /* task_base.py:40-5
     real keep_bf = t->bf_max_pitch; /* BackFlip.max_pitch is only initialised in __init__ (robot_tasks.py:524) */
     memset(t, 0, sizeof(*t));
     t->bf_max_pitch = keep_bf;
+    t->first_jump = 1;
     if (cfg->task == QSO_TASK_NO_TASK) return;
     t->t_takeoff = sim_time(cfg, e);
     memcpy(t->pose_to, e->s.pos, sizeof(t->pose_to));
@@ -314,6 +353,17 @@ static real task_reward(const qso_config* cfg, const qso_env* e) {
     const qso_task* t = &e->task;
     int ppo_ip = cfg->task == QSO_TASK_JUMPING_IN_PLACE_PPO || cfg->task == QSO_TASK_JUMPING_IN_PLACE_PPO_HP;
     int ppo_fw = cfg->task == QSO_TASK_JUMPING_FORWARD_PPO || cfg->task == QSO_TASK_JUMPING_FORWARD_PPO_HP;
+    if (cfg->task == QSO_TASK_BACKFLIP_PPO) { /* robot_tasks.py:709-800 */
+        real rew_h = (real)0.026 * clipped_height(t->pos[2], (real)0.29, (real)0.7);
+        real nd = 0; for (int i = 0; i < 12; i++) { real d = t->old_tau[i] - t->new_tau[i]; nd += d * d; }
+        real rew_smooth = (real)0.015 * exp(-(real)0.1 * sqrt(nd));
+        real cf = e->foot_force[0] + e->foot_force[1] + e->foot_force[2] + e->foot_force[3];
+        real rew_contact = -(real)3e-4 * (cf > 800 ? cf : 0);
+        real rew_pitch = (real)0.014 * (t->pos[2] > (real)0.5 ? qso_pitch_backflip(e->s.quat, t->switched) : 0);
+        return (real)0.4 * rew_contact + (real)0.2 * rew_smooth + (real)0.25 * rew_h + (real)0.3 * rew_pitch;
+    }
+    /* ContinuousJumpingForwardPPO._reward tests a bound method (`if not self.is_switched_controller:`, robot_tasks.py:669),
+       which is always truthy: its step reward is the constant 0 */
     if (!ppo_ip && !ppo_fw) return 0;
     /* robot_tasks.py:258-344 / :369-472 */
     real max_h = ppo_ip ? (cfg->task == QSO_TASK_JUMPING_IN_PLACE_PPO ? (real)1.0 : (real)1.25)
@@ -381,6 +431,25 @@ static real task_reward_end(const qso_config* cfg, const qso_env* e) {
         real pm = t->bf_max_pitch / (2 * PI);
         r += pm * (real)0.4; r += h * (real)0.4; r += h * pm;
         if (t->switched && !term) r += (real)0.2;
+        break; }
+    case QSO_TASK_BACKFLIP_PPO: /* robot_tasks.py:802-809 */
+        if (!term) r += (real)0.2 * ((real)0.7 * t->max_pitch / 5 + (real)0.3 * t->max_h) / 2;
+        break;
+    case QSO_TASK_CONT_JUMPING_FORWARD3: { /* robot_tasks.py:181-212 */
+        real n = t->jump_count < 3 ? 3 : t->jump_count;
+        real avg = t->sum_perf / n, mx = t->max_perf > 0 ? t->max_perf : 0;
+        real rew_entropy = exp((cj2_entropy(t) - 1) / (real)0.3);
+        real ra = avg * (real)0.15 * exp(-t->max_pitch * t->max_pitch / ((real)0.15 * (real)0.15));
+        ra += avg * (real)0.4 * (sim_time(cfg, e) / 10);
+        ra += avg * rew_entropy * (real)0.2;
+        ra += avg * (real)0.25;
+        r = (real)0.8 * ra + (real)0.2 * mx + (real)0.1 * t->good_jumps;
+        if (!term) r += (real)0.2 * avg;
+        break; }
+    case QSO_TASK_CONT_JUMPING_FORWARD_PPO: { /* robot_tasks.py:686-698 */
+        real n = t->jump_count < 3 ? 3 : t->jump_count;
+        r = (t->sum_perf / n) * exp((cj2_entropy(t) - 1) / (real)0.3);
+        if (term) r -= 1;
         break; }
     default: break;
     }
@@ -624,13 +693,15 @@ int qso_get_info(qso_handle* h, int which, real* out) {
         case QSO_INFO_LAST_ACTION: for (int k = 0; k < 12; k++) out[12 * i + k] = e->last_action[k]; break;
         case QSO_INFO_TERMINAL_OBS: for (int k = 0; k < h->cfg.obs_dim; k++) out[(size_t)i * h->cfg.obs_dim + k] = e->term_obs[k]; break;
         case QSO_INFO_TASK: {
-            real* o = out + 32 * i; memset(o, 0, 32 * sizeof(real));
+            real* o = out + 48 * i; memset(o, 0, 48 * sizeof(real));
             o[0] = t->switched; o[1] = t->all_air; o[2] = t->is_jumping; o[3] = t->t_takeoff;
             o[4] = t->pose_to[0]; o[5] = t->pose_to[1]; o[6] = t->pose_to[2]; o[7] = t->yaw_to; o[8] = t->init_h;
             o[9] = t->max_flight; o[10] = t->max_fwd; o[11] = t->max_pitch; o[12] = t->rel_max_h; o[13] = t->max_dx; o[14] = t->max_h;
             o[15] = t->cum_fwd; o[16] = t->cum_ft; o[17] = t->old_fwd; o[18] = t->actual_fwd; o[19] = t->bf_max_pitch;
-            for (int k = 0; k < 3; k++) { o[20 + k] = t->pos[k]; o[23 + k] = t->vel[k]; o[26 + k] = t->rpy[k]; }
-            o[29] = e->n_invalid; o[30] = e->foot_force[0] + e->foot_force[1] + e->foot_force[2] + e->foot_force[3]; o[31] = e->sim_step;
+            o[20] = t->jump_count; o[21] = t->good_jumps; o[22] = t->sum_fwd; o[23] = t->sum_flogf; o[24] = t->sum_height; o[25] = t->sum_perf;
+            o[26] = t->max_perf; o[27] = t->last_perf; o[28] = t->max_jump_h; o[29] = t->first_jump; o[30] = t->end_jump;
+            for (int k = 0; k < 3; k++) { o[32 + k] = t->pos[k]; o[35 + k] = t->vel[k]; o[38 + k] = t->rpy[k]; }
+            o[41] = e->n_invalid; o[42] = e->foot_force[0] + e->foot_force[1] + e->foot_force[2] + e->foot_force[3]; o[43] = e->sim_step;
             break; }
         default: FAIL("unknown info id %d", which);
         }
@@ -662,15 +733,17 @@ int qso_set_params(qso_handle* h, int which, const real* v) {
 
 int qso_set_task(qso_handle* h, const real* in) {
     for (int i = 0; i < h->cfg.n_envs; i++) {
-        qso_env* e = &h->env[i]; qso_task* t = &e->task; const real* o = in + 32 * i;
+        qso_env* e = &h->env[i]; qso_task* t = &e->task; const real* o = in + 48 * i;
         t->switched = o[0] != 0; t->all_air = o[1] != 0; t->is_jumping = o[2] != 0; t->t_takeoff = o[3];
         t->pose_to[0] = o[4]; t->pose_to[1] = o[5]; t->pose_to[2] = o[6]; t->yaw_to = o[7]; t->init_h = o[8];
         t->max_flight = o[9]; t->max_fwd = o[10]; t->max_pitch = o[11]; t->rel_max_h = o[12]; t->max_dx = o[13]; t->max_h = o[14];
         t->cum_fwd = o[15]; t->cum_ft = o[16]; t->old_fwd = o[17]; t->actual_fwd = o[18]; t->bf_max_pitch = o[19];
-        for (int k = 0; k < 3; k++) { t->pos[k] = o[20 + k]; t->vel[k] = o[23 + k]; t->rpy[k] = o[26 + k]; }
-        e->n_invalid = (int)o[29];
-        e->foot_force[0] = o[30]; e->foot_force[1] = e->foot_force[2] = e->foot_force[3] = 0;
-        e->sim_step = (int)o[31];
+        t->jump_count = o[20]; t->good_jumps = o[21]; t->sum_fwd = o[22]; t->sum_flogf = o[23]; t->sum_height = o[24]; t->sum_perf = o[25];
+        t->max_perf = o[26]; t->last_perf = o[27]; t->max_jump_h = o[28]; t->first_jump = o[29]; t->end_jump = o[30];
+        for (int k = 0; k < 3; k++) { t->pos[k] = o[32 + k]; t->vel[k] = o[35 + k]; t->rpy[k] = o[38 + k]; }
+        e->n_invalid = (int)o[41];
+        e->foot_force[0] = o[42]; e->foot_force[1] = e->foot_force[2] = e->foot_force[3] = 0;
+        e->sim_step = (int)o[43];
     }
     return 0;
 }

@@ -36,6 +36,8 @@ typedef struct {
     real cum_fwd, cum_ft;
     real old_fwd, actual_fwd;
     real bf_max_pitch;
+    /* TaskContinuousJumping2: sufficient statistics of fwd_array / height_array / performance_array */
+    real jump_count, good_jumps, sum_fwd, sum_flogf, sum_height, sum_perf, max_perf, last_perf, max_jump_h, first_jump, end_jump;
 } qso_task;
 
 typedef struct {

@@ -161,6 +161,7 @@ template <class T> struct Env {
     struct Task {
         V switched, all_air, is_jumping, t_takeoff, pose_to[3], yaw_to, init_h, max_flight, max_fwd, max_pitch, rel_max_h, max_dx,
             max_h, cum_fwd, cum_ft, old_fwd, actual_fwd, bf_max_pitch;
+        V jump_count, good_jumps, sum_fwd, sum_flogf, sum_height, sum_perf, max_perf, last_perf, max_jump_h, first_jump, end_jump;
         V pos[3], vel[3], rpy[3];
         V dtau2;  // |old_torque - new_torque|^2
     };
@@ -173,6 +174,9 @@ template <class T> struct Env {
         t.max_pitch = T::ld(p, T_MAX_PITCH); t.rel_max_h = T::ld(p, T_REL_MAX_H); t.max_dx = T::ld(p, T_MAX_DX); t.max_h = T::ld(p, T_MAX_H);
         t.cum_fwd = T::ld(p, T_CUM_FWD); t.cum_ft = T::ld(p, T_CUM_FT); t.old_fwd = T::ld(p, T_OLD_FWD); t.actual_fwd = T::ld(p, T_ACTUAL_FWD);
         t.bf_max_pitch = T::ld(p, T_BF_MAX_PITCH);
+        t.jump_count = T::ld(p, T_JUMP_COUNT); t.good_jumps = T::ld(p, T_GOOD_JUMPS); t.sum_fwd = T::ld(p, T_SUM_FWD); t.sum_flogf = T::ld(p, T_SUM_FLOGF);
+        t.sum_height = T::ld(p, T_SUM_HEIGHT); t.sum_perf = T::ld(p, T_SUM_PERF); t.max_perf = T::ld(p, T_MAX_PERF); t.last_perf = T::ld(p, T_LAST_PERF);
+        t.max_jump_h = T::ld(p, T_MAX_JUMP_H); t.first_jump = T::ld(p, T_FIRST_JUMP); t.end_jump = T::ld(p, T_END_JUMP);
         t.dtau2 = V(0.0f);
     }
     static QS_FN void store_task(float* rec, const Task& t) {
@@ -184,8 +188,20 @@ template <class T> struct Env {
         T::st(p, T_MAX_PITCH, t.max_pitch); T::st(p, T_REL_MAX_H, t.rel_max_h); T::st(p, T_MAX_DX, t.max_dx); T::st(p, T_MAX_H, t.max_h);
         T::st(p, T_CUM_FWD, t.cum_fwd); T::st(p, T_CUM_FT, t.cum_ft); T::st(p, T_OLD_FWD, t.old_fwd); T::st(p, T_ACTUAL_FWD, t.actual_fwd);
         T::st(p, T_BF_MAX_PITCH, t.bf_max_pitch);
+        T::st(p, T_JUMP_COUNT, t.jump_count); T::st(p, T_GOOD_JUMPS, t.good_jumps); T::st(p, T_SUM_FWD, t.sum_fwd); T::st(p, T_SUM_FLOGF, t.sum_flogf);
+        T::st(p, T_SUM_HEIGHT, t.sum_height); T::st(p, T_SUM_PERF, t.sum_perf); T::st(p, T_MAX_PERF, t.max_perf); T::st(p, T_LAST_PERF, t.last_perf);
+        T::st(p, T_MAX_JUMP_H, t.max_jump_h); T::st(p, T_FIRST_JUMP, t.first_jump); T::st(p, T_END_JUMP, t.end_jump);
     }
     static QS_FN bool continuous(int task) { return task == QS_TASK_CONT_JUMPING_FORWARD || task == QS_TASK_CONT_JUMPING_FORWARD2; }
+    static QS_FN bool continuous2(int task) { return task == QS_TASK_CONT_JUMPING_FORWARD3 || task == QS_TASK_CONT_JUMPING_FORWARD_PPO; }
+    // get_entropy_fwd (task_base.py:376-383) from the sums: -sum p log2 p = log2 S - (sum f log2 f) / S over max(n, 3) entries
+    static QS_FN V cj2_entropy(const Task& t) {
+        const float il2 = 1.4426950408889634f;
+        V n = qmax(t.jump_count, V(3.0f));
+        V S = qmax(t.sum_fwd, V(1e-30f));
+        V h = (qlog(S) * il2 - t.sum_flogf * qrcp(S)) * qrcp(qlog(n) * il2);
+        return qsel(qor(qlt(t.jump_count, V(0.5f)), qlt(t.sum_fwd, V(0.05f))), V(0.0f), h);
+    }
     static QS_FN V jump_distance(const Task& t) {  // task_base.py:108-116
         V dx = t.pos[0] - t.pose_to[0], dy = t.pos[1] - t.pose_to[1];
         return qmax(qcos(t.yaw_to) * dx - qsin(t.yaw_to) * dy, V(0.0f));
@@ -219,7 +235,28 @@ template <class T> struct Env {
         V dist = jump_distance(t);
         V fwd_upd = qmax(dist, t.max_fwd);
         V flight_upd = qmax(now - t_takeoff0, t.max_flight);
-        if (!continuous(cfg.task)) {  // task_base.py:92-106
+        if (continuous2(cfg.task)) {  // TaskContinuousJumping2, task_base.py:321-355
+            const float jump_limit = 0.6f, height_limit = cfg.task == QS_TASK_CONT_JUMPING_FORWARD3 ? 0.45f : 0.5f;
+            const float bound = cfg.task == QS_TASK_CONT_JUMPING_FORWARD3 ? 0.7f : 0.85f;
+            M in_flight = qand(flying, air);
+            t.is_jumping = qsel(take, qflag(takeoff_v), qsel(land, zero, t.is_jumping));
+            t.max_jump_h = qsel(take, zero, qsel(in_flight, qmax(t.max_jump_h, z), t.max_jump_h));  // :327-332
+            t.max_flight = qsel(land, flight_upd, t.max_flight);
+            M count = qand(land, qlt(t.first_jump, V(0.5f)));                                          // :342, first jump ignored
+            V fwd = qmin(dist, V(jump_limit)), hgt = qmin(t.max_jump_h, V(height_limit));
+            V perf = fwd * (0.7f / jump_limit) + hgt * (0.3f / height_limit);
+            V flogf = qsel(qgt(fwd, zero), fwd * qlog(qmax(fwd, V(1e-30f))) * 1.4426950408889634f, zero);
+            t.jump_count = qsel(count, t.jump_count + 1.0f, t.jump_count);
+            t.sum_fwd = qsel(count, t.sum_fwd + fwd, t.sum_fwd);
+            t.sum_flogf = qsel(count, t.sum_flogf + flogf, t.sum_flogf);
+            t.sum_height = qsel(count, t.sum_height + hgt, t.sum_height);
+            t.sum_perf = qsel(count, t.sum_perf + perf, t.sum_perf);
+            t.max_perf = qsel(count, qmax(t.max_perf, perf), t.max_perf);
+            t.last_perf = qsel(count, perf, t.last_perf);
+            t.good_jumps = qsel(qand(count, qge(perf, V(bound))), t.good_jumps + 1.0f, t.good_jumps);
+            t.end_jump = qflag(count);
+            t.first_jump = qsel(land, zero, t.first_jump);
+        } else if (!continuous(cfg.task)) {  // task_base.py:92-106
             M in_flight = qand(flying, air);
             t.max_flight = qsel(land, flight_upd, t.max_flight);
             t.max_fwd = qsel(qor(in_flight, land), fwd_upd, qsel(qand(qnot(flying), qnot(air)), zero, t.max_fwd));
@@ -234,6 +271,7 @@ template <class T> struct Env {
         t.all_air = qsel(take, one, qsel(land, zero, t.all_air));
         if (cfg.task == QS_TASK_JUMPING_FORWARD_PPO || cfg.task == QS_TASK_JUMPING_FORWARD_PPO_HP) { t.old_fwd = t.actual_fwd; t.actual_fwd = t.max_fwd; }  // robot_tasks.py:418-425
         if (cfg.task == QS_TASK_BACKFLIP) t.bf_max_pitch = qmax(t.bf_max_pitch, pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched));   // :527-530
+        if (cfg.task == QS_TASK_BACKFLIP_PPO) t.max_pitch = qmax(t.max_pitch, pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched));  // :752-754
     }
     static QS_FN V task_terminated(const qs_config& cfg, const Task& t, const typename S::State& s, V n_invalid) {
         if (cfg.task == QS_TASK_NO_TASK) return V(0.0f);
@@ -244,7 +282,16 @@ template <class T> struct Env {
         V r22 = V(1.0f) - (s.qx * s.qx + s.qy * s.qy) * (V(2.0f) / d);
         return qflag(qor(qand(qlt(r22, V(0.85f)), low), bad));                    // task_base.py:126-135
     }
-    static QS_FN V task_reward(const qs_config& cfg, const Task& t, V contact_force) {
+    static QS_FN V task_reward(const qs_config& cfg, const Task& t, V contact_force, V bf_pitch) {
+        if (cfg.task == QS_TASK_BACKFLIP_PPO) {  // robot_tasks.py:709-800
+            V z = t.pos[2];
+            V rew_h = qsel(qor(qlt(z, V(0.29f)), qgt(z, V(0.7f))), V(0.0f), z) * 0.026f;
+            V rew_smooth = qexp(qsqrt(t.dtau2) * (-0.1f)) * 0.015f;
+            V rew_contact = qsel(qgt(contact_force, V(800.0f)), contact_force, V(0.0f)) * (-3e-4f);
+            V rew_pitch = qsel(qgt(z, V(0.5f)), bf_pitch, V(0.0f)) * 0.014f;
+            return rew_contact * 0.4f + rew_smooth * 0.2f + rew_h * 0.25f + rew_pitch * 0.3f;
+        }
+        // ContinuousJumpingForwardPPO._reward is the constant 0 in the reference (bound-method test at robot_tasks.py:669)
         const bool ip = cfg.task == QS_TASK_JUMPING_IN_PLACE_PPO || cfg.task == QS_TASK_JUMPING_IN_PLACE_PPO_HP;
         const bool fw = cfg.task == QS_TASK_JUMPING_FORWARD_PPO || cfg.task == QS_TASK_JUMPING_FORWARD_PPO_HP;
         if (!ip && !fw) return V(0.0f);
@@ -300,6 +347,20 @@ template <class T> struct Env {
             V pm = t.bf_max_pitch * (1.0f / (2.0f * PI));
             return pm * 0.4f + h * 0.4f + h * pm + qsel(qand(qgt(t.switched, V(0.5f)), alive), V(0.2f), zero);
         }
+        case QS_TASK_BACKFLIP_PPO:            // :802-809
+            return qsel(alive, (t.max_pitch * (0.7f / 5.0f) + t.max_h * 0.3f) * 0.1f, zero);
+        case QS_TASK_CONT_JUMPING_FORWARD3: { // :181-212
+            V n = qmax(t.jump_count, V(3.0f));
+            V avg = t.sum_perf * qrcp(n), mx = qmax(t.max_perf, zero);
+            V rew_entropy = qexp((cj2_entropy(t) - 1.0f) * (1.0f / 0.3f));
+            V ra = avg * 0.15f * g + avg * 0.4f * (now * 0.1f) + avg * rew_entropy * 0.2f + avg * 0.25f;
+            return ra * 0.8f + mx * 0.2f + t.good_jumps * 0.1f + qsel(alive, avg * 0.2f, zero);
+        }
+        case QS_TASK_CONT_JUMPING_FORWARD_PPO: {  // :686-698
+            V n = qmax(t.jump_count, V(3.0f));
+            V r = t.sum_perf * qrcp(n) * qexp((cj2_entropy(t) - 1.0f) * (1.0f / 0.3f));
+            return qsel(alive, r, r - 1.0f);
+        }
         default: return zero;
         }
     }
@@ -311,6 +372,8 @@ template <class T> struct Env {
         V r, p, y; quat_to_rpy(s.qx, s.qy, s.qz, s.qw, r, p, y); t.yaw_to = y;
         t.max_flight = zero; t.max_fwd = zero; t.max_pitch = zero; t.rel_max_h = zero; t.max_dx = zero; t.max_h = zero;
         t.cum_fwd = zero; t.cum_ft = zero; t.old_fwd = zero; t.actual_fwd = zero; t.bf_max_pitch = keep;
+        t.jump_count = zero; t.good_jumps = zero; t.sum_fwd = zero; t.sum_flogf = zero; t.sum_height = zero; t.sum_perf = zero;
+        t.max_perf = zero; t.last_perf = zero; t.max_jump_h = zero; t.first_jump = V(1.0f); t.end_jump = zero;
         task_on_step(cfg, t, s, o, o.tau_pd, now);  // old == new torque at reset
     }
 
@@ -439,7 +502,7 @@ template <class T> struct Env {
         V now = V((float)((double)sim_step * cfg.dt));
         task_on_step(cfg, t, s, o, old_tau, now);
         V force = T::quad_sum(o.foot_force);
-        V reward = task_reward(cfg, t, force);
+        V reward = task_reward(cfg, t, force, cfg.task == QS_TASK_BACKFLIP_PPO ? pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched) : V(0.0f));
         V term = task_terminated(cfg, t, s, o.n_invalid);
         bool timeout = sim_step > cfg.max_sim_steps;   // gym_env.py:245
         V done = timeout ? V(1.0f) : term;

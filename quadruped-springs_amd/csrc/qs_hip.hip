@@ -51,7 +51,7 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
     LaneDev::sync();
     if ((threadIdx.x & 3) == 0) {
         r[R_EPISODE] = qs::i2f(-1);
-        r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f;
+        r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f; r[R_TASK + T_FIRST_JUMP] = 1.0f;
         for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
     }
     E::randomize(cfg, r, (uint32_t)(env + cfg.env_id_offset), -1, true);
@@ -187,11 +187,12 @@ __global__ void k_task_info(const float* __restrict__ recs, int n, float* __rest
     if (e >= n) return;
     const float* r = recs + (size_t)e * QS_REC;
     float* o = out + (size_t)e * QS_TASK_DIM;
-    for (int k = 0; k < 20; k++) o[k] = r[R_TASK + k];
-    for (int k = 0; k < 9; k++) o[20 + k] = r[R_POSE_CACHE + k];
-    o[29] = r[R_N_INVALID];
-    o[30] = r[R_FOOT_FORCE] + r[R_FOOT_FORCE + 1] + r[R_FOOT_FORCE + 2] + r[R_FOOT_FORCE + 3];
-    o[31] = (float)qs::f2i(r[R_SIM_STEP]);
+    for (int k = 0; k < T_N; k++) o[k] = r[R_TASK + k];
+    for (int k = 0; k < 9; k++) o[T_N + k] = r[R_POSE_CACHE + k];
+    o[41] = r[R_N_INVALID];
+    o[42] = r[R_FOOT_FORCE] + r[R_FOOT_FORCE + 1] + r[R_FOOT_FORCE + 2] + r[R_FOOT_FORCE + 3];
+    o[43] = (float)qs::f2i(r[R_SIM_STEP]);
+    for (int k = 44; k < QS_TASK_DIM; k++) o[k] = 0.0f;
 }
 
 // ------------------------------------------------------------------ host side of the C ABI

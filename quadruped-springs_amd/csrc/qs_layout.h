@@ -14,24 +14,26 @@ enum {
     R_YHIST = 77,         // 2 x 12
     R_SIM_STEP = 101, R_ENV_STEP = 102, R_EPISODE = 103, R_TOTAL_STEPS = 104,  // integers stored as float bit patterns
     // task scalars (task_base.py:44-59, 228-233; robot_tasks.py:418-425, 524-530), order of QS_INFO_TASK
-    R_TASK = 105,         // 20: switched, all_air, is_jumping, t_takeoff, pose_to[3], yaw_to, init_h, max_flight, max_fwd,
-                          //     max_pitch, rel_max_h, max_dx, max_h, cum_fwd, cum_ft, old_fwd, actual_fwd, bf_max_pitch
-    R_NEW_TAU = 125,      // 12: task._new_torque
-    R_PARAMS = 137,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
-    R_FOOT_FORCE = 161,   // 4
-    R_FOOT_CONTACT = 165, // 4
-    R_N_INVALID = 169,
-    R_TAU_PD = 170,       // 12: observed motor torque of the last substep (quadruped.py:299)
-    R_TAU_SPRING = 182,   // 12
-    R_POSE_CACHE = 194,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
-    R_FLAGS = 203,        // bit 0: needs reset
-    R_CPG = 204,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
-    QS_REC = 212,         // multiple of 4 (16-byte vector moves)
+    R_TASK = 105,         // 32 slots, see T_* below
+    R_NEW_TAU = 137,      // 12: task._new_torque
+    R_PARAMS = 149,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
+    R_FOOT_FORCE = 173,   // 4
+    R_FOOT_CONTACT = 177, // 4
+    R_N_INVALID = 181,
+    R_TAU_PD = 182,       // 12: observed motor torque of the last substep (quadruped.py:299)
+    R_TAU_SPRING = 194,   // 12
+    R_POSE_CACHE = 206,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
+    R_FLAGS = 215,
+    R_CPG = 216,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
+    QS_REC = 224,         // multiple of 4 (16-byte vector moves)
 };
 enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };
 enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO = 4, T_YAW_TO = 7, T_INIT_H = 8, T_MAX_FLIGHT = 9,
        T_MAX_FWD = 10, T_MAX_PITCH = 11, T_REL_MAX_H = 12, T_MAX_DX = 13, T_MAX_H = 14, T_CUM_FWD = 15, T_CUM_FT = 16,
-       T_OLD_FWD = 17, T_ACTUAL_FWD = 18, T_BF_MAX_PITCH = 19 };
+       T_OLD_FWD = 17, T_ACTUAL_FWD = 18, T_BF_MAX_PITCH = 19,
+       // TaskContinuousJumping2 (task_base.py:283-400): the unbounded per-jump arrays are only ever reduced to these sums
+       T_JUMP_COUNT = 20, T_GOOD_JUMPS = 21, T_SUM_FWD = 22, T_SUM_FLOGF = 23 /* sum f log2 f */, T_SUM_HEIGHT = 24, T_SUM_PERF = 25,
+       T_MAX_PERF = 26, T_LAST_PERF = 27, T_MAX_JUMP_H = 28, T_FIRST_JUMP = 29, T_END_JUMP = 30, T_N = 32 };
 
 #define QS_ENVS_PER_WAVE 16
 #define QS_WAVE 64

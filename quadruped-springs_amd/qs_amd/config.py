@@ -41,13 +41,12 @@ TASKS = {
     "BACKFLIP": 7,
     "JUMPING_IN_PLACE_PPO_HP": 8,
     "JUMPING_FORWARD_PPO_HP": 9,
+    "BACKFLIP_PPO": 10,
+    "CONTINUOUS_JUMPING_FORWARD3": 11,
+    "CONTINUOUS_JUMPING_FORWARD_PPO": 12,
 }
-# registry keys the reference defines but this build does not run: demo tasks need the
-# absent demonstrations/*.npy; the TaskContinuousJumping2 family keeps unbounded per-jump arrays.
-TASKS_UNSUPPORTED = (
-    "JUMPING_IN_PLACE_DEMO", "JUMPING_FORWARD_DEMO", "BACKFLIP_DEMO", "CONTINUOUS_JUMPING_FORWARD_DEMO",
-    "CONTINUOUS_JUMPING_FORWARD_PPO", "BACKFLIP_PPO", "CONTINUOUS_JUMPING_FORWARD3",
-)
+# registry keys the reference defines but this build does not run: demo tasks need the absent demonstrations/*.npy
+TASKS_UNSUPPORTED = ("JUMPING_IN_PLACE_DEMO", "JUMPING_FORWARD_DEMO", "BACKFLIP_DEMO", "CONTINUOUS_JUMPING_FORWARD_DEMO")
 
 # sensor ids (include/qs_amd.h QS_SENS_*): name, dim, (high, low, noise) attribute names, reference obs-dict key
 SENSORS = {

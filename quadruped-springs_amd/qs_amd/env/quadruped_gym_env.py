@@ -43,7 +43,7 @@ class _RobotView:
         return self._env._vec.get_info("torque")[0].cpu().numpy().astype(np.float64)
 
     def GetBaseOrientationRollPitchYaw(self):
-        return self._env._vec.get_info("task")[0, 26:29].cpu().numpy().astype(np.float64)
+        return self._env._vec.get_info("task")[0, 38:41].cpu().numpy().astype(np.float64)
 
     def GetContactInfo(self):
         force = self._env._vec.get_info("foot_force")[0].cpu().numpy()

@@ -16,7 +16,7 @@ struct Emu {
 static void init_record(const qs_config& cfg, float* r, int env) {
     memset(r, 0, QS_REC * sizeof(float));
     r[R_EPISODE] = qs::i2f(-1);
-    r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f;
+    r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f; r[R_TASK + T_FIRST_JUMP] = 1.0f;
     for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
     E::randomize(cfg, r, (uint32_t)(env + cfg.env_id_offset), -1, true);
 }

@@ -61,6 +61,9 @@ def test_reset_settle_matches():
     dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", action_space_mode="SYMMETRIC_NO_HIP"),
     dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="LANDING_SENSOR"),
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP"),
+    dict(task_env="BACKFLIP_PPO", observation_space_mode="PPO_BACKFLIP"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD3", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD_PPO", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
 ])
 def test_env_step_parity_resynced(kw):
     """Every step starts from the oracle's state, so chaotic divergence cannot accumulate."""

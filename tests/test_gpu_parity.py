@@ -83,6 +83,9 @@ CASES = [
     dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="LANDING_SENSOR"),
     dict(task_env="JUMPING_IN_PLACE_PPO", observation_space_mode="PPO_BASIC_X"),
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP"),
+    dict(task_env="BACKFLIP_PPO", observation_space_mode="PPO_BACKFLIP"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD3", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD_PPO", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
     dict(time_step=0.002, action_repeat=5),   # BASELINE.json config 2: dt = 1/500 s, 60 solver sweeps
     dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", env_randomizer_mode="SPRING_RANDOMIZER", seed=9),  # config 3
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER", seed=4),  # config 5
@@ -124,7 +127,7 @@ def test_env_step_parity_resynced(torch_cuda, kw):
             o.reset(do.astype(np.uint8)); v.reset_tensor(do.astype(np.uint8))
 
 
-@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "cart_s1"])
+@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1"])
 def test_reference_traces(torch_cuda, golden, name):
     """Traces recorded from the REFERENCE's QuadrupedGymEnv (tests/golden/traces.npz).  Trajectories are chaotic, so the
     device state is re-synchronised to the recorded state before every step; what is compared is one full env.step."""

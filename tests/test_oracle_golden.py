@@ -143,7 +143,8 @@ def test_g12_euler_and_backflip_pitch(golden):
 
 
 TASKS = ["JUMPING_IN_PLACE", "JUMPING_FORWARD", "CONTINUOUS_JUMPING_FORWARD", "CONTINUOUS_JUMPING_FORWARD2",
-         "JUMPING_IN_PLACE_PPO", "JUMPING_FORWARD_PPO", "JUMPING_IN_PLACE_PPO_HP", "JUMPING_FORWARD_PPO_HP", "BACKFLIP"]
+         "JUMPING_IN_PLACE_PPO", "JUMPING_FORWARD_PPO", "JUMPING_IN_PLACE_PPO_HP", "JUMPING_FORWARD_PPO_HP", "BACKFLIP",
+         "BACKFLIP_PPO", "CONTINUOUS_JUMPING_FORWARD3", "CONTINUOUS_JUMPING_FORWARD_PPO"]
 
 
 @pytest.mark.parametrize("task", TASKS)
@@ -154,5 +155,10 @@ def test_g9_rewards(golden, task):
     o = Oracle(cfg)
     # torque history: two synthetic task steps cannot inject it, so use the dedicated layout (old/new via INFO_TORQUE is
     # read-only); the step reward's smoothing term is checked through set_task + the trace tests instead.
+    st = o.get_state()
+    st[:, 3:7] = g[f"g9_{task}_quat"]
+    o.set_state(st)
     o.set_task(rows)
     np.testing.assert_allclose(o.eval_reward(1), g[f"g9_{task}_rew_end"], atol=1e-9, rtol=1e-9)
+    if task in ("CONTINUOUS_JUMPING_FORWARD_PPO", "CONTINUOUS_JUMPING_FORWARD3"):   # constant-zero step rewards (App. C-5)
+        assert np.all(g[f"g9_{task}_rew_step"] == 0) and np.all(o.eval_reward(0) == 0)

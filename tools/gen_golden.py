@@ -392,11 +392,12 @@ def gen_rewards():
                "CONTINUOUS_JUMPING_FORWARD": rt.JumpingForwardContinuous, "CONTINUOUS_JUMPING_FORWARD2": rt.JumpingForwardContinuous2,
                "JUMPING_IN_PLACE_PPO": rt.JumpingInPlacePPO, "JUMPING_FORWARD_PPO": rt.JumpingForwardPPO,
                "JUMPING_IN_PLACE_PPO_HP": rt.JumpingInPlacePPOHP, "JUMPING_FORWARD_PPO_HP": rt.JumpingForwardPPOHP,
-               "BACKFLIP": rt.BackFlip}
+               "BACKFLIP": rt.BackFlip, "BACKFLIP_PPO": rt.BackflipPPO,
+               "CONTINUOUS_JUMPING_FORWARD3": rt.JumpingForwardContinuous3, "CONTINUOUS_JUMPING_FORWARD_PPO": rt.ContinuousJumpingForwardPPO}
     mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs")
     n = 96
     for name, cls in classes.items():
-        rows, rew_step, rew_end, old_tau, new_tau = [], [], [], [], []
+        rows, rew_step, rew_end, old_tau, new_tau, quats = [], [], [], [], [], []
         for i in range(n):
             term = bool(i % 2)
             env = types.SimpleNamespace()
@@ -423,19 +424,37 @@ def gen_rewards():
             t.old_fwd = float(rng.uniform(0, 1.5))
             t.actual_fwd = t.old_fwd if i % 5 == 0 else float(rng.uniform(0, 1.5))
             t.max_pitch = float(rng.uniform(0, 6.5))
-            row = np.zeros(32)
+            # TaskContinuousJumping2 per-jump arrays (task_base.py:295-297): 0..6 recorded jumps
+            nj = int(rng.integers(0, 7)) if i % 4 else 0
+            jl = getattr(t, "jump_limit", 0.5); hl = getattr(t, "height_limit", 0.5)
+            t.fwd_array = np.minimum(rng.uniform(0, 0.8, nj), jl) * (rng.uniform(size=nj) > 0.15)
+            t.height_array = np.minimum(rng.uniform(0.2, 0.7, nj), hl)
+            t.performance_array = getattr(t, "fwd_weight", 0.7) * t.fwd_array / jl + getattr(t, "height_weight", 0.3) * t.height_array / hl
+            t.jump_counter = nj
+            t.good_jump_counter = int(np.sum(t.performance_array >= getattr(t, "performance_bound", 0.85)))
+            quat = np.array([0.0, np.sin(0.5 * t._orient_rpy[1]), 0.0, np.cos(0.5 * t._orient_rpy[1])])
+            env.robot.GetBaseOrientation = lambda quat=quat: quat
+            env.task = t
+            row = np.zeros(48)
             row[0] = t._switched_controller; row[9] = t._max_flight_time; row[10] = t._max_forward_distance
             row[11] = t._max_pitch; row[12] = t._relative_max_height; row[13] = t._max_delta_x; row[14] = t._max_height
             row[15] = t.cumulative_fwd; row[16] = t.cumulative_flight_time; row[17] = t.old_fwd; row[18] = t.actual_fwd
-            row[19] = t.max_pitch; row[20:23] = t._pos_abs; row[26:29] = t._orient_rpy
-            row[29] = 1 if term else 0; row[30] = sum(ff); row[31] = sim_step
+            row[19] = t.max_pitch
+            f = t.fwd_array
+            row[20] = nj; row[21] = t.good_jump_counter; row[22] = f.sum(); row[23] = np.sum(f[f > 0] * np.log2(f[f > 0]))
+            row[24] = t.height_array.sum(); row[25] = t.performance_array.sum()
+            row[26] = t.performance_array.max() if nj else 0.0; row[27] = t.performance_array[-1] if nj else 0.0
+            row[32:35] = t._pos_abs; row[38:41] = t._orient_rpy
+            row[41] = 1 if term else 0; row[42] = sum(ff); row[43] = sim_step
             if not term:
-                row[22] = max(row[22], 0.2)  # keep "not fallen" consistent with the forced _terminated()
-                t._pos_abs[2] = row[22]
+                row[34] = max(row[34], 0.2)  # keep "not fallen" consistent with the forced _terminated()
+                t._pos_abs[2] = row[34]
+            quats.append(quat)
             rows.append(row); old_tau.append(t._old_torque); new_tau.append(t._new_torque)
             rew_step.append(float(t._reward())); rew_end.append(float(t._reward_end_episode()))
         out[f"g9_{name}_task"], out[f"g9_{name}_old_tau"], out[f"g9_{name}_new_tau"] = np.array(rows), np.array(old_tau), np.array(new_tau)
         out[f"g9_{name}_rew_step"], out[f"g9_{name}_rew_end"] = np.array(rew_step), np.array(rew_end)
+        out[f"g9_{name}_quat"] = np.array(quats)
     np.savez_compressed(os.path.join(OUT, "rewards.npz"), **out)
     print("rewards.npz:", len(out), "arrays")
 
@@ -480,6 +499,12 @@ def gen_traces():
              enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
         dict(name="bf_s1", task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", enable_springs=True,
              enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="bfppo_s1", task_env="BACKFLIP_PPO", observation_space_mode="PPO_BACKFLIP", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="cjf3_s1", task_env="CONTINUOUS_JUMPING_FORWARD3", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+             enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=420, jump_at=70),
+        dict(name="cjfppo_s1", task_env="CONTINUOUS_JUMPING_FORWARD_PPO", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+             enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=420, jump_at=70),
         dict(name="cart_s1", task_env="JUMPING_IN_PLACE", observation_space_mode="CARTESIAN_NO_IMU", enable_springs=True,
              enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="CARTESIAN_PD", steps=150, jump_at=70),
     ]
