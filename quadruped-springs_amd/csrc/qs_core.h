@@ -183,21 +183,23 @@ template <class T> struct Sim {
         V q[3], qd[3];                              // own leg
         V warm;                                     // own foot
     };
-    struct Par {            // per-environment parameters (replicated) + own-leg model constants
+    struct Par {            // per-environment parameters (replicated over the quad)
         V mu, k[3], b[3], rest[3], kp[3], kd[3];
+        V m_leg[3];
         SI<V> I0;                                   // base + trunk + imu (+ payload) about the base origin
+        V mtot;
+    };
+    struct Model {          // link constants of the own leg (mirror signs, mass scaling), rebuilt inside every substep
         V m_hip, m_thigh, m_calf;
         V3v c_hip, c_thigh; S3<V> I_hip, I_thigh, I_calf;
-        V mtot;
     };
     struct Out {            // results of the last substep
         V tau_pd[3], tau_spring[3], foot_force, foot_contact, n_invalid;
     };
 
     // per-env model from the randomizable masses (env_randomizer.py:56-83); link inertias scale with link mass
-    static QS_FN void build_par(Par& P, V m_trunk, const V* m_leg, V m_pay, V3v r_pay) {
+    static QS_FN void build_base(Par& P, V m_trunk, V m_pay, V3v r_pay) {
         using namespace go1;
-        V fx = T::fx(), sy = T::sy();
         V st = m_trunk * (1.0f / TRUNK_M);
         SI<V> I0 = point_inertia<V>(V(BASE_M), V(BASE_I), mk3<V>(V(0.0f), V(0.0f), V(0.0f)));
         S3<V> It; It.xx = st * TRUNK_I[0]; It.xy = st * TRUNK_I[1]; It.xz = st * TRUNK_I[2]; It.yy = st * TRUNK_I[3]; It.yz = st * TRUNK_I[4]; It.zz = st * TRUNK_I[5];
@@ -207,6 +209,11 @@ template <class T> struct Sim {
         I0 = I0 + point_inertia<V>(V(IMU_M), V(IMU_I), mk3<V>(V(IMU_X), V(IMU_Y), V(IMU_Z)));
         I0 = I0 + point_inertia<V>(m_pay, m_pay * PAYLOAD_I, r_pay);
         P.I0 = I0;
+        P.mtot = I0.m + 4.0f * (P.m_leg[0] + P.m_leg[1] + P.m_leg[2] + FOOT_M);
+    }
+    static QS_FN void build_model(Model& P, const V* m_leg) {
+        using namespace go1;
+        V fx = T::fx(), sy = T::sy();
         V s1 = m_leg[0] * (1.0f / HIP_M), s2 = m_leg[1] * (1.0f / THIGH_M), s3 = m_leg[2] * (1.0f / CALF_M);
         P.m_hip = m_leg[0]; P.m_thigh = m_leg[1]; P.m_calf = m_leg[2];
         P.c_hip = mk3<V>(fx * (-HIP_C[0]), sy * (-HIP_C[1]), V(HIP_C[2]));
@@ -217,7 +224,6 @@ template <class T> struct Sim {
         P.I_thigh.yy = s2 * THIGH_I[3]; P.I_thigh.yz = s2 * sy * THIGH_I[4]; P.I_thigh.zz = s2 * THIGH_I[5];
         P.I_calf.xx = s3 * CALF_I[0]; P.I_calf.xy = s3 * CALF_I[1]; P.I_calf.xz = s3 * CALF_I[2];
         P.I_calf.yy = s3 * CALF_I[3]; P.I_calf.yz = s3 * CALF_I[4]; P.I_calf.zz = s3 * CALF_I[5];
-        P.mtot = I0.m + 4.0f * (m_leg[0] + m_leg[1] + m_leg[2] + FOOT_M);
     }
 
     // PD law + torque clip (quadruped_motor.py:45-99) and unilateral PEA (quadruped_motor.py:101-104, springs.py:34-74)
@@ -416,8 +422,15 @@ template <class T> struct Sim {
         s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), zero - cap, cap);
     }
 
-    static QS_FN void substep(const qs_config& cfg, const Par& P, State& s, const V* tau, Out& o) {
+    static QS_FN void substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o) {
         using namespace go1;
+        Model P;
+        {   // opaque copies keep the compiler from hoisting the 24 leg constants out of the substep loop (where they would
+            // occupy registers for the whole env step); rebuilding them is ~40 multiplications per substep
+            V ml[3] = {Pr.m_leg[0], Pr.m_leg[1], Pr.m_leg[2]};
+            T::opaque(ml[0]); T::opaque(ml[1]); T::opaque(ml[2]);
+            build_model(P, ml);
+        }
         const float dt = (float)cfg.dt;
         const V zero = V(0.0f), one = V(1.0f);
         V fx = T::fx(), sy = T::sy();
@@ -456,13 +469,29 @@ template <class T> struct Sim {
         SI<V> I2 = part_inertia<V>(P.m_thigh, P.c_thigh, P.I_thigh, p2, X2, Y, Z2);
         SI<V> I3 = part_inertia<V>(P.m_calf, mk3<V>(V(CALF_C[0]), V(CALF_C[1]), V(CALF_C[2])), P.I_calf, p3, X3, Y, Z3) +
                    point_inertia<V>(V(FOOT_M), V(FOOT_I), rf);
-        SI<V> Ic2 = I2 + I3, Ic1 = I1 + Ic2;
         // motion subspaces S_j = (a_j ; p_j x a_j)
         Spv S1, S2, S3j;
         S1.a = ax1; S1.l = cross(p1, ax1);
         S2.a = Y; S2.l = cross(p2, Y);
         S3j.a = Y; S3j.l = cross(p3, Y);
+        // ---- RNEA bias with qdd = 0, base acceleration 0, gravity as the fictitious base acceleration -g
+        Spv a0; a0.a = mk3<V>(zero, zero, zero); a0.l = Rz * V(cfg.gravity);
+        Spv vj1, vj2, vj3;
+        vj1.a = S1.a * s.qd[0]; vj1.l = S1.l * s.qd[0];
+        vj2.a = S2.a * s.qd[1]; vj2.l = S2.l * s.qd[1];
+        vj3.a = S3j.a * s.qd[2]; vj3.l = S3j.l * s.qd[2];
+        Spv v1 = v0 + vj1, v2 = v1 + vj2, v3 = v2 + vj3;
+        Spv a1 = a0 + crm(v0, vj1), a2 = a1 + crm(v1, vj2), a3 = a2 + crm(v2, vj3);
+        Spv f1 = apply(I1, a1) + crf(v1, apply(I1, v1));
+        Spv f2 = apply(I2, a2) + crf(v2, apply(I2, v2));
+        Spv f3 = apply(I3, a3) + crf(v3, apply(I3, v3));
+        Spv fs2 = f2 + f3, fs1 = f1 + fs2;
+        V C1 = dot(S1, fs1), C2 = dot(S2, fs2), C3 = dot(S3j, f3);
+        Spv f0 = apply(Pr.I0, a0) + crf(v0, apply(Pr.I0, v0));
+        V Cb[6] = {T::quad_sum(fs1.a.x) + f0.a.x, T::quad_sum(fs1.a.y) + f0.a.y, T::quad_sum(fs1.a.z) + f0.a.z,
+                   T::quad_sum(fs1.l.x) + f0.l.x, T::quad_sum(fs1.l.y) + f0.l.y, T::quad_sum(fs1.l.z) + f0.l.z};
         // ---- CRBA: B = [F1 F2 F3] (6x3), D (3x3 symmetric)
+        SI<V> Ic2 = I2 + I3, Ic1 = I1 + Ic2;
         Spv F1 = apply(Ic1, S1), F2 = apply(Ic2, S2), F3 = apply(I3, S3j);
         V D11 = dot(S1, F1), D12 = dot(S1, F2), D13 = dot(S1, F3), D22 = dot(S2, F2), D23 = dot(S2, F3), D33 = dot(S3j, F3);
         // K = D^-1 (symmetric cofactor inverse)
@@ -484,12 +513,12 @@ template <class T> struct Sim {
         }
         // ---- S = Hbb - sum_legs B K B^T, then Cholesky (replicated)
         SI<V> Itot;
-        Itot.m = P.mtot;
+        Itot.m = Pr.mtot;
         {
             SI<V> Il = Ic1;
-            Itot.h = mk3<V>(T::quad_sum(Il.h.x), T::quad_sum(Il.h.y), T::quad_sum(Il.h.z)) + P.I0.h;
-            Itot.I.xx = T::quad_sum(Il.I.xx) + P.I0.I.xx; Itot.I.xy = T::quad_sum(Il.I.xy) + P.I0.I.xy; Itot.I.xz = T::quad_sum(Il.I.xz) + P.I0.I.xz;
-            Itot.I.yy = T::quad_sum(Il.I.yy) + P.I0.I.yy; Itot.I.yz = T::quad_sum(Il.I.yz) + P.I0.I.yz; Itot.I.zz = T::quad_sum(Il.I.zz) + P.I0.I.zz;
+            Itot.h = mk3<V>(T::quad_sum(Il.h.x), T::quad_sum(Il.h.y), T::quad_sum(Il.h.z)) + Pr.I0.h;
+            Itot.I.xx = T::quad_sum(Il.I.xx) + Pr.I0.I.xx; Itot.I.xy = T::quad_sum(Il.I.xy) + Pr.I0.I.xy; Itot.I.xz = T::quad_sum(Il.I.xz) + Pr.I0.I.xz;
+            Itot.I.yy = T::quad_sum(Il.I.yy) + Pr.I0.I.yy; Itot.I.yz = T::quad_sum(Il.I.yz) + Pr.I0.I.yz; Itot.I.zz = T::quad_sum(Il.I.zz) + Pr.I0.I.zz;
         }
         V Sm[21];
 #pragma unroll
@@ -510,22 +539,6 @@ template <class T> struct Sim {
         V Ld[6];
         chol6<V>(Sm, Ld);
 
-        // ---- RNEA bias with qdd = 0, base acceleration 0, gravity as the fictitious base acceleration -g
-        Spv a0; a0.a = mk3<V>(zero, zero, zero); a0.l = Rz * V(cfg.gravity);
-        Spv vj1, vj2, vj3;
-        vj1.a = S1.a * s.qd[0]; vj1.l = S1.l * s.qd[0];
-        vj2.a = S2.a * s.qd[1]; vj2.l = S2.l * s.qd[1];
-        vj3.a = S3j.a * s.qd[2]; vj3.l = S3j.l * s.qd[2];
-        Spv v1 = v0 + vj1, v2 = v1 + vj2, v3 = v2 + vj3;
-        Spv a1 = a0 + crm(v0, vj1), a2 = a1 + crm(v1, vj2), a3 = a2 + crm(v2, vj3);
-        Spv f1 = apply(I1, a1) + crf(v1, apply(I1, v1));
-        Spv f2 = apply(I2, a2) + crf(v2, apply(I2, v2));
-        Spv f3 = apply(I3, a3) + crf(v3, apply(I3, v3));
-        Spv fs2 = f2 + f3, fs1 = f1 + fs2;
-        V C1 = dot(S1, fs1), C2 = dot(S2, fs2), C3 = dot(S3j, f3);
-        Spv f0 = apply(P.I0, a0) + crf(v0, apply(P.I0, v0));
-        V Cb[6] = {T::quad_sum(fs1.a.x) + f0.a.x, T::quad_sum(fs1.a.y) + f0.a.y, T::quad_sum(fs1.a.z) + f0.a.z,
-                   T::quad_sum(fs1.l.x) + f0.l.x, T::quad_sum(fs1.l.y) + f0.l.y, T::quad_sum(fs1.l.z) + f0.l.z};
         // ---- unconstrained accelerations
         V t1 = tau[0] - C1, t2 = tau[1] - C2, t3 = tau[2] - C3;
         V y1 = K11 * t1 + K12 * t2 + K13 * t3, y2 = K12 * t1 + K22 * t2 + K23 * t3, y3 = K13 * t1 + K23 * t2 + K33 * t3;
@@ -660,9 +673,9 @@ template <class T> struct Sim {
                 for (int i = 0; i < 6; i++) a.BK[j][i] = BK[j][i];
 #pragma unroll
             for (int i = 0; i < 9; i++) a.R[i] = R[i];
-            solve_with_limits(cfg, P.mu, s, o, a);
+            solve_with_limits(cfg, Pr.mu, s, o, a);
         } else {
-            solve_and_integrate<3>(cfg, P.mu, s, o, rows, Sm, Ld, BK, R);
+            solve_and_integrate<3>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
         }
         // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
         s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;

@@ -148,13 +148,12 @@ template <class T> struct Env {
     static QS_FN void load_par(const float* rec, typename S::Par& P) {
         const float* p = rec + R_PARAMS;
         P.mu = T::ld(p, P_MU);
-        V ml[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             P.k[j] = T::ld(p, P_K + j); P.b[j] = T::ld(p, P_B + j); P.rest[j] = T::ld(p, P_REST + j);
-            P.kp[j] = T::ld(p, P_KP + j); P.kd[j] = T::ld(p, P_KD + j); ml[j] = T::ld(p, P_M_LEG + j);
+            P.kp[j] = T::ld(p, P_KP + j); P.kd[j] = T::ld(p, P_KD + j); P.m_leg[j] = T::ld(p, P_M_LEG + j);
         }
-        S::build_par(P, T::ld(p, P_M_TRUNK), ml, T::ld(p, P_M_PAY), mk3<V>(T::ld(p, P_R_PAY), T::ld(p, P_R_PAY + 1), T::ld(p, P_R_PAY + 2)));
+        S::build_base(P, T::ld(p, P_M_TRUNK), T::ld(p, P_M_PAY), mk3<V>(T::ld(p, P_R_PAY), T::ld(p, P_R_PAY + 1), T::ld(p, P_R_PAY + 2)));
     }
 
     // ---- task state machine (tasks/task_base.py:61-166, 222-280) on replicated values

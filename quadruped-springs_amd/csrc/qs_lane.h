@@ -90,6 +90,7 @@ struct LaneDev {
     static QS_DEV float ld(const float* rec, int i) { return rec[i]; }
     static QS_DEV void st(float* rec, int i, float v) { if ((threadIdx.x & 3u) == 0) rec[i] = v; }
     static QS_DEV float first(float x) { return x; }
+    static QS_DEV void opaque(float& x) { asm volatile("" : "+v"(x)); }
     // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
     static QS_DEV void sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -152,6 +153,7 @@ struct LaneEmu {
     static V4 ld(const float* rec, int i) { return V4(rec[i]); }
     static void st(float* rec, int i, V4 v) { rec[i] = v.v[0]; }
     static float first(V4 x) { return x.v[0]; }
+    static void opaque(V4&) {}
     static void sync() {}
 };
 #endif
