@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--reset-pool", type=int, default=4096, help="pre-settled reset states per GPU (0 = settle inside the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solver-residual-threshold", type=float, default=0.0,
+                    help="PyBullet solverResidualThreshold (its default is 1e-7); 0 = always int(300/action_repeat) sweeps")
     args = ap.parse_args()
 
     import torch
@@ -85,6 +87,7 @@ def main():
 
     from qs_amd.vec_env import QuadrupedVecEnv
     n_default, kw = workload(args.workload)
+    kw["solver_residual_threshold"] = args.solver_residual_threshold
     n = args.envs_per_gpu or n_default
     env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, seed=1234 + 7919 * rank, **kw)
     env.reset_tensor()
@@ -138,7 +141,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
-                       "solver_sweeps": int(300 / kw["action_repeat"]), "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
+                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True, "reset": (f"pre-settled pool of {args.reset_pool} states per GPU" if args.reset_pool else "2500-substep settle inside the step"),
                        "resets_in_timed_region": int((stats1["resets"] - stats0["resets"]) * args.steps / (args.steps + min(args.steps, 50))),
                        "parallelism": f"env-sharded x{world}, no data-path collective"},

@@ -105,7 +105,9 @@ typedef struct qs_config {
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
     float cpg_lo[5], cpg_hi[5];/* action -> (omega_swing, omega_stance, mu, des_step_len, robot_height) */
     float cpg_clearance, cpg_penetration, cpg_coupling, cpg_alpha;  /* :42-43, :35, :142 */
-    float reserved_g[2];
+    float solver_residual_threshold; /* PyBullet setPhysicsEngineParameter(solverResidualThreshold): a sweep whose largest
+                                      * squared velocity change is <= this ends the solve; 0 = always `solver_iters` sweeps */
+    float reserved_g[1];
 } qs_config;
 
 typedef struct qs_handle qs_handle;

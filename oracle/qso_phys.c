@@ -368,6 +368,7 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
     for (int i = 0; i < nn; i++)
         if (nor[i].lam != 0) for (int k = 0; k < NV; k++) dv[k] += nor[i].W[k] * nor[i].lam;
     for (int it = 0; it < cfg->solver_iters; it++) {
+        real maxres2 = 0; /* btMultiBodyConstraintSolver: leastSquaredResidual = max over rows of (deltaImpulse / jacDiagABInv)^2 */
         for (int jj = 0; jj < nlim + nn + nf; jj++) {
             row* r;
             if (jj < nlim) r = &lim[(it & 1) ? jj : nlim - 1 - jj];
@@ -385,7 +386,12 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             else if (sum > r->hi) { dl = r->hi - r->lam; sum = r->hi; }
             r->lam = sum;
             for (int k = 0; k < NV; k++) dv[k] += r->W[k] * dl;
+            real resid = dl / r->dinv;
+            if (resid * resid > maxres2) maxres2 = resid * resid;
         }
+        /* solverResidualThreshold (PyBullet default 1e-7; this build's default 0: only an exactly stationary sweep ends early,
+           which cannot change the result) */
+        if (maxres2 <= (real)cfg->solver_residual_threshold) break;
     }
     for (int i = 0; i < nn; i++) {
         e->foot_force[nor_foot[i]] = nor[i].lam / dt;

@@ -245,10 +245,13 @@ template <class T> struct Sim {
         }
     }
 
-    struct Row { V jq[3], u[3], w[6], rhs, dinv, act; };
+    struct Row { V jq[3], u[3], w[6], rhs, dinv, act, diag; };
 
     // One stepSimulation() (gym_env.py:218-219) under joint torques tau[3] per leg.
-    template <int NR> static QS_FN void solve_and_integrate(const qs_config& cfg, V mu, State& s, Out& o, const Row* rows,
+    // TRACK: follow PyBullet's solverResidualThreshold -- an environment whose sweep changed no row velocity by more than
+    // sqrt(threshold) is frozen (its residuals are zeroed, so later sweeps leave it untouched) and the wave leaves the
+    // loop when all of its 16 environments are frozen.  Without TRACK every sweep is executed.
+    template <int NR, bool TRACK> static QS_FN void solve_and_integrate(const qs_config& cfg, V mu, State& s, Out& o, const Row* rows,
                                                             const V* Lc, const V* Ld, const V (*BK)[6], const V* R) {
         constexpr int NT = 4 * NR;
         const float dt = (float)cfg.dt;
@@ -260,6 +263,7 @@ template <class T> struct Sim {
         V Ap[NT][NR];
         V lam_own[NR], res[NR];
         V loc[NR][NR];
+        V diag_all[TRACK ? NT : 1];
 #pragma unroll
         for (int r = 0; r < NR; r++)
 #pragma unroll
@@ -275,6 +279,7 @@ template <class T> struct Sim {
                       wk[4] * rows[c].w[4] + wk[5] * rows[c].w[5];                                                     \
                 Ap[NR * K + r][c] = (d + qsel(own, loc[r][c], V(0.0f))) * rows[c].dinv;                                \
             }                                                                                                          \
+            if (TRACK) diag_all[TRACK ? NR * K + r : 0] = T::template bcast<K>(rows[r].diag);                          \
         }                                                                                                              \
     }
         QS_GATHER(0) QS_GATHER(1) QS_GATHER(2) QS_GATHER(3)
@@ -289,7 +294,9 @@ template <class T> struct Sim {
             for (int c = 0; c < NR; c++) res[c] = res[c] - (Ap[NR * 0][c] * l0 + Ap[NR * 1][c] * l1 + Ap[NR * 2][c] * l2 + Ap[NR * 3][c] * l3);
         }
         const V big = V(1e10f), zero = V(0.0f);
+        const V thr = V(sqrtf(cfg.solver_residual_threshold));
         for (int it = 0; it < cfg.solver_iters; it++) {
+            V dvmax = zero;   // largest |row velocity change| of this sweep (replicated over the quad)
 #define QS_ROW_UPDATE(K, RR, KIND)                                                                                    \
     {                                                                                                                  \
         constexpr int i_ = NR * (K) + (RR);                                                                            \
@@ -304,11 +311,18 @@ template <class T> struct Sim {
         V dk = T::template bcast<K>(cand - lam_own[RR]);                                                               \
         lam_own[RR] = qsel(T::is_leg(K), cand, lam_own[RR]);                                                           \
         _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] - Ap[i_][c] * dk;                               \
+        if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
             QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
             QS_ROW_UPDATE(2, 1, 1) QS_ROW_UPDATE(2, 2, 1) QS_ROW_UPDATE(3, 1, 1) QS_ROW_UPDATE(3, 2, 1)
 #undef QS_ROW_UPDATE
+            if (TRACK) {
+                M conv = qle(dvmax, thr);
+#pragma unroll
+                for (int c = 0; c < NR; c++) res[c] = qsel(conv, zero, res[c]);
+                if (!T::any(qnot(conv))) break;
+            }
         }
         o.foot_force = lam_own[0] * (1.0f / dt);   // getContactPoints()[9] = normal impulse / dt
         s.warm = lam_own[0];
@@ -378,7 +392,10 @@ template <class T> struct Sim {
 #pragma clang loop unroll(disable)
             for (int c = 0; c < 6; c++) res[c] = res[c] - Ap[6 * k][c] * lk;
         }
+        const bool track = cfg.solver_residual_threshold > 0.0f;
+        const V thr = V(sqrtf(cfg.solver_residual_threshold));
         for (int it = 0; it < cfg.solver_iters; it++) {
+            V dvmax = zero;
             // 36 row updates per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), 4 normals, 8 frictions
 #pragma clang loop unroll(disable)
             for (int n = 0; n < 24; n++) {
@@ -393,6 +410,13 @@ template <class T> struct Sim {
                 lam[r] = qsel(T::is_leg(k), cand, lam[r]);
 #pragma clang loop unroll(disable)
                 for (int c = 0; c < 6; c++) res[c] = res[c] - Ap[6 * k + r][c] * dk;
+                if (track) dvmax = qmax(dvmax, qabs(dk * T::bcast_dyn(a.rows[r].diag, k)));
+            }
+            if (track) {
+                M conv = qle(dvmax, thr);
+#pragma clang loop unroll(disable)
+                for (int c = 0; c < 6; c++) res[c] = qsel(conv, zero, res[c]);
+                if (!T::any(qnot(conv))) break;
             }
         }
         o.foot_force = lam[0] * (1.0f / dt);
@@ -613,7 +637,7 @@ template <class T> struct Sim {
         lsolve6<V>(Sm, Ld, r_.w);                                                                                      \
         V diag = r_.jq[0] * r_.u[0] + r_.jq[1] * r_.u[1] + r_.jq[2] * r_.u[2];                                         \
         _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
-        r_.dinv = qrcp(diag);                                                                                          \
+        r_.dinv = qrcp(diag); r_.diag = diag;                                                                          \
         V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
         if (NORMAL) {                                                                                                  \
             V pos_err = qsel(qgt(dist, zero), zero, (zero - dist) * (cfg.contact_erp * inv_dt));                       \
@@ -656,7 +680,7 @@ template <class T> struct Sim {
                 V diag = Kc[j][j];
 #pragma unroll
                 for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];
-                r_.dinv = qrcp(diag);
+                r_.dinv = qrcp(diag); r_.diag = diag;
                 V rel = lim_sgn[j] * s.qd[j];
                 r_.rhs = ((zero - lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
             }
@@ -675,7 +699,8 @@ template <class T> struct Sim {
             for (int i = 0; i < 9; i++) a.R[i] = R[i];
             solve_with_limits(cfg, Pr.mu, s, o, a);
         } else {
-            solve_and_integrate<3>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+            else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
         }
         // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
         s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;

@@ -119,7 +119,7 @@ class QsConfig(C.Structure):
         ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("reserved_f", C.c_float * 8),
         ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
         ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
-        ("reserved_g", C.c_float * 2),
+        ("solver_residual_threshold", C.c_float), ("reserved_g", C.c_float * 1),
     ]
 
 
@@ -219,6 +219,7 @@ def build_config(
     settle_steps=2500,
     env_id_offset=0,
     cpg_gait="BOUND",
+    solver_residual_threshold=0.0,
     robot_config=None,
     **_ignored,
 ):
@@ -318,6 +319,7 @@ def build_config(
     cfg.fallen_height = rc.IS_FALLEN_HEIGHT
     # engine constants assumed for PyBullet defaults (DESIGN.md "contact model")
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = 0.2, 0.2, 0.1, rc.VELOCITY_LIMITS[0]
+    cfg.solver_residual_threshold = float(solver_residual_threshold)
     for i, s in enumerate(lay["std"]):
         cfg.obs_noise_std[i] = s
     if not isRLGymInterface:

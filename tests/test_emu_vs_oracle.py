@@ -61,6 +61,7 @@ def test_reset_settle_matches():
     dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", action_space_mode="SYMMETRIC_NO_HIP"),
     dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="LANDING_SENSOR"),
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP"),
+    dict(solver_residual_threshold=1e-7),   # PyBullet's default solverResidualThreshold: per-environment early exit
     dict(task_env="BACKFLIP_PPO", observation_space_mode="PPO_BACKFLIP"),
     dict(task_env="CONTINUOUS_JUMPING_FORWARD3", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
     dict(task_env="CONTINUOUS_JUMPING_FORWARD_PPO", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
@@ -135,3 +136,18 @@ def test_noise_stream_matches_oracle():
     # randomised friction (Philox stream 1) is identical on both sides
     np.testing.assert_allclose(e.get("R_PARAMS", 1)[:, 0], o.get_info(6)[:, 0], rtol=1e-6)
     assert np.all((o.get_info(6)[:, 0] >= 0.5) & (o.get_info(6)[:, 0] <= 1.0))
+
+
+def test_residual_threshold_is_a_small_perturbation():
+    """Early exit at PyBullet's default threshold (1e-7 on the squared row velocity change) vs all 30 sweeps."""
+    o30, _, cfg = pair()
+    o_thr, _, _ = pair(solver_residual_threshold=1e-7)
+    o30.reset(); o_thr.reset()
+    rng = np.random.default_rng(8)
+    worst = 0.0
+    for i in range(60):
+        a = rng.uniform(-1, 1, size=(1, 6)).astype(np.float32)
+        o_thr.set_state(o30.get_state())
+        s30 = o30.step(a)[0]; st = o_thr.step(a)[0]
+        worst = max(worst, np.abs(s30 - st).max())
+    assert worst < 2e-2   # velocity-level differences of the order of the threshold, amplified over the 10 substeps

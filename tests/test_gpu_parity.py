@@ -86,6 +86,7 @@ CASES = [
     dict(task_env="BACKFLIP_PPO", observation_space_mode="PPO_BACKFLIP"),
     dict(task_env="CONTINUOUS_JUMPING_FORWARD3", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
     dict(task_env="CONTINUOUS_JUMPING_FORWARD_PPO", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
+    dict(solver_residual_threshold=1e-7),     # PyBullet's default solverResidualThreshold (per-environment early exit)
     dict(time_step=0.002, action_repeat=5),   # BASELINE.json config 2: dt = 1/500 s, 60 solver sweeps
     dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", env_randomizer_mode="SPRING_RANDOMIZER", seed=9),  # config 3
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER", seed=4),  # config 5
