@@ -232,13 +232,13 @@ template <class T> struct Sim {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             V lim = V(cfg.tau_max[j]);
-            V t = cfg.motor_control_mode == QS_MOTOR_TORQUE ? cmd[j] : (V(0.0f) - (P.kp[j] * (s.q[j] - cmd[j])) - P.kd[j] * s.qd[j]);
-            o.tau_pd[j] = clampv<V>(t, V(0.0f) - lim, lim);
+            V t = cfg.motor_control_mode == QS_MOTOR_TORQUE ? cmd[j] : (-(P.kp[j] * (s.q[j] - cmd[j])) - P.kd[j] * s.qd[j]);
+            o.tau_pd[j] = clampv<V>(t, -lim, lim);
             V ts = V(0.0f);
             if (cfg.enable_springs) {
                 V dq = s.q[j] - P.rest[j];
                 M off = j == 0 ? qlt(sy * dq, V(0.0f)) : (j == 1 ? qlt(dq, V(0.0f)) : qgt(dq, V(0.0f)));
-                ts = qsel(off, V(0.0f), V(0.0f) - P.k[j] * dq - P.b[j] * s.qd[j]);
+                ts = qsel(off, V(0.0f), -P.k[j] * dq - P.b[j] * s.qd[j]);
             }
             o.tau_spring[j] = ts;
             tau[j] = o.tau_pd[j] + ts;
@@ -256,10 +256,12 @@ template <class T> struct Sim {
         constexpr int NT = 4 * NR;
         const float dt = (float)cfg.dt;
         // Delassus columns of the own rows, pre-scaled by the own row's 1/diag:
-        //   Ap[(k,r)][c] = (w_kr . w_c + [k == own] jq_r . u_c) * dinv_c
-        // Projected Gauss-Seidel then runs on the lane-private residual  res_c = rhs_c - dinv_c * sum_j A_cj lam_j :
-        //   candidate lam_i = lam_i + res_i, clamp, delta broadcast over the quad (one DPP move), res_c -= Ap[i][c] * delta.
-        // Rows of inactive contacts / limits have w = jq = u = rhs = 0, so their residual stays 0 and lam stays 0.
+        //   Ap[(k,r)][c] = -(w_kr . w_c + [k == own] jq_r . u_c) * dinv_c      (negated: the update is a v_fmac_f32_dpp)
+        // Projected Gauss-Seidel then runs on the lane-private UNCLAMPED candidates
+        //   cand_c = lam_c + rhs_c - dinv_c * sum_j A_cj lam_j        (the Gauss-Seidel update of row c is lam_c <- clamp(cand_c))
+        // A row's own update leaves its candidate unchanged (A_cc * dinv_c = 1), so per row the loop needs: clamp, delta =
+        // clamp(cand) - lam, one DPP broadcast of delta over the quad, and cand_c -= Ap[i][c] * delta for the other rows
+        // (the self entry of Ap is zeroed).  Rows of inactive contacts / limits have w = jq = u = rhs = 0: cand = lam = 0.
         V Ap[NT][NR];
         V lam_own[NR], res[NR];
         V loc[NR][NR];
@@ -277,7 +279,8 @@ template <class T> struct Sim {
             _Pragma("unroll") for (int c = 0; c < NR; c++) {                                                           \
                 V d = wk[0] * rows[c].w[0] + wk[1] * rows[c].w[1] + wk[2] * rows[c].w[2] + wk[3] * rows[c].w[3] +      \
                       wk[4] * rows[c].w[4] + wk[5] * rows[c].w[5];                                                     \
-                Ap[NR * K + r][c] = (d + qsel(own, loc[r][c], V(0.0f))) * rows[c].dinv;                                \
+                V a_ = -((d + qsel(own, loc[r][c], V(0.0f))) * rows[c].dinv);                                          \
+                Ap[NR * K + r][c] = (r == c) ? qsel(own, V(0.0f), a_) : a_;                                            \
             }                                                                                                          \
             if (TRACK) diag_all[TRACK ? NR * K + r : 0] = T::template bcast<K>(rows[r].diag);                          \
         }                                                                                                              \
@@ -286,12 +289,12 @@ template <class T> struct Sim {
 #undef QS_GATHER
         // warm start: normal rows only, factor cfg.warmstart (btMultiBodyConstraintSolver, SOLVER_USE_WARMSTARTING)
 #pragma unroll
-        for (int r = 0; r < NR; r++) { lam_own[r] = V(0.0f); res[r] = rows[r].rhs; }
+        for (int r = 0; r < NR; r++) { lam_own[r] = V(0.0f); res[r] = rows[r].rhs; }   // res[] holds the candidates: rhs_c - dinv_c sum_{j != c} A_cj lam_j
         lam_own[0] = s.warm * cfg.warmstart * rows[0].act;
         {
             V l0 = T::template bcast<0>(lam_own[0]), l1 = T::template bcast<1>(lam_own[0]), l2 = T::template bcast<2>(lam_own[0]), l3 = T::template bcast<3>(lam_own[0]);
 #pragma unroll
-            for (int c = 0; c < NR; c++) res[c] = res[c] - (Ap[NR * 0][c] * l0 + Ap[NR * 1][c] * l1 + Ap[NR * 2][c] * l2 + Ap[NR * 3][c] * l3);
+            for (int c = 0; c < NR; c++) res[c] = res[c] + (Ap[NR * 0][c] * l0 + Ap[NR * 1][c] * l1 + Ap[NR * 2][c] * l2 + Ap[NR * 3][c] * l3);
         }
         const V big = V(1e10f), zero = V(0.0f);
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
@@ -300,18 +303,18 @@ template <class T> struct Sim {
 #define QS_ROW_UPDATE(K, RR, KIND)                                                                                    \
     {                                                                                                                  \
         constexpr int i_ = NR * (K) + (RR);                                                                            \
-        V cand = lam_own[RR] + res[RR];                                                                                \
+        V cand;                                                                                                        \
         if (KIND == 0) { /* unilateral row: [0, 1e10] */                                                               \
-            cand = qmin(qmax(cand, zero), big);                                                                        \
+            cand = qmed3(res[RR], zero, big);                                                                          \
         } else { /* friction row bounded by mu * current normal impulse; skipped while that impulse is not positive */ \
             V tot = lam_own[0];                                                                                        \
             V lim = mu * tot;                                                                                          \
-            cand = qsel(qgt(tot, zero), qmin(qmax(cand, zero - lim), lim), lam_own[RR]);                               \
+            cand = qsel(qgt(tot, zero), qmed3(res[RR], -lim, lim), lam_own[RR]);                                       \
         }                                                                                                              \
-        V dk = T::template bcast<K>(cand - lam_own[RR]);                                                               \
+        V dl = cand - lam_own[RR];                                                                                     \
         lam_own[RR] = qsel(T::is_leg(K), cand, lam_own[RR]);                                                           \
-        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] - Ap[i_][c] * dk;                               \
-        if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
+        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = T::template fma_bcast<K>(dl, Ap[i_][c], res[c]);       \
+        if (TRACK) dvmax = qmax(dvmax, qabs(T::template bcast<K>(dl) * diag_all[TRACK ? i_ : 0]));                     \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
             QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
@@ -320,7 +323,7 @@ template <class T> struct Sim {
             if (TRACK) {
                 M conv = qle(dvmax, thr);
 #pragma unroll
-                for (int c = 0; c < NR; c++) res[c] = qsel(conv, zero, res[c]);
+                for (int c = 0; c < NR; c++) res[c] = qsel(conv, lam_own[c], res[c]);   // frozen: clamp(cand) == lam from now on
                 if (!T::any(qnot(conv))) break;
             }
         }
@@ -347,12 +350,12 @@ template <class T> struct Sim {
             s.qd[j] = clampv<V>(s.qd[j] + t, V(-cfg.vel_cap), V(cfg.vel_cap));
         }
         const V cap = V(cfg.vel_cap);
-        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), zero - cap, cap);
-        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), zero - cap, cap);
-        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), zero - cap, cap);
-        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), zero - cap, cap);
-        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), zero - cap, cap);
-        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), zero - cap, cap);
+        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), -cap, cap);
+        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), -cap, cap);
+        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), -cap, cap);
+        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), -cap, cap);
+        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), -cap, cap);
+        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
     }
 
     // The joint-limit path (6 rows per leg: contact rows + one row per violated limit) is rare (falls).  It is written
@@ -405,7 +408,7 @@ template <class T> struct Sim {
                 else { k = (n - 16) >> 1; r = 1 + ((n - 16) & 1); kind = 1; }
                 V cand = lam[r] + res[r];
                 if (kind == 0) cand = qmin(qmax(cand, zero), big);
-                else { V tot = lam[0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, zero - lim), lim), lam[r]); }
+                else { V tot = lam[0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[r]); }
                 V dk = T::bcast_dyn(cand - lam[r], k);
                 lam[r] = qsel(T::is_leg(k), cand, lam[r]);
 #pragma clang loop unroll(disable)
@@ -435,15 +438,15 @@ template <class T> struct Sim {
 #pragma clang loop unroll(disable)
             for (int r = 0; r < 6; r++) t = t + a.rows[r].u[j] * lam[r];
             for (int i = 0; i < 6; i++) t = t - a.BK[j][i] * z[i];
-            s.qd[j] = clampv<V>(s.qd[j] + t, zero - cap, cap);
+            s.qd[j] = clampv<V>(s.qd[j] + t, -cap, cap);
         }
         const V* R = a.R;
-        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), zero - cap, cap);
-        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), zero - cap, cap);
-        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), zero - cap, cap);
-        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), zero - cap, cap);
-        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), zero - cap, cap);
-        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), zero - cap, cap);
+        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), -cap, cap);
+        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), -cap, cap);
+        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), -cap, cap);
+        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), -cap, cap);
+        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), -cap, cap);
+        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
     }
 
     static QS_FN void substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o) {
@@ -481,11 +484,11 @@ template <class T> struct Sim {
         V3v p1 = mk3<V>(fx * HIP_X, sy * HIP_Y, zero);
         V3v ax1 = mk3<V>(one, zero, zero);
         V3v Y = mk3<V>(zero, c1, s1);                       // joint axis of thigh and calf
-        V3v Z1 = mk3<V>(zero, zero - s1, c1);
+        V3v Z1 = mk3<V>(zero, -s1, c1);
         V3v p2 = p1 + Y * (sy * THIGH_Y);
-        V3v X2 = mk3<V>(c2, s1 * s2, zero - c1 * s2), Z2 = mk3<V>(s2, zero - s1 * c2, c1 * c2);
+        V3v X2 = mk3<V>(c2, s1 * s2, -c1 * s2), Z2 = mk3<V>(s2, -s1 * c2, c1 * c2);
         V3v p3 = p2 + Z2 * V(LEG_Z);
-        V3v X3 = mk3<V>(c23, s1 * s23, zero - c1 * s23), Z3 = mk3<V>(s23, zero - s1 * c23, c1 * c23);
+        V3v X3 = mk3<V>(c23, s1 * s23, -c1 * s23), Z3 = mk3<V>(s23, -s1 * c23, c1 * c23);
         V3v rf = p3 + Z3 * V(LEG_Z);                        // foot centre
 
         // ---- link inertias about the base origin
@@ -553,9 +556,9 @@ template <class T> struct Sim {
             V H[21];
             H[tri(0, 0)] = Itot.I.xx; H[tri(1, 0)] = Itot.I.xy; H[tri(1, 1)] = Itot.I.yy; H[tri(2, 0)] = Itot.I.xz; H[tri(2, 1)] = Itot.I.yz; H[tri(2, 2)] = Itot.I.zz;
             // rows 3..5 (linear) x cols 0..2 (angular): -[h]x  ; diagonal block m
-            H[tri(3, 0)] = zero; H[tri(3, 1)] = Itot.h.z; H[tri(3, 2)] = zero - Itot.h.y;
-            H[tri(4, 0)] = zero - Itot.h.z; H[tri(4, 1)] = zero; H[tri(4, 2)] = Itot.h.x;
-            H[tri(5, 0)] = Itot.h.y; H[tri(5, 1)] = zero - Itot.h.x; H[tri(5, 2)] = zero;
+            H[tri(3, 0)] = zero; H[tri(3, 1)] = Itot.h.z; H[tri(3, 2)] = -Itot.h.y;
+            H[tri(4, 0)] = -Itot.h.z; H[tri(4, 1)] = zero; H[tri(4, 2)] = Itot.h.x;
+            H[tri(5, 0)] = Itot.h.y; H[tri(5, 1)] = -Itot.h.x; H[tri(5, 2)] = zero;
             H[tri(3, 3)] = Itot.m; H[tri(4, 3)] = zero; H[tri(4, 4)] = Itot.m; H[tri(5, 3)] = zero; H[tri(5, 4)] = zero; H[tri(5, 5)] = Itot.m;
 #pragma unroll
             for (int i = 0; i < 21; i++) Sm[i] = H[i] - Sm[i];
@@ -568,7 +571,7 @@ template <class T> struct Sim {
         V y1 = K11 * t1 + K12 * t2 + K13 * t3, y2 = K12 * t1 + K22 * t2 + K23 * t3, y3 = K13 * t1 + K23 * t2 + K33 * t3;
         V ab[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) ab[i] = zero - Cb[i] - T::quad_sum(Bm[0][i] * y1 + Bm[1][i] * y2 + Bm[2][i] * y3);
+        for (int i = 0; i < 6; i++) ab[i] = -Cb[i] - T::quad_sum(Bm[0][i] * y1 + Bm[1][i] * y2 + Bm[2][i] * y3);
         lsolve6<V>(Sm, Ld, ab);
         ltsolve6<V>(Sm, Ld, ab);
         V qdd[3] = {y1, y2, y3};
@@ -581,14 +584,14 @@ template <class T> struct Sim {
         {
             V3v wxv = cross(v0.a, v0.l);
             V3v al = mk3<V>(ab[3] + wxv.x, ab[4] + wxv.y, ab[5] + wxv.z);
-            s.vang.x = clampv<V>(s.vang.x + dt * (R[0] * ab[0] + R[1] * ab[1] + R[2] * ab[2]), zero - cap, cap);
-            s.vang.y = clampv<V>(s.vang.y + dt * (R[3] * ab[0] + R[4] * ab[1] + R[5] * ab[2]), zero - cap, cap);
-            s.vang.z = clampv<V>(s.vang.z + dt * (R[6] * ab[0] + R[7] * ab[1] + R[8] * ab[2]), zero - cap, cap);
-            s.vlin.x = clampv<V>(s.vlin.x + dt * (R[0] * al.x + R[1] * al.y + R[2] * al.z), zero - cap, cap);
-            s.vlin.y = clampv<V>(s.vlin.y + dt * (R[3] * al.x + R[4] * al.y + R[5] * al.z), zero - cap, cap);
-            s.vlin.z = clampv<V>(s.vlin.z + dt * (R[6] * al.x + R[7] * al.y + R[8] * al.z), zero - cap, cap);
+            s.vang.x = clampv<V>(s.vang.x + dt * (R[0] * ab[0] + R[1] * ab[1] + R[2] * ab[2]), -cap, cap);
+            s.vang.y = clampv<V>(s.vang.y + dt * (R[3] * ab[0] + R[4] * ab[1] + R[5] * ab[2]), -cap, cap);
+            s.vang.z = clampv<V>(s.vang.z + dt * (R[6] * ab[0] + R[7] * ab[1] + R[8] * ab[2]), -cap, cap);
+            s.vlin.x = clampv<V>(s.vlin.x + dt * (R[0] * al.x + R[1] * al.y + R[2] * al.z), -cap, cap);
+            s.vlin.y = clampv<V>(s.vlin.y + dt * (R[3] * al.x + R[4] * al.y + R[5] * al.z), -cap, cap);
+            s.vlin.z = clampv<V>(s.vlin.z + dt * (R[6] * al.x + R[7] * al.y + R[8] * al.z), -cap, cap);
 #pragma unroll
-            for (int j = 0; j < 3; j++) s.qd[j] = clampv<V>(s.qd[j] + dt * qdd[j], zero - cap, cap);
+            for (int j = 0; j < 3; j++) s.qd[j] = clampv<V>(s.qd[j] + dt * qdd[j], -cap, cap);
         }
         Spv vs;  // predicted base velocity in base coordinates
         vs.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
@@ -640,17 +643,17 @@ template <class T> struct Sim {
         r_.dinv = qrcp(diag); r_.diag = diag;                                                                          \
         V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
         if (NORMAL) {                                                                                                  \
-            V pos_err = qsel(qgt(dist, zero), zero, (zero - dist) * (cfg.contact_erp * inv_dt));                       \
-            V vel_err = (zero - rel) - qsel(qgt(dist, zero), dist * inv_dt, zero);                                     \
+            V pos_err = qsel(qgt(dist, zero), zero, (-dist) * (cfg.contact_erp * inv_dt));                       \
+            V vel_err = (-rel) - qsel(qgt(dist, zero), dist * inv_dt, zero);                                     \
             r_.rhs = (pos_err + vel_err) * r_.dinv * active;                                                           \
         } else {                                                                                                       \
-            r_.rhs = (zero - rel) * r_.dinv * active;                                                                  \
+            r_.rhs = (-rel) * r_.dinv * active;                                                                  \
         }                                                                                                              \
         r_.act = active;                                                                                               \
         _Pragma("unroll") for (int j = 0; j < 3; j++) { r_.jq[j] = r_.jq[j] * active; r_.u[j] = r_.u[j] * active; }    \
     }
         QS_CONTACT_ROW(0, Rz, true)
-        QS_CONTACT_ROW(1, (mk3<V>(zero - Ry.x, zero - Ry.y, zero - Ry.z)), false)
+        QS_CONTACT_ROW(1, (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false)
         QS_CONTACT_ROW(2, Rx, false)
 #undef QS_CONTACT_ROW
         // joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint)
@@ -661,7 +664,7 @@ template <class T> struct Sim {
             V plo = s.q[j] - JLO[j], phi = V(JHI[j]) - s.q[j];
             M vlo = qle(plo, zero), vhi = qle(phi, zero);
             lim_pen[j] = qsel(vlo, plo, phi);
-            lim_sgn[j] = qsel(vlo, one, zero - one);
+            lim_sgn[j] = qsel(vlo, one, -one);
             M v = qor(vlo, vhi);
             rows[3 + j].act = qflag(v);
             any_lim = qor(any_lim, v);
@@ -675,14 +678,14 @@ template <class T> struct Sim {
 #pragma unroll
                 for (int c = 0; c < 3; c++) { r_.jq[c] = c == j ? a_ : zero; r_.u[c] = Kc[c][j] * a_; }
 #pragma unroll
-                for (int i = 0; i < 6; i++) r_.w[i] = zero - BK[j][i] * a_;
+                for (int i = 0; i < 6; i++) r_.w[i] = -BK[j][i] * a_;
                 lsolve6<V>(Sm, Ld, r_.w);
                 V diag = Kc[j][j];
 #pragma unroll
                 for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];
                 r_.dinv = qrcp(diag); r_.diag = diag;
                 V rel = lim_sgn[j] * s.qd[j];
-                r_.rhs = ((zero - lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
+                r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
             }
             RareArgs a;
 #pragma unroll

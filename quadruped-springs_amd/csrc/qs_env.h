@@ -20,12 +20,12 @@ template <class T> struct Env {
         const float sh = cfg.leg_len[0], el = cfg.leg_len[1], wr = cfg.leg_len[2];
         V D = (y * y + z * z - sh * sh + x * x - el * el - wr * wr) * (1.0f / (2.0f * wr * el));
         D = clampv<V>(D, V(-1.0f), V(1.0f));
-        V wrist = qatan2(V(0.0f) - qsqrt(V(1.0f) - D * D), D);
+        V wrist = qatan2(-qsqrt(V(1.0f) - D * D), D);
         V sc = qmax(y * y + z * z - sh * sh, V(0.0f));
         V rt = qsqrt(sc);
-        V shoulder = V(0.0f) - qatan2(z, y) - qatan2(rt, T::sy() * sh);
-        V elbow = qatan2(V(0.0f) - x, rt) - qatan2(qsin(wrist) * wr, qcos(wrist) * wr + el);
-        q[0] = V(0.0f) - shoulder; q[1] = elbow; q[2] = wrist;
+        V shoulder = -qatan2(z, y) - qatan2(rt, T::sy() * sh);
+        V elbow = qatan2(-x, rt) - qatan2(qsin(wrist) * wr, qcos(wrist) * wr + el);
+        q[0] = -shoulder; q[1] = elbow; q[2] = wrist;
     }
     // ---- analytic leg FK + Jacobian (quadruped.py:348-392)
     static QS_FN void leg_fk(const qs_config& cfg, const V* q, V* J, V* p) {
@@ -34,10 +34,10 @@ template <class T> struct Env {
         V s1 = qsin(q[0]), s2 = qsin(q[1]), s3 = qsin(q[2]), c1 = qcos(q[0]), c2 = qcos(q[1]), c3 = qcos(q[2]);
         V c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
         V zero = V(0.0f);
-        J[0] = zero; J[3] = zero - sg * l1 * s1 + c2 * c1 * l2 + c23 * c1 * l3; J[6] = sg * l1 * c1 + c2 * s1 * l2 + c23 * s1 * l3;
-        J[1] = zero - c23 * l3 - c2 * l2; J[4] = zero - s2 * s1 * l2 - s23 * s1 * l3; J[7] = s2 * c1 * l2 + s23 * c1 * l3;
-        J[2] = zero - c23 * l3; J[5] = zero - s23 * s1 * l3; J[8] = s23 * c1 * l3;
-        p[0] = zero - s23 * l3 - s2 * l2;
+        J[0] = zero; J[3] = -sg * l1 * s1 + c2 * c1 * l2 + c23 * c1 * l3; J[6] = sg * l1 * c1 + c2 * s1 * l2 + c23 * s1 * l3;
+        J[1] = -c23 * l3 - c2 * l2; J[4] = -s2 * s1 * l2 - s23 * s1 * l3; J[7] = s2 * c1 * l2 + s23 * c1 * l3;
+        J[2] = -c23 * l3; J[5] = -s23 * s1 * l3; J[8] = s23 * c1 * l3;
+        p[0] = -s23 * l3 - s2 * l2;
         p[1] = sg * c1 * l1 + (s1 * c23) * l3 + c2 * s1 * l2;
         p[2] = sg * s1 * l1 - (c1 * c23) * l3 - c1 * c2 * l2;
     }
@@ -50,13 +50,13 @@ template <class T> struct Env {
         V yw = qatan2(V(2.0f) * (x * y + w * z), w * w + x * x - y * y - z * z);
         pitch = qsel(lo, V(-0.5f * PI), qsel(hi, V(0.5f * PI), p));
         roll = qsel(qor(lo, hi), V(0.0f), r);
-        yaw = qsel(lo, V(2.0f) * qatan2(x, V(0.0f) - y), qsel(hi, V(2.0f) * qatan2(V(0.0f) - x, y), yw));
+        yaw = qsel(lo, V(2.0f) * qatan2(x, -y), qsel(hi, V(2.0f) * qatan2(-x, y), yw));
     }
     // ---- PitchBackFlip sensor (robot_sensors.py:333-340)
     static QS_FN V pitch_backflip(V x, V y, V z, V w, V switched) {
         V d = x * x + y * y + z * z + w * w, sc = V(2.0f) / d;
         V r20 = (x * z - w * y) * sc, r22 = V(1.0f) - (x * x + y * y) * sc;
-        V pitch = V(0.0f) - qatan2(V(0.0f) - r20, r22);
+        V pitch = -qatan2(-r20, r22);
         return qsel(qand(qlt(pitch, V(0.0f)), qgt(switched, V(0.5f))), pitch + 2.0f * PI, pitch);
     }
 
@@ -76,7 +76,7 @@ template <class T> struct Env {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 V t = qsel(front, act[j], act[3 + j]);
-                a[j] = j == cfg.symm_idx ? t * (V(0.0f) - T::sy()) : t;  // left legs mirror index symm_idx
+                a[j] = j == cfg.symm_idx ? t * (-T::sy()) : t;  // left legs mirror index symm_idx
             }
         } else {
             int k = 0;
@@ -116,7 +116,7 @@ template <class T> struct Env {
         V t2 = th + td * dt;
         th = t2 - qfloor(t2 * (1.0f / (2.0f * PI))) * (2.0f * PI);                                   // :170
         qsincos(th, s_th, c_th);
-        V x = zero - p[3] * r * c_th;                                                                // :128
+        V x = -p[3] * r * c_th;                                                                // :128
         V z = qsel(qgt(s_th, zero), s_th * cfg.cpg_clearance, s_th * cfg.cpg_penetration) - p[4];    // :129-132
         leg_ik(cfg, x, T::sy() * cfg.leg_len[0], z, cmd);
     }
@@ -315,19 +315,19 @@ template <class T> struct Env {
     static QS_FN V task_reward_end(const qs_config& cfg, const Task& t, V term, V now) {
         const V zero = V(0.0f), one = V(1.0f);
         M alive = qlt(term, V(0.5f));
-        V g = qexp(zero - t.max_pitch * t.max_pitch * (1.0f / (0.15f * 0.15f)));
+        V g = qexp(-t.max_pitch * t.max_pitch * (1.0f / (0.15f * 0.15f)));
         switch (cfg.task) {
         case QS_TASK_JUMPING_IN_PLACE: {  // robot_tasks.py:31-57
             V hn = qsel(qgt(t.rel_max_h, V(0.9f)), one, t.rel_max_h * (1.0f / 0.9f));
-            V r = hn * 0.7f + hn * 0.3f * g + hn * 0.05f * qexp(zero - t.max_dx * t.max_dx * (1.0f / 0.05f));
-            return r + qsel(alive, hn * 0.1f, zero - (one + hn * 0.8f) * 0.08f);
+            V r = hn * 0.7f + hn * 0.3f * g + hn * 0.05f * qexp(-t.max_dx * t.max_dx * (1.0f / 0.05f));
+            return r + qsel(alive, hn * 0.1f, -(one + hn * 0.8f) * 0.08f);
         }
         case QS_TASK_JUMPING_FORWARD: {   // :70-99
             V hn = qsel(qgt(t.rel_max_h, V(0.3f)), one, t.rel_max_h * (1.0f / 0.3f));
             V fn = qsel(qgt(t.max_fwd, V(1.3f)), one, t.max_fwd * (1.0f / 1.3f));
             V bm = (hn + fn) * 0.5f;
             V r = hn * 0.25f + fn * hn * 0.5f + hn * 0.25f * g;
-            return r + qsel(alive, bm * 0.1f, zero - (one + bm * 1.2f) * 0.08f);
+            return r + qsel(alive, bm * 0.1f, -(one + bm * 1.2f) * 0.08f);
         }
         case QS_TASK_CONT_JUMPING_FORWARD: {  // :112-131
             V tn = t.cum_ft * (1.0f / 0.15f), dn = t.cum_fwd * (1.0f / 0.5f), bm = (tn + dn) * 0.5f;
@@ -338,7 +338,7 @@ template <class T> struct Env {
             return tn * 0.25f + dn * 0.5f + dn * 0.15f * g + (now * 0.1f) * bm * 0.4f + qsel(alive, bm * 0.2f, zero);
         }
         case QS_TASK_JUMPING_IN_PLACE_PPO: case QS_TASK_JUMPING_IN_PLACE_PPO_HP:  // :348-358
-            return qsel(alive, zero, zero - t.max_h * 0.25f);
+            return qsel(alive, zero, -t.max_h * 0.25f);
         case QS_TASK_JUMPING_FORWARD_PPO: case QS_TASK_JUMPING_FORWARD_PPO_HP:    // :475-485
             return qsel(alive, (t.max_fwd + t.max_h) * 0.025f, zero);
         case QS_TASK_BACKFLIP: {              // :535-550

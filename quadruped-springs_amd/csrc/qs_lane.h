@@ -55,6 +55,11 @@ QS_FN void qsincos(float x, float& s, float& c) {
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+QS_FN float qmed3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }   // clamp in one instruction
+#else
+QS_FN float qmed3(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+#endif
 QS_FN float qsel(bool m, float a, float b) { return m ? a : b; }
 QS_FN bool qlt(float a, float b) { return a < b; }
 QS_FN bool qgt(float a, float b) { return a > b; }
@@ -79,6 +84,12 @@ struct LaneDev {
         return x;
     }
     template <int K> static QS_DEV float bcast(float x) { return dpp<K * 0x55>(x); }
+    // acc + bcast<K>(d) * a as ONE v_fmac_f32_dpp: the DPP move is given the accumulator as its (ignored, bound_ctrl) old
+    // value so that the three uses per row are not merged into one shared v_mov_dpp, which the DPP combiner could not fold
+    template <int K> static QS_DEV float fma_bcast(float d, float a, float acc) {
+        float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, d), K * 0x55, 0xF, 0xF, true));
+        return fmaf(b, a, acc);
+    }
     static QS_DEV float bcast_dyn(float x, int k) { return __shfl(x, (int)((threadIdx.x & 60u) | (unsigned)k), 64); }  // rare path only
     static QS_DEV int leg() { return (int)(threadIdx.x & 3u); }
     static QS_DEV float fx() { return (threadIdx.x & 2u) ? -1.0f : 1.0f; }  // front +, rear -
@@ -125,6 +136,7 @@ inline void qsincos(V4 x, V4& s, V4& c) { for (int i = 0; i < 4; i++) qsincos(x.
 inline V4 qmin(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
 inline V4 qmax(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }
 inline V4 qatan2(V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = atan2f(a.v[i], b.v[i]); return r; }
+inline V4 qmed3(V4 x, V4 lo, V4 hi) { return qmin(qmax(x, lo), hi); }
 inline V4 qsel(M4 m, V4 a, V4 b) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 #define QS_V4_CMP(name, op) inline M4 name(V4 a, V4 b) { M4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
 QS_V4_CMP(qlt, <) QS_V4_CMP(qgt, >) QS_V4_CMP(qle, <=) QS_V4_CMP(qge, >=)
@@ -144,6 +156,7 @@ struct LaneEmu {
     }
     template <int K> static V4 bcast(V4 x) { return V4(x.v[K]); }
     static V4 bcast_dyn(V4 x, int k) { return V4(x.v[k]); }
+    template <int K> static V4 fma_bcast(V4 d, V4 a, V4 acc) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = acc.v[i] + d.v[K] * a.v[i]; return r; }
     static V4 fx() { return V4(1, 1, -1, -1); }
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
