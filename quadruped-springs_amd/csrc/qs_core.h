@@ -289,17 +289,25 @@ template <class T> struct Sim {
 #undef QS_GATHER
         // warm start: normal rows only, factor cfg.warmstart (btMultiBodyConstraintSolver, SOLVER_USE_WARMSTARTING)
 #pragma unroll
-        for (int r = 0; r < NR; r++) { lam_own[r] = V(0.0f); res[r] = rows[r].rhs; }   // res[] holds the candidates: rhs_c - dinv_c sum_{j != c} A_cj lam_j
-        lam_own[0] = s.warm * cfg.warmstart * rows[0].act;
-        {
-            V l0 = T::template bcast<0>(lam_own[0]), l1 = T::template bcast<1>(lam_own[0]), l2 = T::template bcast<2>(lam_own[0]), l3 = T::template bcast<3>(lam_own[0]);
+        for (int r = 0; r < NR; r++) res[r] = rows[r].rhs;   // res[] holds the candidates: rhs_c - dinv_c sum_{j != c} A_cj lam_j
+        V lam_all[NT];                                         // every impulse of the environment, replicated over the quad
 #pragma unroll
-            for (int c = 0; c < NR; c++) res[c] = res[c] + (Ap[NR * 0][c] * l0 + Ap[NR * 1][c] * l1 + Ap[NR * 2][c] * l2 + Ap[NR * 3][c] * l3);
+        for (int i = 0; i < NT; i++) lam_all[i] = V(0.0f);
+        {
+            V l_own = s.warm * cfg.warmstart * rows[0].act;
+            lam_all[NR * 0] = T::template bcast<0>(l_own); lam_all[NR * 1] = T::template bcast<1>(l_own);
+            lam_all[NR * 2] = T::template bcast<2>(l_own); lam_all[NR * 3] = T::template bcast<3>(l_own);
+#pragma unroll
+            for (int c = 0; c < NR; c++)
+                res[c] = res[c] + (Ap[NR * 0][c] * lam_all[NR * 0] + Ap[NR * 1][c] * lam_all[NR * 1] + Ap[NR * 2][c] * lam_all[NR * 2] + Ap[NR * 3][c] * lam_all[NR * 3]);
         }
         const V big = V(1e10f), zero = V(0.0f);
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
         for (int it = 0; it < cfg.solver_iters; it++) {
             V dvmax = zero;   // largest |row velocity change| of this sweep (replicated over the quad)
+            // Row (K, RR): every lane clamps the candidate of ITS row RR, lane K's result is the real one; one DPP-fused
+            // subtract fetches it (delta = bcast_K(cand) - lam), the replicated impulse is advanced and the candidates of the
+            // lane's own rows move by Ap * delta.
 #define QS_ROW_UPDATE(K, RR, KIND)                                                                                    \
     {                                                                                                                  \
         constexpr int i_ = NR * (K) + (RR);                                                                            \
@@ -307,14 +315,14 @@ template <class T> struct Sim {
         if (KIND == 0) { /* unilateral row: [0, 1e10] */                                                               \
             cand = qmed3(res[RR], zero, big);                                                                          \
         } else { /* friction row bounded by mu * current normal impulse; skipped while that impulse is not positive */ \
-            V tot = lam_own[0];                                                                                        \
+            V tot = lam_all[NR * (K)];                                                                                 \
             V lim = mu * tot;                                                                                          \
-            cand = qsel(qgt(tot, zero), qmed3(res[RR], -lim, lim), lam_own[RR]);                                       \
+            cand = qsel(qgt(tot, zero), qmed3(res[RR], -lim, lim), lam_all[i_]);                                       \
         }                                                                                                              \
-        V dl = cand - lam_own[RR];                                                                                     \
-        lam_own[RR] = qsel(T::is_leg(K), cand, lam_own[RR]);                                                           \
-        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = T::template fma_bcast<K>(dl, Ap[i_][c], res[c]);       \
-        if (TRACK) dvmax = qmax(dvmax, qabs(T::template bcast<K>(dl) * diag_all[TRACK ? i_ : 0]));                     \
+        V dk = T::template bcast<K>(cand) - lam_all[i_];                                                               \
+        lam_all[i_] = lam_all[i_] + dk;                                                                                \
+        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk;                               \
+        if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
             QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
@@ -322,11 +330,18 @@ template <class T> struct Sim {
 #undef QS_ROW_UPDATE
             if (TRACK) {
                 M conv = qle(dvmax, thr);
+                // frozen environment: make clamp(cand) == lam for its rows from now on
 #pragma unroll
-                for (int c = 0; c < NR; c++) res[c] = qsel(conv, lam_own[c], res[c]);   // frozen: clamp(cand) == lam from now on
+                for (int c = 0; c < NR; c++) {
+                    V mine = qsel(T::is_leg(0), lam_all[NR * 0 + c], qsel(T::is_leg(1), lam_all[NR * 1 + c], qsel(T::is_leg(2), lam_all[NR * 2 + c], lam_all[NR * 3 + c])));
+                    res[c] = qsel(conv, mine, res[c]);
+                }
                 if (!T::any(qnot(conv))) break;
             }
         }
+#pragma unroll
+        for (int c = 0; c < NR; c++)
+            lam_own[c] = qsel(T::is_leg(0), lam_all[NR * 0 + c], qsel(T::is_leg(1), lam_all[NR * 1 + c], qsel(T::is_leg(2), lam_all[NR * 2 + c], lam_all[NR * 3 + c])));
         o.foot_force = lam_own[0] * (1.0f / dt);   // getContactPoints()[9] = normal impulse / dt
         s.warm = lam_own[0];
 
