@@ -53,6 +53,8 @@ enum {                                                                          
 #define QS_RAND_MASSES 2   /* env_randomizer.py:19-83 */
 #define QS_RAND_SPRINGS 4  /* env_randomizer.py:86-122 */
 #define QS_RAND_KEEP 8     /* reset keeps the parameters last written by qs_set_params */
+enum { QS_WRAP_NONE = 0, QS_WRAP_LANDING = 1, QS_WRAP_GO_TO_REST = 2 };
+enum { QS_PHASE_POLICY = 0, QS_PHASE_TAKEOFF = 1, QS_PHASE_LANDING = 2, QS_PHASE_REST = 3 };
 
 #define QS_MAX_SENSORS 16
 #define QS_MAX_OBS 64
@@ -85,7 +87,7 @@ typedef struct qs_config {
     int32_t auto_reset;          /* SB3 VecEnv convention: finished environments are reset inside qs_step */
     int32_t reset_pool;          /* 0: every reset runs the 2500-substep settle; P > 0: resets draw from P pre-settled states */
     int32_t env_id_offset;       /* global id of environment 0 (sharded runs): RNG streams are keyed by the global id */
-    int32_t reserved_i[1];
+    int32_t wrapper_mode;        /* 0 none, 1 LandingWrapper, 2 GoToRestWrapper as a per-environment mode machine */
     uint64_t seed;
     double dt;
     double filt_b[3], filt_a[3]; /* scipy.signal.butter(2, 3 Hz) at 1/env_dt, action_filter.py:191-213 */
@@ -108,6 +110,11 @@ typedef struct qs_config {
     float solver_residual_threshold; /* PyBullet setPhysicsEngineParameter(solverResidualThreshold): a sweep whose largest
                                       * squared velocity change is <= this ends the solve; 0 = always `solver_iters` sweeps */
     float reserved_g[1];
+    /* scripted phases of env/wrappers/landing_wrapper.py:18-69 and go_to_rest_wrapper.py:22-95 */
+    float landing_action[12];  /* get_landing_action(), gym_env.py:375-379 */
+    float landing_kp, landing_kd; /* landing_wrapper.py:22-27 */
+    float rest_kp, rest_kd, rest_time; /* go_to_rest_wrapper.py:16-19, 26-32 */
+    float reserved_h[3];
 } qs_config;
 
 typedef struct qs_handle qs_handle;
@@ -125,6 +132,8 @@ int qs_set_state(qs_handle* h, const float* state /*[N,37]*/);
 enum {
     QS_INFO_FOOT_FORCE = 0, QS_INFO_FOOT_CONTACT = 1, QS_INFO_TORQUE = 2, QS_INFO_SPRING_TORQUE = 3, QS_INFO_TASK = 4,
     QS_INFO_N_INVALID = 5, QS_INFO_PARAMS = 6, QS_INFO_COUNTERS = 7, QS_INFO_LAST_ACTION = 8, QS_INFO_TERMINAL_OBS = 9,
+    QS_INFO_WRAPPER = 10,  /* [N,4]: phase after the step (0 policy, 1 take-off hold, 2 landing, 3 rest), scripted (the step just
+                            * made ignored the caller's action), timer, end time */
 };
 int qs_info_dim(const qs_handle* h, int which);
 int qs_get_info(qs_handle* h, int which, float* out /*[N, qs_info_dim]*/);

@@ -72,7 +72,7 @@ class Oracle:
         s = np.ascontiguousarray(s, self.real).reshape(self.n, 37)
         self._check(self.lib.qso_set_state(self.h, self._p(s)))
 
-    _INFO_DIM = {0: 4, 1: 4, 2: 12, 3: 12, 4: 48, 5: 1, 6: 24, 7: 4, 8: 12}
+    _INFO_DIM = {0: 4, 1: 4, 2: 12, 3: 12, 4: 48, 5: 1, 6: 24, 7: 4, 8: 12, 10: 4}
 
     def get_info(self, which):
         dim = self.o if which == 9 else self._INFO_DIM[which]

@@ -582,6 +582,8 @@ static void reset_env(qso_handle* h, int i) {
         uint32_t rr[4]; qso_philox(cfg->seed, (uint32_t)(i + cfg->env_id_offset), 3, (uint32_t)e->episode, 0, rr);
         for (int L = 0; L < 4; L++) { e->cpg[L] = (real)0.1 * qso_u01(rr[L]); e->cpg[4 + L] = cfg->cpg_phi[L]; }
     }
+    memset(&e->wrap, 0, sizeof(e->wrap));
+    e->wrap.h_old = e->wrap.h_act = e->s.pos[2];   /* go_to_rest_wrapper.py:86-90 */
     task_reset(cfg, e);
     read_sensors(cfg, e, e->obs);
     add_noise(cfg, e, i, e->obs);
@@ -626,8 +628,32 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
     for (int i = 0; i < cfg->n_envs; i++) {
         qso_env* e = &h->env[i];
         /* gym_env.py:227-256 */
-        real act[12];
-        for (int k = 0; k < d; k++) { act[k] = actions[(size_t)i * d + k]; e->last_action[k] = act[k]; }
+        real act[12], act_in[12];
+        for (int k = 0; k < d; k++) act_in[k] = act[k] = actions[(size_t)i * d + k];
+        /* scripted phases of the wrappers, one inner env.step per call (landing_wrapper.py:40-69, go_to_rest_wrapper.py:43-80) */
+        real kp_save[3], kd_save[3]; int swapped = 0;
+        const real env_dt = (real)cfg->action_repeat * (real)cfg->dt;
+        if (cfg->wrapper_mode == QSO_WRAP_LANDING) {
+            if (e->wrap.phase == QSO_PHASE_TAKEOFF) { /* take_off_phase: repeat the last action until the timer is up */
+                if (e->wrap.timer > e->wrap.end) e->wrap.phase = QSO_PHASE_LANDING;
+                else { e->wrap.timer += env_dt; for (int k = 0; k < d; k++) act[k] = e->wrap.action[k]; }
+            }
+            if (e->wrap.phase == QSO_PHASE_LANDING) { /* landing_phase with kp = 60, kd = 1.5 */
+                for (int k = 0; k < d; k++) act[k] = cfg->landing_action[k];
+                for (int k = 0; k < 3; k++) { kp_save[k] = e->kp[k]; kd_save[k] = e->kd[k]; e->kp[k] = cfg->landing_kp; e->kd[k] = cfg->landing_kd; }
+                swapped = 1;
+            }
+        } else if (cfg->wrapper_mode == QSO_WRAP_GO_TO_REST && e->wrap.phase == QSO_PHASE_REST) { /* go_to_rest: ramp to the init action */
+            real t = sim_time(cfg, e), t0 = e->wrap.t_start, t1 = t0 + (real)cfg->rest_time;
+            for (int k = 0; k < d; k++) { /* interface_base.py:111-119 generate_ramp */
+                real u0 = e->wrap.action[k], u1 = cfg->settle_action[k];
+                act[k] = t < t0 ? u0 : (t > t1 ? u1 : u0 + (u1 - u0) * (t - t0) / (t1 - t0));
+            }
+            for (int k = 0; k < 3; k++) { kp_save[k] = e->kp[k]; kd_save[k] = e->kd[k]; e->kp[k] = cfg->rest_kp; e->kd[k] = cfg->rest_kd; }
+            swapped = 1;
+        }
+        e->wrap.scripted = e->wrap.phase != QSO_PHASE_POLICY;
+        for (int k = 0; k < d; k++) e->last_action[k] = act[k];
         if (cfg->enable_filter) { qso_filter_step(cfg->filt_b, cfg->filt_a, d, act, e->xhist, e->yhist, act); memcpy(e->last_filtered, act, d * sizeof(real)); }
         /* _interpolate_actions (:187-205) is an identity in the reference: _last_action/_last_filtered_action
            were overwritten with the current action at :230/:234 before the substeps run. */
@@ -646,6 +672,19 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         int term = task_terminated(cfg, e);
         int dn = term || e->sim_step > cfg->max_sim_steps;
         if (dn) r += task_reward_end(cfg, e);
+        if (swapped) for (int k = 0; k < 3; k++) { e->kp[k] = kp_save[k]; e->kd[k] = kd_save[k]; }
+        if (cfg->wrapper_mode == QSO_WRAP_GO_TO_REST) { e->wrap.h_old = e->wrap.h_act; e->wrap.h_act = e->s.pos[2]; }
+        if (!dn && e->wrap.phase == QSO_PHASE_POLICY && e->task.switched) {
+            if (cfg->wrapper_mode == QSO_WRAP_LANDING) { /* landing_wrapper.py:54-66 */
+                e->wrap.phase = QSO_PHASE_TAKEOFF;
+                e->wrap.timer = sim_time(cfg, e); e->wrap.end = e->wrap.timer + e->s.vlin[2] / (real)9.81;
+                for (int k = 0; k < d; k++) e->wrap.action[k] = act_in[k];
+            } else if (cfg->wrapper_mode == QSO_WRAP_GO_TO_REST && /* go_to_rest_wrapper.py:88-95 */
+                       e->foot_contact[0] && e->foot_contact[1] && e->foot_contact[2] && e->foot_contact[3] && e->wrap.h_act - e->wrap.h_old > 0) {
+                e->wrap.phase = QSO_PHASE_REST; e->wrap.t_start = sim_time(cfg, e);
+                qso_command_to_action(cfg, e->s.q, e->wrap.action);   /* get_start_action, :55-57 */
+            }
+        }
         read_sensors(cfg, e, e->obs);
         add_noise(cfg, e, i, e->obs);
         rew[i] = (float)r; done[i] = (uint8_t)dn; trunc[i] = (uint8_t)(dn && !term);
@@ -692,6 +731,7 @@ int qso_get_info(qso_handle* h, int which, real* out) {
         case QSO_INFO_COUNTERS: out[4 * i] = e->sim_step; out[4 * i + 1] = e->env_step; out[4 * i + 2] = e->episode; out[4 * i + 3] = e->total_steps; break;
         case QSO_INFO_LAST_ACTION: for (int k = 0; k < 12; k++) out[12 * i + k] = e->last_action[k]; break;
         case QSO_INFO_TERMINAL_OBS: for (int k = 0; k < h->cfg.obs_dim; k++) out[(size_t)i * h->cfg.obs_dim + k] = e->term_obs[k]; break;
+        case QSO_INFO_WRAPPER: out[4 * i] = e->wrap.phase; out[4 * i + 1] = e->wrap.scripted; out[4 * i + 2] = e->wrap.timer; out[4 * i + 3] = e->wrap.end; break;
         case QSO_INFO_TASK: {
             real* o = out + 48 * i; memset(o, 0, 48 * sizeof(real));
             o[0] = t->switched; o[1] = t->all_air; o[2] = t->is_jumping; o[3] = t->t_takeoff;

@@ -444,12 +444,61 @@ template <class T> struct Env {
         load_state(rec, s); load_par(rec, P);
         const int d = cfg.action_dim;
         // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
-        V act[15];
+        // raw action: d == 12 -> every lane holds the 3 entries of its own leg in act[12..14];
+        //             d  < 12 -> the d values are replicated over the quad in act[0..d)
+        V act[15], act_in[15];
         for (int k = 0; k < 15; k++) act[k] = V(0.0f);
-        if (d == 12) {  // DEFAULT space / raw commands: every lane handles the 3 entries of its own leg
+        if (d == 12) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) act[12 + j] = T::ld_leg(act_row, j, 3);
+        } else {
+            for (int k = 0; k < d; k++) act[k] = T::ld(act_row, k);
+        }
+        for (int k = 0; k < 15; k++) act_in[k] = act[k];
+        // scripted phases of the landing / go-to-rest wrappers (one inner env.step per call)
+        V w_phase = V(0.0f), w_timer = V(0.0f), w_end = V(0.0f), w_tstart = V(0.0f);
+        if (cfg.wrapper_mode != QS_WRAP_NONE) {
+            const float* w = rec + R_WRAP;
+            w_phase = T::ld(w, W_PHASE); w_timer = T::ld(w, W_TIMER); w_end = T::ld(w, W_END); w_tstart = T::ld(w, W_TSTART);
+            const float env_dt = (float)((double)cfg.action_repeat * cfg.dt);
+            V now0 = V((float)((double)f2i(rec[R_SIM_STEP]) * cfg.dt));
+            M scripted_gain = qlt(V(1.0f), V(0.0f));
+            V gkp = V(0.0f), gkd = V(0.0f);
+            if (cfg.wrapper_mode == QS_WRAP_LANDING) {      // landing_wrapper.py:40-69
+                M in_to = qand(qgt(w_phase, V(0.5f)), qlt(w_phase, V(1.5f)));
+                M up = qand(in_to, qgt(w_timer, w_end));
+                w_phase = qsel(up, V(2.0f), w_phase);
+                M hold = qand(in_to, qnot(up));
+                w_timer = qsel(hold, w_timer + env_dt, w_timer);
+                M land = qgt(w_phase, V(1.5f));
+                for (int k = 0; k < 15; k++) {
+                    if ((d == 12) != (k >= 12)) continue;
+                    V held = d == 12 ? T::ld_leg(w, W_ACTION + (k - 12), 3) : T::ld(w, W_ACTION + k);
+                    V la = d == 12 ? T::ld_leg(cfg.landing_action, k - 12, 3) : V(cfg.landing_action[k < 12 ? k : 0]);
+                    act[k] = qsel(land, la, qsel(hold, held, act[k]));
+                }
+                scripted_gain = land; gkp = V(cfg.landing_kp); gkd = V(cfg.landing_kd);
+            } else {                                          // go_to_rest_wrapper.py:59-80, interface_base.py:111-119
+                M rest = qgt(w_phase, V(2.5f));
+                V t1 = w_tstart + cfg.rest_time;
+                V frac = clampv<V>((now0 - w_tstart) * qrcp(V(cfg.rest_time)), V(0.0f), V(1.0f));
+                for (int k = 0; k < 15; k++) {
+                    if ((d == 12) != (k >= 12)) continue;
+                    V u0 = d == 12 ? T::ld_leg(w, W_ACTION + (k - 12), 3) : T::ld(w, W_ACTION + k);
+                    V u1 = d == 12 ? T::ld_leg(cfg.settle_action, k - 12, 3) : V(cfg.settle_action[k < 12 ? k : 0]);
+                    V u = qsel(qlt(now0, w_tstart), u0, qsel(qgt(now0, t1), u1, u0 + (u1 - u0) * frac));
+                    act[k] = qsel(rest, u, act[k]);
+                }
+                scripted_gain = rest; gkp = V(cfg.rest_kp); gkd = V(cfg.rest_kd);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) { P.kp[j] = qsel(scripted_gain, gkp, P.kp[j]); P.kd[j] = qsel(scripted_gain, gkd, P.kd[j]); }
+            T::st(rec, R_WRAP + W_SCRIPTED, qflag(qgt(w_phase, V(0.5f))));
+        }
+        if (d == 12) {  // DEFAULT space / raw commands: every lane filters the 3 entries of its own leg
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                V a = T::ld_leg(act_row, j, 3);
+                V a = act[12 + j];
                 T::st_leg(rec, R_LAST_ACTION + j, 3, a);
                 if (cfg.enable_filter) {
                     V x1 = T::ld_leg(rec, R_XHIST + j, 3), x2 = T::ld_leg(rec, R_XHIST + 12 + j, 3), y1 = T::ld_leg(rec, R_YHIST + j, 3), y2 = T::ld_leg(rec, R_YHIST + 12 + j, 3);
@@ -459,9 +508,9 @@ template <class T> struct Env {
                 }
                 act[12 + j] = a;
             }
-        } else {        // SYMMETRIC (6) / SYMMETRIC_NO_HIP (4): the few values are replicated over the quad
+        } else {        // SYMMETRIC (6) / SYMMETRIC_NO_HIP (4) / CPG (5): the few values are replicated over the quad
             for (int k = 0; k < d; k++) {
-                V a = T::ld(act_row, k);
+                V a = act[k];
                 T::st(rec, R_LAST_ACTION + k, a);
                 if (cfg.enable_filter) {
                     V x1 = T::ld(rec, R_XHIST + k), x2 = T::ld(rec, R_XHIST + 12 + k), y1 = T::ld(rec, R_YHIST + k), y2 = T::ld(rec, R_YHIST + 12 + k);
@@ -507,6 +556,47 @@ template <class T> struct Env {
         V done = timeout ? V(1.0f) : term;
         reward = reward + qsel(qgt(done, V(0.5f)), task_reward_end(cfg, t, term, now), V(0.0f));  // :250-251
         StepOut r; r.reward = reward; r.done = done; r.trunc = qsel(qgt(term, V(0.5f)), V(0.0f), done);  // :246
+        if (cfg.wrapper_mode != QS_WRAP_NONE) {
+            float* w = rec + R_WRAP;
+            M running = qlt(done, V(0.5f));
+            M go = qand(qand(running, qlt(w_phase, V(0.5f))), qgt(t.switched, V(0.5f)));
+            if (cfg.wrapper_mode == QS_WRAP_LANDING) {          // landing_wrapper.py:54-66
+                w_phase = qsel(go, V(1.0f), w_phase);
+                w_timer = qsel(go, now, w_timer);
+                w_end = qsel(go, now + s.vlin.z * (1.0f / 9.81f), w_end);
+                for (int k = 0; k < 15; k++) {
+                    if ((d == 12) != (k >= 12)) continue;
+                    if (d == 12) T::st_leg(w, W_ACTION + (k - 12), 3, qsel(go, act_in[k], T::ld_leg(w, W_ACTION + (k - 12), 3)));
+                    else if (k < d) T::st(w, W_ACTION + k, qsel(go, act_in[k], T::ld(w, W_ACTION + k)));
+                }
+            } else {                                              // go_to_rest_wrapper.py:43-57, 88-95
+                V h_old = T::ld(w, W_HACT), h_act = s.pos.z;
+                T::st(w, W_HOLD, h_old); T::st(w, W_HACT, h_act);
+                go = qand(go, qand(qgt(T::quad_sum(o.foot_contact), V(3.5f)), qgt(h_act - h_old, V(0.0f))));
+                w_phase = qsel(go, V(3.0f), w_phase);
+                w_tstart = qsel(go, now, w_tstart);
+                V a_own[3];                                       // interface_base.py:92-100 on the current joint angles
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    V lo = T::ld_leg(cfg.cmd_lo, j, 3), hi = T::ld_leg(cfg.cmd_hi, j, 3);
+                    a_own[j] = clampv<V>((clampv<V>(s.q[j], lo, hi) - lo) * qrcp(hi - lo) * 2.0f - 1.0f, V(-1.0f), V(1.0f));
+                }
+                if (d == 12) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) T::st_leg(w, W_ACTION + j, 3, qsel(go, a_own[j], T::ld_leg(w, W_ACTION + j, 3)));
+                } else {                                          // action_interface.py:41-44, 67-74: FR and RR legs
+                    int kk = 0;
+                    for (int half = 0; half < 2; half++)
+                        for (int j = 0; j < 3; j++) {
+                            if (cfg.action_space_mode == QS_ACT_SYMMETRIC_NO_HIP && j == cfg.symm_idx) continue;
+                            V v = half == 0 ? T::template bcast<0>(a_own[j]) : T::template bcast<2>(a_own[j]);
+                            T::st(w, W_ACTION + kk, qsel(go, v, T::ld(w, W_ACTION + kk)));
+                            kk++;
+                        }
+                }
+            }
+            T::st(w, W_PHASE, w_phase); T::st(w, W_TIMER, w_timer); T::st(w, W_END, w_end); T::st(w, W_TSTART, w_tstart);
+        }
         store_state(rec, s, o); store_task(rec, t);
 #pragma unroll
         for (int j = 0; j < 3; j++) T::st_leg(rec, R_NEW_TAU + j, 3, o.tau_pd[j]);
@@ -582,6 +672,10 @@ template <class T> struct Env {
         if (cfg.action_space_mode == QS_ACT_CPG) {  // hopf_network.py:62-63: r ~ 0.1 U(0,1), theta = PHI[0,:]
             uint32_t rr[4]; philox4x32(cfg.seed, env_id, 3u, (uint32_t)episode, 0u, rr);
             for (int L = 0; L < 4; L++) { T::st(rec, R_CPG + L, V(0.1f * u01(rr[L]))); T::st(rec, R_CPG + 4 + L, V(cfg.cpg_phi[L])); }
+        }
+        if (cfg.wrapper_mode != QS_WRAP_NONE) {
+            for (int k = 0; k < 20; k++) T::st(rec, R_WRAP + k, V(0.0f));
+            T::st(rec, R_WRAP + W_HOLD, s.pos.z); T::st(rec, R_WRAP + W_HACT, s.pos.z);   // go_to_rest_wrapper.py:86-90
         }
         task_reset(cfg, t, s, o, V(0.0f));
         store_task(rec, t);

@@ -235,6 +235,8 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (cfg->n_envs <= 0) QS_FAIL(-1, "n_envs must be positive");
     if (cfg->obs_dim <= 0 || cfg->obs_dim > QS_MAX_OBS || cfg->n_sensors > QS_MAX_SENSORS) QS_FAIL(-1, "observation bundle too large");
     if (cfg->action_dim != 12 && cfg->action_dim != 6 && cfg->action_dim != 4 && cfg->action_dim != 5) QS_FAIL(-1, "action_dim must be 12, 6, 4 or 5 (CPG)");
+    if (cfg->wrapper_mode != QS_WRAP_NONE && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
+        QS_FAIL(-1, "the landing / go-to-rest phase machine needs an RL action space (not CPG, not raw commands)");
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
     int od = 0;
@@ -343,6 +345,18 @@ static int scatter(qs_handle* h, int off, int dim, const float* in, int zero_war
     return 0;
 }
 
+__global__ void k_wrapper_info(const float* __restrict__ recs, int n, float* __restrict__ out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* w = recs + (size_t)e * QS_REC + R_WRAP;
+    out[4 * e] = w[W_PHASE]; out[4 * e + 1] = w[W_SCRIPTED]; out[4 * e + 2] = w[W_TIMER]; out[4 * e + 3] = w[W_END];
+}
+static int gather_wrapper(qs_handle* h, float* out) {
+    hipLaunchKernelGGL(k_wrapper_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
 int qs_get_state(qs_handle* h, float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); return gather(h, R_POS, QS_STATE_DIM, st, 0); }
 int qs_set_state(qs_handle* h, const float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); return scatter(h, R_POS, QS_STATE_DIM, st, 1); }
 
@@ -354,6 +368,7 @@ int qs_info_dim(const qs_handle* h, int which) {
     case QS_INFO_N_INVALID: return 1;
     case QS_INFO_PARAMS: return QS_PARAM_DIM;
     case QS_INFO_TERMINAL_OBS: return h ? h->cfg.obs_dim : -1;
+    case QS_INFO_WRAPPER: return 4;
     default: return -1;
     }
 }
@@ -369,6 +384,7 @@ int qs_get_info(qs_handle* h, int which, float* out) {
     case QS_INFO_PARAMS: return gather(h, R_PARAMS, QS_PARAM_DIM, out, 0);
     case QS_INFO_COUNTERS: return gather(h, R_SIM_STEP, 4, out, 1);
     case QS_INFO_LAST_ACTION: return gather(h, R_LAST_ACTION, 12, out, 0);
+    case QS_INFO_WRAPPER: return gather_wrapper(h, out);
     case QS_INFO_TASK:
         hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out);
         QS_HIP(hipGetLastError());

@@ -25,7 +25,9 @@ enum {
     R_POSE_CACHE = 206,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
     R_FLAGS = 215,
     R_CPG = 216,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
-    QS_REC = 224,         // multiple of 4 (16-byte vector moves)
+    R_WRAP = 224,         // 18: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
+                          //     h_actual, held or ramp-start action [12]
+    QS_REC = 244,         // multiple of 4 (16-byte vector moves)
 };
 enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };
 enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO = 4, T_YAW_TO = 7, T_INIT_H = 8, T_MAX_FLIGHT = 9,
@@ -34,6 +36,8 @@ enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO
        // TaskContinuousJumping2 (task_base.py:283-400): the unbounded per-jump arrays are only ever reduced to these sums
        T_JUMP_COUNT = 20, T_GOOD_JUMPS = 21, T_SUM_FWD = 22, T_SUM_FLOGF = 23 /* sum f log2 f */, T_SUM_HEIGHT = 24, T_SUM_PERF = 25,
        T_MAX_PERF = 26, T_LAST_PERF = 27, T_MAX_JUMP_H = 28, T_FIRST_JUMP = 29, T_END_JUMP = 30, T_N = 32 };
+
+enum { W_PHASE = 0, W_TIMER = 1, W_END = 2, W_TSTART = 3, W_HOLD = 4, W_HACT = 5, W_ACTION = 6, W_SCRIPTED = 18 /* not stored: info only */ };
 
 #define QS_ENVS_PER_WAVE 16
 #define QS_WAVE 64

@@ -108,7 +108,7 @@ class QsConfig(C.Structure):
         ("obs_dim", C.c_int32), ("enable_springs", C.c_int32), ("enable_filter", C.c_int32),
         ("enable_interp", C.c_int32), ("action_repeat", C.c_int32), ("solver_iters", C.c_int32),
         ("settle_steps", C.c_int32), ("max_sim_steps", C.c_int32), ("randomizer_flags", C.c_int32),
-        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_pool", C.c_int32), ("env_id_offset", C.c_int32), ("reserved_i", C.c_int32 * 1),
+        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_pool", C.c_int32), ("env_id_offset", C.c_int32), ("wrapper_mode", C.c_int32),
         ("seed", C.c_uint64), ("dt", C.c_double), ("filt_b", C.c_double * 3), ("filt_a", C.c_double * 3), ("gravity", C.c_float),
         ("kp", C.c_float * 3), ("kd", C.c_float * 3), ("tau_max", C.c_float * 3),
         ("cmd_lo", C.c_float * 12), ("cmd_hi", C.c_float * 12),
@@ -120,6 +120,8 @@ class QsConfig(C.Structure):
         ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
         ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
         ("solver_residual_threshold", C.c_float), ("reserved_g", C.c_float * 1),
+        ("landing_action", C.c_float * 12), ("landing_kp", C.c_float), ("landing_kd", C.c_float),
+        ("rest_kp", C.c_float), ("rest_kd", C.c_float), ("rest_time", C.c_float), ("reserved_h", C.c_float * 3),
     ]
 
 
@@ -220,6 +222,7 @@ def build_config(
     env_id_offset=0,
     cpg_gait="BOUND",
     solver_residual_threshold=0.0,
+    wrapper=None,
     robot_config=None,
     **_ignored,
 ):
@@ -328,6 +331,13 @@ def build_config(
         landing_action = np.zeros(5)
     else:
         landing_action = to_actual_action_space(scale_command_to_action(np.asarray(landing_pose, float), lo, hi), action_space_mode, symm)
+    WRAPPERS = {None: 0, "NONE": 0, "LANDING": 1, "GO_TO_REST": 2}
+    cfg.wrapper_mode = _lookup(WRAPPERS, wrapper, "wrapper")
+    for i in range(12):
+        cfg.landing_action[i] = landing_action[i] if i < len(landing_action) else 0.0
+    cfg.landing_kp, cfg.landing_kd = 60.0, 1.5                                        # landing_wrapper.py:22-27
+    cfg.rest_kp, cfg.rest_kd = 60.0, (0.8 if enable_springs else 1.5)                 # go_to_rest_wrapper.py:26-32
+    cfg.rest_time = 1.0 if enable_springs else 0.3                                    # go_to_rest_wrapper.py:16-19
     meta = dict(robot_config=rc, layout=lay, lower=np.array(lo, float), upper=np.array(hi, float), symm_idx=symm,
                 init_pose=np.array(init_pose, float), landing_pose=np.array(landing_pose, float),
                 settle_action=np.array(settle_action, float), landing_action=np.array(landing_action, float),

@@ -13,7 +13,8 @@ from .config import OBSERVATION_EPS, build_config
 from .spaces import Box, SB3VecEnv
 
 INFO = dict(foot_force=0, foot_contact=1, torque=2, spring_torque=3, task=4, n_invalid=5, params=6, counters=7,
-            last_action=8, terminal_obs=9)
+            last_action=8, terminal_obs=9, wrapper=10)
+PHASE = ("policy", "take_off", "landing", "rest")
 PARAM = dict(mu=0, spring_k=1, spring_b=2, kp=3, kd=4, all=5)
 
 
@@ -148,6 +149,13 @@ class QuadrupedVecEnv(SB3VecEnv):
             for i in np.nonzero(done)[0]:
                 infos[i]["TimeLimit.truncated"] = bool(trunc[i])  # gym_env.py:246
                 infos[i]["terminal_observation"] = term[i].copy()
+        if self.cfg.wrapper_mode:
+            # the reference's LandingWrapper / GoToRestWrapper loop over env.step inside one wrapper.step; here every inner
+            # step is one launch and the ones whose action was scripted are flagged, so a learner can mask them out
+            w = self.get_info("wrapper").cpu().numpy()
+            for i in range(self.num_envs):
+                infos[i]["scripted"] = bool(w[i, 1])
+                infos[i]["phase"] = PHASE[int(w[i, 0])]
         return obs, rew, done, infos
 
     def step(self, actions):

@@ -151,3 +151,37 @@ def test_residual_threshold_is_a_small_perturbation():
         s30 = o30.step(a)[0]; st = o_thr.step(a)[0]
         worst = max(worst, np.abs(s30 - st).max())
     assert worst < 2e-2   # velocity-level differences of the order of the threshold, amplified over the 10 substeps
+
+
+@pytest.mark.parametrize("name", ["land_s1", "land_s0", "rest_s1", "rest_s0"])
+def test_wrapper_phase_machine(golden, name):
+    """Landing / go-to-rest machine of the kernel code vs the oracle's (itself pinned by the reference's wrappers in
+    test_oracle_wrappers.py), on the golden action scripts, dynamic state re-synchronised before every step."""
+    import ast
+    g = golden("wrappers.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    o, e, cfg = pair(**kw)
+    o.reset(); e.reset()
+    acts, outer = g[f"{name}_actions"], g[f"{name}_outer_of_inner"]
+    d = cfg.action_dim
+    seen = set()
+    for i in range(min(len(outer), 700)):
+        s = o.get_state()
+        o.set_state(s); e.set_state(s)
+        a = acts[outer[i]][None].astype(np.float32)
+        oo, ro, do, to = o.step(a)
+        eo, re, de, te = e.step(a)
+        wo, we = o.get_info(10)[0], e.get("R_WRAP", 19)[0]
+        assert (wo[0], wo[1]) == (we[0], we[18]), f"phase / scripted at step {i}: {wo} vs {we[[0, 18]]}"
+        seen.add(int(wo[0]))
+        np.testing.assert_allclose(we[[1, 2]], wo[[2, 3]], atol=2e-4, err_msg=f"timer step {i}")
+        np.testing.assert_allclose(e.get("R_LAST_ACTION", 12)[0][:d], o.get_info(8)[0][:d], atol=2e-5, err_msg=f"action step {i}")
+        so, se = o.get_state()[0], e.get_state()[0]
+        np.testing.assert_allclose(se[13:25], so[13:25], atol=TOL_Q, err_msg=f"q step {i}")
+        np.testing.assert_allclose(se[25:], so[25:], atol=TOL_QD, err_msg=f"qd step {i}")
+        assert do[0] == de[0] and to[0] == te[0], f"done/trunc step {i}"
+        np.testing.assert_allclose(re, ro, atol=2e-4, rtol=1e-3, err_msg=f"reward step {i}")
+        np.testing.assert_allclose(eo, oo, atol=TOL_QD, err_msg=f"obs step {i}")
+        if do[0]:
+            o.reset(); e.reset()
+    assert seen == ({0, 1, 2} if kw["wrapper"] == "LANDING" else {0, 3})

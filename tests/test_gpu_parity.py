@@ -158,6 +158,43 @@ def test_reference_traces(torch_cuda, golden, name):
             np.testing.assert_allclose(v.reset()[0], reset_obs[ep], atol=1e-3)
 
 
+@pytest.mark.parametrize("name", ["land_s1", "land_s0", "rest_s1", "rest_s0"])
+def test_reference_wrapper_traces(torch_cuda, golden, name):
+    """Inner env.step calls of the REFERENCE's LandingWrapper / GoToRestWrapper (tests/golden/wrappers.npz) vs the on-device
+    phase machine: scripted actions, swapped gains (through the state), scripted flag, rewards, dones.  Re-synchronised to
+    the recorded dynamic state before every step; the phase machine's own state runs free."""
+    g = golden("wrappers.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    _, v, cfg = make_pair(1, torch_cuda, oracle=False, keep_params=True, **kw)
+    acts, outer, state_ref = g[f"{name}_actions"], g[f"{name}_outer_of_inner"], g[f"{name}_state"]
+    reset_at, mus, d = list(g[f"{name}_reset_at"]), g[f"{name}_mu"], cfg.action_dim
+    ep = 0
+    v.set_params("mu", np.array([[mus[0]]], np.float32))
+    np.testing.assert_allclose(v.reset()[0], g[f"{name}_reset_obs"][0], atol=1e-3)
+    phases = set()
+    for i in range(len(outer)):
+        if i > 0 and i not in reset_at:
+            v.set_state(state_ref[i - 1][None].astype(np.float32))
+        ob, r, dn, infos = v.step(acts[outer[i]][None].astype(np.float32))
+        assert infos[0]["scripted"] == (i > 0 and outer[i] == outer[i - 1]), f"scripted flag at inner step {i}"
+        phases.add(infos[0]["phase"])
+        assert bool(dn[0]) == bool(g[f"{name}_done"][i]), f"done mismatch at inner step {i}"
+        assert bool(infos[0].get("TimeLimit.truncated", False)) == bool(g[f"{name}_trunc"][i])
+        np.testing.assert_allclose(v.get_info("last_action").cpu().numpy()[0, :d], g[f"{name}_inner_action"][i], atol=1e-4, err_msg=f"action {i}")
+        sv = v.get_state().cpu().numpy()[0]
+        np.testing.assert_allclose(sv[13:25], state_ref[i][13:25], atol=1e-4, err_msg=f"q step {i}")
+        np.testing.assert_allclose(sv[25:], state_ref[i][25:], atol=2e-2, err_msg=f"qd step {i}")
+        np.testing.assert_allclose(r[0], g[f"{name}_rew"][i], atol=5e-4, rtol=1e-3, err_msg=f"reward {i}")
+        if i not in reset_at:
+            np.testing.assert_allclose(ob[0], g[f"{name}_obs"][i], atol=2e-2, rtol=1e-3, err_msg=f"obs step {i}")
+        if dn[0]:
+            ep += 1
+            v.set_params("mu", np.array([[mus[ep]]], np.float32))
+            np.testing.assert_allclose(v.reset()[0], g[f"{name}_reset_obs"][ep], atol=1e-3)
+    assert ep == len(reset_at) - 1
+    assert phases == ({"policy", "take_off", "landing"} if kw["wrapper"] == "LANDING" else {"policy", "rest"})
+
+
 def test_full_size_properties(torch_cuda):
     """BASELINE.json size (N = 8192): size-independent properties instead of the (slow) oracle."""
     torch = torch_cuda

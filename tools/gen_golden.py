@@ -91,6 +91,19 @@ def install_shims():
     sys.modules["absl.logging"] = logging
     cv2 = types.ModuleType("cv2")
     sys.modules["cv2"] = cv2
+    sb3, sb3c, sb3e = (types.ModuleType(n) for n in ("stable_baselines3", "stable_baselines3.common", "stable_baselines3.common.env_util"))
+
+    def is_wrapped(env, cls):
+        while env is not None:
+            if isinstance(env, cls):
+                return True
+            env = env.__dict__.get("env")
+        return False
+
+    sb3e.is_wrapped = is_wrapped
+    sb3.common, sb3c.env_util = sb3c, sb3e
+    for m in (sb3, sb3c, sb3e):
+        sys.modules[m.__name__] = m
     import matplotlib
     matplotlib.use = lambda *a, **k: None
 
@@ -460,19 +473,21 @@ def gen_rewards():
 
 
 # --------------------------------------------------------------------------------------------- G15 differential traces
-def scripted_actions(rng, n, d, jump_at):
-    """crouch, explosive extension, then smooth random actions: produces flight phases and landings."""
+def scripted_actions(rng, n, d, jump_at, land=None, ext=(-0.8, 1.0)):
+    """crouch, explosive extension, then smooth random actions (or a noisy landing pose): produces flight phases and landings."""
     a = np.zeros((n, d))
     for t in range(n):
         ph = t % jump_at
         if ph < jump_at * 0.5:
             base = np.array([0.0, 0.9, -0.9])
         elif ph < jump_at * 0.62:
-            base = np.array([0.0, -0.8, 1.0])
+            base = np.array([0.0, ext[0], ext[1]])
         else:
             base = np.array([0.0, 0.1, 0.2])
         full = np.tile(base, d // 3) if d % 3 == 0 else np.tile(base[1:], d // 2)
         a[t] = full + 0.15 * rng.standard_normal(d)
+        if land is not None and ph >= jump_at * 0.62:
+            a[t] = np.asarray(land) + 0.05 * rng.standard_normal(d)
     return a
 
 
@@ -565,6 +580,102 @@ def gen_traces():
     print("traces.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- landing / go-to-rest wrappers
+def gen_wrappers():
+    """The reference's LandingWrapper / GoToRestWrapper around its own QuadrupedGymEnv (fake Bullet on oracle physics): every
+    inner env.step the wrappers issue is logged, so the on-device phase machine can be checked step by step."""
+    import importlib
+    import gym
+    from qs_amd.config import build_config
+    from oracle.qso import Oracle
+    from quadruped_spring.env.quadruped_gym_env import QuadrupedGymEnv
+    from quadruped_spring.env.wrappers.landing_wrapper import LandingWrapper
+    from quadruped_spring.env.wrappers.go_to_rest_wrapper import GoToRestWrapper
+
+    class InnerLog(gym.Wrapper):
+        def __init__(self, env):
+            super().__init__(env)
+            self.rows = []
+
+        def step(self, a):
+            kp = float(np.atleast_1d(self.env.robot._motor_model._kp)[0])
+            ob, r, dn, info = self.env.step(a)
+            self.rows.append((np.array(a, float), ob, r, dn, bool(info.get("TimeLimit.truncated", False)),
+                              self.env._pybullet_client.o.get_state()[0].copy(), kp))
+            return ob, r, dn, info
+
+    cases = [
+        dict(name="land_s1", wrapper="LANDING", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=130, jump_at=90),
+        dict(name="land_s0", wrapper="LANDING", task_env="JUMPING_FORWARD", observation_space_mode="ARS_BASIC", enable_springs=False,
+             enable_action_filter=True, action_space_mode="DEFAULT", motor_control_mode="PD", steps=110, jump_at=70),
+        dict(name="rest_s1", wrapper="GO_TO_REST", task_env="JUMPING_IN_PLACE_PPO", observation_space_mode="PPO_BASIC_X", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=260, jump_at=80, ext=(-0.5, 0.6)),
+        dict(name="rest_s0", wrapper="GO_TO_REST", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=False,
+             enable_action_filter=False, action_space_mode="SYMMETRIC_NO_HIP", motor_control_mode="PD", steps=260, jump_at=70),
+    ]
+    out = {}
+    for case in cases:
+        name = case["name"]
+        kw = {k: v for k, v in case.items() if k not in ("name", "steps", "jump_at", "wrapper", "ext")}
+        mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs" if kw["enable_springs"]
+                                      else "quadruped_spring.go1.configs_go1_without_springs")
+        saved = {}
+        for attr in dir(mod):
+            if attr.endswith("_NOISE"):
+                saved[attr] = getattr(mod, attr)
+                setattr(mod, attr, np.zeros_like(np.asarray(saved[attr], float)))
+
+        def factory(dt, iters, kw=kw):
+            cfg, _ = build_config(n_envs=1, time_step=dt, noise=False, env_randomizer_mode="NONE", **kw)
+            cfg.solver_iters = iters
+            cfg.randomizer_flags = 8
+            return Oracle(cfg)
+
+        FakeBulletClient.oracle_factory = factory
+        np.random.seed(1234)
+        rng = np.random.default_rng(11)
+        log = InnerLog(QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", **kw))
+        env = (LandingWrapper if case["wrapper"] == "LANDING" else GoToRestWrapper)(log)
+        acts = scripted_actions(rng, case["steps"], log.env.action_dim, case["jump_at"],
+                                land=log.env.get_landing_action() if case["wrapper"] == "GO_TO_REST" else None,
+                                ext=case.get("ext", (-0.8, 1.0)))
+        o = env.reset()
+        keys = list(o.keys())
+        flat = lambda ob: np.concatenate([np.atleast_1d(np.asarray(ob[k], float)).flatten() for k in keys])
+        reset_obs, reset_at, outer_of_inner, outer_obs, outer_rew, outer_done = [flat(o)], [0], [], [], [], []
+        mus = [log.env._pybullet_client.mu]
+        for t in range(case["steps"]):
+            n0 = len(log.rows)
+            ob, r, dn, info = env.step(acts[t])
+            outer_of_inner += [t] * (len(log.rows) - n0)
+            outer_obs.append(flat(ob)); outer_rew.append(r); outer_done.append(dn)
+            if dn:
+                o = env.reset()
+                reset_obs.append(flat(o)); reset_at.append(len(log.rows)); mus.append(log.env._pybullet_client.mu)
+        rows = log.rows
+        out[f"{name}_mu"] = np.array(mus)
+        out[f"{name}_actions"] = acts
+        out[f"{name}_outer_of_inner"] = np.array(outer_of_inner)
+        out[f"{name}_inner_action"] = np.array([r[0] for r in rows])
+        out[f"{name}_obs"] = np.array([flat(r[1]) for r in rows])
+        out[f"{name}_rew"] = np.array([r[2] for r in rows], float)
+        out[f"{name}_done"] = np.array([r[3] for r in rows])
+        out[f"{name}_trunc"] = np.array([r[4] for r in rows])
+        out[f"{name}_state"] = np.array([r[5] for r in rows])
+        out[f"{name}_kp"] = np.array([r[6] for r in rows])
+        out[f"{name}_outer_obs"], out[f"{name}_outer_rew"], out[f"{name}_outer_done"] = np.array(outer_obs), np.array(outer_rew, float), np.array(outer_done)
+        out[f"{name}_reset_obs"], out[f"{name}_reset_at"] = np.array(reset_obs), np.array(reset_at)
+        out[f"{name}_kwargs"] = np.array(repr(dict(kw, wrapper=case["wrapper"])))
+        scripted = np.array([i > 0 and outer_of_inner[i] == outer_of_inner[i - 1] for i in range(len(rows))])
+        print(f"wrapper {name}: outer={case['steps']} inner={len(rows)} scripted={int(scripted.sum())} episodes={len(reset_at)} "
+              f"dones={int(np.sum(out[name + '_done']))} kp_set={sorted(set(out[name + '_kp']))}")
+        for attr, v in saved.items():
+            setattr(mod, attr, v)
+    np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **out)
+    print("wrappers.npz:", len(out), "arrays")
+
+
 # --------------------------------------------------------------------------------------------- G13 Hopf CPG
 def gen_cpg():
     from quadruped_spring.hopf_network import HopfNetwork
@@ -593,6 +704,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg"]
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers"]
     for w in which:
-        {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg}[w]()
+        {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers}[w]()
