@@ -53,7 +53,8 @@ enum {                                                                          
 #define QS_RAND_MASSES 2   /* env_randomizer.py:19-83 */
 #define QS_RAND_SPRINGS 4  /* env_randomizer.py:86-122 */
 #define QS_RAND_KEEP 8     /* reset keeps the parameters last written by qs_set_params */
-enum { QS_WRAP_NONE = 0, QS_WRAP_LANDING = 1, QS_WRAP_GO_TO_REST = 2 };
+enum { QS_WRAP_NONE = 0, QS_WRAP_LANDING = 1, QS_WRAP_GO_TO_REST = 2, QS_WRAP_LANDING2 = 3, QS_WRAP_LANDING_BACKFLIP = 4,
+       QS_WRAP_LANDING_BACKFLIP2 = 5, QS_WRAP_LANDING_CONTINUOUS = 6 };
 enum { QS_PHASE_POLICY = 0, QS_PHASE_TAKEOFF = 1, QS_PHASE_LANDING = 2, QS_PHASE_REST = 3 };
 
 #define QS_MAX_SENSORS 16

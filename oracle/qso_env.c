@@ -584,6 +584,7 @@ static void reset_env(qso_handle* h, int i) {
     }
     memset(&e->wrap, 0, sizeof(e->wrap));
     e->wrap.h_old = e->wrap.h_act = e->s.pos[2];   /* go_to_rest_wrapper.py:86-90 */
+    e->wrap.armed = 1;                             /* _enable_landing, landing_wrapper_2.py:73-76 */
     task_reset(cfg, e);
     read_sensors(cfg, e, e->obs);
     add_noise(cfg, e, i, e->obs);
@@ -623,6 +624,19 @@ int qso_get_obs(qso_handle* h, float* obs) {
     return 0;
 }
 
+/* what distinguishes the reference's six landing wrappers (env/wrappers/landing_wrapper*.py) */
+typedef struct { int landing_family, trigger_jumping, pitch_takeoff, gains, exit_kind /* 0 done, 1 while flying, 2 while jumping */, one_shot; } wrap_traits;
+static wrap_traits wrap_traits_of(int mode) {
+    switch (mode) {
+    case QSO_WRAP_LANDING:            return (wrap_traits){1, 0, 0, 1, 0, 0};
+    case QSO_WRAP_LANDING2:           return (wrap_traits){1, 0, 0, 0, 1, 1};
+    case QSO_WRAP_LANDING_BACKFLIP:   return (wrap_traits){1, 0, 1, 0, 0, 0};
+    case QSO_WRAP_LANDING_BACKFLIP2:  return (wrap_traits){1, 0, 1, 0, 1, 1};
+    case QSO_WRAP_LANDING_CONTINUOUS: return (wrap_traits){1, 1, 0, 0, 2, 0};
+    default:                          return (wrap_traits){0, 0, 0, 0, 0, 0};
+    }
+}
+
 int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     const qso_config* cfg = &h->cfg; int d = cfg->action_dim;
     for (int i = 0; i < cfg->n_envs; i++) {
@@ -630,18 +644,24 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         /* gym_env.py:227-256 */
         real act[12], act_in[12];
         for (int k = 0; k < d; k++) act_in[k] = act[k] = actions[(size_t)i * d + k];
-        /* scripted phases of the wrappers, one inner env.step per call (landing_wrapper.py:40-69, go_to_rest_wrapper.py:43-80) */
+        /* scripted phases of the wrappers, one inner env.step per call (landing_wrapper*.py, go_to_rest_wrapper.py:43-80) */
         real kp_save[3], kd_save[3]; int swapped = 0;
         const real env_dt = (real)cfg->action_repeat * (real)cfg->dt;
-        if (cfg->wrapper_mode == QSO_WRAP_LANDING) {
-            if (e->wrap.phase == QSO_PHASE_TAKEOFF) { /* take_off_phase: repeat the last action until the timer is up */
-                if (e->wrap.timer > e->wrap.end) e->wrap.phase = QSO_PHASE_LANDING;
+        const wrap_traits wt = wrap_traits_of(cfg->wrapper_mode);
+        if (wt.landing_family) {
+            if (e->wrap.phase == QSO_PHASE_TAKEOFF) {
+                if (wt.pitch_takeoff) { /* landing_wrapper_backflip.py:22,55-62: fixed take-off action until the pitch trigger */
+                    static const real TAKE_OFF_ACTION[6] = {0, 1, -1, 0, 1, -1};
+                    for (int k = 0; k < d; k++) act[k] = TAKE_OFF_ACTION[k % 6];
+                } else if (e->wrap.timer > e->wrap.end) e->wrap.phase = QSO_PHASE_LANDING; /* landing_wrapper.py:47-54 + utils/timer.py */
                 else { e->wrap.timer += env_dt; for (int k = 0; k < d; k++) act[k] = e->wrap.action[k]; }
             }
-            if (e->wrap.phase == QSO_PHASE_LANDING) { /* landing_phase with kp = 60, kd = 1.5 */
+            if (e->wrap.phase == QSO_PHASE_LANDING) {
                 for (int k = 0; k < d; k++) act[k] = cfg->landing_action[k];
-                for (int k = 0; k < 3; k++) { kp_save[k] = e->kp[k]; kd_save[k] = e->kd[k]; e->kp[k] = cfg->landing_kp; e->kd[k] = cfg->landing_kd; }
-                swapped = 1;
+                if (wt.gains) { /* only landing_wrapper.py:39 keeps the decorator: kp = 60, kd = 1.5 */
+                    for (int k = 0; k < 3; k++) { kp_save[k] = e->kp[k]; kd_save[k] = e->kd[k]; e->kp[k] = cfg->landing_kp; e->kd[k] = cfg->landing_kd; }
+                    swapped = 1;
+                }
             }
         } else if (cfg->wrapper_mode == QSO_WRAP_GO_TO_REST && e->wrap.phase == QSO_PHASE_REST) { /* go_to_rest: ramp to the init action */
             real t = sim_time(cfg, e), t0 = e->wrap.t_start, t1 = t0 + (real)cfg->rest_time;
@@ -674,16 +694,30 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         if (dn) r += task_reward_end(cfg, e);
         if (swapped) for (int k = 0; k < 3; k++) { e->kp[k] = kp_save[k]; e->kd[k] = kd_save[k]; }
         if (cfg->wrapper_mode == QSO_WRAP_GO_TO_REST) { e->wrap.h_old = e->wrap.h_act; e->wrap.h_act = e->s.pos[2]; }
-        if (!dn && e->wrap.phase == QSO_PHASE_POLICY && e->task.switched) {
-            if (cfg->wrapper_mode == QSO_WRAP_LANDING) { /* landing_wrapper.py:54-66 */
-                e->wrap.phase = QSO_PHASE_TAKEOFF;
-                e->wrap.timer = sim_time(cfg, e); e->wrap.end = e->wrap.timer + e->s.vlin[2] / (real)9.81;
-                for (int k = 0; k < d; k++) e->wrap.action[k] = act_in[k];
-            } else if (cfg->wrapper_mode == QSO_WRAP_GO_TO_REST && /* go_to_rest_wrapper.py:88-95 */
-                       e->foot_contact[0] && e->foot_contact[1] && e->foot_contact[2] && e->foot_contact[3] && e->wrap.h_act - e->wrap.h_old > 0) {
-                e->wrap.phase = QSO_PHASE_REST; e->wrap.t_start = sim_time(cfg, e);
-                qso_command_to_action(cfg, e->s.q, e->wrap.action);   /* get_start_action, :55-57 */
+        if (!dn && wt.landing_family) {
+            const int flying = !(e->foot_contact[0] || e->foot_contact[1] || e->foot_contact[2] || e->foot_contact[3]); /* quadruped.py:260-262 */
+            const int trigger = wt.trigger_jumping ? e->task.is_jumping : e->task.switched;
+            if (e->wrap.phase == QSO_PHASE_POLICY) {
+                if (trigger && e->wrap.armed) { /* landing_wrapper.py:54-66 */
+                    e->wrap.phase = QSO_PHASE_TAKEOFF;
+                    e->wrap.timer = sim_time(cfg, e); e->wrap.end = e->wrap.timer + e->s.vlin[2] / (real)9.81;
+                    for (int k = 0; k < d; k++) e->wrap.action[k] = act_in[k];
+                }
+            } else if (e->wrap.phase == QSO_PHASE_TAKEOFF) {
+                if (wt.pitch_takeoff && qso_pitch_backflip(e->s.quat, e->task.switched) >= (real)(5.0 * PI / 8.0)) /* landing_wrapper_backflip.py:23-24 */
+                    e->wrap.phase = QSO_PHASE_LANDING;
+            } else if (e->wrap.phase == QSO_PHASE_LANDING) {
+                /* landing_wrapper_2.py:41-45 (while flying), landing_wrapper_continuous.py:41-45 (while the task says jumping) */
+                if ((wt.exit_kind == 1 && !flying) || (wt.exit_kind == 2 && !e->task.is_jumping)) {
+                    e->wrap.phase = QSO_PHASE_POLICY;
+                    if (wt.one_shot) e->wrap.armed = 0;   /* _enable_landing = False, landing_wrapper_2.py:68 */
+                }
             }
+        } else if (!dn && cfg->wrapper_mode == QSO_WRAP_GO_TO_REST && e->wrap.phase == QSO_PHASE_POLICY && e->task.switched &&
+                   /* go_to_rest_wrapper.py:88-95 */
+                   e->foot_contact[0] && e->foot_contact[1] && e->foot_contact[2] && e->foot_contact[3] && e->wrap.h_act - e->wrap.h_old > 0) {
+            e->wrap.phase = QSO_PHASE_REST; e->wrap.t_start = sim_time(cfg, e);
+            qso_command_to_action(cfg, e->s.q, e->wrap.action);   /* get_start_action, :55-57 */
         }
         read_sensors(cfg, e, e->obs);
         add_noise(cfg, e, i, e->obs);

@@ -58,7 +58,7 @@ typedef struct {
     uint32_t total_steps;
     qso_task task;
     real cpg[8];            /* Hopf oscillators: r[4], theta[4] */
-    struct { int phase, scripted; real timer, end, t_start, h_old, h_act, action[12]; } wrap; /* landing / go-to-rest machine */
+    struct { int phase, scripted, armed; real timer, end, t_start, h_old, h_act, action[12]; } wrap; /* landing / go-to-rest machine */
     float obs[QSO_MAX_OBS], term_obs[QSO_MAX_OBS];
 } qso_env;
 

@@ -435,6 +435,18 @@ template <class T> struct Env {
         return y1 + (y1 - y2) * a2 + (x - y1) * b0 + (x1 - y1) * b1 + (x2 - y1) * b2;
     }
 
+    // what distinguishes the reference's landing wrappers (env/wrappers/landing_wrapper*.py)
+    struct WrapTraits { bool landing_family, trigger_jumping, pitch_takeoff, gains; int exit_kind; bool one_shot; };
+    static QS_FN WrapTraits wrap_traits(int mode) {
+        switch (mode) {
+        case QS_WRAP_LANDING: return {true, false, false, true, 0, false};
+        case QS_WRAP_LANDING2: return {true, false, false, false, 1, true};
+        case QS_WRAP_LANDING_BACKFLIP: return {true, false, true, false, 0, false};
+        case QS_WRAP_LANDING_BACKFLIP2: return {true, false, true, false, 1, true};
+        case QS_WRAP_LANDING_CONTINUOUS: return {true, true, false, false, 2, false};
+        default: return {false, false, false, false, 0, false};
+        }
+    }
     struct StepOut { V reward, done, trunc; };
 
     // One env.step(action) (gym_env.py:227-256).  `rec` = this environment's record, `act` = its action row,
@@ -464,20 +476,25 @@ template <class T> struct Env {
             V now0 = V((float)((double)f2i(rec[R_SIM_STEP]) * cfg.dt));
             M scripted_gain = qlt(V(1.0f), V(0.0f));
             V gkp = V(0.0f), gkd = V(0.0f);
-            if (cfg.wrapper_mode == QS_WRAP_LANDING) {      // landing_wrapper.py:40-69
+            const WrapTraits wt = wrap_traits(cfg.wrapper_mode);
+            if (wt.landing_family) {                        // landing_wrapper*.py
                 M in_to = qand(qgt(w_phase, V(0.5f)), qlt(w_phase, V(1.5f)));
-                M up = qand(in_to, qgt(w_timer, w_end));
-                w_phase = qsel(up, V(2.0f), w_phase);
-                M hold = qand(in_to, qnot(up));
-                w_timer = qsel(hold, w_timer + env_dt, w_timer);
+                M hold = in_to;
+                if (!wt.pitch_takeoff) {                    // landing_wrapper.py:47-54 + utils/timer.py: hold the last action until the timer is up
+                    M up = qand(in_to, qgt(w_timer, w_end));
+                    w_phase = qsel(up, V(2.0f), w_phase);
+                    hold = qand(in_to, qnot(up));
+                    w_timer = qsel(hold, w_timer + env_dt, w_timer);
+                }
                 M land = qgt(w_phase, V(1.5f));
                 for (int k = 0; k < 15; k++) {
                     if ((d == 12) != (k >= 12)) continue;
                     V held = d == 12 ? T::ld_leg(w, W_ACTION + (k - 12), 3) : T::ld(w, W_ACTION + k);
+                    if (wt.pitch_takeoff) held = V(k % 3 == 0 ? 0.0f : (k % 3 == 1 ? 1.0f : -1.0f));   // landing_wrapper_backflip.py:22
                     V la = d == 12 ? T::ld_leg(cfg.landing_action, k - 12, 3) : V(cfg.landing_action[k < 12 ? k : 0]);
                     act[k] = qsel(land, la, qsel(hold, held, act[k]));
                 }
-                scripted_gain = land; gkp = V(cfg.landing_kp); gkd = V(cfg.landing_kd);
+                if (wt.gains) { scripted_gain = land; gkp = V(cfg.landing_kp); gkd = V(cfg.landing_kd); }   // only landing_wrapper.py:39
             } else {                                          // go_to_rest_wrapper.py:59-80, interface_base.py:111-119
                 M rest = qgt(w_phase, V(2.5f));
                 V t1 = w_tstart + cfg.rest_time;
@@ -560,8 +577,11 @@ template <class T> struct Env {
             float* w = rec + R_WRAP;
             M running = qlt(done, V(0.5f));
             M go = qand(qand(running, qlt(w_phase, V(0.5f))), qgt(t.switched, V(0.5f)));
-            if (cfg.wrapper_mode == QS_WRAP_LANDING) {          // landing_wrapper.py:54-66
-                w_phase = qsel(go, V(1.0f), w_phase);
+            const WrapTraits wt = wrap_traits(cfg.wrapper_mode);
+            if (wt.landing_family) {
+                V disarmed = T::ld(w, W_DISARMED);
+                M pol = qlt(w_phase, V(0.5f)), tko = qand(qgt(w_phase, V(0.5f)), qlt(w_phase, V(1.5f))), lnd = qgt(w_phase, V(1.5f));
+                go = qand(qand(running, pol), qand(qgt(wt.trigger_jumping ? t.is_jumping : t.switched, V(0.5f)), qlt(disarmed, V(0.5f))));   // landing_wrapper.py:54-66
                 w_timer = qsel(go, now, w_timer);
                 w_end = qsel(go, now + s.vlin.z * (1.0f / 9.81f), w_end);
                 for (int k = 0; k < 15; k++) {
@@ -569,6 +589,14 @@ template <class T> struct Env {
                     if (d == 12) T::st_leg(w, W_ACTION + (k - 12), 3, qsel(go, act_in[k], T::ld_leg(w, W_ACTION + (k - 12), 3)));
                     else if (k < d) T::st(w, W_ACTION + k, qsel(go, act_in[k], T::ld(w, W_ACTION + k)));
                 }
+                M to_land = qand(running, tko);
+                if (wt.pitch_takeoff) to_land = qand(to_land, qge(pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched), V(5.0f * 3.14159265358979f / 8.0f)));  // landing_wrapper_backflip.py:23-24
+                else to_land = qlt(V(1.0f), V(0.0f));
+                M leave = qlt(V(1.0f), V(0.0f));
+                if (wt.exit_kind == 1) leave = qand(qand(running, lnd), qgt(T::quad_sum(o.foot_contact), V(0.5f)));   // landing_wrapper_2.py:41-45
+                if (wt.exit_kind == 2) leave = qand(qand(running, lnd), qlt(t.is_jumping, V(0.5f)));               // landing_wrapper_continuous.py:41-45
+                w_phase = qsel(go, V(1.0f), qsel(to_land, V(2.0f), qsel(leave, V(0.0f), w_phase)));
+                if (wt.one_shot) T::st(w, W_DISARMED, qsel(leave, V(1.0f), disarmed));                                  // landing_wrapper_2.py:68
             } else {                                              // go_to_rest_wrapper.py:43-57, 88-95
                 V h_old = T::ld(w, W_HACT), h_act = s.pos.z;
                 T::st(w, W_HOLD, h_old); T::st(w, W_HACT, h_act);

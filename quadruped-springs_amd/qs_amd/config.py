@@ -331,7 +331,11 @@ def build_config(
         landing_action = np.zeros(5)
     else:
         landing_action = to_actual_action_space(scale_command_to_action(np.asarray(landing_pose, float), lo, hi), action_space_mode, symm)
-    WRAPPERS = {None: 0, "NONE": 0, "LANDING": 1, "GO_TO_REST": 2}
+    # env/wrappers/: LandingWrapper, GoToRestWrapper, LandingWrapper2, LandingWrapperBackflip, LandingWrapperBackflip2,
+    # LandingWrapperContinuous.  LandingWrapperContinuous2 can never trigger in the reference (landing_wrapper_continuous2.py:66
+    # tests the bound method `self.robot._is_flying`, which is always truthy), so it is the identity.
+    WRAPPERS = {None: 0, "NONE": 0, "LANDING": 1, "GO_TO_REST": 2, "LANDING2": 3, "LANDING_BACKFLIP": 4, "LANDING_BACKFLIP2": 5,
+                "LANDING_CONTINUOUS": 6, "LANDING_CONTINUOUS2": 0}
     cfg.wrapper_mode = _lookup(WRAPPERS, wrapper, "wrapper")
     for i in range(12):
         cfg.landing_action[i] = landing_action[i] if i < len(landing_action) else 0.0

@@ -153,7 +153,7 @@ def test_residual_threshold_is_a_small_perturbation():
     assert worst < 2e-2   # velocity-level differences of the order of the threshold, amplified over the 10 substeps
 
 
-@pytest.mark.parametrize("name", ["land_s1", "land_s0", "rest_s1", "rest_s0"])
+@pytest.mark.parametrize("name", ["land_s1", "land_s0", "rest_s1", "rest_s0", "land2_s1", "landbf_s1", "landbf2_s1", "landc_s1", "landc2_s1"])
 def test_wrapper_phase_machine(golden, name):
     """Landing / go-to-rest machine of the kernel code vs the oracle's (itself pinned by the reference's wrappers in
     test_oracle_wrappers.py), on the golden action scripts, dynamic state re-synchronised before every step."""
@@ -184,4 +184,5 @@ def test_wrapper_phase_machine(golden, name):
         np.testing.assert_allclose(eo, oo, atol=TOL_QD, err_msg=f"obs step {i}")
         if do[0]:
             o.reset(); e.reset()
-    assert seen == ({0, 1, 2} if kw["wrapper"] == "LANDING" else {0, 3})
+    expect = dict(rest_s1={0, 3}, rest_s0={0, 3}, landbf_s1={0, 1}, landc2_s1={0})   # as the oracle run against the reference's wrappers
+    assert seen == expect.get(name, {0, 1, 2})

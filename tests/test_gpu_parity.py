@@ -158,7 +158,7 @@ def test_reference_traces(torch_cuda, golden, name):
             np.testing.assert_allclose(v.reset()[0], reset_obs[ep], atol=1e-3)
 
 
-@pytest.mark.parametrize("name", ["land_s1", "land_s0", "rest_s1", "rest_s0"])
+@pytest.mark.parametrize("name", ["land_s1", "land_s0", "rest_s1", "rest_s0", "land2_s1", "landbf_s1", "landbf2_s1", "landc_s1", "landc2_s1"])
 def test_reference_wrapper_traces(torch_cuda, golden, name):
     """Inner env.step calls of the REFERENCE's LandingWrapper / GoToRestWrapper (tests/golden/wrappers.npz) vs the on-device
     phase machine: scripted actions, swapped gains (through the state), scripted flag, rewards, dones.  Re-synchronised to
@@ -176,8 +176,8 @@ def test_reference_wrapper_traces(torch_cuda, golden, name):
         if i > 0 and i not in reset_at:
             v.set_state(state_ref[i - 1][None].astype(np.float32))
         ob, r, dn, infos = v.step(acts[outer[i]][None].astype(np.float32))
-        assert infos[0]["scripted"] == (i > 0 and outer[i] == outer[i - 1]), f"scripted flag at inner step {i}"
-        phases.add(infos[0]["phase"])
+        assert infos[0].get("scripted", False) == (i > 0 and outer[i] == outer[i - 1]), f"scripted flag at inner step {i}"
+        phases.add(infos[0].get("phase", "policy"))
         assert bool(dn[0]) == bool(g[f"{name}_done"][i]), f"done mismatch at inner step {i}"
         assert bool(infos[0].get("TimeLimit.truncated", False)) == bool(g[f"{name}_trunc"][i])
         np.testing.assert_allclose(v.get_info("last_action").cpu().numpy()[0, :d], g[f"{name}_inner_action"][i], atol=1e-4, err_msg=f"action {i}")
@@ -192,7 +192,8 @@ def test_reference_wrapper_traces(torch_cuda, golden, name):
             v.set_params("mu", np.array([[mus[ep]]], np.float32))
             np.testing.assert_allclose(v.reset()[0], g[f"{name}_reset_obs"][ep], atol=1e-3)
     assert ep == len(reset_at) - 1
-    assert phases == ({"policy", "take_off", "landing"} if kw["wrapper"] == "LANDING" else {"policy", "rest"})
+    expect = dict(rest_s1={"policy", "rest"}, rest_s0={"policy", "rest"}, landbf_s1={"policy", "take_off"}, landc2_s1={"policy"})
+    assert phases == expect.get(name, {"policy", "take_off", "landing"})
 
 
 def test_full_size_properties(torch_cuda):

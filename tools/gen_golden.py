@@ -591,6 +591,14 @@ def gen_wrappers():
     from quadruped_spring.env.quadruped_gym_env import QuadrupedGymEnv
     from quadruped_spring.env.wrappers.landing_wrapper import LandingWrapper
     from quadruped_spring.env.wrappers.go_to_rest_wrapper import GoToRestWrapper
+    from quadruped_spring.env.wrappers.landing_wrapper_2 import LandingWrapper2
+    from quadruped_spring.env.wrappers.landing_wrapper_backflip import LandingWrapperBackflip
+    from quadruped_spring.env.wrappers.landing_wrapper_backflip2 import LandingWrapperBackflip2
+    from quadruped_spring.env.wrappers.landing_wrapper_continuous import LandingWrapperContinuous
+    from quadruped_spring.env.wrappers.landing_wrapper_continuous2 import LandingWrapperContinuous2
+    classes = dict(LANDING=LandingWrapper, GO_TO_REST=GoToRestWrapper, LANDING2=LandingWrapper2, LANDING_BACKFLIP=LandingWrapperBackflip,
+                   LANDING_BACKFLIP2=LandingWrapperBackflip2, LANDING_CONTINUOUS=LandingWrapperContinuous,
+                   LANDING_CONTINUOUS2=LandingWrapperContinuous2)
 
     class InnerLog(gym.Wrapper):
         def __init__(self, env):
@@ -610,14 +618,26 @@ def gen_wrappers():
         dict(name="land_s0", wrapper="LANDING", task_env="JUMPING_FORWARD", observation_space_mode="ARS_BASIC", enable_springs=False,
              enable_action_filter=True, action_space_mode="DEFAULT", motor_control_mode="PD", steps=110, jump_at=70),
         dict(name="rest_s1", wrapper="GO_TO_REST", task_env="JUMPING_IN_PLACE_PPO", observation_space_mode="PPO_BASIC_X", enable_springs=True,
-             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=260, jump_at=80, ext=(-0.5, 0.6)),
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=150, jump_at=80, ext=(-0.5, 0.6)),
         dict(name="rest_s0", wrapper="GO_TO_REST", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=False,
              enable_action_filter=False, action_space_mode="SYMMETRIC_NO_HIP", motor_control_mode="PD", steps=260, jump_at=70),
+        dict(name="land2_s1", wrapper="LANDING2", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80, ext=(-0.5, 0.6), land=True),
+        dict(name="landbf_s1", wrapper="LANDING_BACKFLIP", task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=170, jump_at=80),
+        dict(name="landbf2_s1", wrapper="LANDING_BACKFLIP2", task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", enable_springs=True,
+             enable_action_filter=False, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=170, jump_at=80),
+        dict(name="landc_s1", wrapper="LANDING_CONTINUOUS", task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+             enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=260, jump_at=60,
+             ext=(-0.5, 0.6), land=True),
+        dict(name="landc2_s1", wrapper="LANDING_CONTINUOUS2", task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD",
+             enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=130, jump_at=60,
+             ext=(-0.5, 0.6), land=True),
     ]
     out = {}
     for case in cases:
         name = case["name"]
-        kw = {k: v for k, v in case.items() if k not in ("name", "steps", "jump_at", "wrapper", "ext")}
+        kw = {k: v for k, v in case.items() if k not in ("name", "steps", "jump_at", "wrapper", "ext", "land")}
         mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs" if kw["enable_springs"]
                                       else "quadruped_spring.go1.configs_go1_without_springs")
         saved = {}
@@ -625,6 +645,7 @@ def gen_wrappers():
             if attr.endswith("_NOISE"):
                 saved[attr] = getattr(mod, attr)
                 setattr(mod, attr, np.zeros_like(np.asarray(saved[attr], float)))
+        saved_upper = mod.RL_UPPER_ANGLE_JOINT.copy()   # the BACKFLIP tasks mutate the module-level limits in place
 
         def factory(dt, iters, kw=kw):
             cfg, _ = build_config(n_envs=1, time_step=dt, noise=False, env_randomizer_mode="NONE", **kw)
@@ -636,9 +657,9 @@ def gen_wrappers():
         np.random.seed(1234)
         rng = np.random.default_rng(11)
         log = InnerLog(QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", **kw))
-        env = (LandingWrapper if case["wrapper"] == "LANDING" else GoToRestWrapper)(log)
+        env = classes[case["wrapper"]](log)
         acts = scripted_actions(rng, case["steps"], log.env.action_dim, case["jump_at"],
-                                land=log.env.get_landing_action() if case["wrapper"] == "GO_TO_REST" else None,
+                                land=log.env.get_landing_action() if case["wrapper"] == "GO_TO_REST" or case.get("land") else None,
                                 ext=case.get("ext", (-0.8, 1.0)))
         o = env.reset()
         keys = list(o.keys())
@@ -672,6 +693,7 @@ def gen_wrappers():
               f"dones={int(np.sum(out[name + '_done']))} kp_set={sorted(set(out[name + '_kp']))}")
         for attr, v in saved.items():
             setattr(mod, attr, v)
+        mod.RL_UPPER_ANGLE_JOINT[:] = saved_upper
     np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **out)
     print("wrappers.npz:", len(out), "arrays")
 
