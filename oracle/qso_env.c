@@ -555,7 +555,8 @@ static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
         e->r_pay[0] = (real)-0.1 + (real)0.2 * qso_u01(r[11]);
         e->r_pay[1] = 0;
         e->r_pay[2] = (real)-0.1 + (real)0.2 * qso_u01(r[13]);
-        e->m_trunk = QSO_M_TRUNK + legs0 - legs - e->m_pay;
+        /* :43-47,61-65: total_mass sums EVERY URDF link, so the imu (0.001) and floating-base (1e-5) masses end up in the trunk too */
+        e->m_trunk = QSO_M_TRUNK + (real)0.00101 + legs0 - legs - e->m_pay;
     }
     qso_model_build(&e->model, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
 }

@@ -651,7 +651,7 @@ template <class T> struct Env {
             float legs = 0, legs0 = 0;
             for (int j = 0; j < 3; j++) { float m0 = ml[j]; ml[j] = m0 * 0.9f + (m0 * 1.1f - m0 * 0.9f) * u01(r[8 + j]); legs += 4 * ml[j]; legs0 += 4 * m0; }
             mp = u01(r[7]); rp[0] = -0.1f + 0.2f * u01(r[11]); rp[2] = -0.1f + 0.2f * u01(r[13]);
-            mt = go1::TRUNK_M + legs0 - legs - mp;
+            mt = go1::TRUNK_M + 0.00101f + legs0 - legs - mp;   // env_randomizer.py:43-47,61-65: total_mass also counts the imu and floating-base links
         }
         T::st(p, P_MU, V(mu));
         for (int j = 0; j < 3; j++) {

@@ -40,7 +40,7 @@ def test_cpg_action_layer_emu_vs_oracle():
     np.testing.assert_allclose(e.get("R_PARAMS", 24)[0], o.get_info(6)[0], rtol=1e-6)   # masses, payload, springs, friction
     par = o.get_info(6)[0]
     assert 0.5 <= par[0] <= 1.0 and 0 <= par[20] <= 1.0 and abs(par[21]) <= 0.1 and par[22] == 0 and abs(par[23]) <= 0.1
-    assert abs(par[16] + 4 * par[17:20].sum() + par[20] + 4 * 0.06 + 0.00101 - 12.01301) < 1e-5   # total mass is kept (env_randomizer.py:61-65)
+    assert abs(par[16] + 4 * par[17:20].sum() + par[20] + 4 * 0.06 - 12.01301) < 1e-5   # env_randomizer.py:43-47,61-65
     rng = np.random.default_rng(0)
     for i in range(80):
         a = rng.uniform(-1, 1, size=(1, 5)).astype(np.float32)

@@ -162,3 +162,34 @@ def test_g9_rewards(golden, task):
     np.testing.assert_allclose(o.eval_reward(1), g[f"g9_{task}_rew_end"], atol=1e-9, rtol=1e-9)
     if task in ("CONTINUOUS_JUMPING_FORWARD_PPO", "CONTINUOUS_JUMPING_FORWARD3"):   # constant-zero step rewards (App. C-5)
         assert np.all(g[f"g9_{task}_rew_step"] == 0) and np.all(o.eval_reward(0) == 0)
+
+
+def test_g11_randomizer_distributions(golden):
+    """The reference's TEST_RANDOMIZER stack (ground + masses/payload + springs, env_randomizer.py:19-122,279-291) sampled 4000
+    times through its own Quadruped setters vs the oracle's counter-based draws: same laws (two-sample KS), same invariants."""
+    from scipy.stats import ks_2samp
+    g = golden("randomizers.npz")
+    ref = g["g11_params"]
+    n = 4000
+    cfg, _ = build_config(n_envs=n, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+                          env_randomizer_mode="TEST_RANDOMIZER", seed=21, settle_steps=0, noise=False)
+    o = Oracle(cfg)
+    o.reset()
+    par = o.get_info(6)
+    cols = {"mu": 0, "k_hip": 1, "k_thigh": 2, "k_calf": 3, "b_hip": 4, "b_thigh": 5, "b_calf": 6, "m_trunk": 16, "m_hip": 17,
+            "m_thigh": 18, "m_calf": 19, "m_pay": 20, "x_pay": 21, "z_pay": 23}
+    for name, c in cols.items():
+        lo, hi = ref[:, c].min(), ref[:, c].max()
+        span = hi - lo
+        if name != "m_trunk":   # uniform draws: the sample extremes sit at the bounds; the trunk mass is a derived sum (thin tails)
+            assert par[:, c].min() >= lo - 2e-3 * span and par[:, c].max() <= hi + 2e-3 * span, name
+        assert ks_2samp(par[:, c], ref[:, c]).pvalue > 1e-3, name
+    assert np.all(ref[:, 22] == 0) and np.all(par[:, 22] == 0)                      # MAX_POS_MASS_OFFSET y = 0
+    # the payload mass is taken out of the trunk: trunk + legs + feet + payload = the URDF total INCLUDING the imu and
+    # floating-base links, which therefore count twice (env_randomizer.py:43-47,61-65)
+    np.testing.assert_allclose(ref[:, 16] + 4 * ref[:, 17:20].sum(axis=1) + ref[:, 20] + 4 * 0.06, float(g["g11_total_mass"]), atol=1e-9)
+    np.testing.assert_allclose(par[:, 16] + 4 * par[:, 17:20].sum(axis=1) + par[:, 20] + 4 * 0.06, float(g["g11_total_mass"]), atol=1e-5)
+    assert float(g["g11_leg_spread"]) == 0.0                                        # "each leg in the same way" (:67-76)
+    # independence of the draws that the reference makes independently (leg links, payload, springs)
+    c = np.corrcoef(par[:, [0, 1, 2, 3, 4, 5, 6, 17, 18, 19, 20, 21, 23]].T)
+    assert np.abs(c - np.eye(len(c))).max() < 0.08

@@ -189,7 +189,28 @@ class FakeBulletClient:
     def getDynamicsInfo(self, body, link):
         return (_LINK_MASS[link], 1.0, (0.0, 0.0, 0.0))
 
-    def changeDynamics(self, body, link, lateralFriction=None, **k):
+    GEOM_BOX = 3
+    rand_log = None   # set by gen_randomizers: list collecting what the randomizers write through the client
+
+    def createCollisionShape(self, *a, **k):
+        return 7
+
+    def createMultiBody(self, baseMass=0, baseCollisionShapeIndex=-1, basePosition=None, baseOrientation=None, **k):
+        if FakeBulletClient.rand_log is not None:
+            FakeBulletClient.rand_log.append(("payload", float(baseMass), np.array(basePosition, float) - self._state()[:3]))
+        return 2
+
+    def createConstraint(self, *a, **k):
+        if FakeBulletClient.rand_log is not None:
+            FakeBulletClient.rand_log.append(("constraint", a[4], np.array(a[7], float)))
+        return 3
+
+    def setCollisionFilterPair(self, *a, **k):
+        pass
+
+    def changeDynamics(self, body, link, lateralFriction=None, mass=None, **k):
+        if mass is not None and FakeBulletClient.rand_log is not None:
+            FakeBulletClient.rand_log.append(("mass", int(link), float(mass)))
         if body == 0 and link == -1 and lateralFriction is not None:
             self.mu = float(lateralFriction)
             self.mu_log.append(self.mu)
@@ -580,6 +601,54 @@ def gen_traces():
     print("traces.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- G11 randomizers
+def gen_randomizers():
+    """What the reference's randomizer stack (env_randomizer.py) writes into Bullet and into the motor model, draw by draw:
+    ground friction, the three leg-link masses (same for every leg), payload mass + position, trunk mass, spring k and b."""
+    from qs_amd.config import build_config
+    from oracle.qso import Oracle
+    from quadruped_spring.env.quadruped_gym_env import QuadrupedGymEnv
+
+    def factory(dt, iters):
+        cfg, _ = build_config(n_envs=1, time_step=dt, noise=False, env_randomizer_mode="NONE", task_env="JUMPING_IN_PLACE",
+                              observation_space_mode="PPO_BASIC", enable_springs=True)
+        cfg.solver_iters = iters
+        cfg.randomizer_flags = 8
+        return Oracle(cfg)
+
+    FakeBulletClient.oracle_factory = factory
+    out = {}
+    np.random.seed(77)
+    env = QuadrupedGymEnv(env_randomizer_mode="TEST_RANDOMIZER", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                          enable_springs=True, action_space_mode="SYMMETRIC", motor_control_mode="PD")
+    client = env._pybullet_client
+    n = 4000
+    rows = np.zeros((n, 24))     # layout of QS_INFO_PARAMS: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
+    leg_spread = 0.0
+    for i in range(n):
+        FakeBulletClient.rand_log = log = []
+        client.mu_log.clear()
+        env._env_randomizers.randomize_env()
+        masses = {l: m for tag, l, m in [x for x in log if x[0] == "mass"]}
+        pay = [x for x in log if x[0] == "payload"][0]
+        con = [x for x in log if x[0] == "constraint"][0]
+        assert con[1] == client.JOINT_FIXED and np.allclose(con[2], -pay[2])
+        legs = np.array([[masses[b + j] for j in range(3)] for b in (2, 6, 10, 14)])
+        leg_spread = max(leg_spread, np.abs(legs - legs[0]).max())
+        k, b, _ = env.robot._motor_model._springs.get_spring_nominal_params()
+        rows[i, 0] = client.mu_log[-1]
+        rows[i, 1:4], rows[i, 4:7] = np.asarray(k, float)[:3], np.asarray(b, float)[:3]
+        rows[i, 16], rows[i, 17:20], rows[i, 20], rows[i, 21:24] = masses[0], legs[0], pay[1], pay[2]
+    FakeBulletClient.rand_log = None
+    out["g11_params"] = rows
+    out["g11_leg_spread"] = np.array(leg_spread)
+    out["g11_total_mass"] = np.array(sum(_LINK_MASS.values()))
+    print("g11: mu [%.3f, %.3f]  k_thigh [%.2f, %.2f]  m_pay [%.3f, %.3f]  m_trunk [%.3f, %.3f]  leg spread %.1e" % (
+        rows[:, 0].min(), rows[:, 0].max(), rows[:, 2].min(), rows[:, 2].max(), rows[:, 20].min(), rows[:, 20].max(),
+        rows[:, 16].min(), rows[:, 16].max(), leg_spread))
+    np.savez_compressed(os.path.join(OUT, "randomizers.npz"), **out)
+
+
 # --------------------------------------------------------------------------------------------- landing / go-to-rest wrappers
 def gen_wrappers():
     """The reference's LandingWrapper / GoToRestWrapper around its own QuadrupedGymEnv (fake Bullet on oracle physics): every
@@ -726,6 +795,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers"]
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers"]
     for w in which:
-        {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers}[w]()
+        {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers,
+         "randomizers": gen_randomizers}[w]()
