@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the batched Go1 + PEA step (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 1000 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one QuadrupedGymEnv.step() of every environment (10 physics substeps x 30 solver sweeps + task / reward /
@@ -62,11 +62,13 @@ def cpu_baseline(cfg_kwargs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="jump_in_place_8192")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--reset-pool", type=int, default=4096, help="pre-settled reset states per GPU (0 = settle inside the step)")
+    ap.add_argument("--no-pool-streaming", action="store_true",
+                    help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-residual-threshold", type=float, default=0.0,
                     help="PyBullet solverResidualThreshold (its default is 1e-7); 0 = always int(300/action_repeat) sweeps")
@@ -101,24 +103,43 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # Auto-reset draws pre-settled states from a pool; with streaming on, as many entries as were consumed are re-settled by
+    # extra workgroups of the step kernel (2500 substeps per state, new randomizer draws, action_repeat substeps per launch),
+    # so the settle work of the resets consumed in the timed region is done in the timed region, next to the stepping.
+    streaming = bool(args.reset_pool) and not args.no_pool_streaming
+    if streaming:
+        env.pool_streaming(True)
+    # Untimed preparation: put the environments at evenly spread episode phases, as in the steady state of a training run
+    # (they would otherwise all hit the 1000-step limit of gym_env.py:35 in the same step: one burst of N resets).
+    groups = 16
+    ids = torch.arange(n, device=dev)
+    for gidx in range(groups):
+        env.reset_tensor((ids % groups == gidx).to(torch.uint8))
+        for i in range(1000 // groups):
+            env.step_tensor(acts[i % n_act])
+        torch.cuda.current_stream().synchronize()
     for i in range(args.warmup):
         env.step_tensor(acts[i % n_act])
-    stats0 = env.stats()
-    env.enable_timing(True)
     kernel_ms = []
     barrier()
+    stats0 = env.stats()
+    refills0 = env.pool_streaming(True) if streaming else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         env.step_tensor(acts[i % n_act])
     barrier()
     elapsed = time.perf_counter() - t0
+    stats1 = env.stats()
+    refills1 = env.pool_streaming(True) if streaming else 0
+    env.enable_timing(True)
     # per-launch duration of the step kernel from HIP events on the kernel's own stream (separate short loop so that
     # the event synchronisation does not sit inside the timed region)
     for i in range(min(args.steps, 50)):
         env.step_tensor(acts[i % n_act])
         kernel_ms.append(env.last_step_kernel_ms())
     env.enable_timing(False)
-    stats1 = env.stats()
+    if streaming:
+        env.pool_streaming(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -142,8 +163,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
                        "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
-                       "auto_reset": True, "reset": (f"pre-settled pool of {args.reset_pool} states per GPU" if args.reset_pool else "2500-substep settle inside the step"),
-                       "resets_in_timed_region": int((stats1["resets"] - stats0["resets"]) * args.steps / (args.steps + min(args.steps, 50))),
+                       "auto_reset": True,
+                       "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
+                                  ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))
+                                 if args.reset_pool else "2500-substep settle inside the step"),
+                       "resets_in_timed_region": int(stats1["resets"] - stats0["resets"]),
+                       "pool_states_settled_in_timed_region": int(refills1 - refills0),
+                       "settle_substeps_in_timed_region": int(stats1["settle_substeps"] - stats0["settle_substeps"]),
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_step", "kernel_ms": kavg * 1e3,

@@ -148,6 +148,15 @@ int qs_enable_timing(qs_handle* h, int on);
 int qs_last_step_kernel_ms(qs_handle* h, float* ms);
 /* redraw the pool of pre-settled reset states (cfg.reset_pool > 0): new parameter draws, 2500 settle substeps each */
 int qs_refresh_pool(qs_handle* h);
+/* Demand-driven refill of the pool while the environments step ("settle lanes").  While on, every qs_step launch carries
+ * extra workgroups that advance records of a staging copy through a reset's settle (gym_env.py:278-297, 325-327: randomizer
+ * draws, spawn, 2500 substeps under the settling command), action_repeat substeps per launch through the same substep loop
+ * as the environments.  An epoch = the settle_steps/action_repeat launches one settle takes; between epochs the finished
+ * records replace pool entries at a rotating cursor, and the next epoch settles as many records as auto-resets have consumed
+ * since (at most reset_pool).  Every pooled reset is thus backed by settle work executed next to the stepping, and the
+ * schedule depends only on the sequence of qs_step calls (bitwise reproducible).  `refilled` (may be NULL; reading it
+ * synchronises the stream) receives the number of entries re-settled so far; qs_stats counts their substeps. */
+int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled);
 const char* qs_last_error(void);
 const char* qs_version(void);
 

@@ -451,10 +451,13 @@ template <class T> struct Env {
 
     // One env.step(action) (gym_env.py:227-256).  `rec` = this environment's record, `act` = its action row,
     // `obs` = QS_MAX_OBS floats of staging for its observation.
-    static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id) {
+    // `settle_n` > 0 turns the call into a slice of a reset's settle (gym_env.py:325-327) for a record of the streaming reset
+    // pool: that many substeps under the settling command and nothing else.  It goes through the SAME substep loop as a
+    // regular step, so a wave of settling records costs what a wave of environments costs and shares its instructions.
+    static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0) {
         typename S::State s; typename S::Par P; typename S::Out o;
         load_state(rec, s); load_par(rec, P);
-        const int d = cfg.action_dim;
+        const int d = settle_n > 0 ? 0 : cfg.action_dim;
         // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
         // raw action: d == 12 -> every lane holds the 3 entries of its own leg in act[12..14];
         //             d  < 12 -> the d values are replicated over the quad in act[0..d)
@@ -469,7 +472,7 @@ template <class T> struct Env {
         for (int k = 0; k < 15; k++) act_in[k] = act[k];
         // scripted phases of the landing / go-to-rest wrappers (one inner env.step per call)
         V w_phase = V(0.0f), w_timer = V(0.0f), w_end = V(0.0f), w_tstart = V(0.0f);
-        if (cfg.wrapper_mode != QS_WRAP_NONE) {
+        if (cfg.wrapper_mode != QS_WRAP_NONE && settle_n == 0) {
             const float* w = rec + R_WRAP;
             w_phase = T::ld(w, W_PHASE); w_timer = T::ld(w, W_TIMER); w_end = T::ld(w, W_END); w_tstart = T::ld(w, W_TSTART);
             const float env_dt = (float)((double)cfg.action_repeat * cfg.dt);
@@ -541,9 +544,12 @@ template <class T> struct Env {
         // _interpolate_actions (gym_env.py:187-205) is the identity in the reference (both "last" actions are overwritten
         // with the current one at :230/:234 before the substeps run), so there is nothing to do for enable_interp.
         V cmd[3];
-        const bool cpg = cfg.action_space_mode == QS_ACT_CPG;
+        const bool cpg = cfg.action_space_mode == QS_ACT_CPG && settle_n == 0;
         V cpg_p[5], cpg_r = V(0.0f), cpg_th = V(0.0f);
-        if (cpg) {
+        if (settle_n > 0) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
+        } else if (cpg) {
 #pragma unroll
             for (int k = 0; k < 5; k++) cpg_p[k] = clampv<V>(act[k], V(-1.0f), V(1.0f)) * (0.5f * (cfg.cpg_hi[k] - cfg.cpg_lo[k])) + 0.5f * (cfg.cpg_hi[k] + cfg.cpg_lo[k]);
             cpg_r = T::ld_leg(rec, R_CPG, 1); cpg_th = T::ld_leg(rec, R_CPG + 4, 1);
@@ -554,12 +560,14 @@ template <class T> struct Env {
         V old_tau[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) old_tau[j] = T::ld_leg(rec, R_NEW_TAU + j, 3);
-        for (int k = 0; k < cfg.action_repeat; k++) {  // gym_env.py:236-237, 207-216
+        const int n_sub = settle_n > 0 ? settle_n : cfg.action_repeat;
+        for (int k = 0; k < n_sub; k++) {  // gym_env.py:236-237, 207-216
             V tau[3];
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             S::actuate(cfg, P, s, cmd, o, tau);
             S::substep(cfg, P, s, tau, o);
         }
+        if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); return z; }
         if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;
         Task t;
@@ -663,6 +671,21 @@ template <class T> struct Env {
 
     // env.reset() (gym_env.py:278-297): randomize, spawn (quadruped.py:487-519), settle 2500 substeps toward the init pose
     // with the sim counter frozen (interface_base.py:182-200), task / sensor / filter reset.
+    // First half of reset(): randomizer draws + the spawn state (quadruped.py:454-519), written into the record.  Used by the
+    // streaming reset pool, whose settle then proceeds in slices through step(..., settle_n).
+    static QS_FN void settle_spawn(const qs_config& cfg, float* rec, uint32_t env_id, int episode) {
+        randomize(cfg, rec, env_id, episode, false);
+        T::sync();
+        typename S::State s; typename S::Out o;
+        const V zero = V(0.0f);
+        s.pos = mk3<V>(zero, zero, V(0.32f)); s.qx = zero; s.qy = zero; s.qz = zero; s.qw = V(1.0f);
+        s.vlin = mk3<V>(zero, zero, zero); s.vang = mk3<V>(zero, zero, zero);
+        s.q[0] = zero; s.q[1] = V(0.25f * PI); s.q[2] = V(-0.5f * PI);
+        s.qd[0] = zero; s.qd[1] = zero; s.qd[2] = zero; s.warm = zero;
+        o.foot_force = zero; o.foot_contact = zero; o.n_invalid = zero;
+        for (int j = 0; j < 3; j++) { o.tau_pd[j] = zero; o.tau_spring[j] = zero; }
+        store_state(rec, s, o);
+    }
     static QS_FN void reset(const qs_config& cfg, float* rec, float* obs, uint32_t env_id, bool settle) {
         int episode = f2i(rec[R_EPISODE]) + 1;
         int total = f2i(rec[R_TOTAL_STEPS]);

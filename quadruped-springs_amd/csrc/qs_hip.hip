@@ -33,6 +33,10 @@ __device__ __forceinline__ void tile_store(const float* lds, float* __restrict__
 }
 
 struct PoolView { const float* pool; int size; };
+// Streaming refill of the reset pool ("settle lanes"): workgroups beyond the environments' ones advance records of the
+// staging copy through a reset's settle, one slice of substeps per launch; ctl = the counters in qs_handle::d_stats.
+struct SettleLanes { float* staging; int n_env_waves, spawn, settle_n, generation; };
+enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_R = 4, CTL_REFILLED = 5, CTL_CURSOR = 6, CTL_N = 8 };
 
 // settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
 __device__ __forceinline__ void copy_settled(float* rec, const float* src) {
@@ -63,26 +67,38 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
                                                      float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                      uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                      float* __restrict__ term_obs, PoolView pool,
-                                                     unsigned long long* __restrict__ stats) {
+                                                     unsigned long long* __restrict__ stats, SettleLanes lanes) {
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
     const qs_config& cfg = *cfgp;
-    const int first = blockIdx.x * QS_ENVS_PER_WAVE;
+    const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles pool records
+    const int first = (settling ? (int)blockIdx.x - lanes.n_env_waves : (int)blockIdx.x) * QS_ENVS_PER_WAVE;
+    const int limit = settling ? (int)stats[CTL_R] : cfg.n_envs;         // CTL_R is only written between launches (k_pool_plan)
+    if (first >= limit) return;
+    float* const base = settling ? lanes.staging : recs;
     const int slot = threadIdx.x >> 2;
     const int env = first + slot;
-    const bool valid = env < cfg.n_envs;
+    const bool valid = env < limit;
     const int d = cfg.action_dim, od = cfg.obs_dim;
-    tile_load(s_rec, recs, first, cfg.n_envs);
-    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * d; i += QS_WAVE) {
-        int e = first + i / d;
-        s_act[(i / d) * 12 + (i % d)] = e < cfg.n_envs ? actions[(size_t)first * d + i] : 0.0f;
-    }
+    tile_load(s_rec, base, first, limit);
+    if (!settling)
+        for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * d; i += QS_WAVE) {
+            int e = first + i / d;
+            s_act[(i / d) * 12 + (i % d)] = e < cfg.n_envs ? actions[(size_t)first * d + i] : 0.0f;
+        }
     __syncthreads();
     float* rec = s_rec + slot * QS_REC;
     float* ob = s_obs + slot * QS_MAX_OBS;
-    const uint32_t gid = (uint32_t)(env + cfg.env_id_offset);
-    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid);
+    const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
+    if (settling && lanes.spawn) { E::settle_spawn(cfg, rec, gid, lanes.generation); LaneDev::sync(); }
+    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settling ? lanes.settle_n : 0);
+    if (settling) {
+        if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)lanes.settle_n);
+        __syncthreads();
+        tile_store(s_rec, base, first, limit);
+        return;
+    }
     const bool dn = r.done > 0.5f;
     if (valid && (threadIdx.x & 3) == 0) {
         rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0;
@@ -100,6 +116,7 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
                     uint32_t rr[4];
                     qs::philox4x32(cfg.seed, gid, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
                     copy_settled(rec, pool.pool + (size_t)(rr[0] % (uint32_t)pool.size) * QS_REC);
+                    if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_CONSUMED], 1ull);   // pool entries consumed: what the streaming refill owes
                 }
                 LaneDev::sync();
                 if (do_reset) E::reset(cfg, rec, ob, gid, false);
@@ -120,6 +137,32 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
         obs_out[(size_t)first * od + i] = v;
         obs_keep[(size_t)first * od + i] = v;
     }
+}
+
+// Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
+// settling into the pool (they replace the entries at the rotating cursor) ...
+__global__ void k_pool_publish(const unsigned long long* __restrict__ ctl, const float* __restrict__ staging, float* __restrict__ pool, int pool_size) {
+    const size_t total = (size_t)ctl[CTL_R] * QS_REC;
+    const size_t cursor = (size_t)ctl[CTL_CURSOR];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t e = i / QS_REC, f = i % QS_REC;
+        pool[((cursor + e) % (size_t)pool_size) * QS_REC + f] = staging[i];
+    }
+}
+// ... then decide how many records the next epoch settles: as many as auto-resets have consumed and no refill has matched yet.
+__global__ void k_pool_plan(unsigned long long* __restrict__ ctl, int pool_size, int abort_epoch) {
+    if (blockIdx.x || threadIdx.x) return;
+    const unsigned long long P = (unsigned long long)pool_size;
+    if (abort_epoch) { ctl[CTL_BACKED] -= ctl[CTL_R]; ctl[CTL_R] = 0; return; }   // streaming switched off mid-epoch: nothing was delivered
+    ctl[CTL_CURSOR] = (ctl[CTL_CURSOR] + ctl[CTL_R]) % P;
+    ctl[CTL_REFILLED] += ctl[CTL_R];
+    unsigned long long consumed = ctl[CTL_CONSUMED], backed = ctl[CTL_BACKED];
+    unsigned long long want = consumed > backed ? consumed - backed : 0;
+    if (want > P) { backed = consumed - P; want = P; }       // demand beyond a fully fresh pool is not owed later
+    want -= want % QS_ENVS_PER_WAVE;
+    if (want < 64) want = 0;                                  // not worth a wave yet
+    ctl[CTL_BACKED] = backed + want;
+    ctl[CTL_R] = want;
 }
 
 // QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297); all settles run side by side.
@@ -152,11 +195,11 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restric
 }
 
 // Pre-settled reset states: entry p = reset of a virtual environment id 0x40000000 + p (its own parameter draw).
-__global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(const qs_config* __restrict__ cfgp, float* __restrict__ pool, int size, int generation) {
+__global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(const qs_config* __restrict__ cfgp, float* __restrict__ pool, int first, int size, int generation) {
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     const qs_config& cfg = *cfgp;
-    const int slot = threadIdx.x >> 2, p = blockIdx.x * QS_ENVS_PER_WAVE + slot;
+    const int slot = threadIdx.x >> 2, p = first + blockIdx.x * QS_ENVS_PER_WAVE + slot;   // entries [first, size) of the pool
     float* rec = s_rec + slot * QS_REC;
     for (int i = threadIdx.x & 3; i < QS_REC; i += 4) rec[i] = 0.0f;
     LaneDev::sync();
@@ -208,8 +251,10 @@ struct qs_handle {
     float* d_rec;
     float* d_obs;       // last observation of every environment [N, obs_dim]
     float* d_term_obs;  // [N, obs_dim]
-    float* d_pool;
+    float* d_pool;      // pre-settled reset states the step kernel draws from
+    float* d_pool_back; // streaming refill: staging records that are being settled by the extra workgroups of k_step
     int pool_size, pool_generation;
+    int streaming, phase;   // phase = launch index inside the current epoch
     unsigned long long* d_stats;
     hipEvent_t ev0, ev1;
     int timing;
@@ -257,11 +302,11 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     QS_HIP(hipMalloc(&h->d_rec, n * QS_REC * sizeof(float)));
     QS_HIP(hipMalloc(&h->d_obs, n * cfg->obs_dim * sizeof(float)));
     QS_HIP(hipMalloc(&h->d_term_obs, n * cfg->obs_dim * sizeof(float)));
-    QS_HIP(hipMalloc(&h->d_stats, 2 * sizeof(unsigned long long)));
+    QS_HIP(hipMalloc(&h->d_stats, CTL_N * sizeof(unsigned long long)));
     QS_HIP(hipMemcpy(h->d_cfg, &h->cfg, sizeof(qs_config), hipMemcpyHostToDevice));
     QS_HIP(hipMemset(h->d_obs, 0, n * cfg->obs_dim * sizeof(float)));
     QS_HIP(hipMemset(h->d_term_obs, 0, n * cfg->obs_dim * sizeof(float)));
-    QS_HIP(hipMemset(h->d_stats, 0, 2 * sizeof(unsigned long long)));
+    QS_HIP(hipMemset(h->d_stats, 0, CTL_N * sizeof(unsigned long long)));
     QS_HIP(hipEventCreate(&h->ev0));
     QS_HIP(hipEventCreate(&h->ev1));
     hipLaunchKernelGGL(k_init, dim3(n_waves(cfg->n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec);
@@ -270,7 +315,7 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (cfg->reset_pool > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
         h->pool_size = cfg->reset_pool;
         QS_HIP(hipMalloc(&h->d_pool, (size_t)h->pool_size * QS_REC * sizeof(float)));
-        hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, h->pool_size, 0);
+        hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, 0);
         QS_HIP(hipGetLastError());
     }
     QS_HIP(hipStreamSynchronize(h->stream));
@@ -284,6 +329,7 @@ void qs_destroy(qs_handle* h) {
     hipStreamSynchronize(h->stream);
     hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
     if (h->d_pool) hipFree(h->d_pool);
+    if (h->d_pool_back) hipFree(h->d_pool_back);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     delete h;
 }
@@ -304,12 +350,49 @@ int qs_get_obs(qs_handle* h, float* obs) {
     return 0;
 }
 
+int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
+    if (!h) QS_FAIL(-1, "null handle");
+    if (on && h->pool_size <= 0) QS_FAIL(-1, "streaming refill needs a reset pool (cfg.reset_pool > 0)");
+    if (on && !h->d_pool_back) QS_HIP(hipMalloc(&h->d_pool_back, (size_t)h->pool_size * QS_REC * sizeof(float)));
+    if (on && !h->streaming) {          // resets that happened while streaming was off are not owed
+        QS_HIP(hipMemcpyAsync(&h->d_stats[CTL_BACKED], &h->d_stats[CTL_CONSUMED], sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+        h->phase = 0;
+    }
+    if (!on && h->streaming && h->phase != 0) {   // the epoch in progress is dropped
+        hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, 1);
+        QS_HIP(hipGetLastError());
+    }
+    h->streaming = on ? 1 : 0;
+    if (refilled) {
+        unsigned long long v = 0;
+        QS_HIP(hipStreamSynchronize(h->stream));
+        QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_REFILLED], sizeof(v), hipMemcpyDeviceToHost));
+        *refilled = v;
+    }
+    return 0;
+}
+
 int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     if (!h || !actions || !obs || !rew || !done || !trunc) QS_FAIL(-1, "null argument");
     PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
+    SettleLanes lanes; lanes.staging = nullptr; lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.spawn = 0; lanes.settle_n = 0; lanes.generation = 0;
+    int grid = lanes.n_env_waves;
+    if (h->streaming) {
+        // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder)
+        const int rep = h->cfg.action_repeat, epoch = (h->cfg.settle_steps + rep - 1) / rep;
+        if (h->phase == 0) {
+            hipLaunchKernelGGL(k_pool_publish, dim3(256), dim3(256), 0, h->stream, h->d_stats, h->d_pool_back, h->d_pool, h->pool_size);
+            hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, 0);
+            h->pool_generation++;
+        }
+        lanes.staging = h->d_pool_back; lanes.spawn = h->phase == 0; lanes.generation = h->pool_generation;
+        lanes.settle_n = h->phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
+        grid += n_waves(h->pool_size);
+        h->phase = (h->phase + 1) % epoch;
+    }
     if (h->timing) hipEventRecord(h->ev0, h->stream);
-    hipLaunchKernelGGL(k_step, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                       h->d_obs, h->d_term_obs, pv, h->d_stats);
+    hipLaunchKernelGGL(k_step, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
+                       h->d_obs, h->d_term_obs, pv, h->d_stats, lanes);
     if (h->timing) hipEventRecord(h->ev1, h->stream);
     QS_HIP(hipGetLastError());
     return 0;
@@ -327,7 +410,7 @@ int qs_refresh_pool(qs_handle* h) {  // redraw the pre-settled reset states (new
     if (!h) QS_FAIL(-1, "null handle");
     if (h->pool_size <= 0) return 0;
     h->pool_generation++;
-    hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, h->pool_size, h->pool_generation);
+    hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
     QS_HIP(hipGetLastError());
     return 0;
 }

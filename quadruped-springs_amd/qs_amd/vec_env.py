@@ -131,6 +131,13 @@ class QuadrupedVecEnv(SB3VecEnv):
         self._stream()
         _lib.check(self.lib.qs_refresh_pool(self.h))
 
+    def pool_streaming(self, on=True):
+        """Demand-driven background refill of the reset pool (qs_pool_streaming); returns the number of entries re-settled so far."""
+        n = C.c_uint64(0)
+        self._stream()
+        _lib.check(self.lib.qs_pool_streaming(self.h, int(bool(on)), C.byref(n)))
+        return int(n.value)
+
     # ---- SB3 VecEnv surface (numpy)
     def reset(self):
         return self.reset_tensor().cpu().numpy().copy()

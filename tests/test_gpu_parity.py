@@ -269,6 +269,38 @@ def test_pooled_reset_states_are_settled(torch_cuda):
     assert n_done > 0
 
 
+def test_streaming_pool_refill(torch_cuda):
+    """Demand-driven refill: the pool entries consumed by auto-resets are re-settled by the settle lanes of k_step, fresh draws."""
+    import time
+    from qs_amd.vec_env import QuadrupedVecEnv
+    v = QuadrupedVecEnv(num_envs=1024, auto_reset=True, reset_pool=256, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                        enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=False)
+    v.reset()
+    assert v.pool_streaming(True) == 0
+    rng = np.random.default_rng(3)
+    n_done, mus = 0, set()
+    t0 = time.time()
+    while time.time() - t0 < 30.0:
+        a = rng.uniform(-1, 1, size=(1024, 6)).astype(np.float32)
+        a[:, 1::3] = -1.0; a[:, 2::3] = 1.0 if (n_done // 50) % 2 else -0.5      # violent leg motions: frequent falls
+        obs, rew, done, infos = v.step(a)
+        if done.any():
+            n_done += int(done.sum())
+            st = v.get_state().cpu().numpy()[done]
+            assert np.all(np.abs(st[:, 2] - 0.328) < 0.01) and np.abs(st[:, 7:13]).max() < 0.05   # settled, at rest
+            mus.update(np.round(v.get_info("params").cpu().numpy()[done, 0], 6).tolist())
+        if v.pool_streaming(True) >= 1024 and n_done > 1200:
+            break
+    refilled = v.pool_streaming(False)
+    resets = v.stats()["resets"] - 1024          # the initial reset() of every environment is not a pooled one
+    assert n_done > 1200 and refilled >= 1024
+    assert refilled <= resets   # never more than was consumed (demand above the pool's capacity is forgiven, not owed)
+    assert len(mus) > 256                        # more distinct friction draws than one pool generation holds
+    assert min(mus) >= 0.5 and max(mus) <= 1.0
+    v.step(rng.uniform(-1, 1, size=(1024, 6)).astype(np.float32))   # static pool again: stepping stays valid
+    v.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
