@@ -36,6 +36,9 @@ def workload(name):
     if name == "config5_8192":         # configs[4]: backflip task, Hopf CPG action layer, masses + payload + springs + friction randomised
         return 8192, dict(base, task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", env_randomizer_mode="TEST_RANDOMIZER",
                           action_space_mode="CPG", time_step=0.001, action_repeat=10)
+    if name == "config4_sharded":      # configs[3]: 8192 envs per GPU, JUMPING_FORWARD, actions broadcast + ONE all-gather of [n, o+2]
+        return 8192, dict(base, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", env_randomizer_mode="GROUND_RANDOMIZER",
+                          time_step=0.001, action_repeat=10)   # per rank and step, rank 0 fills an SB3-PPO-shaped rollout buffer
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -78,10 +81,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    sharded = args.workload == "config4_sharded"
+    if world > 1 or sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the simulation step has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -91,12 +96,36 @@ def main():
     n_default, kw = workload(args.workload)
     kw["solver_residual_threshold"] = args.solver_residual_threshold
     n = args.envs_per_gpu or n_default
-    env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, seed=1234 + 7919 * rank, **kw)
+    env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, env_id_offset=n * rank if sharded else 0,
+                          seed=1234 + (0 if sharded else 7919 * rank), **kw)
     env.reset_tensor()
     d = env.action_dim
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     n_act = 64  # a ring of pre-generated U(-1,1) action batches, resident in HBM
     acts = torch.rand((n_act, n, d), generator=gen, device=dev) * 2 - 1
+    local_step = step_fn = env.step_tensor
+    if sharded:
+        # the centralised-learner exchange of SURVEY.md 8e on top of the same local step: rank 0 owns the global action batch
+        # and an SB3-PPO-shaped rollout buffer (n_steps = 128) that every gathered step is written into
+        from qs_amd.sharded import ShardedVecEnv
+        shard = ShardedVecEnv(env, learner_rank=0)
+        n_glob, o_dim = n * world, env.obs_dim
+        g_acts = (torch.rand((8, n_glob, d), generator=gen, device=dev) * 2 - 1) if rank == 0 else None
+        if rank == 0:
+            buf = dict(obs=torch.zeros((128, n_glob, o_dim), device=dev), act=torch.zeros((128, n_glob, d), device=dev),
+                       rew=torch.zeros((128, n_glob), device=dev), start=torch.zeros((128, n_glob), device=dev))
+        state = dict(t=0)
+
+        def sharded_step(_unused):
+            t = state["t"]
+            a = g_acts[t % 8] if rank == 0 else None
+            obs, rew, done, trunc = shard.step(a)
+            if rank == 0:
+                k = t % 128
+                buf["obs"][k].copy_(obs); buf["act"][k].copy_(a); buf["rew"][k].copy_(rew); buf["start"][k].copy_(done)
+            state["t"] = t + 1
+
+        step_fn = sharded_step
 
     def barrier():
         if world > 1:
@@ -116,17 +145,17 @@ def main():
     for gidx in range(groups):
         env.reset_tensor((ids % groups == gidx).to(torch.uint8))
         for i in range(1000 // groups):
-            env.step_tensor(acts[i % n_act])
+            local_step(acts[i % n_act])
         torch.cuda.current_stream().synchronize()
     for i in range(args.warmup):
-        env.step_tensor(acts[i % n_act])
+        step_fn(acts[i % n_act])
     kernel_ms = []
     barrier()
     stats0 = env.stats()
     refills0 = env.pool_streaming(True) if streaming else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        env.step_tensor(acts[i % n_act])
+        step_fn(acts[i % n_act])
     barrier()
     elapsed = time.perf_counter() - t0
     stats1 = env.stats()
@@ -135,7 +164,7 @@ def main():
     # per-launch duration of the step kernel from HIP events on the kernel's own stream (separate short loop so that
     # the event synchronisation does not sit inside the timed region)
     for i in range(min(args.steps, 50)):
-        env.step_tensor(acts[i % n_act])
+        local_step(acts[i % n_act])
         kernel_ms.append(env.last_step_kernel_ms())
     env.enable_timing(False)
     if streaming:
@@ -170,7 +199,8 @@ def main():
                        "resets_in_timed_region": int(stats1["resets"] - stats0["resets"]),
                        "pool_states_settled_in_timed_region": int(refills1 - refills0),
                        "settle_substeps_in_timed_region": int(stats1["settle_substeps"] - stats0["settle_substeps"]),
-                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+                       "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step, rollout buffer on rank 0" if sharded
+                                       else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_step", "kernel_ms": kavg * 1e3,
                          "note": "1112 algorithmic bytes per env-step (SURVEY 8d); the step is ~0.6 MFLOP of dependent fp32 work per env-step, latency-bound, not HBM-bound"},
@@ -178,7 +208,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or sharded:
         torch.distributed.destroy_process_group()
 
 
