@@ -61,7 +61,8 @@ enum { QS_PHASE_POLICY = 0, QS_PHASE_TAKEOFF = 1, QS_PHASE_LANDING = 2, QS_PHASE
 #define QS_MAX_OBS 64
 #define QS_STATE_DIM 37    /* pos3 quat4(xyzw) vlin3 vang3 q12 qd12 */
 #define QS_PARAM_DIM 24    /* mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_payload, r_payload3 */
-#define QS_TASK_DIM 48    /* 32 task scalars, pose cache 9 (pos, vel, rpy), n_invalid, foot-force sum, sim_step, 4 spare */
+#define QS_TASK_DIM 48
+#define QS_TRACE_DIM 70 /* floats per substep row of the trace tap, see qs_set_trace */    /* 32 task scalars, pose cache 9 (pos, vel, rpy), n_invalid, foot-force sum, sim_step, 4 spare */
 
 /* Keyword arguments of QuadrupedGymEnv.__init__ (gym_env.py:52-70) resolved to numbers by the host
  * (quadruped-springs_amd/qs_amd/config.py); constants come from go1/configs_go1_*.py. */
@@ -157,6 +158,12 @@ int qs_refresh_pool(qs_handle* h);
  * schedule depends only on the sequence of qs_step calls (bitwise reproducible).  `refilled` (may be NULL; reading it
  * synchronises the stream) receives the number of entries re-settled so far; qs_stats counts their substeps. */
 int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled);
+/* Per-substep trace tap for ONE environment (evaluation_wrapper.py:14,36-41 set_sub_step_callback; monitor_state.py:66-85):
+ * while set, every qs_step writes action_repeat rows of QS_TRACE_DIM floats into `rows` (device memory, caller owned), one per
+ * physics substep of environment `env`: sim time, base position 3, quaternion xyzw 4, linear velocity 3, angular velocity 3,
+ * joint angles 12, joint velocities 12, applied motor torque 12, spring torque 12, foot normal force 4, foot contact 4.
+ * env < 0 or rows == NULL switches it off. */
+int qs_set_trace(qs_handle* h, int env, float* rows);
 const char* qs_last_error(void);
 const char* qs_version(void);
 

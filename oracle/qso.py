@@ -80,6 +80,12 @@ class Oracle:
         self._check(self.lib.qso_get_info(self.h, which, self._p(out)))
         return out
 
+    def set_trace(self, env):
+        """Per-substep rows of one environment (layout of qs_set_trace); returns the array the next step() calls fill."""
+        self._trace = np.zeros((self.cfg.action_repeat, 70), self.real)
+        self._check(self.lib.qso_set_trace(self.h, int(env), self._p(self._trace)))
+        return self._trace
+
     def set_params(self, which, vals):
         v = np.ascontiguousarray(vals, self.real)
         self._check(self.lib.qso_set_params(self.h, which, self._p(v)))

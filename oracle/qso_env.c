@@ -686,6 +686,14 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         for (int s = 0; s < cfg->action_repeat; s++) {
             if (cpg) cpg_command(cfg, e, cpgp, cmd);   /* the oscillators tick at the physics rate (hopf_network.py:241-289) */
             apply_and_step(cfg, e, cmd, h->gravity); e->sim_step++;
+            if (h->trace && i == h->trace_env) { /* monitor_state.py:66-85 */
+                real* r = h->trace + (size_t)s * QSO_TRACE_DIM;
+                r[0] = sim_time(cfg, e);
+                memcpy(r + 1, e->s.pos, 3 * sizeof(real)); memcpy(r + 4, e->s.quat, 4 * sizeof(real)); memcpy(r + 8, e->s.vlin, 3 * sizeof(real));
+                memcpy(r + 11, e->s.vang, 3 * sizeof(real)); memcpy(r + 14, e->s.q, 12 * sizeof(real)); memcpy(r + 26, e->s.qd, 12 * sizeof(real));
+                memcpy(r + 38, e->tau_pd, 12 * sizeof(real)); memcpy(r + 50, e->tau_spring, 12 * sizeof(real));
+                for (int f = 0; f < 4; f++) { r[62 + f] = e->foot_force[f]; r[66 + f] = (real)e->foot_contact[f]; }
+            }
         }
         e->env_step++; e->total_steps++;
         task_on_step(cfg, e);
@@ -728,6 +736,8 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
     }
     return 0;
 }
+
+int qso_set_trace(qso_handle* h, int env, real* rows) { h->trace_env = env; h->trace = env >= 0 ? rows : NULL; return 0; }
 
 int qso_get_state(qso_handle* h, real* st) {
     for (int i = 0; i < h->cfg.n_envs; i++) {

@@ -66,6 +66,7 @@ struct qso_handle {
     qso_config cfg;
     qso_env* env;
     real gravity;
+    real* trace; int trace_env;
 };
 
 /* qso_model.c */

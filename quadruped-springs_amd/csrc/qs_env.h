@@ -454,7 +454,23 @@ template <class T> struct Env {
     // `settle_n` > 0 turns the call into a slice of a reset's settle (gym_env.py:325-327) for a record of the streaming reset
     // pool: that many substeps under the settling command and nothing else.  It goes through the SAME substep loop as a
     // regular step, so a wave of settling records costs what a wave of environments costs and shares its instructions.
-    static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0) {
+    // `trace` (null except in the lanes of a traced environment; `any_trace` is the wave-uniform "some lane has one") receives
+    // one row per substep (qs_set_trace).
+    static QS_FN void write_trace(float* row, float time, const typename S::State& s, const typename S::Out& o) {
+        T::st(row, TR_TIME, V(time));
+        T::st(row, TR_POS, s.pos.x); T::st(row, TR_POS + 1, s.pos.y); T::st(row, TR_POS + 2, s.pos.z);
+        T::st(row, TR_QUAT, s.qx); T::st(row, TR_QUAT + 1, s.qy); T::st(row, TR_QUAT + 2, s.qz); T::st(row, TR_QUAT + 3, s.qw);
+        T::st(row, TR_VLIN, s.vlin.x); T::st(row, TR_VLIN + 1, s.vlin.y); T::st(row, TR_VLIN + 2, s.vlin.z);
+        T::st(row, TR_VANG, s.vang.x); T::st(row, TR_VANG + 1, s.vang.y); T::st(row, TR_VANG + 2, s.vang.z);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T::st_leg(row, TR_Q + j, 3, s.q[j]); T::st_leg(row, TR_QD + j, 3, s.qd[j]);
+            T::st_leg(row, TR_TAU + j, 3, o.tau_pd[j]); T::st_leg(row, TR_TAU_SPRING + j, 3, o.tau_spring[j]);
+        }
+        T::st_leg(row, TR_FOOT_FORCE, 1, o.foot_force); T::st_leg(row, TR_FOOT_CONTACT, 1, o.foot_contact);
+    }
+    static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0,
+                              float* trace = nullptr, bool any_trace = false) {
         typename S::State s; typename S::Par P; typename S::Out o;
         load_state(rec, s); load_par(rec, P);
         const int d = settle_n > 0 ? 0 : cfg.action_dim;
@@ -566,6 +582,9 @@ template <class T> struct Env {
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             S::actuate(cfg, P, s, cmd, o, tau);
             S::substep(cfg, P, s, tau, o);
+            if (any_trace) {
+                if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
+            }
         }
         if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); return z; }
         if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }

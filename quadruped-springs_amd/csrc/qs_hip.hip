@@ -36,6 +36,7 @@ struct PoolView { const float* pool; int size; };
 // Streaming refill of the reset pool ("settle lanes"): workgroups beyond the environments' ones advance records of the
 // staging copy through a reset's settle, one slice of substeps per launch; ctl = the counters in qs_handle::d_stats.
 struct SettleLanes { float* staging; int n_env_waves, spawn, settle_n, generation; };
+struct TraceTap { float* rows; int env; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_R = 4, CTL_REFILLED = 5, CTL_CURSOR = 6, CTL_N = 8 };
 
 // settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
                                                      float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                      uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                      float* __restrict__ term_obs, PoolView pool,
-                                                     unsigned long long* __restrict__ stats, SettleLanes lanes) {
+                                                     unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap) {
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
     if (settling && lanes.spawn) { E::settle_spawn(cfg, rec, gid, lanes.generation); LaneDev::sync(); }
-    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settling ? lanes.settle_n : 0);
+    const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
+    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settling ? lanes.settle_n : 0, any_trace && env == tap.env ? tap.rows : nullptr, any_trace);
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)lanes.settle_n);
         __syncthreads();
@@ -255,6 +257,7 @@ struct qs_handle {
     float* d_pool_back; // streaming refill: staging records that are being settled by the extra workgroups of k_step
     int pool_size, pool_generation;
     int streaming, phase;   // phase = launch index inside the current epoch
+    float* trace_rows; int trace_env;
     unsigned long long* d_stats;
     hipEvent_t ev0, ev1;
     int timing;
@@ -376,6 +379,7 @@ int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t*
     if (!h || !actions || !obs || !rew || !done || !trunc) QS_FAIL(-1, "null argument");
     PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
     SettleLanes lanes; lanes.staging = nullptr; lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.spawn = 0; lanes.settle_n = 0; lanes.generation = 0;
+    TraceTap tap; tap.rows = h->trace_rows; tap.env = h->trace_env;
     int grid = lanes.n_env_waves;
     if (h->streaming) {
         // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder)
@@ -392,9 +396,16 @@ int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t*
     }
     if (h->timing) hipEventRecord(h->ev0, h->stream);
     hipLaunchKernelGGL(k_step, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                       h->d_obs, h->d_term_obs, pv, h->d_stats, lanes);
+                       h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap);
     if (h->timing) hipEventRecord(h->ev1, h->stream);
     QS_HIP(hipGetLastError());
+    return 0;
+}
+
+int qs_set_trace(qs_handle* h, int env, float* rows) {
+    if (!h) QS_FAIL(-1, "null handle");
+    if (env >= h->cfg.n_envs) QS_FAIL(-1, "trace environment %d out of range (%d environments)", env, h->cfg.n_envs);
+    h->trace_env = env; h->trace_rows = env >= 0 ? rows : nullptr;
     return 0;
 }
 

@@ -37,6 +37,9 @@ enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO
        T_JUMP_COUNT = 20, T_GOOD_JUMPS = 21, T_SUM_FWD = 22, T_SUM_FLOGF = 23 /* sum f log2 f */, T_SUM_HEIGHT = 24, T_SUM_PERF = 25,
        T_MAX_PERF = 26, T_LAST_PERF = 27, T_MAX_JUMP_H = 28, T_FIRST_JUMP = 29, T_END_JUMP = 30, T_N = 32 };
 
+// one row of the per-substep trace tap (qs_set_trace), monitor_state.py:66-85
+enum { TR_TIME = 0, TR_POS = 1, TR_QUAT = 4, TR_VLIN = 8, TR_VANG = 11, TR_Q = 14, TR_QD = 26, TR_TAU = 38, TR_TAU_SPRING = 50, TR_FOOT_FORCE = 62,
+       TR_FOOT_CONTACT = 66 };
 enum { W_PHASE = 0, W_TIMER = 1, W_END = 2, W_TSTART = 3, W_HOLD = 4, W_HACT = 5, W_ACTION = 6, W_SCRIPTED = 18, W_DISARMED = 19 };
 
 #define QS_ENVS_PER_WAVE 16

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libqs_hip.so")
 EXPORTS = (
     "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_get_obs", "qs_step", "qs_get_state", "qs_set_state",
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
-    "qs_refresh_pool", "qs_pool_streaming", "qs_last_error", "qs_version",
+    "qs_refresh_pool", "qs_pool_streaming", "qs_set_trace", "qs_last_error", "qs_version",
 )
 
 _lib = None
@@ -49,6 +49,7 @@ def load():
     lib.qs_last_step_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.qs_refresh_pool.argtypes = [vp]
     lib.qs_pool_streaming.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    lib.qs_set_trace.argtypes = [vp, C.c_int, vp]
     lib.qs_last_error.restype = C.c_char_p
     lib.qs_version.restype = C.c_char_p
     _lib = lib

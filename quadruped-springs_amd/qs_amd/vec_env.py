@@ -45,6 +45,7 @@ class QuadrupedVecEnv(SB3VecEnv):
             self._trunc = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self._act = torch.zeros((n, d), dtype=torch.float32, device=self.device)
         self._actions = None
+        self._trace = None
         self._closed = False
         self.render_mode = None
 
@@ -130,6 +131,30 @@ class QuadrupedVecEnv(SB3VecEnv):
     def refresh_pool(self):
         self._stream()
         _lib.check(self.lib.qs_refresh_pool(self.h))
+
+    TRACE_FIELDS = dict(time=(0, 1), base_position=(1, 4), base_quaternion=(4, 8), base_linear_velocity=(8, 11), base_angular_velocity=(11, 14),
+                        joint_angles=(14, 26), joint_velocities=(26, 38), torques=(38, 50), spring_tau=(50, 62), feet_normal_forces=(62, 66),
+                        feet_in_contact=(66, 70))
+
+    def set_trace(self, env=0):
+        """Per-substep tap on one environment (the reference's set_sub_step_callback users: evaluation_wrapper.py:14,
+        monitor_state.py:66-85).  env=None switches it off.  Read the rows of the last step with get_trace()."""
+        if env is None:
+            self._trace = None
+            _lib.check(self.lib.qs_set_trace(self.h, -1, None))
+            return
+        self._trace = self.torch.zeros((self.cfg.action_repeat, 70), dtype=self.torch.float32, device=self.device)
+        _lib.check(self.lib.qs_set_trace(self.h, int(env), self._ptr(self._trace)))
+
+    def get_trace(self, as_dict=True):
+        """Rows [action_repeat, 70] of the traced environment for the most recent step; with as_dict the monitor_state.py
+        quantities, incl. the spring energy 0.5 k (q - q_rest)^2 with the gated stiffness of springs.py:34-61."""
+        rows = self._trace.cpu().numpy().astype(np.float64)
+        if not as_dict:
+            return rows
+        out = {k: rows[:, a:b] for k, (a, b) in self.TRACE_FIELDS.items()}
+        out["time"] = out["time"][:, 0]
+        return out
 
     def pool_streaming(self, on=True):
         """Demand-driven background refill of the reset pool (qs_pool_streaming); returns the number of entries re-settled so far."""

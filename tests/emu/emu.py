@@ -58,6 +58,11 @@ class Emu:
         self.lib.qse_step(self.h, self._p(a), self._p(obs), self._p(rew), self._p(done), self._p(trunc))
         return obs, rew, done.astype(bool), trunc.astype(bool)
 
+    def set_trace(self, env):
+        self._trace = np.zeros((self.cfg.action_repeat, 70), np.float32)
+        self.lib.qse_set_trace(self.h, int(env), self._p(self._trace))
+        return self._trace
+
     def get_state(self):
         s = np.zeros((self.n, 37), np.float32)
         self.lib.qse_get_state(self.h, self._p(s))

@@ -11,6 +11,7 @@ using E = qs::Env<LaneEmu>;
 struct Emu {
     qs_config cfg;
     std::vector<float> rec, obs, term_obs;
+    float* trace = nullptr; int trace_env = -1;
 };
 
 static void init_record(const qs_config& cfg, float* r, int env) {
@@ -32,6 +33,7 @@ void* qse_create(const qs_config* cfg) {
     return e;
 }
 void qse_destroy(void* h) { delete (Emu*)h; }
+int qse_set_trace(void* h, int env, float* rows) { Emu* e = (Emu*)h; e->trace_env = env; e->trace = env >= 0 ? rows : nullptr; return 0; }
 int qse_reset(void* h, const uint8_t* mask) {
     Emu* e = (Emu*)h;
     for (int i = 0; i < e->cfg.n_envs; i++)
@@ -49,7 +51,8 @@ int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* don
     for (int i = 0; i < e->cfg.n_envs; i++) {
         float* rec = &e->rec[(size_t)i * QS_REC];
         float* ob = &e->obs[(size_t)i * QS_MAX_OBS];
-        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset));
+        float* tr = (e->trace && i == e->trace_env) ? e->trace : nullptr;
+        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset), 0, tr, tr != nullptr);
         rew[i] = r.reward.v[0]; done[i] = r.done.v[0] > 0.5f; trunc[i] = r.trunc.v[0] > 0.5f;
         if (done[i] && e->cfg.auto_reset) {
             memcpy(&e->term_obs[(size_t)i * QS_MAX_OBS], ob, QS_MAX_OBS * sizeof(float));

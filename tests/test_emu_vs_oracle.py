@@ -186,3 +186,24 @@ def test_wrapper_phase_machine(golden, name):
             o.reset(); e.reset()
     expect = dict(rest_s1={0, 3}, rest_s0={0, 3}, landbf_s1={0, 1}, landc2_s1={0})   # as the oracle run against the reference's wrappers
     assert seen == expect.get(name, {0, 1, 2})
+
+
+def test_trace_tap_rows():
+    """qs_set_trace: one row per physics substep of the chosen environment, same layout and values as the oracle's tap."""
+    o, e, cfg = pair(n=3)
+    o.reset(); e.reset()
+    to, te = o.set_trace(1), e.set_trace(1)
+    rng = np.random.default_rng(2)
+    for i in range(12):
+        s = o.get_state()
+        o.set_state(s); e.set_state(s)
+        a = rng.uniform(-1, 1, size=(3, cfg.action_dim)).astype(np.float32)
+        o.step(a); e.step(a)
+        np.testing.assert_allclose(to[:, 0], (np.arange(10) + 1 + 10 * i) * 1e-3, atol=1e-9)   # sim time of every substep
+        np.testing.assert_allclose(te[:, 0], to[:, 0], atol=1e-6)
+        np.testing.assert_allclose(to[-1, 1:38], o.get_state()[1], atol=0)                      # the last row is the state after the step
+        np.testing.assert_allclose(te[:, 1:8], to[:, 1:8], atol=2e-5)
+        np.testing.assert_allclose(te[:, 14:26], to[:, 14:26], atol=5e-5)
+        np.testing.assert_allclose(te[:, 26:38], to[:, 26:38], atol=2e-2)
+        np.testing.assert_allclose(te[:, 38:62], to[:, 38:62], atol=5e-2)                       # torques follow q, qd (kp = 75)
+        np.testing.assert_array_equal(te[:, 66:70], to[:, 66:70])

@@ -301,6 +301,54 @@ def test_streaming_pool_refill(torch_cuda):
     v.close()
 
 
+def test_trace_tap(torch_cuda):
+    """qs_set_trace: one row per physics substep of the chosen environment (evaluation_wrapper.py / monitor_state.py taps)."""
+    n = 48
+    o, v, cfg = make_pair(n, torch_cuda)
+    o.reset(); v.reset()
+    to = o.set_trace(37)
+    v.set_trace(37)
+    rng = np.random.default_rng(2)
+    for i in range(20):
+        s = o.get_state()
+        o.set_state(s); v.set_state(s.astype(np.float32))
+        a = rng.uniform(-1, 1, size=(n, cfg.action_dim)).astype(np.float32)
+        o.step(a); v.step(a)
+        tv = v.get_trace(as_dict=False)
+        np.testing.assert_allclose(tv[:, 0], to[:, 0], atol=1e-6)
+        np.testing.assert_allclose(tv[-1, 1:38], v.get_state().cpu().numpy()[37], atol=0)   # last row = state after the step
+        np.testing.assert_allclose(tv[:, 1:8], to[:, 1:8], atol=2e-5)
+        np.testing.assert_allclose(tv[:, 14:26], to[:, 14:26], atol=5e-5)
+        np.testing.assert_allclose(tv[:, 26:38], to[:, 26:38], atol=2e-2)
+        np.testing.assert_allclose(tv[:, 38:62], to[:, 38:62], atol=5e-2)
+        np.testing.assert_array_equal(tv[:, 66:70], to[:, 66:70])
+    d = v.get_trace()
+    assert d["joint_angles"].shape == (10, 12) and d["time"].shape == (10,)
+    v.set_trace(None)
+    v.step(a)
+
+
+def test_streaming_refill_is_reproducible(torch_cuda):
+    """The settle lanes follow the sequence of step calls only: two handles stepping the same actions stay bitwise equal."""
+    from qs_amd.vec_env import QuadrupedVecEnv
+    kw = dict(num_envs=512, auto_reset=True, reset_pool=256, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+              enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=True, settle_steps=300)
+    a, b = QuadrupedVecEnv(**kw), QuadrupedVecEnv(**kw)
+    a.reset(); b.reset()
+    a.pool_streaming(True); b.pool_streaming(True)
+    rng = np.random.default_rng(3)
+    n_done = 0
+    for i in range(150):      # five 30-launch epochs
+        act = rng.uniform(-1, 1, size=(512, 6)).astype(np.float32)
+        act[:, 1::3] = -1.0; act[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        n_done += int(da.sum())
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
+    assert n_done > 100 and a.pool_streaming(False) == b.pool_streaming(False) > 0
+    a.close(); b.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
