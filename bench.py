@@ -177,6 +177,15 @@ def main():
     if rank == 0:
         kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
         achieved = n * ALGO_BYTES_PER_ENV_STEP / kavg / 1e9
+        # HBM bytes per launch from the committed PMC passes of this very configuration (rocprofv3 cannot run inside this
+        # process); null when the run differs from the profiled one
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_d_pmc.json")))
+            if (pmc["workload"], pmc["envs_per_gpu"], pmc["reset_pool"], pmc["settle_lanes"]) == (args.workload, n, args.reset_pool, streaming):
+                traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "env-steps/sec (whole node), Go1+PEA jump-in-place, N=8192 envs",
             "value": total_steps / elapsed,
@@ -202,8 +211,8 @@ def main():
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step, rollout buffer on rank 0" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_step", "kernel_ms": kavg * 1e3,
-                         "note": "1112 algorithmic bytes per env-step (SURVEY 8d); the step is ~0.6 MFLOP of dependent fp32 work per env-step, latency-bound, not HBM-bound"},
+                         "traffic": traffic, "kernel": "k_step", "kernel_ms": kavg * 1e3,
+                         "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (profiles/r01_d_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~55 k dependent fp32 VALU instructions per wave per env-step (78 % VALU-active): latency/issue-bound, not HBM-bound"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw)

@@ -8,7 +8,7 @@ import os
 import sys
 
 root, kernel = sys.argv[1], sys.argv[2]
-for f in glob.glob(os.path.join(root, "*", "*_kernel_stats.csv")):
+for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=True):
     print("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
     for r in csv.DictReader(open(f)):
         n = r["Name"].split("(")[0]
@@ -16,9 +16,9 @@ for f in glob.glob(os.path.join(root, "*", "*_kernel_stats.csv")):
             print(f"| {n[:50]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {r['Percentage']} |")
 print()
 print("| counter | per-launch avg | min | max | launches |\n|---|---|---|---|---|")
-for f in sorted(glob.glob(os.path.join(root, "*", "*_counter_collection.csv"))):
+meta = None
+for f in sorted(glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True)):
     d = collections.defaultdict(list)
-    meta = None
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"].split("(")[0] == kernel:
             d[r["Counter_Name"]].append(float(r["Counter_Value"]))
