@@ -164,6 +164,24 @@ int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled);
  * joint angles 12, joint velocities 12, applied motor torque 12, spring torque 12, foot normal force 4, foot contact 4.
  * env < 0 or rows == NULL switches it off. */
 int qs_set_trace(qs_handle* h, int env, float* rows);
+
+/* ---- SB3 VecNormalize on device (stable_baselines3 1.5.1a7: common/vec_env/vec_normalize.py, common/running_mean_std.py),
+ * as applied by the reference at load_model.py:109-137 and get_demonstrations.py:71.  Operates in place on the device arrays
+ * a step / reset produced; statistics are float64.  norm handles are independent of simulation handles. */
+typedef struct qs_norm qs_norm;
+int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, float gamma, float epsilon, int device, qs_norm** out);
+void qs_norm_destroy(qs_norm* h);
+int qs_norm_set_stream(qs_norm* h, void* hip_stream);
+/* host arrays [obs_dim]; RunningMeanStd.mean / .var / .count of obs_rms and ret_rms (VecNormalize.load / save) */
+int qs_norm_set_stats(qs_norm* h, const double* obs_mean, const double* obs_var, double obs_count, double ret_mean, double ret_var, double ret_count);
+int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs_count, double* ret_mean, double* ret_var, double* ret_count);
+/* VecNormalize.reset: returns <- 0, obs_rms.update(obs) if training && norm_obs, obs <- normalize_obs(obs) */
+int qs_norm_reset(qs_norm* h, float* obs /* [N,o] */, int training, int norm_obs);
+/* VecNormalize.step_wait: obs_rms.update(obs); obs <- normalize_obs(obs); returns <- returns*gamma + rew; ret_rms.update(returns);
+ * rew <- normalize_reward(rew); term_obs (may be NULL) <- normalize_obs(term_obs); returns[done] <- 0 */
+int qs_norm_step(qs_norm* h, float* obs /* [N,o] */, float* rew /* [N] */, const uint8_t* done /* [N] */, float* term_obs /* [N,o] or NULL */,
+                 int training, int norm_obs, int norm_reward);
+
 const char* qs_last_error(void);
 const char* qs_version(void);
 

@@ -11,7 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "qs_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h")] + \
+SRC_NORM = os.path.join(HERE, "csrc", "qs_norm.hip")
+DEPS = [SRC, SRC_NORM] + [os.path.join(HERE, "csrc", f) for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h")] + \
        [os.path.join(REPO, "include", "qs_amd.h")]
 OUT = os.path.join(HERE, "qs_amd", "libqs_hip.so")
 
@@ -27,7 +28,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
-           "-I" + os.path.join(REPO, "include"), "-o", OUT, SRC]
+           "-I" + os.path.join(REPO, "include"), "-o", OUT, SRC, SRC_NORM]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -241,7 +241,8 @@ __global__ void k_task_info(const float* __restrict__ recs, int n, float* __rest
 }
 
 // ------------------------------------------------------------------ host side of the C ABI
-static thread_local char g_err[512] = "";
+thread_local char qs_g_err[512] = "";   // shared with qs_norm.hip
+#define g_err qs_g_err
 #define QS_FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
 #define QS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) QS_FAIL(-2, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 

@@ -11,4 +11,10 @@ def __getattr__(name):  # lazy: importing the package must not need torch / a GP
     if name == "QuadrupedGymEnv":
         from .env.quadruped_gym_env import QuadrupedGymEnv
         return QuadrupedGymEnv
+    if name == "DeviceVecNormalize":
+        from .vec_normalize import DeviceVecNormalize
+        return DeviceVecNormalize
+    if name == "ShardedVecEnv":
+        from .sharded import ShardedVecEnv
+        return ShardedVecEnv
     raise AttributeError(name)

@@ -349,6 +349,58 @@ def test_streaming_refill_is_reproducible(torch_cuda):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("training,norm_reward", [(True, True), (False, False)])
+def test_device_vec_normalize(torch_cuda, training, norm_reward):
+    """DeviceVecNormalize vs the numpy restatement of SB3's VecNormalize (oracle/vecnorm.py) on the same raw step outputs."""
+    from oracle.vecnorm import VecNormalizeRef
+    from qs_amd.vec_env import QuadrupedVecEnv
+    from qs_amd.vec_normalize import DeviceVecNormalize
+    n = 1000   # not a multiple of the block size
+    venv = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_pool=64, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                           enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5)
+    env = DeviceVecNormalize(venv, training=training, norm_reward=norm_reward)
+    ref = VecNormalizeRef(n, venv.obs_dim, training=training, norm_reward=norm_reward, moments_dtype=np.float64)
+    sb3 = VecNormalizeRef(n, venv.obs_dim, training=training, norm_reward=norm_reward)   # batch moments in float32, as SB3 takes them
+    if not training:   # evaluation as in load_model.py:114-116: statistics come from a file
+        rng0 = np.random.default_rng(0)
+        mean, var = rng0.normal(size=venv.obs_dim), rng0.uniform(0.5, 4.0, size=venv.obs_dim)
+        env.set_stats(mean, var, 12345.0, 0.3, 2.0, 777.0)
+        ref.obs_rms.mean, ref.obs_rms.var, ref.obs_rms.count = mean, var, 12345.0
+        ref.ret_rms.mean, ref.ret_rms.var, ref.ret_rms.count = 0.3, 2.0, 777.0
+        sb3.obs_rms.mean, sb3.obs_rms.var, sb3.obs_rms.count = mean, var, 12345.0
+        sb3.ret_rms.mean, sb3.ret_rms.var, sb3.ret_rms.count = 0.3, 2.0, 777.0
+    obs = env.reset()
+    np.testing.assert_allclose(obs, ref.reset(env.get_original_obs()), atol=2e-5)
+    sb3.reset(env.get_original_obs())
+    rng = np.random.default_rng(1)
+    n_done = 0
+    for i in range(60):
+        a = rng.uniform(-1, 1, size=(n, 6)).astype(np.float32)
+        a[:, 1::3] = -1.0; a[:, 2::3] = 1.0 if (i // 6) % 2 else -0.5
+        obs, rew, done, infos = env.step(a)
+        raw_obs, raw_rew = env.get_original_obs(), env.get_original_reward()
+        term_raw = venv.get_info("terminal_obs").cpu().numpy()
+        o_ref, r_ref, t_ref = ref.step(raw_obs, raw_rew, done, term_raw)
+        o_sb3, r_sb3, _ = sb3.step(raw_obs, raw_rew, done, term_raw)
+        wide = sb3.obs_rms.var > 1e-3   # where var + epsilon does not amplify float32 summation noise of the batch mean
+        np.testing.assert_allclose(obs[:, wide], o_sb3[:, wide], atol=2e-3, err_msg=f"obs vs float32-moment variant, step {i}")
+        np.testing.assert_allclose(rew, r_sb3, atol=2e-3, rtol=1e-3)
+        np.testing.assert_allclose(obs, o_ref, atol=2e-5, err_msg=f"obs step {i}")
+        np.testing.assert_allclose(rew, r_ref, atol=2e-5, rtol=1e-5, err_msg=f"reward step {i}")
+        for k in np.nonzero(done)[0]:
+            np.testing.assert_allclose(infos[k]["terminal_observation"], t_ref[k], atol=2e-5)
+        n_done += int(done.sum())
+    s = env.get_stats()
+    np.testing.assert_allclose(s["obs_mean"], ref.obs_rms.mean, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(s["obs_var"], ref.obs_rms.var, rtol=1e-5)
+    np.testing.assert_allclose([s["obs_count"], s["ret_mean"], s["ret_var"], s["ret_count"]],
+                               [ref.obs_rms.count, ref.ret_rms.mean, ref.ret_rms.var, ref.ret_rms.count], rtol=1e-5)
+    assert n_done > 0
+    if training:
+        assert abs(s["obs_count"] - (1e-4 + 61 * n)) < 1e-6
+    env.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
