@@ -543,6 +543,11 @@ def gen_traces():
              enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=420, jump_at=70),
         dict(name="cart_s1", task_env="JUMPING_IN_PLACE", observation_space_mode="CARTESIAN_NO_IMU", enable_springs=True,
              enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="CARTESIAN_PD", steps=150, jump_at=70),
+        # gym_env.py:187-205 _interpolate_actions, with and without the filter
+        dict(name="interp_f1", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_interpolation=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=120, jump_at=60),
+        dict(name="interp_f0", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=False, enable_action_interpolation=True,
+             enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="PD", steps=120, jump_at=60),
     ]
     out = {}
     for case in cases:
