@@ -634,8 +634,27 @@ template <class T> struct Sim {
             o.n_invalid = T::quad_sum(n) + trunk;
         }
 
+        // joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint)
+        V lim_pen[3], lim_sgn[3], lim_act[3];
+        M any_lim = qlt(one, zero);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            V plo = s.q[j] - JLO[j], phi = V(JHI[j]) - s.q[j];
+            M vlo = qle(plo, zero), vhi = qle(phi, zero);
+            lim_pen[j] = qsel(vlo, plo, phi);
+            lim_sgn[j] = qsel(vlo, one, -one);
+            M v = qor(vlo, vhi);
+            lim_act[j] = qflag(v);
+            any_lim = qor(any_lim, v);
+        }
+        // Nothing to solve when no foot of the wave's 16 environments is within contact range and no joint sits at a stop:
+        // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
+        // rows, the Delassus columns and the sweeps.
+        if (T::any(qor(act_m, any_lim))) {
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
         Row rows[6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) rows[3 + j].act = lim_act[j];
         V3v rc = rf - Rz * V(FOOT_R);                   // contact point on the sphere, base coordinates
         V3v d1 = rc - p1, d2 = rc - p2, d3 = rc - p3;
         V3v g1 = cross(ax1, d1), g2 = cross(Y, d2), g3 = cross(Y, d3);  // d(point)/dq_j
@@ -671,19 +690,6 @@ template <class T> struct Sim {
         QS_CONTACT_ROW(1, (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false)
         QS_CONTACT_ROW(2, Rx, false)
 #undef QS_CONTACT_ROW
-        // joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint)
-        V lim_pen[3], lim_sgn[3];
-        M any_lim = qlt(one, zero);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            V plo = s.q[j] - JLO[j], phi = V(JHI[j]) - s.q[j];
-            M vlo = qle(plo, zero), vhi = qle(phi, zero);
-            lim_pen[j] = qsel(vlo, plo, phi);
-            lim_sgn[j] = qsel(vlo, one, -one);
-            M v = qor(vlo, vhi);
-            rows[3 + j].act = qflag(v);
-            any_lim = qor(any_lim, v);
-        }
         V Kc[3][3] = {{K11, K12, K13}, {K12, K22, K23}, {K13, K23, K33}};
         if (T::any(any_lim)) {
 #pragma unroll
@@ -719,6 +725,9 @@ template <class T> struct Sim {
         } else {
             if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
             else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+        }
+        } else {
+            o.foot_force = zero; s.warm = zero;
         }
         // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
         s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;
