@@ -7,7 +7,7 @@ import os
 from .config import QsConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqs_hip.so")
+LIB_PATH = os.environ.get("QS_LIB_PATH") or os.path.join(_HERE, "libqs_hip.so")   # QS_LIB_PATH: kernel experiments (another build of the same ABI)
 
 EXPORTS = (
     "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_get_obs", "qs_step", "qs_get_state", "qs_set_state",
