@@ -8,6 +8,7 @@
 // accesses, plus the action / observation / reward rows.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "qs_env.h"
@@ -63,12 +64,13 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
 }
 
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
-__global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
-                                                     const float* __restrict__ actions, float* __restrict__ obs_out,
-                                                     float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
-                                                     uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
-                                                     float* __restrict__ term_obs, PoolView pool,
-                                                     unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap) {
+// The body is compiled twice (k_step / k_step_dense below) under different register budgets.
+static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+                                                 const float* __restrict__ actions, float* __restrict__ obs_out,
+                                                 float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                                 uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
+                                                 float* __restrict__ term_obs, PoolView pool,
+                                                 unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap) {
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
@@ -140,6 +142,18 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_step(const qs_config* __restrict
         obs_keep[(size_t)first * od + i] = v;
     }
 }
+
+#define QS_STEP_ARGS const qs_config* __restrict__ cfgp, float* __restrict__ recs, const float* __restrict__ actions, float* __restrict__ obs_out,    \
+                     float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep, \
+                     float* __restrict__ term_obs, PoolView pool, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap
+#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap
+// One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
+// wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
+__global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body(QS_STEP_PASS); }
+// Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
+// issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
+// (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
+__global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body(QS_STEP_PASS); }
 
 // Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
 // settling into the pool (they replace the entries at the rotating cursor) ...
@@ -259,6 +273,7 @@ struct qs_handle {
     int pool_size, pool_generation;
     int streaming, phase;   // phase = launch index inside the current epoch
     float* trace_rows; int trace_env;
+    int n_simd, step_variant;   // SIMDs of the device; 0 = pick k_step / k_step_dense by grid size, 1 / 2 = forced (QS_STEP_VARIANT)
     unsigned long long* d_stats;
     hipEvent_t ev0, ev1;
     int timing;
@@ -301,6 +316,13 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (!h) QS_FAIL(-4, "out of host memory");
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg; h->device = device; h->stream = nullptr;
+    {
+        hipDeviceProp_t prop;
+        QS_HIP(hipGetDeviceProperties(&prop, device));
+        h->n_simd = 4 * prop.multiProcessorCount;
+        const char* v = getenv("QS_STEP_VARIANT");
+        h->step_variant = v ? atoi(v) : 0;
+    }
     const size_t n = (size_t)cfg->n_envs;
     QS_HIP(hipMalloc(&h->d_cfg, sizeof(qs_config)));
     QS_HIP(hipMalloc(&h->d_rec, n * QS_REC * sizeof(float)));
@@ -396,8 +418,12 @@ int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t*
         h->phase = (h->phase + 1) % epoch;
     }
     if (h->timing) hipEventRecord(h->ev0, h->stream);
-    hipLaunchKernelGGL(k_step, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                       h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap);
+    // more waves than 1.5 x the SIMDs of the device: the two-waves-per-SIMD build of the same body wins (see k_step_dense)
+    const bool dense = h->step_variant == 2 || (h->step_variant == 0 && 2 * grid > 3 * h->n_simd);
+    if (dense) hipLaunchKernelGGL(k_step_dense, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
+                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap);
+    else hipLaunchKernelGGL(k_step, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
+                            h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap);
     if (h->timing) hipEventRecord(h->ev1, h->stream);
     QS_HIP(hipGetLastError());
     return 0;
