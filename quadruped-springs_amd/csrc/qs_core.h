@@ -270,23 +270,46 @@ template <class T> struct Sim {
         for (int r = 0; r < NR; r++)
 #pragma unroll
             for (int c = 0; c < NR; c++) loc[r][c] = rows[r].jq[0] * rows[c].u[0] + rows[r].jq[1] * rows[c].u[1] + rows[r].jq[2] * rows[c].u[2];
-#define QS_GATHER(K)                                                                                                   \
+        // The 12 x 12 Delassus matrix restricted to the own columns is, per pair (r, c) of row kinds, a 4 x 4 matrix over
+        // (leg K, own leg): sum_t w[K,r][t] * w[own,c][t] -- six rank-1 updates that ONE 4x4x1 MFMA each performs for all
+        // sixteen environments of the wave.  The columns are pre-scaled by -1/diag_c, the leg-local term jq_r . u_c is added on
+        // the diagonal block, and the self entries are zeroed.
+        {
+            V wc[NR][6], locs[NR][NR];
+#pragma unroll
+            for (int c = 0; c < NR; c++) {
+                V nd = -rows[c].dinv;
+#pragma unroll
+                for (int i = 0; i < 6; i++) wc[c][i] = rows[c].w[i] * nd;
+#pragma unroll
+                for (int r = 0; r < NR; r++) locs[r][c] = loc[r][c] * nd;
+            }
+            typename T::Acc4 acc[NR][NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int c = 0; c < NR; c++) acc[r][c] = T::acc4_zero();
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int r = 0; r < NR; r++)
+#pragma unroll
+                    for (int c = 0; c < NR; c++) T::outer_fma(rows[r].w[i], wc[c][i], acc[r][c]);
+#define QS_SCATTER(K)                                                                                                  \
     {                                                                                                                  \
         M own = T::is_leg(K);                                                                                          \
+        V ownf = qflag(own);                                                                                           \
         _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                               \
-            V wk[6];                                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < 6; i++) wk[i] = T::template bcast<K>(rows[r].w[i]);                  \
             _Pragma("unroll") for (int c = 0; c < NR; c++) {                                                           \
-                V d = wk[0] * rows[c].w[0] + wk[1] * rows[c].w[1] + wk[2] * rows[c].w[2] + wk[3] * rows[c].w[3] +      \
-                      wk[4] * rows[c].w[4] + wk[5] * rows[c].w[5];                                                     \
-                V a_ = -((d + qsel(own, loc[r][c], V(0.0f))) * rows[c].dinv);                                          \
+                V a_ = T::template acc4_get<K>(acc[r][c]) + ownf * locs[r][c];                                         \
                 Ap[NR * K + r][c] = (r == c) ? qsel(own, V(0.0f), a_) : a_;                                            \
             }                                                                                                          \
             if (TRACK) diag_all[TRACK ? NR * K + r : 0] = T::template bcast<K>(rows[r].diag);                          \
         }                                                                                                              \
     }
-        QS_GATHER(0) QS_GATHER(1) QS_GATHER(2) QS_GATHER(3)
-#undef QS_GATHER
+            QS_SCATTER(0) QS_SCATTER(1) QS_SCATTER(2) QS_SCATTER(3)
+#undef QS_SCATTER
+        }
         // warm start: normal rows only, factor cfg.warmstart (btMultiBodyConstraintSolver, SOLVER_USE_WARMSTARTING)
 #pragma unroll
         for (int r = 0; r < NR; r++) res[r] = rows[r].rhs;   // res[] holds the candidates: rhs_c - dinv_c sum_{j != c} A_cj lam_j

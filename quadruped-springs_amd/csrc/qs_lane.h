@@ -90,6 +90,13 @@ struct LaneDev {
         float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, d), K * 0x55, 0xF, 0xF, true));
         return fmaf(b, a, acc);
     }
+    // acc[K] += (a of lane K of the quad) * (b of this lane), K = 0..3: one v_mfma_f32_4x4x1_16b_f32 does it for the sixteen
+    // quads of the wave (16 independent 4x4 outer products, block = quad; measured layout: tools/mfma_layout.hip).  The
+    // instruction ignores EXEC, so it may only be used where the whole wave runs the same path.
+    typedef float Acc4 __attribute__((ext_vector_type(4)));
+    static QS_DEV Acc4 acc4_zero() { Acc4 z = {0.0f, 0.0f, 0.0f, 0.0f}; return z; }
+    static QS_DEV void outer_fma(float a, float b, Acc4& acc) { acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0); }
+    template <int K> static QS_DEV float acc4_get(const Acc4& acc) { return acc[K]; }
     static QS_DEV float bcast_dyn(float x, int k) { return __shfl(x, (int)((threadIdx.x & 60u) | (unsigned)k), 64); }  // rare path only
     static QS_DEV int leg() { return (int)(threadIdx.x & 3u); }
     static QS_DEV float fx() { return (threadIdx.x & 2u) ? -1.0f : 1.0f; }  // front +, rear -
@@ -160,6 +167,10 @@ struct LaneEmu {
     static V4 fx() { return V4(1, 1, -1, -1); }
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
+    struct Acc4 { V4 k[4]; };
+    static Acc4 acc4_zero() { Acc4 z; for (int i = 0; i < 4; i++) z.k[i] = V4(0.0f); return z; }
+    static void outer_fma(V4 a, V4 b, Acc4& acc) { for (int K = 0; K < 4; K++) for (int l = 0; l < 4; l++) acc.k[K].v[l] = fmaf(a.v[K], b.v[l], acc.k[K].v[l]); }
+    template <int K> static V4 acc4_get(const Acc4& acc) { return acc.k[K]; }
     static bool any(M4 m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
     static V4 ld_leg(const float* rec, int base, int stride) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = rec[base + stride * i]; return r; }
     static void st_leg(float* rec, int base, int stride, V4 v) { for (int i = 0; i < 4; i++) rec[base + stride * i] = v.v[i]; }
