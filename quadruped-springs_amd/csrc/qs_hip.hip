@@ -36,9 +36,12 @@ __device__ __forceinline__ void tile_store(const float* lds, float* __restrict__
 struct PoolView { const float* pool; int size; };
 // Streaming refill of the reset pool ("settle lanes"): workgroups beyond the environments' ones advance records of the
 // staging copy through a reset's settle, one slice of substeps per launch; ctl = the counters in qs_handle::d_stats.
-struct SettleLanes { float* staging; int n_env_waves, spawn, settle_n, generation; };
+// The staging copy is split into QS_COHORTS slices whose settles start QS_COHORTS-th of an epoch apart, so that finished
+// records reach the pool (and the demand is re-read) every epoch / QS_COHORTS launches instead of once per epoch.
+#define QS_COHORTS 5
+struct SettleLanes { float* staging; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], settle_n[QS_COHORTS], generation[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
-enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_R = 4, CTL_REFILLED = 5, CTL_CURSOR = 6, CTL_N = 8 };
+enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_REFILLED = 4, CTL_CURSOR = 5, CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
 
 // settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
 __device__ __forceinline__ void copy_settled(float* rec, const float* src) {
@@ -76,9 +79,14 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
     const qs_config& cfg = *cfgp;
     const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles pool records
-    const int first = (settling ? (int)blockIdx.x - lanes.n_env_waves : (int)blockIdx.x) * QS_ENVS_PER_WAVE;
-    const int limit = settling ? (int)stats[CTL_R] : cfg.n_envs;         // CTL_R is only written between launches (k_pool_plan)
+    const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
+    const int first = settling ? cohort * lanes.slice + (((int)blockIdx.x - lanes.n_env_waves) % lanes.waves_per_cohort) * QS_ENVS_PER_WAVE
+                               : (int)blockIdx.x * QS_ENVS_PER_WAVE;
+    // CTL_R[cohort] is only written between launches (k_pool_plan)
+    const int limit = settling ? cohort * lanes.slice + (int)stats[CTL_R + cohort] : cfg.n_envs;
     if (first >= limit) return;
+    const int settle_n = settling ? lanes.settle_n[cohort] : 0;
+    if (settling && settle_n == 0) return;                               // cohort not started yet
     float* const base = settling ? lanes.staging : recs;
     const int slot = threadIdx.x >> 2;
     const int env = first + slot;
@@ -94,11 +102,11 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     float* rec = s_rec + slot * QS_REC;
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
-    if (settling && lanes.spawn) { E::settle_spawn(cfg, rec, gid, lanes.generation); LaneDev::sync(); }
+    if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
-    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settling ? lanes.settle_n : 0, any_trace && env == tap.env ? tap.rows : nullptr, any_trace);
+    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace);
     if (settling) {
-        if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)lanes.settle_n);
+        if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
         __syncthreads();
         tile_store(s_rec, base, first, limit);
         return;
@@ -157,28 +165,34 @@ __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_
 
 // Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
 // settling into the pool (they replace the entries at the rotating cursor) ...
-__global__ void k_pool_publish(const unsigned long long* __restrict__ ctl, const float* __restrict__ staging, float* __restrict__ pool, int pool_size) {
-    const size_t total = (size_t)ctl[CTL_R] * QS_REC;
+__global__ void k_pool_publish(const unsigned long long* __restrict__ ctl, const float* __restrict__ staging, float* __restrict__ pool, int pool_size,
+                               int cohort, int slice) {
+    const size_t total = (size_t)ctl[CTL_R + cohort] * QS_REC;
     const size_t cursor = (size_t)ctl[CTL_CURSOR];
+    const float* src = staging + (size_t)cohort * slice * QS_REC;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t e = i / QS_REC, f = i % QS_REC;
-        pool[((cursor + e) % (size_t)pool_size) * QS_REC + f] = staging[i];
+        pool[((cursor + e) % (size_t)pool_size) * QS_REC + f] = src[i];
     }
 }
-// ... then decide how many records the next epoch settles: as many as auto-resets have consumed and no refill has matched yet.
-__global__ void k_pool_plan(unsigned long long* __restrict__ ctl, int pool_size, int abort_epoch) {
+// ... then decide how many records this cohort settles next: as many as auto-resets have consumed and no refill has matched yet.
+__global__ void k_pool_plan(unsigned long long* __restrict__ ctl, int pool_size, int cohort, int slice, int abort_all) {
     if (blockIdx.x || threadIdx.x) return;
     const unsigned long long P = (unsigned long long)pool_size;
-    if (abort_epoch) { ctl[CTL_BACKED] -= ctl[CTL_R]; ctl[CTL_R] = 0; return; }   // streaming switched off mid-epoch: nothing was delivered
-    ctl[CTL_CURSOR] = (ctl[CTL_CURSOR] + ctl[CTL_R]) % P;
-    ctl[CTL_REFILLED] += ctl[CTL_R];
+    if (abort_all) {   // streaming switched off: settles in progress are dropped, nothing was delivered for them
+        for (int c = 0; c < QS_COHORTS; c++) { ctl[CTL_BACKED] -= ctl[CTL_R + c]; ctl[CTL_R + c] = 0; }
+        return;
+    }
+    ctl[CTL_CURSOR] = (ctl[CTL_CURSOR] + ctl[CTL_R + cohort]) % P;
+    ctl[CTL_REFILLED] += ctl[CTL_R + cohort];
     unsigned long long consumed = ctl[CTL_CONSUMED], backed = ctl[CTL_BACKED];
     unsigned long long want = consumed > backed ? consumed - backed : 0;
     if (want > P) { backed = consumed - P; want = P; }       // demand beyond a fully fresh pool is not owed later
+    if (want > (unsigned long long)slice) want = (unsigned long long)slice;
     want -= want % QS_ENVS_PER_WAVE;
-    if (want < 64) want = 0;                                  // not worth a wave yet
+    if (want < 32) want = 0;                                  // not worth two waves yet
     ctl[CTL_BACKED] = backed + want;
-    ctl[CTL_R] = want;
+    ctl[CTL_R + cohort] = want;
 }
 
 // QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297); all settles run side by side.
@@ -271,7 +285,9 @@ struct qs_handle {
     float* d_pool;      // pre-settled reset states the step kernel draws from
     float* d_pool_back; // streaming refill: staging records that are being settled by the extra workgroups of k_step
     int pool_size, pool_generation;
-    int streaming, phase;   // phase = launch index inside the current epoch
+    int streaming;
+    long long tick;         // qs_step launches since streaming was switched on
+    int cohort_generation[QS_COHORTS];
     float* trace_rows; int trace_env;
     int n_simd, step_variant;   // SIMDs of the device; 0 = pick k_step / k_step_dense by grid size, 1 / 2 = forced (QS_STEP_VARIANT)
     unsigned long long* d_stats;
@@ -378,14 +394,14 @@ int qs_get_obs(qs_handle* h, float* obs) {
 
 int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
     if (!h) QS_FAIL(-1, "null handle");
-    if (on && h->pool_size <= 0) QS_FAIL(-1, "streaming refill needs a reset pool (cfg.reset_pool > 0)");
+    if (on && h->pool_size < QS_COHORTS * QS_ENVS_PER_WAVE) QS_FAIL(-1, "streaming refill needs a reset pool of at least %d entries (cfg.reset_pool)", QS_COHORTS * QS_ENVS_PER_WAVE);
     if (on && !h->d_pool_back) QS_HIP(hipMalloc(&h->d_pool_back, (size_t)h->pool_size * QS_REC * sizeof(float)));
     if (on && !h->streaming) {          // resets that happened while streaming was off are not owed
         QS_HIP(hipMemcpyAsync(&h->d_stats[CTL_BACKED], &h->d_stats[CTL_CONSUMED], sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
-        h->phase = 0;
+        h->tick = 0;
     }
-    if (!on && h->streaming && h->phase != 0) {   // the epoch in progress is dropped
-        hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, 1);
+    if (!on && h->streaming) {   // settles in progress are dropped
+        hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, 0, 0, 1);
         QS_HIP(hipGetLastError());
     }
     h->streaming = on ? 1 : 0;
@@ -401,21 +417,32 @@ int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
 int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     if (!h || !actions || !obs || !rew || !done || !trunc) QS_FAIL(-1, "null argument");
     PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
-    SettleLanes lanes; lanes.staging = nullptr; lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.spawn = 0; lanes.settle_n = 0; lanes.generation = 0;
+    SettleLanes lanes;
+    memset(&lanes, 0, sizeof(lanes));
+    lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.waves_per_cohort = 1; lanes.slice = 0;
     TraceTap tap; tap.rows = h->trace_rows; tap.env = h->trace_env;
     int grid = lanes.n_env_waves;
     if (h->streaming) {
-        // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder)
+        // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder);
+        // cohort c runs the same schedule c * epoch / QS_COHORTS launches later
         const int rep = h->cfg.action_repeat, epoch = (h->cfg.settle_steps + rep - 1) / rep;
-        if (h->phase == 0) {
-            hipLaunchKernelGGL(k_pool_publish, dim3(256), dim3(256), 0, h->stream, h->d_stats, h->d_pool_back, h->d_pool, h->pool_size);
-            hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, 0);
-            h->pool_generation++;
+        const int slice = (h->pool_size / QS_COHORTS) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE;
+        lanes.staging = h->d_pool_back; lanes.slice = slice; lanes.waves_per_cohort = slice / QS_ENVS_PER_WAVE;
+        for (int c = 0; c < QS_COHORTS; c++) {
+            const long long t = h->tick - (long long)c * epoch / QS_COHORTS;
+            if (t < 0) continue;                       // not started yet: settle_n stays 0
+            const int phase = (int)(t % epoch);
+            if (phase == 0) {
+                hipLaunchKernelGGL(k_pool_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_pool_back, h->d_pool, h->pool_size, c, slice);
+                hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, c, slice, 0);
+                h->pool_generation++;
+                h->cohort_generation[c] = h->pool_generation;
+            }
+            lanes.spawn[c] = phase == 0; lanes.generation[c] = h->cohort_generation[c];
+            lanes.settle_n[c] = phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
         }
-        lanes.staging = h->d_pool_back; lanes.spawn = h->phase == 0; lanes.generation = h->pool_generation;
-        lanes.settle_n = h->phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
-        grid += n_waves(h->pool_size);
-        h->phase = (h->phase + 1) % epoch;
+        grid += QS_COHORTS * lanes.waves_per_cohort;
+        h->tick++;
     }
     if (h->timing) hipEventRecord(h->ev0, h->stream);
     // more waves than 1.5 x the SIMDs of the device: the two-waves-per-SIMD build of the same body wins (see k_step_dense)
