@@ -18,6 +18,24 @@
 #include "qs_layout.h"
 #include "../../include/qs_amd.h"
 
+// Optional cycle accounting per phase of the substep (build with -DQS_PROFILE_PHASES; tools/phase_profile.py): s_memtime at
+// the phase boundaries of workgroup 0, accumulated in a __device__ array.  Compiled out otherwise.
+#if defined(QS_PROFILE_PHASES) && defined(__HIPCC__)
+__device__ unsigned long long qs_phase_cycles[16];
+__device__ unsigned long long qs_phase_t0;   // written by one lane of workgroup 0 only
+#endif
+#if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define QS_PHASE_BEGIN if (blockIdx.x == 0 && threadIdx.x == 0) qs_phase_t0 = __builtin_readcyclecounter();
+#define QS_PHASE_G(k) if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); qs_phase_cycles[k] += n_ - qs_phase_t0; qs_phase_t0 = n_; }
+#define QS_PHASE(k) QS_PHASE_G(k)
+#define QS_PHASE_END
+#else
+#define QS_PHASE_BEGIN
+#define QS_PHASE_G(k)
+#define QS_PHASE(k)
+#define QS_PHASE_END
+#endif
+
 namespace qs {
 
 // ------------------------------------------------------------------ Go1 model constants (go1.urdf)
@@ -324,6 +342,7 @@ template <class T> struct Sim {
             for (int c = 0; c < NR; c++)
                 res[c] = res[c] + (Ap[NR * 0][c] * lam_all[NR * 0] + Ap[NR * 1][c] * lam_all[NR * 1] + Ap[NR * 2][c] * lam_all[NR * 2] + Ap[NR * 3][c] * lam_all[NR * 3]);
         }
+        QS_PHASE_G(9)
         const V big = V(1e10f), zero = V(0.0f);
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
         for (int it = 0; it < cfg.solver_iters; it++) {
@@ -365,6 +384,7 @@ template <class T> struct Sim {
 #pragma unroll
         for (int c = 0; c < NR; c++)
             lam_own[c] = qsel(T::is_leg(0), lam_all[NR * 0 + c], qsel(T::is_leg(1), lam_all[NR * 1 + c], qsel(T::is_leg(2), lam_all[NR * 2 + c], lam_all[NR * 3 + c])));
+        QS_PHASE_G(10)
         o.foot_force = lam_own[0] * (1.0f / dt);   // getContactPoints()[9] = normal impulse / dt
         s.warm = lam_own[0];
 
@@ -496,6 +516,7 @@ template <class T> struct Sim {
             T::opaque(ml[0]); T::opaque(ml[1]); T::opaque(ml[2]);
             build_model(P, ml);
         }
+        QS_PHASE_BEGIN
         const float dt = (float)cfg.dt;
         const V zero = V(0.0f), one = V(1.0f);
         V fx = T::fx(), sy = T::sy();
@@ -516,6 +537,7 @@ template <class T> struct Sim {
         v0.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
         v0.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
 
+        QS_PHASE(1)
         // ---- leg kinematics in base coordinates
         V s1, c1, s2, c2, s23, c23;
         qsincos(s.q[0], s1, c1); qsincos(s.q[1], s2, c2); qsincos(s.q[1] + s.q[2], s23, c23);
@@ -529,6 +551,7 @@ template <class T> struct Sim {
         V3v X3 = mk3<V>(c23, s1 * s23, -c1 * s23), Z3 = mk3<V>(s23, -s1 * c23, c1 * c23);
         V3v rf = p3 + Z3 * V(LEG_Z);                        // foot centre
 
+        QS_PHASE(2)
         // ---- link inertias about the base origin
         SI<V> I1 = part_inertia<V>(P.m_hip, P.c_hip, P.I_hip, p1, ax1, Y, Z1);
         SI<V> I2 = part_inertia<V>(P.m_thigh, P.c_thigh, P.I_thigh, p2, X2, Y, Z2);
@@ -539,6 +562,7 @@ template <class T> struct Sim {
         S1.a = ax1; S1.l = cross(p1, ax1);
         S2.a = Y; S2.l = cross(p2, Y);
         S3j.a = Y; S3j.l = cross(p3, Y);
+        QS_PHASE(3)
         // ---- RNEA bias with qdd = 0, base acceleration 0, gravity as the fictitious base acceleration -g
         Spv a0; a0.a = mk3<V>(zero, zero, zero); a0.l = Rz * V(cfg.gravity);
         Spv vj1, vj2, vj3;
@@ -555,6 +579,7 @@ template <class T> struct Sim {
         Spv f0 = apply(Pr.I0, a0) + crf(v0, apply(Pr.I0, v0));
         V Cb[6] = {T::quad_sum(fs1.a.x) + f0.a.x, T::quad_sum(fs1.a.y) + f0.a.y, T::quad_sum(fs1.a.z) + f0.a.z,
                    T::quad_sum(fs1.l.x) + f0.l.x, T::quad_sum(fs1.l.y) + f0.l.y, T::quad_sum(fs1.l.z) + f0.l.z};
+        QS_PHASE(4)
         // ---- CRBA: B = [F1 F2 F3] (6x3), D (3x3 symmetric)
         SI<V> Ic2 = I2 + I3, Ic1 = I1 + Ic2;
         Spv F1 = apply(Ic1, S1), F2 = apply(Ic2, S2), F3 = apply(I3, S3j);
@@ -576,6 +601,7 @@ template <class T> struct Sim {
             BK[1][i] = Bm[0][i] * K12 + Bm[1][i] * K22 + Bm[2][i] * K23;
             BK[2][i] = Bm[0][i] * K13 + Bm[1][i] * K23 + Bm[2][i] * K33;
         }
+        QS_PHASE(5)
         // ---- S = Hbb - sum_legs B K B^T, then Cholesky (replicated)
         SI<V> Itot;
         Itot.m = Pr.mtot;
@@ -604,6 +630,7 @@ template <class T> struct Sim {
         V Ld[6];
         chol6<V>(Sm, Ld);
 
+        QS_PHASE(6)
         // ---- unconstrained accelerations
         V t1 = tau[0] - C1, t2 = tau[1] - C2, t3 = tau[2] - C3;
         V y1 = K11 * t1 + K12 * t2 + K13 * t3, y2 = K12 * t1 + K22 * t2 + K23 * t3, y3 = K13 * t1 + K23 * t2 + K33 * t3;
@@ -635,6 +662,7 @@ template <class T> struct Sim {
         vs.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
         vs.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
 
+        QS_PHASE(7)
         // ---- collision: foot sphere vs plane z = 0 ; other link primitives only flag invalid contacts (quadruped.py:243-249)
         V dist = s.pos.z + dot(Rz, rf) - FOOT_R;
         M act_m = qlt(dist, V(THR_FOOT));
@@ -674,6 +702,7 @@ template <class T> struct Sim {
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
         if (T::any(qor(act_m, any_lim))) {
+        QS_PHASE(8)
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
         Row rows[6];
 #pragma unroll
@@ -752,6 +781,7 @@ template <class T> struct Sim {
         } else {
             o.foot_force = zero; s.warm = zero;
         }
+        QS_PHASE(11)
         // ---- positions: semi-implicit Euler, quaternion by the exponential map of w_world * dt
         s.pos.x = s.pos.x + dt * s.vlin.x; s.pos.y = s.pos.y + dt * s.vlin.y; s.pos.z = s.pos.z + dt * s.vlin.z;
         {
@@ -769,6 +799,8 @@ template <class T> struct Sim {
         }
 #pragma unroll
         for (int j = 0; j < 3; j++) s.q[j] = s.q[j] + dt * s.qd[j];
+        QS_PHASE(12)
+        QS_PHASE_END
     }
 };
 

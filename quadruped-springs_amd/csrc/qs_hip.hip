@@ -78,6 +78,7 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
     const qs_config& cfg = *cfgp;
+    QS_PHASE_BEGIN
     const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles pool records
     const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
     const int first = settling ? cohort * lanes.slice + (((int)blockIdx.x - lanes.n_env_waves) % lanes.waves_per_cohort) * QS_ENVS_PER_WAVE
@@ -104,7 +105,9 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
     if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
+    QS_PHASE(13)
     E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace);
+    QS_PHASE(14)
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
         __syncthreads();
@@ -149,6 +152,7 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
         obs_out[(size_t)first * od + i] = v;
         obs_keep[(size_t)first * od + i] = v;
     }
+    QS_PHASE(15)
 }
 
 #define QS_STEP_ARGS const qs_config* __restrict__ cfgp, float* __restrict__ recs, const float* __restrict__ actions, float* __restrict__ obs_out,    \
@@ -566,5 +570,15 @@ int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets) {
     if (resets) *resets = v[1];
     return 0;
 }
+
+#ifdef QS_PROFILE_PHASES
+// debug builds only (tools/phase_profile.py): cycles of workgroup 0 per substep phase, summed over all substeps so far
+int qs_debug_phases(unsigned long long* out16, int reset) {
+    QS_HIP(hipDeviceSynchronize());
+    QS_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(qs_phase_cycles), 16 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[16] = {0}; QS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(qs_phase_cycles), z, sizeof(z))); }
+    return 0;
+}
+#endif
 
 }  // extern "C"

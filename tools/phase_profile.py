@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Cycles per phase of the rigid-body substep, measured with s_memtime in workgroup 0 of a -DQS_PROFILE_PHASES build:
+
+    QS_HIPCC_EXTRA=-DQS_PROFILE_PHASES QS_BUILD_OUT=quadruped-springs_amd/qs_amd/exp/prof.so python quadruped-springs_amd/build.py --force
+    QS_LIB_PATH=$PWD/quadruped-springs_amd/qs_amd/exp/prof.so python tools/phase_profile.py
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "quadruped-springs_amd"))
+import torch
+from qs_amd.vec_env import QuadrupedVecEnv
+
+NAMES = {1: "base rotation, velocities", 2: "leg kinematics", 3: "link inertias", 4: "RNEA bias", 5: "CRBA (B, D, K)", 6: "Schur + Cholesky",
+         7: "accelerations, v*", 8: "collision", 9: "contact rows + Delassus", 10: "PGS sweeps", 11: "delta v", 12: "integrate positions"}
+env = QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_pool=4096, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                      enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1)
+env.reset_tensor()
+a = torch.rand((16, 8192, 6), device="cuda") * 2 - 1
+for i in range(20):
+    env.step_tensor(a[i % 16])
+out = (C.c_uint64 * 16)()
+env.lib.qs_debug_phases(out, 1)
+n = 200
+for i in range(n):
+    env.step_tensor(a[i % 16])
+env.lib.qs_debug_phases(out, 0)
+tot = sum(out)
+print(f"{'phase':32s} cycles/substep   share")
+for k in range(1, 13):
+    print(f"{NAMES[k]:32s} {out[k] / (n * 10):12.0f}   {100 * out[k] / tot:5.1f} %")
+print(f"{'substeps total':32s} {sum(out[1:13]) / (n * 10):12.0f}")
+print(f"per env-step: tile load {out[13] / n:.0f}, E::step outside the substeps {(out[14] - 0) / n:.0f} (phase 14 = after the last substep marker .. end of E::step, "
+      f"phase 1 also absorbs the action prologue of the first substep), auto-reset + stores {out[15] / n:.0f} cycles")
