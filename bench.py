@@ -181,7 +181,9 @@ def main():
         # process); null when the run differs from the profiled one
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_d_pmc.json")))
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))[-1]   # the latest committed PMC passes
+            pmc = json.load(open(pmc_file))
             if (pmc["workload"], pmc["envs_per_gpu"], pmc["reset_pool"], pmc["settle_lanes"]) == (args.workload, n, args.reset_pool, streaming):
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
         except (OSError, KeyError, ValueError):
@@ -212,7 +214,7 @@ def main():
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_step", "kernel_ms": kavg * 1e3,
-                         "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (profiles/r01_d_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~55 k dependent fp32 VALU instructions per wave per env-step (78 % VALU-active): latency/issue-bound, not HBM-bound"},
+                         "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (latest profiles/r*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step (80 % VALU-active): latency/issue-bound, not HBM-bound"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw)
