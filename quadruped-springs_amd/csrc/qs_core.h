@@ -21,18 +21,22 @@
 // Optional cycle accounting per phase of the substep (build with -DQS_PROFILE_PHASES; tools/phase_profile.py): s_memtime at
 // the phase boundaries of workgroup 0, accumulated in a __device__ array.  Compiled out otherwise.
 #if defined(QS_PROFILE_PHASES) && defined(__HIPCC__)
-__device__ unsigned long long qs_phase_cycles[16];
-__device__ unsigned long long qs_phase_t0;   // written by one lane of workgroup 0 only
+__device__ unsigned long long qs_phase_cycles[32];
+__device__ unsigned long long qs_phase_t0, qs_phase_sub0;   // written by one lane of workgroup 0 only
 #endif
 #if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
 #define QS_PHASE_BEGIN if (blockIdx.x == 0 && threadIdx.x == 0) qs_phase_t0 = __builtin_readcyclecounter();
 #define QS_PHASE_G(k) if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); qs_phase_cycles[k] += n_ - qs_phase_t0; qs_phase_t0 = n_; }
 #define QS_PHASE(k) QS_PHASE_G(k)
+#define QS_PHASE_SUB(k) if (blockIdx.x == 0 && threadIdx.x == 0) { qs_phase_cycles[16 + ((k) < 15 ? (k) : 15)] += __builtin_readcyclecounter() - qs_phase_sub0; }
+#define QS_PHASE_SUB_BEGIN if (blockIdx.x == 0 && threadIdx.x == 0) qs_phase_sub0 = __builtin_readcyclecounter();
 #define QS_PHASE_END
 #else
 #define QS_PHASE_BEGIN
 #define QS_PHASE_G(k)
 #define QS_PHASE(k)
+#define QS_PHASE_SUB(k)
+#define QS_PHASE_SUB_BEGIN
 #define QS_PHASE_END
 #endif
 

@@ -580,8 +580,10 @@ template <class T> struct Env {
         for (int k = 0; k < n_sub; k++) {  // gym_env.py:236-237, 207-216
             V tau[3];
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
+            QS_PHASE_SUB_BEGIN
             S::actuate(cfg, P, s, cmd, o, tau);
             S::substep(cfg, P, s, tau, o);
+            QS_PHASE_SUB(k)
             if (any_trace) {
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
             }

@@ -20,16 +20,17 @@ env.reset_tensor()
 a = torch.rand((16, 8192, 6), device="cuda") * 2 - 1
 for i in range(20):
     env.step_tensor(a[i % 16])
-out = (C.c_uint64 * 16)()
+out = (C.c_uint64 * 32)()
 env.lib.qs_debug_phases(out, 1)
 n = 200
 for i in range(n):
     env.step_tensor(a[i % 16])
 env.lib.qs_debug_phases(out, 0)
-tot = sum(out)
+tot = sum(out[:16])
 print(f"{'phase':32s} cycles/substep   share")
 for k in range(1, 13):
     print(f"{NAMES[k]:32s} {out[k] / (n * 10):12.0f}   {100 * out[k] / tot:5.1f} %")
 print(f"{'substeps total':32s} {sum(out[1:13]) / (n * 10):12.0f}")
 print(f"per env-step: tile load {out[13] / n:.0f}, E::step outside the substeps {(out[14] - 0) / n:.0f} (phase 14 = after the last substep marker .. end of E::step, "
       f"phase 1 also absorbs the action prologue of the first substep), auto-reset + stores {out[15] / n:.0f} cycles")
+print("cycles of substep k of the env step (k = 0 pays the cold instruction cache): " + ", ".join(f"{out[16 + k] / n:.0f}" for k in range(10)))
