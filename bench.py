@@ -43,11 +43,14 @@ def workload(name):
 
 
 def cpu_baseline(cfg_kwargs, budget_s=12.0):
-    """The oracle (CPU restatement, float64, scalar C, one thread) timed on this box's host cores on a bounded sample."""
+    """The oracle (CPU restatement, float64, scalar C, OpenMP over environments) timed on this box's host cores on a bounded sample."""
     import numpy as np
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)          # read by libgomp when the oracle library is loaded
+    os.environ["OMP_WAIT_POLICY"] = "passive"
     from oracle.qso import Oracle
     from qs_amd.config import build_config
-    n = 8
+    n = 8 * cores
     cfg, _ = build_config(n_envs=n, auto_reset=True, seed=1234, **cfg_kwargs)
     o = Oracle(cfg)
     o.reset()
@@ -58,8 +61,8 @@ def cpu_baseline(cfg_kwargs, budget_s=12.0):
             o.step(rng.uniform(-1, 1, size=(n, cfg.action_dim)).astype(np.float32))
         steps += 20
     dt = time.perf_counter() - t0
-    return dict(value=n * steps / dt, unit="env-steps/s", cores=1, kind="port",
-                sample=f"{n} envs x {steps} env-steps of the same workload on 1 host thread, auto-reset incl. 2500-substep settles ({dt:.1f} s)")
+    return dict(value=n * steps / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{n} envs x {steps} env-steps of the same workload on {cores} host threads (OpenMP over environments), auto-reset incl. 2500-substep settles ({dt:.1f} s)")
 
 
 def main():
@@ -73,9 +76,15 @@ def main():
     ap.add_argument("--no-pool-streaming", action="store_true",
                     help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     ap.add_argument("--solver-residual-threshold", type=float, default=0.0,
                     help="PyBullet solverResidualThreshold (its default is 1e-7); 0 = always int(300/action_repeat) sweeps")
     args = ap.parse_args()
+    if args.cpu_baseline_only:   # runs in a child process that never touches the GPU or torch: its OpenMP runtime starts with the settings below
+        _, kw = workload(args.workload)
+        kw["solver_residual_threshold"] = args.solver_residual_threshold
+        print(json.dumps(cpu_baseline(kw)))
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -217,7 +226,12 @@ def main():
                          "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (latest profiles/r*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step (80 % VALU-active): latency/issue-bound, not HBM-bound"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kw)
+            import subprocess
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+                                    "--solver-residual-threshold", str(args.solver_residual_threshold)], capture_output=True, text=True, timeout=300)
+            if child.returncode != 0:
+                raise SystemExit("cpu_baseline child failed:\n" + child.stderr[-2000:])
+            out["cpu_baseline"] = json.loads(child.stdout.strip().splitlines()[-1])
         print(json.dumps(out))
     if world > 1 or sharded:
         torch.distributed.destroy_process_group()

@@ -1,6 +1,11 @@
 """ctypes loader for the CPU oracle (oracle/qso.h).  TEST INFRASTRUCTURE ONLY: importable from tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from the product package."""
 import ctypes as C
+import os as _os
+
+# the C oracle spreads environments over OpenMP threads; one thread unless the caller (bench.py's cpu_baseline) asks for more
+_os.environ.setdefault("OMP_NUM_THREADS", "1")
+_os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 import os
 import subprocess
 

@@ -617,6 +617,9 @@ int qso_create(const qso_config* cfg, qso_handle** out) {
 void qso_destroy(qso_handle* h) { if (h) { free(h->env); free(h); } }
 
 int qso_reset(qso_handle* h, const uint8_t* mask) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int i = 0; i < h->cfg.n_envs; i++) if (!mask || mask[i]) reset_env(h, i);
     return 0;
 }
@@ -640,6 +643,11 @@ static wrap_traits wrap_traits_of(int mode) {
 
 int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     const qso_config* cfg = &h->cfg; int d = cfg->action_dim;
+    /* environments are independent (gym_env.py:132-137): with -fopenmp they spread over OMP_NUM_THREADS host threads, which is
+       what bench.py's cpu_baseline uses; the default is one thread */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int i = 0; i < cfg->n_envs; i++) {
         qso_env* e = &h->env[i];
         /* gym_env.py:227-256 */
