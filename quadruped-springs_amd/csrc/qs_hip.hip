@@ -314,6 +314,8 @@ extern "C" {
 const char* qs_last_error(void) { return g_err; }
 const char* qs_version(void) { return "qs_amd 0.1 (gfx950, quad-per-env)"; }
 
+static int create_impl(const qs_config* cfg, int device, qs_handle* h);
+
 int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (!cfg || !out) QS_FAIL(-1, "null argument");
     if (cfg->n_envs <= 0) QS_FAIL(-1, "n_envs must be positive");
@@ -335,6 +337,13 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     qs_handle* h = new (std::nothrow) qs_handle();
     if (!h) QS_FAIL(-4, "out of host memory");
     memset(h, 0, sizeof(*h));
+    int rc = create_impl(cfg, device, h);
+    if (rc != 0) { qs_destroy(h); return rc; }   // frees whatever was allocated before the failure (the error text is kept)
+    *out = h;
+    return 0;
+}
+
+static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
     h->cfg = *cfg; h->device = device; h->stream = nullptr;
     {
         hipDeviceProp_t prop;
@@ -365,18 +374,18 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
         QS_HIP(hipGetLastError());
     }
     QS_HIP(hipStreamSynchronize(h->stream));
-    *out = h;
     return 0;
 }
 
-void qs_destroy(qs_handle* h) {
+void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null members are skipped)
     if (!h) return;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
     if (h->d_pool) hipFree(h->d_pool);
     if (h->d_pool_back) hipFree(h->d_pool_back);
-    hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
     delete h;
 }
 

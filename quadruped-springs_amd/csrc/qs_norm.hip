@@ -115,13 +115,15 @@ int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, f
     memset(h, 0, sizeof(*h));
     h->n = n_envs; h->o = obs_dim; h->device = device; h->clip_obs = clip_obs; h->clip_rew = clip_reward; h->gamma = gamma; h->eps = epsilon;
     const int C = obs_dim + 1;
-    QN_HIP(hipMalloc(&h->d_stat, (size_t)(4 * C + 2) * sizeof(double)));
-    QN_HIP(hipMalloc(&h->d_ret, (size_t)n_envs * sizeof(double)));
-    QN_HIP(hipMemset(h->d_ret, 0, (size_t)n_envs * sizeof(double)));
+#define QN_HIP_H(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(qs_g_err, sizeof(qs_g_err), "%s failed: %s", #call, hipGetErrorString(e_)); qs_norm_destroy(h); return -2; } } while (0)
+    QN_HIP_H(hipMalloc(&h->d_stat, (size_t)(4 * C + 2) * sizeof(double)));
+    QN_HIP_H(hipMalloc(&h->d_ret, (size_t)n_envs * sizeof(double)));
+    QN_HIP_H(hipMemset(h->d_ret, 0, (size_t)n_envs * sizeof(double)));
     double init[4 * 256 + 2];
     for (int c = 0; c < C; c++) { init[c] = 0.0; init[C + c] = 1.0; init[2 * C + 2 + c] = 0.0; init[3 * C + 2 + c] = 0.0; }
     init[2 * C] = init[2 * C + 1] = 1e-4;   // RunningMeanStd(epsilon=1e-4)
-    QN_HIP(hipMemcpy(h->d_stat, init, (size_t)(4 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
+    QN_HIP_H(hipMemcpy(h->d_stat, init, (size_t)(4 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
+#undef QN_HIP_H
     *out = h;
     return 0;
 }
