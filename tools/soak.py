@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Long-run sanity of the HIP path: thousands of steps of violent random actions over several configurations, checking that
+states and observations stay finite and physical (unit quaternions, bounded heights / velocities), with both step kernels."""
+import os
+import sys
+
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "quadruped-springs_amd"))
+import numpy as np
+import torch
+from qs_amd.vec_env import QuadrupedVecEnv
+
+CASES = [
+    dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="GROUND_RANDOMIZER"),
+    dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", env_randomizer_mode="TEST_RANDOMIZER", wrapper="LANDING_CONTINUOUS"),
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", env_randomizer_mode="TEST_RANDOMIZER", action_space_mode="CPG"),
+    dict(task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", env_randomizer_mode="MASS_RANDOMIZER", action_space_mode="DEFAULT", wrapper="GO_TO_REST",
+         enable_springs=False),
+    dict(task_env="NO_TASK", observation_space_mode="ENCODER", env_randomizer_mode="GROUND_RANDOMIZER", motor_control_mode="CARTESIAN_PD"),
+]
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for variant in ("1", "2"):
+    os.environ["QS_STEP_VARIANT"] = variant
+    for kw in CASES:
+        kw = dict(dict(enable_springs=True, enable_action_filter=True), **kw)
+        n = 4096
+        env = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_pool=1024, seed=3, **kw)
+        env.reset_tensor()
+        env.pool_streaming(True)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        dones = 0
+        for i in range(steps):
+            a = torch.rand((n, env.action_dim), generator=g, device="cuda") * 2.4 - 1.2     # beyond the action box on purpose
+            if (i // 25) % 3 == 0:
+                a = torch.sign(a)                                                           # bang-bang phases: joint stops, hard landings
+            obs, rew, done, trunc = env.step_tensor(a)
+            dones += int(done.sum())
+            if i % 100 == 99 or i == steps - 1:
+                st = env.get_state()
+                assert torch.isfinite(st).all() and torch.isfinite(obs).all() and torch.isfinite(rew).all(), (kw, i)
+                qn = st[:, 3:7].norm(dim=1)
+                assert (qn - 1).abs().max() < 1e-3, (kw, i, float((qn - 1).abs().max()))
+                # NO_TASK never ends an episode and non-foot links carry no contact force (deviations): a fallen robot
+                # pivots on its feet and its trunk dips below the floor there
+                zmin = -1.0 if kw["task_env"] == "NO_TASK" else -0.05
+                assert st[:, 2].min() > zmin and st[:, 2].max() < 3.0, (kw, i, float(st[:, 2].min()), float(st[:, 2].max()))
+                assert st[:, 7:13].abs().max() <= 30.2 and st[:, 25:].abs().max() <= 30.2, (kw, i)
+        ninv = env.get_info("n_invalid").max().item()
+        print(f"variant {variant} {kw['task_env']:28s} ok: {steps} steps x {n} envs, {dones} episode ends, refilled {env.pool_streaming(False)}, max invalid contacts {ninv:.0f}")
+        env.close()
