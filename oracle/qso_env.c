@@ -1,6 +1,6 @@
 /* qso_env.c -- ORACLE (test infrastructure, not product code).
  * Restatement of the numpy half of the reference's hot path; every function cites the reference lines it follows
- * (paths relative to /root/reference/quadruped_spring/). Pinned by tests/golden/ (tools/gen_golden.py). */
+ * (paths relative to /root/reference/quadruped_spring/). Pinned by tests/golden/ (tests/golden/gen_golden.py). */
 #include "qso_internal.h"
 
 static char g_err[256] = "";

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors by IMPORTING the reference (this container only: /root/reference never travels).
 
-    python tools/gen_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.npz
 
 The reference's numpy half is importable with four tiny shims: a `collections.Sequence`
 alias, fake `pybullet` / `pybullet_data` / `pybullet_utils.bullet_client`, fake `gym`, fake `absl.logging`.
@@ -23,7 +23,7 @@ import types
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "quadruped-springs_amd"))

@@ -1,5 +1,5 @@
 """Pin the oracle's numpy half against golden vectors produced by the reference's own functions
-(tools/gen_golden.py -> tests/golden/stateless.npz, rewards.npz)."""
+(tests/golden/gen_golden.py -> tests/golden/stateless.npz, rewards.npz)."""
 import numpy as np
 import pytest
 

@@ -1,4 +1,4 @@
-"""Oracle full env step vs traces recorded from the REFERENCE's own QuadrupedGymEnv (tools/gen_golden.py, g15).
+"""Oracle full env step vs traces recorded from the REFERENCE's own QuadrupedGymEnv (tests/golden/gen_golden.py, g15).
 
 The reference env ran on a fake BulletClient whose rigid-body step is oracle/qso_phys.c, so every difference found
 here is a difference in the restated caller semantics: action filter, action->command map, PD + PEA torques,

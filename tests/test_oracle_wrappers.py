@@ -1,6 +1,6 @@
 """Landing / go-to-rest phase machine vs the REFERENCE's LandingWrapper and GoToRestWrapper.
 
-tools/gen_golden.py wraps the reference's own QuadrupedGymEnv (fake Bullet on oracle physics) in the reference's wrappers
+tests/golden/gen_golden.py wraps the reference's own QuadrupedGymEnv (fake Bullet on oracle physics) in the reference's wrappers
 and logs every inner env.step they issue; here each of those inner steps is one oracle step in wrapper mode, which has to
 reproduce the scripted action, the swapped motor gains (through the state), the phase flag, rewards and dones."""
 import ast
