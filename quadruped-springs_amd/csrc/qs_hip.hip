@@ -530,6 +530,7 @@ int qs_info_dim(const qs_handle* h, int which) {
     case QS_INFO_PARAMS: return QS_PARAM_DIM;
     case QS_INFO_TERMINAL_OBS: return h ? h->cfg.obs_dim : -1;
     case QS_INFO_WRAPPER: return 4;
+    case QS_INFO_FILTERED_ACTION: return 12;
     default: return -1;
     }
 }
@@ -546,6 +547,7 @@ int qs_get_info(qs_handle* h, int which, float* out) {
     case QS_INFO_COUNTERS: return gather(h, R_SIM_STEP, 4, out, 1);
     case QS_INFO_LAST_ACTION: return gather(h, R_LAST_ACTION, 12, out, 0);
     case QS_INFO_WRAPPER: return gather_wrapper(h, out);
+    case QS_INFO_FILTERED_ACTION: return gather(h, R_YHIST, 12, out, 0);
     case QS_INFO_TASK:
         hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out);
         QS_HIP(hipGetLastError());

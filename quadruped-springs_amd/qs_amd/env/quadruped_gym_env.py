@@ -2,7 +2,7 @@
 view over the batched device step.  Same constructor keywords, same 4-tuple step / old-gym reset, same getters."""
 import numpy as np
 
-from ..config import EPISODE_LENGTH
+from ..config import EPISODE_LENGTH, scale_command_to_action, to_actual_action_space
 from ..kinematics import leg_fk_jacobian, leg_ik
 from ..spaces import GymEnv
 from ..vec_env import QuadrupedVecEnv
@@ -19,6 +19,9 @@ class _RobotView:
         self._robot_config = env._robot_config
 
     def _state(self):
+        row = self._env._replay_row   # inside a sub-step callback: the state after that physics substep (trace tap)
+        if row is not None:
+            return row[1:38]
         return self._env._vec.get_state()[0].cpu().numpy().astype(np.float64)
 
     def GetBasePosition(self):
@@ -40,12 +43,19 @@ class _RobotView:
         return self._state()[25:37]
 
     def GetMotorTorques(self):
+        row = self._env._replay_row
+        if row is not None:
+            return row[38:50]
         return self._env._vec.get_info("torque")[0].cpu().numpy().astype(np.float64)
 
     def GetBaseOrientationRollPitchYaw(self):
         return self._env._vec.get_info("task")[0, 38:41].cpu().numpy().astype(np.float64)
 
     def GetContactInfo(self):
+        row = self._env._replay_row
+        if row is not None:   # invalid contacts are not part of the trace row: the end-of-step count is reported
+            n_invalid = int(self._env._vec.get_info("n_invalid")[0, 0].item())
+            return int(row[66:70].sum()), n_invalid, list(row[62:66]), [int(f) for f in row[66:70]]
         force = self._env._vec.get_info("foot_force")[0].cpu().numpy()
         flag = self._env._vec.get_info("foot_contact")[0].cpu().numpy()
         n_invalid = int(self._env._vec.get_info("n_invalid")[0, 0].item())
@@ -80,9 +90,72 @@ class _RobotView:
         self._env._vec.set_params("spring_b", np.asarray(b, np.float32)[None])
 
 
+class _MotorModelView:
+    """`robot._motor_model._kp / _kd`: the gains the reference's wrappers swap temporarily (landing_wrapper.py:18-37)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def _get(self, a, b):
+        return self._env._vec.get_info("params")[0, a:b].cpu().numpy().astype(np.float64)
+
+    @property
+    def _kp(self):
+        return np.tile(self._get(10, 13), 4)
+
+    @_kp.setter
+    def _kp(self, v):
+        self._env._vec.set_params("kp", np.broadcast_to(np.asarray(v, np.float32).ravel(), (12,))[:3].reshape(1, 3).copy()
+                                  if np.size(v) > 1 else np.full((1, 3), float(np.asarray(v).ravel()[0]), np.float32))
+
+    @property
+    def _kd(self):
+        return np.tile(self._get(13, 16), 4)
+
+    @_kd.setter
+    def _kd(self, v):
+        self._env._vec.set_params("kd", np.broadcast_to(np.asarray(v, np.float32).ravel(), (12,))[:3].reshape(1, 3).copy()
+                                  if np.size(v) > 1 else np.full((1, 3), float(np.asarray(v).ravel()[0]), np.float32))
+
+
+class _ActionInterfaceView:
+    """The part of env.get_ac_interface() the wrappers call (interface_base.py:75-82, 92-100, 111-119)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def get_init_action(self):
+        return np.asarray(self._env._settling_action, float)
+
+    def get_landing_action(self):
+        return np.asarray(self._env.get_landing_action(), float)
+
+    def _transform_motor_command_to_action(self, command):
+        m = self._env._vec.meta
+        a12 = scale_command_to_action(np.asarray(command, float), m["lower"], m["upper"])
+        return to_actual_action_space(a12, self._env._action_space_mode, m["symm_idx"])
+
+    @staticmethod
+    def generate_ramp(i, i_min, i_max, u_min, u_max):
+        if i < i_min:
+            return u_min
+        if i > i_max:
+            return u_max
+        return u_min + (u_max - u_min) * (i - i_min) / (i_max - i_min)
+
+
 class _TaskView:
     def __init__(self, env):
         self._env = env
+
+    def compute_time_for_peak_heihgt(self):   # task_base.py:157-160 (sic)
+        return float(self._env.robot.GetBaseLinearVelocity()[2]) / 9.81
+
+    def get_jumping(self):
+        return bool(self._scalars()[2] > 0.5)
+
+    def enable_rest_mode(self):   # robot_tasks.py:346-347: sets a flag the reference never reads
+        pass
 
     def _scalars(self):
         return self._env._vec.get_info("task")[0].cpu().numpy()
@@ -130,6 +203,7 @@ class QuadrupedGymEnv(GymEnv):
         verbose=0,
         device=0,
         seed=0,
+        noise=True,   # extensions (not in the reference's signature): device, seed of the counter-based RNG, sensor noise on / off
     ):
         if on_rack or render:
             raise NotImplementedError("on_rack / render need the PyBullet GUI path, which this build does not provide")
@@ -139,7 +213,7 @@ class QuadrupedGymEnv(GymEnv):
             action_repeat=action_repeat, motor_control_mode=motor_control_mode, task_env=task_env,
             observation_space_mode=observation_space_mode, action_space_mode=action_space_mode, enable_springs=enable_springs,
             enable_action_interpolation=enable_action_interpolation, enable_action_filter=enable_action_filter,
-            env_randomizer_mode=env_randomizer_mode, seed=seed)
+            env_randomizer_mode=env_randomizer_mode, seed=seed, noise=noise)
         meta = self._vec.meta
         self._robot_config = meta["robot_config"]
         self._enable_springs = enable_springs
@@ -161,8 +235,11 @@ class QuadrupedGymEnv(GymEnv):
         self.action_dim = self._vec.action_dim
         self.action_space = self._vec.action_space
         self.observation_space = self._vec.observation_space
+        self._replay_row = None
         self.robot = _RobotView(self)
+        self.robot._motor_model = _MotorModelView(self)
         self.task = _TaskView(self)
+        self._ac_interface = _ActionInterfaceView(self)
         self._keys, self._dims = meta["layout"]["keys"], meta["layout"]["dims"]
         self._last_action = np.zeros(self.action_dim)
         self._settling_action = meta["settle_action"]
@@ -186,6 +263,13 @@ class QuadrupedGymEnv(GymEnv):
         a = np.asarray(action, dtype=np.float32).reshape(1, self.action_dim)
         self._last_action = a[0].astype(np.float64).copy()
         obs, rew, done, infos = self._vec.step(a)
+        if self.sub_step_callback is not None:   # gym_env.py:207-216 fires it after every physics substep
+            try:
+                for row in self._vec.get_trace(as_dict=False):
+                    self._replay_row = row
+                    self.sub_step_callback()
+            finally:
+                self._replay_row = None
         info = {}
         if done[0]:
             info["TimeLimit.truncated"] = infos[0]["TimeLimit.truncated"]
@@ -206,7 +290,16 @@ class QuadrupedGymEnv(GymEnv):
         return self._as_dict(out[0].cpu().numpy())
 
     def get_sim_time(self):
+        if self._replay_row is not None:
+            return float(self._replay_row[0])
         return float(self._vec.get_info("counters")[0, 0].item()) * self.sim_time_step
+
+    def get_ac_interface(self):
+        return self._ac_interface
+
+    def get_last_filtered_action(self):
+        return self._vec.get_info("filtered_action")[0, : self.action_dim].cpu().numpy().astype(np.float64) if self._enable_action_filter \
+            else self._last_action
 
     def get_motor_control_mode(self):
         return self._motor_control_mode
@@ -239,7 +332,11 @@ class QuadrupedGymEnv(GymEnv):
         return self._env_randomizer_mode
 
     def set_sub_step_callback(self, callback):
-        self.sub_step_callback = callback  # substeps are fused on the device; the callback is kept but never fired
+        """evaluation_wrapper.py:14: the callback reads the robot after every physics substep.  The substeps are fused on the
+        device, so the per-substep trace tap records them and step() replays the rows: while the callback runs, get_sim_time()
+        and the robot's state getters answer for that substep."""
+        self.sub_step_callback = callback
+        self._vec.set_trace(0 if callback is not None else None)
 
     def print_info(self):
         print("\n*** Environment Info ***")

@@ -401,6 +401,84 @@ def test_device_vec_normalize(torch_cuda, training, norm_reward):
     env.close()
 
 
+def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
+    """The N = 1 QuadrupedGymEnv view with the getters the reference's wrappers use (get_sim_time, get_landing_action,
+    task.is_switched_controller, task.compute_time_for_peak_heihgt, robot._motor_model._kp/_kd).  A host-side loop with the control
+    flow of landing_wrapper.py:40-69, written against those getters only, must issue the inner steps the reference's own
+    LandingWrapper issued (tests/golden/wrappers.npz, land_s1): same scripted actions, same dones, same observations."""
+    from qs_amd.env.quadruped_gym_env import QuadrupedGymEnv
+    g = golden("wrappers.npz")
+    name = "land_s1"
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    kw.pop("wrapper")
+    env = QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", seed=3, noise=False, **kw)
+    assert env.action_dim == 6 and abs(env.env_time_step - 0.01) < 1e-12 and env.are_springs_enabled()
+    state_ref, reset_at, mus = g[f"{name}_state"], list(g[f"{name}_reset_at"]), g[f"{name}_mu"]
+    inner = []
+
+    def inner_step(a):
+        i = len(inner)
+        if i > 0 and i not in reset_at:
+            env._vec.set_state(state_ref[i - 1][None].astype(np.float32))
+        out = env.step(a)
+        inner.append((np.array(a, float), out))
+        return out
+
+    def wrapper_step(action):   # landing_wrapper.py:40-69 + utils/timer.py
+        obs, r, done, info = inner_step(action)
+        if env.task.is_switched_controller() and not done:
+            timer = env.get_sim_time()
+            end = timer + env.task.compute_time_for_peak_heihgt()
+            while not (timer > end or done):
+                timer += env.env_time_step
+                _, r, done, info = inner_step(action)
+            if not done:
+                mm = env.robot._motor_model
+                kp, kd = mm._kp, mm._kd
+                mm._kp, mm._kd = 60.0, 1.5
+                while not done:
+                    _, r, done, info = inner_step(env.get_landing_action())
+                mm._kp, mm._kd = kp, kd
+        return obs, r, done, info
+
+    ep = 0
+    obs = env.reset()
+    env._vec.set_params("mu", np.array([[mus[0]]], np.float32))
+    assert list(obs.keys()) == [str(k) for k in golden("traces.npz")["jip_s1_keys"]]
+    for t, a in enumerate(g[f"{name}_actions"]):
+        _, _, done, info = wrapper_step(a)
+        if done:
+            assert "TimeLimit.truncated" in info
+            ep += 1
+            env.reset()
+            env._vec.set_params("mu", np.array([[mus[ep]]], np.float32))
+            np.testing.assert_allclose(env.robot._motor_model._kp, 75.0)   # the swapped gains were restored (and reset re-draws them anyway)
+    assert len(inner) == len(g[f"{name}_inner_action"]) and ep == len(reset_at) - 1
+    keys = list(obs.keys())
+    for i, (a, (ob, r, dn, info)) in enumerate(inner):
+        np.testing.assert_allclose(a, g[f"{name}_inner_action"][i], atol=1e-6, err_msg=f"inner action {i}")
+        assert dn == bool(g[f"{name}_done"][i]), f"done {i}"
+        if i not in reset_at:
+            flat = np.concatenate([np.atleast_1d(ob[k]) for k in keys])
+            np.testing.assert_allclose(flat, g[f"{name}_obs"][i], atol=2e-2, rtol=1e-3, err_msg=f"obs {i}")
+            np.testing.assert_allclose(r, g[f"{name}_rew"][i], atol=5e-4, rtol=1e-3, err_msg=f"reward {i}")
+    # sub-step callback (evaluation_wrapper.py:14,36-41): fired once per physics substep with that substep's time and state
+    seen = []
+    env.set_sub_step_callback(lambda: seen.append((env.get_sim_time(), env.robot.GetBasePosition()[2])))
+    env.reset()
+    env.step(np.zeros(6))
+    env.step(np.zeros(6))
+    assert len(seen) == 20
+    np.testing.assert_allclose([s[0] for s in seen], (np.arange(20) + 1) * 1e-3, atol=1e-6)
+    assert abs(seen[-1][1] - env.robot.GetBasePosition()[2]) < 1e-6 and len(set(round(s[1], 7) for s in seen)) > 3
+    env.set_sub_step_callback(None)
+    np.testing.assert_allclose(env.get_ac_interface().get_init_action(), env.get_settling_action())
+    q = env.robot.GetMotorAngles()
+    assert env.get_ac_interface()._transform_motor_command_to_action(q).shape == (6,)
+    assert env.get_last_filtered_action().shape == (6,)
+    env.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
