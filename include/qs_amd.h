@@ -144,6 +144,10 @@ enum { QS_PARAM_MU = 0, QS_PARAM_SPRING_K = 1, QS_PARAM_SPRING_B = 2, QS_PARAM_K
 int qs_set_params(qs_handle* h, int which, const float* vals);
 /* number of env-steps' worth of settle substeps executed so far (reset cost accounting) */
 int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets);
+/* qs_step with ONE output array: fused[N][obs_dim + 2] = observation | reward | done + 2 * truncated (floats).  This is the
+ * buffer a sharded run all-gathers to the learner rank (one collective per step, qs_amd/sharded.py), written by the step
+ * kernel itself instead of being packed from four arrays afterwards. */
+int qs_step_fused(qs_handle* h, const float* actions, float* fused);
 /* HIP events bracketing the step kernel of the most recent qs_step (on the handle's stream): elapsed milliseconds, for
  * bench.py's roofline leg.  Recording is off by default (qs_enable_timing). */
 int qs_enable_timing(qs_handle* h, int on);

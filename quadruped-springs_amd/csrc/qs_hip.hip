@@ -116,7 +116,11 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     }
     const bool dn = r.done > 0.5f;
     if (valid && (threadIdx.x & 3) == 0) {
-        rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0;
+        if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
+        else {   // fused layout (qs_step_fused): one row [obs | reward | done + 2 * truncated] per environment
+            float* row = obs_out + (size_t)env * (od + 2);
+            row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
+        }
     }
     if (cfg.auto_reset) {
         const bool do_reset = dn && valid;
@@ -149,7 +153,8 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
         float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
-        obs_out[(size_t)first * od + i] = v;
+        if (rew_out) obs_out[(size_t)first * od + i] = v;
+        else obs_out[(size_t)(first + i / od) * (od + 2) + (i % od)] = v;
         obs_keep[(size_t)first * od + i] = v;
     }
     QS_PHASE(15)
@@ -427,8 +432,19 @@ int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
     return 0;
 }
 
+static int launch_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc);
+
 int qs_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     if (!h || !actions || !obs || !rew || !done || !trunc) QS_FAIL(-1, "null argument");
+    return launch_step(h, actions, obs, rew, done, trunc);
+}
+
+int qs_step_fused(qs_handle* h, const float* actions, float* fused) {
+    if (!h || !actions || !fused) QS_FAIL(-1, "null argument");
+    return launch_step(h, actions, fused, nullptr, nullptr, nullptr);   // a null reward pointer selects the fused row layout in the kernel
+}
+
+static int launch_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
     SettleLanes lanes;
     memset(&lanes, 0, sizeof(lanes));

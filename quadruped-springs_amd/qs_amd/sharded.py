@@ -31,25 +31,36 @@ class ShardedVecEnv:
     def env_id_offset(n_local, rank=None):
         return n_local * (dist.get_rank() if rank is None else rank)
 
+    def _unpack(self):
+        g = self._gathered
+        flags = g[:, self.obs_dim + 1]
+        # done = flag 1 or 3, truncated = flag 3 (done without termination, gym_env.py:246); obs / reward are views, not copies
+        return g[:, : self.obs_dim], g[:, self.obs_dim], flags > 0.5, flags > 2.5
+
     def _gather(self, obs, rew=None, done=None, trunc=None):
         f = self._fused
         f[:, : self.obs_dim] = obs
         f[:, self.obs_dim] = 0 if rew is None else rew
         f[:, self.obs_dim + 1] = 0 if done is None else done.to(torch.float32) + 2 * trunc.to(torch.float32)
         dist.all_gather_into_tensor(self._gathered, f, group=self.group)
-        g = self._gathered
-        flags = g[:, self.obs_dim + 1].to(torch.int32)
-        return g[:, : self.obs_dim], g[:, self.obs_dim], (flags & 1).bool(), (flags & 2).bool()
+        return self._unpack()
 
     def reset(self):
         return self._gather(self.env.reset_tensor())[0]
 
     def step(self, actions=None):
         """`actions`: the global [N, d] batch on the learner rank (ignored elsewhere).  Returns the global
-        (obs [N,o], rew [N], done [N], truncated [N]) on every rank."""
-        if self.rank == self.learner_rank:
+        (obs [N,o], rew [N], done [N], truncated [N]) on every rank (views of the gathered buffer, valid until the next call)."""
+        buf = actions if (self.rank == self.learner_rank and actions.is_contiguous() and actions.dtype == torch.float32
+                          and actions.device == self._actions.device) else self._actions
+        if self.rank == self.learner_rank and buf is self._actions:
             self._actions.copy_(actions)
-        dist.broadcast(self._actions, src=self.learner_rank, group=self.group)
+        dist.broadcast(buf, src=self.learner_rank, group=self.group)
         lo = self.rank * self.n_local
-        obs, rew, done, trunc = self.env.step_tensor(self._actions[lo: lo + self.n_local].contiguous())
+        mine = buf[lo: lo + self.n_local]          # a row slice: contiguous
+        if hasattr(self.env, "step_fused"):        # the step kernel writes the fused row itself (qs_step_fused)
+            self.env.step_fused(mine, self._fused)
+            dist.all_gather_into_tensor(self._gathered, self._fused, group=self.group)
+            return self._unpack()
+        obs, rew, done, trunc = self.env.step_tensor(mine.contiguous())
         return self._gather(obs, rew, done, trunc)

@@ -89,6 +89,13 @@ class QuadrupedVecEnv(SB3VecEnv):
         _lib.check(self.lib.qs_step(self.h, self._ptr(a), self._ptr(self._obs), self._ptr(self._rew), self._ptr(self._done), self._ptr(self._trunc)))
         return self._obs, self._rew, self._done, self._trunc
 
+    def step_fused(self, actions, out):
+        """One step with a single output: `out` [N, obs_dim + 2] float32 CUDA tensor = observation | reward | done + 2 * truncated
+        (the row a sharded run all-gathers, qs_amd/sharded.py)."""
+        self._stream()
+        _lib.check(self.lib.qs_step_fused(self.h, self._ptr(actions), self._ptr(out)))
+        return out
+
     def get_state(self):
         out = self.torch.empty((self.num_envs, 37), dtype=self.torch.float32, device=self.device)
         self._stream()

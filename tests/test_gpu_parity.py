@@ -479,6 +479,30 @@ def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
     env.close()
 
 
+def test_fused_step_output(torch_cuda):
+    """qs_step_fused writes [obs | reward | done + 2 truncated] rows: same numbers as the four arrays of qs_step."""
+    from qs_amd.vec_env import QuadrupedVecEnv
+    kw = dict(num_envs=300, auto_reset=True, reset_pool=64, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+              enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5)
+    a, b = QuadrupedVecEnv(**kw), QuadrupedVecEnv(**kw)
+    a.reset(); b.reset()
+    out = torch_cuda.zeros((300, a.obs_dim + 2), dtype=torch_cuda.float32, device="cuda")
+    rng = np.random.default_rng(3)
+    seen = set()
+    for i in range(60):
+        act = rng.uniform(-1, 1, size=(300, 6)).astype(np.float32)
+        act[:, 1::3] = -1.0; act[:, 2::3] = 1.0 if (i // 6) % 2 else -0.5
+        t = torch_cuda.from_numpy(act).cuda()
+        obs, rew, done, trunc = a.step_tensor(t)
+        b.step_fused(t, out)
+        o = out.cpu().numpy()
+        assert np.array_equal(o[:, :-2], obs.cpu().numpy()) and np.array_equal(o[:, -2], rew.cpu().numpy())
+        assert np.array_equal(o[:, -1], done.cpu().numpy() + 2.0 * trunc.cpu().numpy())
+        seen.update(o[:, -1].tolist())
+    assert 1.0 in seen and 0.0 in seen
+    a.close(); b.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
