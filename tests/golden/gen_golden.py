@@ -606,6 +606,52 @@ def gen_traces():
     print("traces.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- G22 Go1 model data
+def gen_urdf():
+    """Numeric tables of the reference's robot description (go1/go1_description/urdf/go1.urdf): per link mass,
+    centre of mass, inertia tensor and collision primitives; per joint type, parent, child, origin, axis and limits."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse("/root/reference/quadruped_spring/go1/go1_description/urdf/go1.urdf").getroot()
+    f3 = lambda t, d="0 0 0": np.array([float(x) for x in (t if t is not None else d).split()])
+    links, joints = root.findall("link"), root.findall("joint")
+    lname = [l.get("name") for l in links]
+    mass, com, com_rpy, inertia, col_type, col_size, col_xyz, col_rpy = [], [], [], [], [], [], [], []
+    for l in links:
+        i = l.find("inertial")
+        mass.append(float(i.find("mass").get("value")))
+        o = i.find("origin")
+        com.append(f3(o.get("xyz") if o is not None else None)); com_rpy.append(f3(o.get("rpy") if o is not None else None))
+        t = i.find("inertia")
+        inertia.append([float(t.get(k)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz")])
+        c = l.find("collision")
+        if c is None:
+            col_type.append("none"); col_size.append(np.zeros(3)); col_xyz.append(np.zeros(3)); col_rpy.append(np.zeros(3))
+            continue
+        g = c.find("geometry")[0]
+        size = {"box": lambda: f3(g.get("size")), "sphere": lambda: np.array([float(g.get("radius")), 0, 0]),
+                "cylinder": lambda: np.array([float(g.get("radius")), float(g.get("length")), 0])}[g.tag]()
+        o = c.find("origin")
+        col_type.append(g.tag); col_size.append(size)
+        col_xyz.append(f3(o.get("xyz") if o is not None else None)); col_rpy.append(f3(o.get("rpy") if o is not None else None))
+    jname, jtype, parent, child, jxyz, jrpy, axis, lim = [], [], [], [], [], [], [], []
+    for j in joints:
+        jname.append(j.get("name")); jtype.append(j.get("type"))
+        parent.append(j.find("parent").get("link")); child.append(j.find("child").get("link"))
+        o = j.find("origin")
+        jxyz.append(f3(o.get("xyz") if o is not None else None)); jrpy.append(f3(o.get("rpy") if o is not None else None))
+        a = j.find("axis")
+        axis.append(f3(a.get("xyz")) if a is not None else np.zeros(3))
+        L = j.find("limit")
+        lim.append([float(L.get(k, 0)) for k in ("lower", "upper", "effort", "velocity")] if L is not None else [0, 0, 0, 0])
+    out = dict(link_name=np.array(lname), mass=np.array(mass), com=np.array(com), com_rpy=np.array(com_rpy), inertia=np.array(inertia),
+               col_type=np.array(col_type), col_size=np.array(col_size), col_xyz=np.array(col_xyz), col_rpy=np.array(col_rpy),
+               joint_name=np.array(jname), joint_type=np.array(jtype), parent=np.array(parent), child=np.array(child),
+               joint_xyz=np.array(jxyz), joint_rpy=np.array(jrpy), axis=np.array(axis), limit=np.array(lim))
+    np.savez_compressed(os.path.join(OUT, "urdf_tables.npz"), **out)
+    print(f"urdf_tables.npz: {len(lname)} links (total mass {sum(mass):.5f} kg), {len(jname)} joints "
+          f"({sum(t == 'revolute' for t in jtype)} revolute), collision primitives {sorted(set(col_type))}")
+
+
 # --------------------------------------------------------------------------------------------- G11 randomizers
 def gen_randomizers():
     """What the reference's randomizer stack (env_randomizer.py) writes into Bullet and into the motor model, draw by draw:
@@ -800,7 +846,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers"]
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf"]
     for w in which:
         {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers,
-         "randomizers": gen_randomizers}[w]()
+         "randomizers": gen_randomizers, "urdf": gen_urdf}[w]()

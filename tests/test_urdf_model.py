@@ -1,0 +1,163 @@
+"""The oracle's Go1 model (oracle/qso_model.c, restated by hand from SURVEY App. A) against the REFERENCE's robot description.
+
+tests/golden/urdf_tables.npz holds the numbers of go1/go1_description/urdf/go1.urdf (extracted by tests/golden/gen_golden.py:
+link masses, centres of mass, inertia tensors, joint origins / axes / limits, collision primitives).  From those tables alone
+this file builds a first-principles model -- homogeneous transforms, link kinetic energies, potential energy -- and derives the
+joint-space mass matrix and the gravity forces by finite differences.  Nothing of the oracle's spatial algebra is used on this
+side, so agreement pins both the restated data and the oracle's CRBA / RNEA to the reference's URDF."""
+import numpy as np
+import pytest
+
+from oracle.qso import Oracle
+from qs_amd.config import build_config
+
+MOTORS = [f"{leg}_{j}_joint" for leg in ("FR", "FL", "RR", "RL") for j in ("hip", "thigh", "calf")]
+
+
+def rpy_R(rpy):
+    r, p, y = rpy
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def axis_R(axis, q):
+    a = axis / np.linalg.norm(axis)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(q) * K + (1 - np.cos(q)) * K @ K
+
+
+def hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+
+
+def expm_so3(w):
+    th = np.linalg.norm(w)
+    return np.eye(3) if th < 1e-300 else axis_R(w / th, th)
+
+
+class UrdfModel:
+    def __init__(self, g):
+        self.g = g
+        self.links = list(g["link_name"])
+        self.children = {}
+        for j, p in enumerate(g["parent"]):
+            self.children.setdefault(str(p), []).append(j)
+        self.root = [l for l in self.links if l not in set(g["child"])][0]
+
+    def link_frames(self, p_base, R_base, q12):
+        """-> {link: (R, p)} in the world frame."""
+        g, out = self.g, {self.root: (R_base, p_base)}
+        stack = [self.root]
+        while stack:
+            l = stack.pop()
+            R, p = out[l]
+            for j in self.children.get(l, []):
+                Rj = R @ rpy_R(g["joint_rpy"][j])
+                pj = p + R @ g["joint_xyz"][j]
+                name = str(g["joint_name"][j])
+                if g["joint_type"][j] == "revolute":
+                    Rj = Rj @ axis_R(g["axis"][j], q12[MOTORS.index(name)])
+                out[str(g["child"][j])] = (Rj, pj)
+                stack.append(str(g["child"][j]))
+        return out
+
+    def bodies(self, p_base, R_base, q12):
+        """-> list of (mass, com_world, R_inertial_world, I_local) for every link."""
+        g, fr, out = self.g, self.link_frames(p_base, R_base, q12), []
+        for i, l in enumerate(self.links):
+            R, p = fr[str(l)]
+            ixx, ixy, ixz, iyy, iyz, izz = g["inertia"][i]
+            I = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+            out.append((g["mass"][i], p + R @ g["com"][i], R @ rpy_R(g["com_rpy"][i]), I))
+        return out
+
+    def displaced(self, p, R, q, v, eps):
+        """configuration reached from (p, R, q) along the generalized velocity v = [w_b, v_b (base frame), qd] for a time eps"""
+        return p + R @ v[3:6] * eps, R @ expm_so3(v[0:3] * eps), q + v[6:] * eps
+
+    def kinetic(self, p, R, q, v, eps=1e-6):
+        a, b = self.bodies(*self.displaced(p, R, q, v, eps)), self.bodies(*self.displaced(p, R, q, v, -eps))
+        T = 0.0
+        for (m, ca, Ra, I), (_, cb, Rb, _) in zip(a, b):
+            vc = (ca - cb) / (2 * eps)
+            W = (Ra @ Rb.T - Rb @ Ra.T) / (4 * eps)            # hat(w_world) to second order
+            w = np.array([W[2, 1], W[0, 2], W[1, 0]])
+            Rm = self.bodies_mid_R(Ra, Rb)
+            T += 0.5 * m * vc @ vc + 0.5 * w @ (Rm @ I @ Rm.T) @ w
+        return T
+
+    @staticmethod
+    def bodies_mid_R(Ra, Rb):
+        U, _, Vt = np.linalg.svd(Ra + Rb)                       # mean rotation
+        return U @ Vt
+
+    def mass_matrix(self, p, R, q):
+        n = 18
+        E = np.eye(n)
+        Td = np.array([self.kinetic(p, R, q, E[i]) for i in range(n)])
+        M = np.zeros((n, n))
+        for i in range(n):
+            M[i, i] = 2 * Td[i]
+            for j in range(i):
+                M[i, j] = M[j, i] = self.kinetic(p, R, q, E[i] + E[j]) - Td[i] - Td[j]
+        return M
+
+    def potential(self, p, R, q, grav):
+        return sum(m * grav * c[2] for m, c, _, _ in self.bodies(p, R, q))
+
+    def gravity_force(self, p, R, q, grav, eps=1e-6):
+        G = np.zeros(18)
+        for i in range(18):
+            e = np.zeros(18); e[i] = 1.0
+            G[i] = (self.potential(*self.displaced(p, R, q, e, eps), grav) - self.potential(*self.displaced(p, R, q, e, -eps), grav)) / (2 * eps)
+        return G
+
+
+def quat_xyzw(R):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_matrix(R).as_quat()
+
+
+@pytest.fixture(scope="module")
+def model(golden):
+    return UrdfModel(golden("urdf_tables.npz"))
+
+
+def test_urdf_totals_and_limits(model, golden):
+    g = model.g
+    assert abs(g["mass"].sum() - 12.01301) < 1e-9 and model.root == "base"
+    cfg, meta = build_config(n_envs=1, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True)
+    rc = meta["robot_config"]
+    for k, name in enumerate(MOTORS):
+        j = list(g["joint_name"]).index(name)
+        lo, hi, effort, vel = g["limit"][j]
+        assert effort >= rc.TORQUE_LIMITS[k] - 1e-9      # configs_go1_*.py clips at or below the URDF's effort limits (calf: 33.55 vs 35.55)
+        assert lo <= rc.RL_LOWER_ANGLE_JOINT[k] + 1e-9 and rc.RL_UPPER_ANGLE_JOINT[k] <= hi + 1e-9   # the RL box sits inside the joint range
+    # collision primitives of App. A: foot spheres r = 0.02, trunk box, hip cylinders, thigh / calf boxes
+    for leg in ("FR", "FL", "RR", "RL"):
+        i = list(g["link_name"]).index(f"{leg}_foot")
+        assert g["col_type"][i] == "sphere" and abs(g["col_size"][i][0] - 0.02) < 1e-12
+    assert g["col_type"][list(g["link_name"]).index("trunk")] == "box"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_mass_matrix_and_gravity_from_first_principles(model, seed):
+    rng = np.random.default_rng(seed)
+    cfg, _ = build_config(n_envs=1, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True, env_randomizer_mode="NONE")
+    o = Oracle(cfg)
+    s = o.get_state()
+    from scipy.spatial.transform import Rotation
+    R = Rotation.random(random_state=seed).as_matrix()
+    p = rng.normal(size=3) + np.array([0, 0, 1.0])
+    q = np.array([0.0, 0.8, -1.6] * 4) + 0.5 * rng.normal(size=12)
+    s[0, :3], s[0, 3:7], s[0, 7:13], s[0, 13:25], s[0, 25:] = p, quat_xyzw(R), 0.0, q, 0.0
+    o.set_state(s)
+    H, Cb = o.crba_rnea(0)
+    M = model.mass_matrix(p, R, q)
+    np.testing.assert_allclose(H, M, atol=2e-6, rtol=1e-6)
+    # at rest H a + Cb = tau, so Cb is the gravity force: dU/d(generalized coordinate)
+    G = model.gravity_force(p, R, q, 9.8)
+    np.testing.assert_allclose(Cb, G, atol=2e-6, rtol=1e-6)
+    assert abs(np.linalg.norm(Cb[3:6]) - 12.01301 * 9.8) < 1e-4   # the base-force part is the robot's weight (g crosses the ABI as float32)
