@@ -161,3 +161,60 @@ def test_mass_matrix_and_gravity_from_first_principles(model, seed):
     G = model.gravity_force(p, R, q, 9.8)
     np.testing.assert_allclose(Cb, G, atol=2e-6, rtol=1e-6)
     assert abs(np.linalg.norm(Cb[3:6]) - 12.01301 * 9.8) < 1e-4   # the base-force part is the robot's weight (g crosses the ABI as float32)
+
+
+def lowest_points(model, p, R, q):
+    """height of the lowest point of every link's collision primitive above the plane z = 0, from the URDF tables"""
+    g, fr, out = model.g, model.link_frames(p, R, q), {}
+    for i, l in enumerate(model.links):
+        t = str(g["col_type"][i])
+        if t == "none":
+            continue
+        Rl, pl = fr[str(l)]
+        Rc, c = Rl @ rpy_R(g["col_rpy"][i]), pl + Rl @ g["col_xyz"][i]
+        size = g["col_size"][i]
+        if t == "sphere":
+            low = c[2] - size[0]
+        elif t == "box":
+            low = c[2] - 0.5 * np.abs(Rc[2, :] * size).sum()
+        else:  # cylinder along its local z
+            az = Rc[2, 2]
+            low = c[2] - 0.5 * size[1] * abs(az) - size[0] * np.sqrt(max(1 - az * az, 0.0))
+        out[str(l)] = low
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_collision_geometry_matches_the_urdf(model, seed):
+    """Contact flags of the oracle's substep vs distances computed from the URDF's collision primitives: feet (sphere r = 0.02
+    at the foot_fixed joint) flagged exactly when closer than the 0.727 mm breaking threshold; trunk / hip / thigh / calf
+    primitives counted as invalid contacts when they clearly penetrate and not when they clearly do not."""
+    rng = np.random.default_rng(seed)
+    from scipy.spatial.transform import Rotation
+    cfg, _ = build_config(n_envs=1, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=False, env_randomizer_mode="NONE")
+    o = Oracle(cfg)
+    feet = ["FR_foot", "FL_foot", "RR_foot", "RL_foot"]
+    for trial in range(6):
+        R = Rotation.from_euler("xyz", rng.uniform(-0.5, 0.5, size=3)).as_matrix()
+        q = np.array([0.0, 0.8, -1.6] * 4) + 0.3 * rng.normal(size=12)
+        low = lowest_points(model, np.zeros(3), R, q)
+        foot_low = np.array([low[f] for f in feet])
+        for gap in (+0.0004, -0.0010, +0.0020):        # lowest foot 0.4 mm above, 1 mm inside, 2 mm above the plane
+            p = np.array([0.3, -0.2, -foot_low.min() + gap])
+            s = o.get_state()
+            s[0, :3], s[0, 3:7], s[0, 7:13], s[0, 13:25], s[0, 25:] = p, quat_xyzw(R), 0.0, q, 0.0
+            o.set_state(s)
+            o.phys_step(0, np.zeros(12))
+            expect = (foot_low - foot_low.min() + gap) < 7.27e-4
+            np.testing.assert_array_equal(o.get_info(1)[0] > 0.5, expect, err_msg=f"trial {trial} gap {gap}")
+            assert o.get_info(5)[0, 0] == 0 or min(v for k, v in low.items() if k not in feet) - foot_low.min() + gap < 2e-3
+    # a robot lying on its belly: trunk box and hips well inside the ground, feet in the air
+    q = np.array([0.0, 1.3, -2.6] * 4)
+    low = lowest_points(model, np.zeros(3), np.eye(3), q)
+    p = np.array([0.0, 0.0, -low["trunk"] - 0.005])
+    s = o.get_state()
+    s[0, :3], s[0, 3:7], s[0, 7:13], s[0, 13:25], s[0, 25:] = p, [0, 0, 0, 1], 0.0, q, 0.0
+    o.set_state(s)
+    o.phys_step(0, np.zeros(12))
+    n_pen = sum(1 for k, v in low.items() if k not in feet and v + p[2] < -1e-3)
+    assert n_pen >= 1 and o.get_info(5)[0, 0] >= 1
