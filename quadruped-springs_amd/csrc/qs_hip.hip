@@ -20,6 +20,9 @@ using E = Env<LaneDev>;
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
 __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs) {
+    // (the 16 rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
+    // 15.6 KB at once -- 8 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
+    // was measured slower)
     const float4* src = reinterpret_cast<const float4*>(g + (size_t)first_env * QS_REC);
     float4* dst = reinterpret_cast<float4*>(lds);
     int nvalid = min(QS_ENVS_PER_WAVE, n_envs - first_env) * (QS_REC / 4);
@@ -93,13 +96,17 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     const int env = first + slot;
     const bool valid = env < limit;
     const int d = cfg.action_dim, od = cfg.obs_dim;
+    QS_PHASE(26)
     tile_load(s_rec, base, first, limit);
-    if (!settling)
-        for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * d; i += QS_WAVE) {
-            int e = first + i / d;
-            s_act[(i / d) * 12 + (i % d)] = e < cfg.n_envs ? actions[(size_t)first * d + i] : 0.0f;
-        }
+    QS_PHASE(27)
+    if (!settling) {   // the quad of an environment fetches its action row: lane l takes entries l, l + 4, l + 8
+#pragma unroll
+        for (int k = (int)(threadIdx.x & 3u); k < 12; k += 4)
+            if (k < d) s_act[slot * 12 + k] = valid ? actions[(size_t)env * d + k] : 0.0f;
+    }
+    QS_PHASE(28)
     __syncthreads();
+    QS_PHASE(29)
     float* rec = s_rec + slot * QS_REC;
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
@@ -218,7 +225,9 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restric
     if (!__any(sel)) return;
     tile_load(s_rec, recs, first, cfg.n_envs);
     const int od = cfg.obs_dim;
+    QS_PHASE(28)
     __syncthreads();
+    QS_PHASE(29)
     float* rec = s_rec + slot * QS_REC;
     float* ob = s_obs + slot * QS_MAX_OBS;
     // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);

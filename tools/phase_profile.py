@@ -34,3 +34,5 @@ print(f"{'substeps total':32s} {sum(out[1:13]) / (n * 10):12.0f}")
 print(f"per env-step: tile load {out[13] / n:.0f}, E::step outside the substeps {(out[14] - 0) / n:.0f} (phase 14 = after the last substep marker .. end of E::step, "
       f"phase 1 also absorbs the action prologue of the first substep), auto-reset + stores {out[15] / n:.0f} cycles")
 print("cycles of substep k of the env step (k = 0 pays the cold instruction cache): " + ", ".join(f"{out[16 + k] / n:.0f}" for k in range(10)))
+print("kernel entry: config / kernarg reads %.0f, issue of the tile loads %.0f, action loads %.0f, wait + barrier %.0f, rest of the prologue %.0f cycles per env-step"
+      % tuple(out[k] / n for k in (26, 27, 28, 29, 13)))
