@@ -503,6 +503,42 @@ def test_fused_step_output(torch_cuda):
     a.close(); b.close()
 
 
+def test_both_step_kernels_agree_bitwise(torch_cuda):
+    """k_step (one wave per SIMD) and k_step_dense (two, with spills) are the same body: same results to the last bit; the
+    automatic choice at the largest BASELINE.json launch size (65536 environments) is the dense one and stays physical."""
+    from qs_amd.vec_env import QuadrupedVecEnv
+    kw = dict(num_envs=2048, auto_reset=True, reset_pool=512, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=True,
+              enable_action_filter=True, env_randomizer_mode="TEST_RANDOMIZER", seed=9)
+    envs = []
+    for variant in ("1", "2"):
+        os.environ["QS_STEP_VARIANT"] = variant
+        envs.append(QuadrupedVecEnv(**kw))
+    os.environ.pop("QS_STEP_VARIANT")
+    a, b = envs
+    np.testing.assert_array_equal(a.reset(), b.reset())
+    rng = np.random.default_rng(3)
+    n_done = 0
+    for i in range(80):
+        act = rng.uniform(-1, 1, size=(2048, 6)).astype(np.float32)
+        act[:, 1::3] = -1.0; act[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db), f"step {i}"
+        n_done += int(da.sum())
+    assert n_done > 50
+    a.close(); b.close()
+    big = QuadrupedVecEnv(num_envs=65536, auto_reset=True, reset_pool=4096, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC",
+                          enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=2)
+    big.reset_tensor()
+    g = torch_cuda.Generator(device="cuda").manual_seed(0)
+    for i in range(30):
+        obs, rew, done, trunc = big.step_tensor(torch_cuda.rand((65536, 6), generator=g, device="cuda") * 2 - 1)
+    st = big.get_state()
+    assert torch_cuda.isfinite(st).all() and torch_cuda.isfinite(obs).all()
+    assert ((st[:, 3:7].norm(dim=1) - 1).abs() < 1e-4).all() and st[:, 2].min() > 0.05 and st[:, 2].max() < 1.0
+    big.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
