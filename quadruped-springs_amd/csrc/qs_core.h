@@ -31,6 +31,14 @@ __device__ unsigned long long qs_phase_t0, qs_phase_sub0;   // written by one la
 #define QS_PHASE_SUB(k) if (blockIdx.x == 0 && threadIdx.x == 0) { qs_phase_cycles[16 + ((k) < 15 ? (k) : 15)] += __builtin_readcyclecounter() - qs_phase_sub0; }
 #define QS_PHASE_SUB_BEGIN if (blockIdx.x == 0 && threadIdx.x == 0) qs_phase_sub0 = __builtin_readcyclecounter();
 #define QS_PHASE_END
+#elif defined(QS_COUNT_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+// static instruction counts per phase: scheduling barriers + assembly comments at the phase boundaries (tools/phase_count.py)
+#define QS_PHASE_BEGIN { __builtin_amdgcn_sched_barrier(0); asm volatile("; QS_PHASE_MARK 0"); __builtin_amdgcn_sched_barrier(0); }
+#define QS_PHASE_G(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("; QS_PHASE_MARK " #k); __builtin_amdgcn_sched_barrier(0); }
+#define QS_PHASE(k) QS_PHASE_G(k)
+#define QS_PHASE_SUB(k)
+#define QS_PHASE_SUB_BEGIN
+#define QS_PHASE_END
 #else
 #define QS_PHASE_BEGIN
 #define QS_PHASE_G(k)
