@@ -163,6 +163,30 @@ class QuadrupedVecEnv(SB3VecEnv):
         out["time"] = out["time"][:, 0]
         return out
 
+    # ---- demonstration rows (get_demonstration_wrapper.py:35-70)
+    def demo_rows(self, done=None):
+        """[N, d + 38] on the device: the row GetDemonstrationWrapper._get_demo records after a step -- filtered action (d), joint
+        angles 12, joint velocities 12, base position 3, quaternion 4, linear velocity 3, angular velocity 3, landing_started 1
+        (latched once the controller has switched and vz <= 0; cleared when the episode ends).  Call it once per step with that
+        step's `done` (tensor or array; default: the buffer step_tensor filled)."""
+        t = self.torch
+        st = self.get_state()
+        if getattr(self, "_landing_started", None) is None:
+            self._landing_started = t.zeros(self.num_envs, dtype=t.bool, device=self.device)
+        switched = self.get_info("task")[:, 0] > 0.5
+        self._landing_started |= switched & (st[:, 9] <= 0.0)
+        act = (self.get_info("filtered_action") if self.cfg.enable_filter else self.get_info("last_action"))[:, : self.action_dim]
+        rows = t.cat([act, st[:, 13:37], st[:, 0:13], self._landing_started.to(t.float32)[:, None]], dim=1)
+        d = self._done.bool() if done is None else t.as_tensor(np.asarray(done) if not t.is_tensor(done) else done, device=self.device).bool()
+        self._landing_started &= ~d
+        return rows
+
+    @staticmethod
+    def read_demo(demo, action_dim=6, num_joints=12):
+        """get_demonstration_wrapper.py:61-70: split one row into (action, q, qd, base_pos, base_quat, lin_vel, ang_vel, landing)."""
+        cuts = np.cumsum([action_dim, num_joints, num_joints, 3, 4, 3, 3, 1])
+        return [demo[a:b] for a, b in zip(np.concatenate(([0], cuts[:-1])), cuts)]
+
     def pool_streaming(self, on=True):
         """Demand-driven background refill of the reset pool (qs_pool_streaming); returns the number of entries re-settled so far."""
         n = C.c_uint64(0)

@@ -539,6 +539,29 @@ def test_both_step_kernels_agree_bitwise(torch_cuda):
     big.close()
 
 
+def test_demo_rows(torch_cuda):
+    """demo_rows(): the layout GetDemonstrationWrapper._get_demo records (get_demonstration_wrapper.py:35-59)."""
+    o, v, cfg = make_pair(8, torch_cuda, auto_reset=False)
+    o.reset(); v.reset()
+    latched = False
+    for i in range(120):
+        a = np.tile([0.0, 0.9, -0.9, 0.0, 0.9, -0.9] if i < 45 else [0.0, -0.8, 1.0, 0.0, -0.8, 1.0], (8, 1)).astype(np.float32)
+        _, _, done, _ = v.step(a)
+        if done[0] or (latched and i > 80):
+            break
+        rows = v.demo_rows(done).cpu().numpy()
+        assert rows.shape == (8, 6 + 38)
+        act, q, qd, pos, quat, lin, ang, landing = v.read_demo(rows[0])
+        st = v.get_state().cpu().numpy()[0]
+        np.testing.assert_array_equal(np.concatenate([q, qd]), st[13:37])
+        np.testing.assert_array_equal(np.concatenate([pos, quat, lin, ang]), st[:13])
+        np.testing.assert_allclose(act, v.get_info("filtered_action").cpu().numpy()[0, :6])
+        sw = v.get_info("task").cpu().numpy()[0, 0] > 0.5
+        latched = latched or (sw and lin[2] <= 0)
+        assert bool(landing[0]) == latched
+    assert latched
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
