@@ -225,7 +225,7 @@ def main():
                          "traffic": traffic, "kernel": "k_step", "kernel_ms": kavg * 1e3,
                          "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (latest profiles/r*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step (80 % VALU-active): latency/issue-bound, not HBM-bound"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is a property of the box, reported with the single-GPU line only
             import subprocess
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
                                     "--solver-residual-threshold", str(args.solver_residual_threshold)], capture_output=True, text=True, timeout=300)
