@@ -516,15 +516,20 @@ static void add_noise(const qso_config* cfg, qso_env* e, int env_id, float* obs)
 }
 
 /* ------------------------------------------------------------------ reset / step */
-static void apply_and_step(const qso_config* cfg, qso_env* e, const real* cmd, real g) {
-    /* quadruped.py:288-320 then gym_env.py:218-219 */
+static void apply_and_step_mode(const qso_config* cfg, qso_env* e, const real* cmd, real g, int settling) {
+    /* quadruped.py:288-320 then gym_env.py:218-219.  settling: control_interface/utils.py:7-31 switches the motor model to "PD"
+       for the settle of a reset, also when the environment itself is driven by raw torques */
     real tau[12];
-    qso_pd_torque(cfg, e->kp, e->kd, cmd, e->s.q, e->s.qd, e->tau_pd);
+    if (settling && cfg->motor_control_mode == QSO_MOTOR_TORQUE) {
+        qso_config pd = *cfg; pd.motor_control_mode = QSO_MOTOR_PD;
+        qso_pd_torque(&pd, e->kp, e->kd, cmd, e->s.q, e->s.qd, e->tau_pd);
+    } else qso_pd_torque(cfg, e->kp, e->kd, cmd, e->s.q, e->s.qd, e->tau_pd);
     if (cfg->enable_springs) qso_spring_torque(e->k, e->b, e->rest, e->s.q, e->s.qd, e->tau_spring);
     else memset(e->tau_spring, 0, sizeof(e->tau_spring));
     for (int i = 0; i < 12; i++) tau[i] = e->tau_pd[i] + e->tau_spring[i];
     qso_physics_substep(cfg, e, tau, g);
 }
+static void apply_and_step(const qso_config* cfg, qso_env* e, const real* cmd, real g) { apply_and_step_mode(cfg, e, cmd, g, 0); }
 
 static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
     if ((cfg->randomizer_flags & QSO_RAND_KEEP) && e->episode >= 0) return;
@@ -577,7 +582,7 @@ static void reset_env(qso_handle* h, int i) {
     memset(e->tau_pd, 0, sizeof(e->tau_pd)); memset(e->tau_spring, 0, sizeof(e->tau_spring));
     /* interface_base.py:182-200: settle, sim counter frozen */
     real cmd[12]; for (int k = 0; k < 12; k++) cmd[k] = cfg->settle_cmd[k];
-    for (int n = 0; n < cfg->settle_steps; n++) apply_and_step(cfg, e, cmd, h->gravity);
+    for (int n = 0; n < cfg->settle_steps; n++) apply_and_step_mode(cfg, e, cmd, h->gravity, 1);
     for (int k = 0; k < 12; k++) e->last_action[k] = k < cfg->action_dim ? (real)cfg->settle_action[k] : 0;
     if (cfg->action_space_mode == QSO_ACT_CPG) { /* hopf_network.py:62-63: r ~ 0.1 U(0,1), theta = PHI[0,:] */
         uint32_t rr[4]; qso_philox(cfg->seed, (uint32_t)(i + cfg->env_id_offset), 3, (uint32_t)e->episode, 0, rr);

@@ -257,12 +257,14 @@ template <class T> struct Sim {
     }
 
     // PD law + torque clip (quadruped_motor.py:45-99) and unilateral PEA (quadruped_motor.py:101-104, springs.py:34-74)
-    static QS_FN void actuate(const qs_config& cfg, const Par& P, const State& s, const V* cmd, Out& o, V* tau) {
+    // `settling`: a reset's settle always runs the PD law (control_interface/utils.py:7-31 switches the motor model to "PD" for it,
+    // also when the environment itself is driven by raw torques)
+    static QS_FN void actuate(const qs_config& cfg, const Par& P, const State& s, const V* cmd, Out& o, V* tau, bool settling = false) {
         V sy = T::sy();
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             V lim = V(cfg.tau_max[j]);
-            V t = cfg.motor_control_mode == QS_MOTOR_TORQUE ? cmd[j] : (-(P.kp[j] * (s.q[j] - cmd[j])) - P.kd[j] * s.qd[j]);
+            V t = (cfg.motor_control_mode == QS_MOTOR_TORQUE && !settling) ? cmd[j] : (-(P.kp[j] * (s.q[j] - cmd[j])) - P.kd[j] * s.qd[j]);
             o.tau_pd[j] = clampv<V>(t, -lim, lim);
             V ts = V(0.0f);
             if (cfg.enable_springs) {

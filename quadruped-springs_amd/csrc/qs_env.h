@@ -581,7 +581,7 @@ template <class T> struct Env {
             V tau[3];
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             QS_PHASE_SUB_BEGIN
-            S::actuate(cfg, P, s, cmd, o, tau);
+            S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
             S::substep(cfg, P, s, tau, o);
             QS_PHASE_SUB(k)
             if (any_trace) {
@@ -726,7 +726,7 @@ template <class T> struct Env {
             V cmd[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
-            for (int n = 0; n < cfg.settle_steps; n++) { V tau[3]; S::actuate(cfg, P, s, cmd, o, tau); S::substep(cfg, P, s, tau, o); }
+            for (int n = 0; n < cfg.settle_steps; n++) { V tau[3]; S::actuate(cfg, P, s, cmd, o, tau, true); S::substep(cfg, P, s, tau, o); }
             store_state(rec, s, o);
         } else {  // the record already holds a settled state (copied from the pre-settled pool)
             load_state(rec, s);

@@ -546,13 +546,18 @@ def gen_traces():
         # gym_env.py:187-205 _interpolate_actions, with and without the filter
         dict(name="interp_f1", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_interpolation=True,
              enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=120, jump_at=60),
+        # hopf_network.py:183-190 style: raw joint torques, no RL interface; reset settles by PD for 1500 steps (control_interface/utils.py:22-31)
+        dict(name="raw_tau", isRLGymInterface=False, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True,
+             enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="TORQUE", steps=150, jump_at=60, raw_torque=True),
+        dict(name="raw_tau_s0", isRLGymInterface=False, task_env="NO_TASK", observation_space_mode="ENCODER_2", enable_springs=False, action_repeat=1,
+             enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="TORQUE", steps=400, jump_at=60, raw_torque=True),
         dict(name="interp_f0", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=False, enable_action_interpolation=True,
              enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="PD", steps=120, jump_at=60),
     ]
     out = {}
     for case in cases:
         name = case["name"]
-        kw = {k: v for k, v in case.items() if k not in ("name", "steps", "jump_at")}
+        kw = {k: v for k, v in case.items() if k not in ("name", "steps", "jump_at", "raw_torque")}
         mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs" if kw["enable_springs"]
                                       else "quadruped_spring.go1.configs_go1_without_springs")
         saved = {}
@@ -575,6 +580,7 @@ def gen_traces():
         client = env._pybullet_client
         d = env.action_dim
         acts = scripted_actions(rng, case["steps"], d, case["jump_at"])
+        raw = bool(case.get("raw_torque"))   # torques of a joint PD toward a slowly moving crouch, evaluated in closed loop on the reference env
         keys = None
         obs_l, rew_l, done_l, trunc_l, reset_obs, reset_at, mu_at_reset, state_l = [], [], [], [], [], [], [], []
         o = env.reset()
@@ -582,6 +588,9 @@ def gen_traces():
         flat = lambda ob: np.concatenate([np.atleast_1d(np.asarray(ob[k], float)).flatten() for k in keys])
         reset_obs.append(flat(o)); reset_at.append(0); mu_at_reset.append(client.mu)
         for t in range(case["steps"]):
+            if raw:
+                q_des = np.array([0.0, 0.8, -1.6] * 4) + 0.25 * np.sin(2 * np.pi * t * env.env_time_step / 0.5) * np.array([0.0, 1.0, -2.0] * 4)
+                acts[t] = np.clip(60.0 * (q_des - env.robot.GetMotorAngles()) - 1.5 * env.robot.GetMotorVelocities() + 0.5 * rng.standard_normal(12), -20, 20)
             ob, r, dn, info = env.step(acts[t])
             obs_l.append(flat(ob)); rew_l.append(r); done_l.append(dn)
             trunc_l.append(bool(info.get("TimeLimit.truncated", False)))
