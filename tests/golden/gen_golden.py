@@ -546,6 +546,13 @@ def gen_traces():
         # gym_env.py:187-205 _interpolate_actions, with and without the filter
         dict(name="interp_f1", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_interpolation=True,
              enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=120, jump_at=60),
+        # the two high-performance PPO tasks, the two remaining sensor bundles, BASELINE.json configs[1] (dt = 2 ms x 5, 60 sweeps)
+        dict(name="jipppohp_s1", task_env="JUMPING_IN_PLACE_PPO_HP", observation_space_mode="ARS_SENSOR", enable_springs=True,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="jfppohp_s0", task_env="JUMPING_FORWARD_PPO_HP", observation_space_mode="ARS_BACKFLIP", enable_springs=False,
+             enable_action_filter=True, action_space_mode="SYMMETRIC_NO_HIP", motor_control_mode="PD", steps=200, jump_at=80),
+        dict(name="dt2_s1", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, time_step=0.002, action_repeat=5,
+             enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=200, jump_at=80),
         # hopf_network.py:183-190 style: raw joint torques, no RL interface; reset settles by PD for 1500 steps (control_interface/utils.py:22-31)
         dict(name="raw_tau", isRLGymInterface=False, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True,
              enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="TORQUE", steps=150, jump_at=60, raw_torque=True),
@@ -568,7 +575,7 @@ def gen_traces():
         saved_upper = mod.RL_UPPER_ANGLE_JOINT.copy()
 
         def factory(dt, iters, kw=kw):
-            cfg, _ = build_config(n_envs=1, time_step=dt, noise=False, env_randomizer_mode="NONE", **kw)
+            cfg, _ = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", **dict(kw, time_step=dt))
             cfg.solver_iters = iters
             cfg.randomizer_flags = 8
             return Oracle(cfg)

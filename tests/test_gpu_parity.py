@@ -128,7 +128,7 @@ def test_env_step_parity_resynced(torch_cuda, kw):
             o.reset(do.astype(np.uint8)); v.reset_tensor(do.astype(np.uint8))
 
 
-@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1", "interp_f1", "interp_f0", "raw_tau", "raw_tau_s0"])
+@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1", "interp_f1", "interp_f0", "raw_tau", "raw_tau_s0", "jipppohp_s1", "jfppohp_s0", "dt2_s1"])
 def test_reference_traces(torch_cuda, golden, name):
     """Traces recorded from the REFERENCE's QuadrupedGymEnv (tests/golden/traces.npz).  Trajectories are chaotic, so the
     device state is re-synchronised to the recorded state before every step; what is compared is one full env.step."""
