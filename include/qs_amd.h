@@ -126,6 +126,10 @@ void qs_destroy(qs_handle* h);
 int qs_set_stream(qs_handle* h, void* hip_stream);
 /* mask: device pointer to n_envs bytes, or NULL for all environments */
 int qs_reset(qs_handle* h, const uint8_t* mask);
+/* Reference-state initialisation (reference_state_initialization_wrapper.py:25-43 -> set_robot_desired_state, quadruped.py:521-525,
+ * gym_env.py:289-290): reset of the masked environments that runs the randomizers, places the robot at states[env] ([N,37], layout of
+ * qs_get_state) instead of spawning and settling it, then resets task, sensors and filter as every reset does. */
+int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states);
 int qs_get_obs(qs_handle* h, float* obs /*[N,obs_dim]*/);
 int qs_step(qs_handle* h, const float* actions /*[N,action_dim]*/, float* obs /*[N,obs_dim]*/, float* rew /*[N]*/,
             uint8_t* done /*[N]*/, uint8_t* truncated /*[N]*/);

@@ -85,6 +85,14 @@ class Oracle:
         self._check(self.lib.qso_get_info(self.h, which, self._p(out)))
         return out
 
+    def reset_to(self, states, mask=None):
+        st = np.ascontiguousarray(states, self.real).reshape(self.n, 37)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._check(self.lib.qso_reset_to(self.h, None if m is None else self._p(m), self._p(st)))
+        obs = np.zeros((self.n, self.o), np.float32)
+        self._check(self.lib.qso_get_obs(self.h, self._p(obs)))
+        return obs
+
     def set_trace(self, env):
         """Per-substep rows of one environment (layout of qs_set_trace); returns the array the next step() calls fill."""
         self._trace = np.zeros((self.cfg.action_repeat, 70), self.real)

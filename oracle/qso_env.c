@@ -566,7 +566,11 @@ static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
     qso_model_build(&e->model, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
 }
 
-static void reset_env(qso_handle* h, int i) {
+static void reset_env_to(qso_handle* h, int i, const real* st37);
+static void reset_env(qso_handle* h, int i) { reset_env_to(h, i, NULL); }
+/* st37 != NULL: reference-state initialisation (reference_state_initialization_wrapper.py:25-43, quadruped.py:521-525,
+   gym_env.py:289-290): the robot is placed at the given state, the settle is skipped and _last_action stays zero (:284) */
+static void reset_env_to(qso_handle* h, int i, const real* st37) {
     const qso_config* cfg = &h->cfg; qso_env* e = &h->env[i];
     /* gym_env.py:278-297 */
     e->episode++;
@@ -581,9 +585,14 @@ static void reset_env(qso_handle* h, int i) {
     memset(e->foot_contact, 0, sizeof(e->foot_contact)); e->n_invalid = 0;
     memset(e->tau_pd, 0, sizeof(e->tau_pd)); memset(e->tau_spring, 0, sizeof(e->tau_spring));
     /* interface_base.py:182-200: settle, sim counter frozen */
-    real cmd[12]; for (int k = 0; k < 12; k++) cmd[k] = cfg->settle_cmd[k];
-    for (int n = 0; n < cfg->settle_steps; n++) apply_and_step_mode(cfg, e, cmd, h->gravity, 1);
-    for (int k = 0; k < 12; k++) e->last_action[k] = k < cfg->action_dim ? (real)cfg->settle_action[k] : 0;
+    if (st37) {
+        memcpy(e->s.pos, st37, 3 * sizeof(real)); memcpy(e->s.quat, st37 + 3, 4 * sizeof(real)); memcpy(e->s.vlin, st37 + 7, 3 * sizeof(real));
+        memcpy(e->s.vang, st37 + 10, 3 * sizeof(real)); memcpy(e->s.q, st37 + 13, 12 * sizeof(real)); memcpy(e->s.qd, st37 + 25, 12 * sizeof(real));
+    } else {
+        real cmd[12]; for (int k = 0; k < 12; k++) cmd[k] = cfg->settle_cmd[k];
+        for (int n = 0; n < cfg->settle_steps; n++) apply_and_step_mode(cfg, e, cmd, h->gravity, 1);
+        for (int k = 0; k < 12; k++) e->last_action[k] = k < cfg->action_dim ? (real)cfg->settle_action[k] : 0;
+    }
     if (cfg->action_space_mode == QSO_ACT_CPG) { /* hopf_network.py:62-63: r ~ 0.1 U(0,1), theta = PHI[0,:] */
         uint32_t rr[4]; qso_philox(cfg->seed, (uint32_t)(i + cfg->env_id_offset), 3, (uint32_t)e->episode, 0, rr);
         for (int L = 0; L < 4; L++) { e->cpg[L] = (real)0.1 * qso_u01(rr[L]); e->cpg[4 + L] = cfg->cpg_phi[L]; }
@@ -626,6 +635,10 @@ int qso_reset(qso_handle* h, const uint8_t* mask) {
 #pragma omp parallel for schedule(static)
 #endif
     for (int i = 0; i < h->cfg.n_envs; i++) if (!mask || mask[i]) reset_env(h, i);
+    return 0;
+}
+int qso_reset_to(qso_handle* h, const uint8_t* mask, const real* states) {
+    for (int i = 0; i < h->cfg.n_envs; i++) if (!mask || mask[i]) reset_env_to(h, i, states + (size_t)i * 37);
     return 0;
 }
 int qso_get_obs(qso_handle* h, float* obs) {

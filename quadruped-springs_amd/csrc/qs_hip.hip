@@ -214,7 +214,7 @@ __global__ void k_pool_plan(unsigned long long* __restrict__ ctl, int pool_size,
 // QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297); all settles run side by side.
 __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ obs_keep,
-                                                      unsigned long long* __restrict__ stats) {
+                                                      unsigned long long* __restrict__ stats, const float* __restrict__ states) {
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     const qs_config& cfg = *cfgp;
@@ -225,15 +225,34 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restric
     if (!__any(sel)) return;
     tile_load(s_rec, recs, first, cfg.n_envs);
     const int od = cfg.obs_dim;
-    QS_PHASE(28)
     __syncthreads();
-    QS_PHASE(29)
     float* rec = s_rec + slot * QS_REC;
     float* ob = s_obs + slot * QS_MAX_OBS;
-    // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);
-    // quads that are not selected work on their LDS copy and simply do not write it back
-    E::reset(cfg, rec, ob, (uint32_t)((valid ? env : 0) + cfg.env_id_offset), true);
-    if (sel && (threadIdx.x & 3) == 0) { atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps); atomicAdd(&stats[1], 1ull); }
+    const uint32_t gid = (uint32_t)((valid ? env : 0) + cfg.env_id_offset);
+    if (states) {   // reference-state initialisation (gym_env.py:278-297 with robot_desired_state set): randomizers, then the given
+                    // rigid-body state instead of spawn + settle, then the task / sensor / filter reset of every reset
+        if (sel) {
+            E::randomize(cfg, rec, gid, qs::f2i(rec[R_EPISODE]) + 1, false);
+            for (int i = threadIdx.x & 3; i < 37; i += 4) rec[R_POS + i] = states[(size_t)env * 37 + i];
+            for (int i = threadIdx.x & 3; i < 4; i += 4) rec[R_WARM + i] = 0.0f;
+            if ((threadIdx.x & 3) == 0) {
+                for (int i = 0; i < 4; i++) { rec[R_FOOT_FORCE + i] = 0.0f; rec[R_FOOT_CONTACT + i] = 0.0f; }
+                rec[R_N_INVALID] = 0.0f;
+                for (int i = 0; i < 24; i++) rec[R_TAU_PD + i] = 0.0f;
+            }
+        }
+        LaneDev::sync();
+        E::reset(cfg, rec, ob, gid, false);
+        LaneDev::sync();
+        if (sel)   // no settle ran, so _last_action and with it the filter history stay zero (gym_env.py:284, 267-269)
+            for (int i = threadIdx.x & 3; i < 12 + 24 + 24; i += 4) rec[R_LAST_ACTION + i] = 0.0f;
+        if (sel && (threadIdx.x & 3) == 0) atomicAdd(&stats[1], 1ull);
+    } else {
+        // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);
+        // quads that are not selected work on their LDS copy and simply do not write it back
+        E::reset(cfg, rec, ob, gid, true);
+        if (sel && (threadIdx.x & 3) == 0) { atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps); atomicAdd(&stats[1], 1ull); }
+    }
     __syncthreads();
     if (sel) {
         float* g = recs + (size_t)env * QS_REC;
@@ -408,7 +427,14 @@ int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle");
 
 int qs_reset(qs_handle* h, const uint8_t* mask) {
     if (!h) QS_FAIL(-1, "null handle");
-    hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats);
+    hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
+int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states) {
+    if (!h || !states) QS_FAIL(-1, "null argument");
+    hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
     QS_HIP(hipGetLastError());
     return 0;
 }

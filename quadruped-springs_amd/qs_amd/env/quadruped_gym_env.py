@@ -236,6 +236,7 @@ class QuadrupedGymEnv(GymEnv):
         self.action_space = self._vec.action_space
         self.observation_space = self._vec.observation_space
         self._replay_row = None
+        self.robot_desired_state = None
         self.robot = _RobotView(self)
         self.robot._motor_model = _MotorModelView(self)
         self.task = _TaskView(self)
@@ -255,9 +256,20 @@ class QuadrupedGymEnv(GymEnv):
         return obs
 
     def reset(self):
+        if self.robot_desired_state is not None:   # gym_env.py:289-290, quadruped.py:521-525: no settle, _last_action stays zero
+            _, q, qd, pos, quat, lin, ang, _ = self.robot_desired_state
+            st = np.concatenate([pos, quat, lin, ang, q, qd]).astype(np.float32)[None]
+            flat = self._vec.reset_tensor(states=st)[0].cpu().numpy()
+            self._last_action = np.zeros(self.action_dim)
+            return self._as_dict(flat)
         flat = self._vec.reset()[0]
         self._last_action = np.asarray(self._settling_action, float)
         return self._as_dict(flat)
+
+    def set_robot_desired_state(self, state):
+        """gym_env.py:400-402: the 8-tuple of GetDemonstrationWrapper.read_demo (action, q, qd, base position, base quaternion, linear
+        velocity, angular velocity, landing flag), or None; the next reset() places the robot there instead of settling it."""
+        self.robot_desired_state = state
 
     def step(self, action):
         a = np.asarray(action, dtype=np.float32).reshape(1, self.action_dim)

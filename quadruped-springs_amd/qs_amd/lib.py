@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QS_LIB_PATH") or os.path.join(_HERE, "libqs_hip.so")   # QS_LIB_PATH: kernel experiments (another build of the same ABI)
 
 EXPORTS = (
-    "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_get_obs", "qs_step", "qs_step_fused", "qs_get_state", "qs_set_state",
+    "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_reset_to", "qs_get_obs", "qs_step", "qs_step_fused", "qs_get_state", "qs_set_state",
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
     "qs_refresh_pool", "qs_pool_streaming", "qs_set_trace", "qs_last_error", "qs_version",
     "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
@@ -38,6 +38,7 @@ def load():
     lib.qs_destroy.restype = None
     lib.qs_set_stream.argtypes = [vp, vp]
     lib.qs_reset.argtypes = [vp, vp]
+    lib.qs_reset_to.argtypes = [vp, vp, vp]
     lib.qs_get_obs.argtypes = [vp, vp]
     lib.qs_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qs_step_fused.argtypes = [vp, vp, vp]

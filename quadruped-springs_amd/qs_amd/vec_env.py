@@ -69,12 +69,18 @@ class QuadrupedVecEnv(SB3VecEnv):
             pass
 
     # ---- device-resident API
-    def reset_tensor(self, mask=None):
+    def reset_tensor(self, mask=None, states=None):
+        """reset() of the masked environments (all when mask is None).  With `states` ([N,37], layout of get_state) the robots are
+        placed there instead of being spawned and settled: reference-state initialisation (set_robot_desired_state)."""
         self._stream()
         m = None
         if mask is not None:
             m = self.torch.as_tensor(mask, device=self.device).to(self.torch.uint8).contiguous()
-        _lib.check(self.lib.qs_reset(self.h, None if m is None else self._ptr(m)))
+        if states is not None:
+            st = self.torch.as_tensor(states, dtype=self.torch.float32, device=self.device).reshape(self.num_envs, 37).contiguous()
+            _lib.check(self.lib.qs_reset_to(self.h, None if m is None else self._ptr(m), self._ptr(st)))
+        else:
+            _lib.check(self.lib.qs_reset(self.h, None if m is None else self._ptr(m)))
         _lib.check(self.lib.qs_get_obs(self.h, self._ptr(self._obs)))
         return self._obs
 

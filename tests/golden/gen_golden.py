@@ -622,6 +622,63 @@ def gen_traces():
     print("traces.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- reference-state initialisation
+def gen_rsi():
+    """reset() with a desired robot state (set_robot_desired_state -> quadruped.py:521-525, gym_env.py:289-290: no settle, _last_action
+    stays zero), as ReferenceStateInitializationWrapper uses it, followed by a few steps."""
+    import importlib
+    from qs_amd.config import build_config
+    from oracle.qso import Oracle
+    from quadruped_spring.env.quadruped_gym_env import QuadrupedGymEnv
+    out = {}
+    tr = np.load(os.path.join(OUT, "traces.npz"))
+    for name, src, at, kw in (
+            ("rsi_s1", "jip_s1", 118, dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
+                                            action_space_mode="SYMMETRIC", motor_control_mode="PD")),
+            ("rsi_s0", "jf_s1", 40, dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="PPO_BASIC_CONTACT", enable_springs=False, enable_action_filter=False,
+                                         action_space_mode="DEFAULT", motor_control_mode="PD"))):
+        mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs" if kw["enable_springs"]
+                                      else "quadruped_spring.go1.configs_go1_without_springs")
+        saved = {}
+        for attr in dir(mod):
+            if attr.endswith("_NOISE"):
+                saved[attr] = getattr(mod, attr)
+                setattr(mod, attr, np.zeros_like(np.asarray(saved[attr], float)))
+
+        def factory(dt, iters, kw=kw):
+            cfg, _ = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", **dict(kw, time_step=dt))
+            cfg.solver_iters = iters
+            cfg.randomizer_flags = 8
+            return Oracle(cfg)
+
+        FakeBulletClient.oracle_factory = factory
+        np.random.seed(4321)
+        rng = np.random.default_rng(17)
+        env = QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", **kw)
+        st = tr[f"{src}_state"][at].copy()      # a state in the middle of a jump
+        d = env.action_dim
+        desired = (np.zeros(d), st[13:25], st[25:37], st[0:3], st[3:7], st[7:10], st[10:13], [0.0])   # the demo-row tuple of read_demo
+        env.set_robot_desired_state(desired)
+        o = env.reset()
+        client = env._pybullet_client
+        keys = list(o.keys())
+        flat = lambda ob: np.concatenate([np.atleast_1d(np.asarray(ob[k], float)).flatten() for k in keys])
+        acts = scripted_actions(rng, 40, d, 200)
+        obs_l, rew_l, done_l, state_l = [], [], [], []
+        for t in range(40):
+            ob, r, dn, info = env.step(acts[t])
+            obs_l.append(flat(ob)); rew_l.append(r); done_l.append(dn); state_l.append(client.o.get_state()[0].copy())
+            if dn:
+                break
+        out[f"{name}_desired"], out[f"{name}_reset_obs"], out[f"{name}_mu"] = st, flat(o), np.array(client.mu)
+        out[f"{name}_actions"], out[f"{name}_obs"], out[f"{name}_rew"] = acts[:len(obs_l)], np.array(obs_l), np.array(rew_l, float)
+        out[f"{name}_done"], out[f"{name}_state"], out[f"{name}_kwargs"] = np.array(done_l), np.array(state_l), np.array(repr(kw))
+        print(f"rsi {name}: start z={st[2]:.3f} vz={st[9]:.3f}, {len(obs_l)} steps, dones={int(np.sum(done_l))}")
+        for attr, v in saved.items():
+            setattr(mod, attr, v)
+    np.savez_compressed(os.path.join(OUT, "rsi.npz"), **out)
+
+
 # --------------------------------------------------------------------------------------------- G22 Go1 model data
 def gen_urdf():
     """Numeric tables of the reference's robot description (go1/go1_description/urdf/go1.urdf): per link mass,
@@ -862,7 +919,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf"]
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf", "rsi"]
     for w in which:
         {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers,
-         "randomizers": gen_randomizers, "urdf": gen_urdf}[w]()
+         "randomizers": gen_randomizers, "urdf": gen_urdf, "rsi": gen_rsi}[w]()

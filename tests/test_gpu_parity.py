@@ -594,6 +594,39 @@ def test_raw_torque_interface_standing_controller(torch_cuda):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["rsi_s1", "rsi_s0"])
+def test_reference_state_initialisation(torch_cuda, golden, name):
+    """qs_reset_to vs the REFERENCE's reset with set_robot_desired_state (tests/golden/rsi.npz): reset observation, then steps."""
+    g = golden("rsi.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    _, v, cfg = make_pair(1, torch_cuda, oracle=False, keep_params=True, **kw)
+    v.reset()
+    v.set_params("mu", np.array([[float(g[f"{name}_mu"])]], np.float32))
+    ob = v.reset_tensor(states=g[f"{name}_desired"][None].astype(np.float32)).cpu().numpy()
+    np.testing.assert_allclose(ob[0], g[f"{name}_reset_obs"], atol=1e-4)
+    np.testing.assert_allclose(v.get_state().cpu().numpy()[0], g[f"{name}_desired"], atol=1e-6)
+    assert np.all(v.get_info("last_action").cpu().numpy() == 0) and np.all(v.get_info("filtered_action").cpu().numpy() == 0)
+    for t, a in enumerate(g[f"{name}_actions"]):
+        if t > 0:
+            v.set_state(g[f"{name}_state"][t - 1][None].astype(np.float32))
+        ob, r, dn, _ = v.step(a[None].astype(np.float32))
+        sv = v.get_state().cpu().numpy()[0]
+        np.testing.assert_allclose(sv[13:25], g[f"{name}_state"][t][13:25], atol=1e-4, err_msg=f"q step {t}")
+        np.testing.assert_allclose(ob[0], g[f"{name}_obs"][t], atol=2e-2, rtol=1e-3, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r[0], g[f"{name}_rew"][t], atol=5e-4, rtol=1e-3)
+        assert bool(dn[0]) == bool(g[f"{name}_done"][t])
+    # the N = 1 view: set_robot_desired_state + reset
+    if name == "rsi_s1":
+        from qs_amd.env.quadruped_gym_env import QuadrupedGymEnv
+        env = QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", seed=1, noise=False, **kw)
+        st = g[f"{name}_desired"]
+        env.set_robot_desired_state((np.zeros(6), st[13:25], st[25:37], st[0:3], st[3:7], st[7:10], st[10:13], [0.0]))
+        o = env.reset()
+        np.testing.assert_allclose(env.robot.GetMotorAngles(), st[13:25], atol=1e-6)
+        np.testing.assert_allclose(np.concatenate([np.atleast_1d(o[k]) for k in o]), g[f"{name}_reset_obs"], atol=1e-4)
+        env.close()
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L

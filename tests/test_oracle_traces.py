@@ -52,3 +52,24 @@ def test_trace(golden, name):
             ob = o.reset()
             np.testing.assert_allclose(ob[0], reset_obs[ep], atol=2e-5, rtol=1e-5)
     assert ep == len(reset_at) - 1
+
+
+@pytest.mark.parametrize("name", ["rsi_s1", "rsi_s0"])
+def test_reference_state_initialisation(golden, name):
+    """reset with a desired robot state (ReferenceStateInitializationWrapper -> set_robot_desired_state): no settle, zero action history."""
+    g = golden("rsi.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    cfg, meta = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", **kw)
+    cfg.randomizer_flags = 8
+    o = Oracle(cfg)
+    o.reset()
+    o.set_params(0, np.array([float(g[f"{name}_mu"])]))
+    ob = o.reset_to(g[f"{name}_desired"][None])
+    np.testing.assert_allclose(ob[0], g[f"{name}_reset_obs"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(o.get_state()[0], g[f"{name}_desired"], atol=1e-12)
+    for t, a in enumerate(g[f"{name}_actions"]):
+        ob, r, dn, tr = o.step(a[None])
+        np.testing.assert_allclose(o.get_state()[0], g[f"{name}_state"][t], atol=5e-4, rtol=1e-4, err_msg=f"state step {t}")
+        np.testing.assert_allclose(ob[0], g[f"{name}_obs"][t], atol=5e-4, rtol=1e-4, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r[0], g[f"{name}_rew"][t], atol=2e-4, rtol=1e-4, err_msg=f"reward step {t}")
+        assert bool(dn[0]) == bool(g[f"{name}_done"][t])
