@@ -343,6 +343,23 @@ class QuadrupedGymEnv(GymEnv):
     def get_randomizer_mode(self):
         return self._env_randomizer_mode
 
+    def get_quadruped_config(self):
+        """gym_env.py:395-397: the keyword set the reference builds its Quadruped with (no Bullet client here)."""
+        return dict(pybullet_client=None, robot_config=self._robot_config, motor_control_mode="PD" if self._motor_control_mode != "TORQUE" else "TORQUE",
+                    on_rack=False, render=False, enable_springs=self._enable_springs, desired_state=self.robot_desired_state)
+
+    def reinit_randomizers(self, env):
+        """gym_env.py:411-413 re-points the Python randomizers at a wrapping env; the randomizers live in the reset kernel here."""
+
+    def reinit_sensors(self, env):
+        """gym_env.py:415-417, same for the sensors (they are part of the step kernel's epilogue)."""
+
+    def increase_curriculum_level(self, value):
+        """gym_env.py:423-426; only the *_CURRICULUM randomizers react to it in the reference, and those are not selectable
+        (env_randomizer_collection.py:15-21 never hands them a working env: SURVEY App. C-4), so the level is just recorded."""
+        assert 0 <= value <= 1, "curriculum level change should be in [0,1]."
+        self.curriculum_level = min(1.0, self.curriculum_level + value)
+
     def set_sub_step_callback(self, callback):
         """evaluation_wrapper.py:14: the callback reads the robot after every physics substep.  The substeps are fused on the
         device, so the per-substep trace tap records them and step() replays the rows: while the callback runs, get_sim_time()
