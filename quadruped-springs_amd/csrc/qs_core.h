@@ -48,6 +48,10 @@ __device__ unsigned long long qs_phase_t0, qs_phase_sub0;   // written by one la
 #define QS_PHASE_END
 #endif
 
+#ifndef QS_PGS_PACKED
+#define QS_PGS_PACKED 1   // candidate updates of the sweep as one packed + one scalar FMA per row (0: three scalar FMAs)
+#endif
+
 namespace qs {
 
 // ------------------------------------------------------------------ Go1 model constants (go1.urdf)
@@ -377,7 +381,8 @@ template <class T> struct Sim {
         }                                                                                                              \
         V dk = T::template bcast<K>(cand) - lam_all[i_];                                                               \
         lam_all[i_] = lam_all[i_] + dk;                                                                                \
-        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk;                               \
+        if (NR == 3 && QS_PGS_PACKED) { T::fma2(Ap[i_][0], Ap[i_][1], dk, res[0], res[1]); res[2] = res[2] + Ap[i_][2] * dk; }      \
+        else { _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk; }                     \
         if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)

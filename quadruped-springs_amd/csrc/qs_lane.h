@@ -90,6 +90,13 @@ struct LaneDev {
         float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, d), K * 0x55, 0xF, 0xF, true));
         return fmaf(b, a, acc);
     }
+    // (c0, c1) += (a0, a1) * b as one packed v_pk_fma_f32 (two fp32 FMAs per lane per issue slot, full rate on CDNA3/4)
+    typedef float F2 __attribute__((ext_vector_type(2)));
+    static QS_DEV void fma2(float a0, float a1, float b, float& c0, float& c1) {
+        F2 a = {a0, a1}, c = {c0, c1}, bb = {b, b};
+        c = __builtin_elementwise_fma(a, bb, c);
+        c0 = c.x; c1 = c.y;
+    }
     // acc[K] += (a of lane K of the quad) * (b of this lane), K = 0..3: one v_mfma_f32_4x4x1_16b_f32 does it for the sixteen
     // quads of the wave (16 independent 4x4 outer products, block = quad; measured layout: tools/mfma_layout.hip).  The
     // instruction ignores EXEC, so it may only be used where the whole wave runs the same path.
@@ -167,6 +174,7 @@ struct LaneEmu {
     static V4 fx() { return V4(1, 1, -1, -1); }
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
+    static void fma2(V4 a0, V4 a1, V4 b, V4& c0, V4& c1) { for (int l = 0; l < 4; l++) { c0.v[l] = fmaf(a0.v[l], b.v[l], c0.v[l]); c1.v[l] = fmaf(a1.v[l], b.v[l], c1.v[l]); } }
     struct Acc4 { V4 k[4]; };
     static Acc4 acc4_zero() { Acc4 z; for (int i = 0; i < 4; i++) z.k[i] = V4(0.0f); return z; }
     static void outer_fma(V4 a, V4 b, Acc4& acc) { for (int K = 0; K < 4; K++) for (int l = 0; l < 4; l++) acc.k[K].v[l] = fmaf(a.v[K], b.v[l], acc.k[K].v[l]); }
