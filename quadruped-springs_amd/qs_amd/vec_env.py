@@ -225,9 +225,10 @@ class QuadrupedVecEnv(SB3VecEnv):
                 infos[i]["terminal_observation"] = term[i].copy()
         if self.cfg.wrapper_mode:
             # the reference's LandingWrapper / GoToRestWrapper loop over env.step inside one wrapper.step; here every inner
-            # step is one launch and the ones whose action was scripted are flagged, so a learner can mask them out
+            # step is one launch and the ones whose action was scripted are flagged, so a learner can mask them out.  Only the
+            # environments in a scripted phase get the keys (read them with infos[i].get("scripted", False)).
             w = self.get_info("wrapper").cpu().numpy()
-            for i in range(self.num_envs):
+            for i in np.nonzero((w[:, 0] > 0.5) | (w[:, 1] > 0.5))[0]:
                 infos[i]["scripted"] = bool(w[i, 1])
                 infos[i]["phase"] = PHASE[int(w[i, 0])]
         return obs, rew, done, infos
