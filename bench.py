@@ -161,6 +161,7 @@ def main():
     kernel_ms = []
     barrier()
     stats0 = env.stats()
+    limit0 = env.counter("limit_path_substeps")
     refills0 = env.pool_streaming(True) if streaming else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -168,6 +169,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stats1 = env.stats()
+    limit1 = env.counter("limit_path_substeps")
     refills1 = env.pool_streaming(True) if streaming else 0
     env.enable_timing(True)
     # per-launch duration of the step kernel from HIP events on the kernel's own stream (separate short loop so that
@@ -219,6 +221,7 @@ def main():
                        "resets_in_timed_region": int(stats1["resets"] - stats0["resets"]),
                        "pool_states_settled_in_timed_region": int(refills1 - refills0),
                        "settle_substeps_in_timed_region": int(stats1["settle_substeps"] - stats0["settle_substeps"]),
+                       "joint_limit_path_wave_substeps": int(limit1 - limit0),
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step, rollout buffer on rank 0" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -152,6 +152,14 @@ int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets);
  * buffer a sharded run all-gathers to the learner rank (one collective per step, qs_amd/sharded.py), written by the step
  * kernel itself instead of being packed from four arrays afterwards. */
 int qs_step_fused(qs_handle* h, const float* actions, float* fused);
+/* Telemetry counters (synchronises the stream). */
+enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset, exact auto-resets, settle lanes) */
+       QS_COUNTER_RESETS = 1,               /* environment resets */
+       QS_COUNTER_POOL_CONSUMED = 2,        /* auto-resets served from the reset pool */
+       QS_COUNTER_POOL_REFILLED = 3,        /* pool entries re-settled by the streaming refill */
+       QS_COUNTER_LIMIT_PATH_SUBSTEPS = 4   /* wave-substeps in which some joint of the wave's 16 environments sat at a stop: those run
+                                               the slow 6-rows-per-leg solver (per process, not per handle) */ };
+int qs_counter(qs_handle* h, int which, uint64_t* value);
 /* HIP events bracketing the step kernel of the most recent qs_step (on the handle's stream): elapsed milliseconds, for
  * bench.py's roofline leg.  Recording is off by default (qs_enable_timing). */
 int qs_enable_timing(qs_handle* h, int on);

@@ -763,6 +763,7 @@ template <class T> struct Sim {
 #undef QS_CONTACT_ROW
         V Kc[3][3] = {{K11, K12, K13}, {K12, K22, K23}, {K13, K23, K33}};
         if (T::any(any_lim)) {
+            T::count_rare_path();
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 Row& r_ = rows[3 + j];

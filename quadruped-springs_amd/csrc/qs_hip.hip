@@ -527,6 +527,22 @@ int qs_set_trace(qs_handle* h, int env, float* rows) {
     return 0;
 }
 
+int qs_counter(qs_handle* h, int which, uint64_t* value) {
+    if (!h || !value) QS_FAIL(-1, "null argument");
+    QS_HIP(hipStreamSynchronize(h->stream));
+    unsigned long long v = 0;
+    switch (which) {
+    case QS_COUNTER_SETTLE_SUBSTEPS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_SETTLE_SUBSTEPS], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_RESETS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_RESETS], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_POOL_CONSUMED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_CONSUMED], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_POOL_REFILLED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_REFILLED], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_LIMIT_PATH_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_rare_path_substeps), sizeof(v))); break;
+    default: QS_FAIL(-1, "unknown counter %d", which);
+    }
+    *value = v;
+    return 0;
+}
+
 int qs_last_step_kernel_ms(qs_handle* h, float* ms) {
     if (!h || !ms) QS_FAIL(-1, "null argument");
     if (!h->timing) QS_FAIL(-1, "timing is off (qs_enable_timing)");

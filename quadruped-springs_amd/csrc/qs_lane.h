@@ -71,6 +71,8 @@ QS_FN bool qnot(bool a) { return !a; }
 QS_FN float qflag(bool m) { return m ? 1.0f : 0.0f; }
 
 #if defined(__HIPCC__)
+// telemetry: wave-substeps that took the joint-limit solver path (all handles of the process; read through qs_counter)
+__device__ unsigned long long qs_rare_path_substeps;
 struct LaneDev {
     using V = float;
     using M = bool;
@@ -116,6 +118,7 @@ struct LaneDev {
     static QS_DEV void st(float* rec, int i, float v) { if ((threadIdx.x & 3u) == 0) rec[i] = v; }
     static QS_DEV float first(float x) { return x; }
     static QS_DEV void opaque(float& x) { asm volatile("" : "+v"(x)); }
+    static QS_DEV void count_rare_path() { if (threadIdx.x == 0) atomicAdd(&qs_rare_path_substeps, 1ull); }
     // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
     static QS_DEV void sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -175,6 +178,7 @@ struct LaneEmu {
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
     static void fma2(V4 a0, V4 a1, V4 b, V4& c0, V4& c1) { for (int l = 0; l < 4; l++) { c0.v[l] = fmaf(a0.v[l], b.v[l], c0.v[l]); c1.v[l] = fmaf(a1.v[l], b.v[l], c1.v[l]); } }
+    static void count_rare_path() {}
     struct Acc4 { V4 k[4]; };
     static Acc4 acc4_zero() { Acc4 z; for (int i = 0; i < 4; i++) z.k[i] = V4(0.0f); return z; }
     static void outer_fma(V4 a, V4 b, Acc4& acc) { for (int K = 0; K < 4; K++) for (int l = 0; l < 4; l++) acc.k[K].v[l] = fmaf(a.v[K], b.v[l], acc.k[K].v[l]); }

@@ -133,6 +133,13 @@ class QuadrupedVecEnv(SB3VecEnv):
         _lib.check(self.lib.qs_stats(self.h, C.byref(a), C.byref(b)))
         return dict(settle_substeps=a.value, resets=b.value)
 
+    COUNTERS = dict(settle_substeps=0, resets=1, pool_consumed=2, pool_refilled=3, limit_path_substeps=4)
+
+    def counter(self, which):
+        v = C.c_uint64(0)
+        _lib.check(self.lib.qs_counter(self.h, self.COUNTERS[which] if isinstance(which, str) else int(which), C.byref(v)))
+        return int(v.value)
+
     def enable_timing(self, on=True):
         _lib.check(self.lib.qs_enable_timing(self.h, int(on)))
 
