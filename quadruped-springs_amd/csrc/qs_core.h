@@ -436,84 +436,109 @@ template <class T> struct Sim {
     }
 
     // The joint-limit path (6 rows per leg: contact rows + one row per violated limit) is rare (falls).  It is written
-    // with ROLLED loops over dynamically indexed arrays, so the compiler keeps its 24 x 6 Delassus block and row data in
-    // private (scratch) memory instead of ~300 extra registers: the common path then needs no spills at all, and the
-    // scratch traffic exists only in waves that actually take this branch.  Same arithmetic as solve_and_integrate<3>.
+    // with its 24 x 6 Delassus block and row data in private (scratch) memory instead of ~300 extra registers: the common path
+    // then needs no spills at all, and the scratch traffic exists only in waves that actually take this branch.  Same arithmetic
+    // as solve_and_integrate<3>.
     struct RareArgs { Row rows[6]; V Sm[21], Ld[6], BK[3][6], R[9]; };
     static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs& a) {
         const float dt = (float)cfg.dt;
         const V zero = V(0.0f), big = V(1e10f);
-        V Ap[24][6], lam[6], res[6], loc[6][6];
+        // Everything that is indexed below goes through a runtime zero, so the 24 x 6 Delassus block and the row data live in
+        // private memory and are fetched row by row with constant offsets; the loops are unrolled, the impulses and residuals of
+        // the own six rows stay in registers and every broadcast is a DPP quad_perm.
+        const int z0 = T::opaque_zero();
+        const Row* rows = a.rows + z0;
+        V Ap[24 * 6], wcs[6 * 6];
+        V* ApB = Ap + z0; V* wc = wcs + z0;
 #pragma clang loop unroll(disable)
-        for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) {
+            V di = rows[c].dinv;
+#pragma unroll
+            for (int i = 0; i < 6; i++) wc[6 * c + i] = rows[c].w[i] * di;
+        }
+        const V own0 = qflag(T::is_leg(0)), own1 = qflag(T::is_leg(1)), own2 = qflag(T::is_leg(2)), own3 = qflag(T::is_leg(3));
+        // the 36 (row kind, column kind) blocks: rolled, six MFMAs each (built once per substep; only the sweeps below are unrolled)
 #pragma clang loop unroll(disable)
-            for (int c = 0; c < 6; c++) loc[r][c] = a.rows[r].jq[0] * a.rows[c].u[0] + a.rows[r].jq[1] * a.rows[c].u[1] + a.rows[r].jq[2] * a.rows[c].u[2];
+        for (int r = 0; r < 6; r++) {
+            V wr[6], jr[3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) wr[i] = rows[r].w[i];
+#pragma unroll
+            for (int j = 0; j < 3; j++) jr[j] = rows[r].jq[j];
 #pragma clang loop unroll(disable)
-        for (int k = 0; k < 4; k++) {
-            M own = T::is_leg(k);
-#pragma clang loop unroll(disable)
-            for (int r = 0; r < 6; r++) {
-                V wk[6];
-                for (int i = 0; i < 6; i++) wk[i] = T::bcast_dyn(a.rows[r].w[i], k);
-#pragma clang loop unroll(disable)
-                for (int c = 0; c < 6; c++) {
-                    V d = wk[0] * a.rows[c].w[0] + wk[1] * a.rows[c].w[1] + wk[2] * a.rows[c].w[2] + wk[3] * a.rows[c].w[3] +
-                          wk[4] * a.rows[c].w[4] + wk[5] * a.rows[c].w[5];
-                    Ap[6 * k + r][c] = (d + qsel(own, loc[r][c], zero)) * a.rows[c].dinv;
-                }
+            for (int c = 0; c < 6; c++) {
+                typename T::Acc4 acc = T::acc4_zero();
+#pragma unroll
+                for (int i = 0; i < 6; i++) T::outer_fma(wr[i], wc[6 * c + i], acc);
+                V locs = (jr[0] * rows[c].u[0] + jr[1] * rows[c].u[1] + jr[2] * rows[c].u[2]) * rows[c].dinv;
+                ApB[(6 * 0 + r) * 6 + c] = T::template acc4_get<0>(acc) + own0 * locs;
+                ApB[(6 * 1 + r) * 6 + c] = T::template acc4_get<1>(acc) + own1 * locs;
+                ApB[(6 * 2 + r) * 6 + c] = T::template acc4_get<2>(acc) + own2 * locs;
+                ApB[(6 * 3 + r) * 6 + c] = T::template acc4_get<3>(acc) + own3 * locs;
             }
         }
-#pragma clang loop unroll(disable)
-        for (int r = 0; r < 6; r++) { lam[r] = zero; res[r] = a.rows[r].rhs; }
-        lam[0] = s.warm * cfg.warmstart * a.rows[0].act;
-#pragma clang loop unroll(disable)
-        for (int k = 0; k < 4; k++) {
-            V lk = T::bcast_dyn(lam[0], k);
-#pragma clang loop unroll(disable)
-            for (int c = 0; c < 6; c++) res[c] = res[c] - Ap[6 * k][c] * lk;
-        }
+        V lam[6], res[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) { lam[r] = zero; res[r] = rows[r].rhs; }
+        lam[0] = s.warm * cfg.warmstart * rows[0].act;
+#define QS_RWARM(K)                                                                                                    \
+    {                                                                                                                  \
+        V lk = T::template bcast<K>(lam[0]);                                                                           \
+        _Pragma("unroll") for (int c = 0; c < 6; c++) res[c] = res[c] - ApB[(6 * (K)) * 6 + c] * lk;                   \
+    }
+        QS_RWARM(0) QS_RWARM(1) QS_RWARM(2) QS_RWARM(3)
+#undef QS_RWARM
         const bool track = cfg.solver_residual_threshold > 0.0f;
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
+        // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the own normal impulse
+#define QS_RROW(K, R, KIND)                                                                                            \
+    {                                                                                                                  \
+        V cand = lam[R] + res[R];                                                                                      \
+        if (KIND == 0) cand = qmin(qmax(cand, zero), big);                                                             \
+        else { V tot = lam[0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[R]); }   \
+        V dk = T::template bcast<K>(cand - lam[R]);                                                                    \
+        lam[R] = qsel(T::is_leg(K), cand, lam[R]);                                                                     \
+        _Pragma("unroll") for (int c = 0; c < 6; c++) res[c] = res[c] - ApB[(6 * (K) + (R)) * 6 + c] * dk;             \
+        if (track) dvmax = qmax(dvmax, qabs(dk * T::template bcast<K>(rows[R].diag)));                                 \
+    }
+#define QS_RLEG_FWD(K) QS_RROW(K, 3, 0) QS_RROW(K, 4, 0) QS_RROW(K, 5, 0) T::sched_fence();
+#define QS_RLEG_BWD(K) QS_RROW(K, 5, 0) QS_RROW(K, 4, 0) QS_RROW(K, 3, 0) T::sched_fence();
         for (int it = 0; it < cfg.solver_iters; it++) {
             V dvmax = zero;
-            // 36 row updates per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), 4 normals, 8 frictions
-#pragma clang loop unroll(disable)
-            for (int n = 0; n < 24; n++) {
-                int k, r, kind = 0;
-                if (n < 12) { int m = (it & 1) ? n : 11 - n; k = m / 3; r = 3 + m % 3; }
-                else if (n < 16) { k = n - 12; r = 0; }
-                else { k = (n - 16) >> 1; r = 1 + ((n - 16) & 1); kind = 1; }
-                V cand = lam[r] + res[r];
-                if (kind == 0) cand = qmin(qmax(cand, zero), big);
-                else { V tot = lam[0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[r]); }
-                V dk = T::bcast_dyn(cand - lam[r], k);
-                lam[r] = qsel(T::is_leg(k), cand, lam[r]);
-#pragma clang loop unroll(disable)
-                for (int c = 0; c < 6; c++) res[c] = res[c] - Ap[6 * k + r][c] * dk;
-                if (track) dvmax = qmax(dvmax, qabs(dk * T::bcast_dyn(a.rows[r].diag, k)));
-            }
+            // 24 row updates per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), 4 normals, 8 frictions
+            if (it & 1) { QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3) }
+            else { QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0) }
+            QS_RROW(0, 0, 0) QS_RROW(1, 0, 0) T::sched_fence(); QS_RROW(2, 0, 0) QS_RROW(3, 0, 0) T::sched_fence();
+            QS_RROW(0, 1, 1) QS_RROW(0, 2, 1) T::sched_fence(); QS_RROW(1, 1, 1) QS_RROW(1, 2, 1) T::sched_fence();
+            QS_RROW(2, 1, 1) QS_RROW(2, 2, 1) T::sched_fence(); QS_RROW(3, 1, 1) QS_RROW(3, 2, 1) T::sched_fence();
             if (track) {
                 M conv = qle(dvmax, thr);
-#pragma clang loop unroll(disable)
+#pragma unroll
                 for (int c = 0; c < 6; c++) res[c] = qsel(conv, zero, res[c]);
                 if (!T::any(qnot(conv))) break;
             }
         }
+#undef QS_RLEG_FWD
+#undef QS_RLEG_BWD
+#undef QS_RROW
         o.foot_force = lam[0] * (1.0f / dt);
         s.warm = lam[0];
         V z[6];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             V t = zero;
-#pragma clang loop unroll(disable)
-            for (int r = 0; r < 6; r++) t = t + a.rows[r].w[i] * lam[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++) t = t + rows[r].w[i] * lam[r];
             z[i] = T::quad_sum(t);
         }
         ltsolve6<V>(a.Sm, a.Ld, z);
         const V cap = V(cfg.vel_cap);
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             V t = zero;
-#pragma clang loop unroll(disable)
-            for (int r = 0; r < 6; r++) t = t + a.rows[r].u[j] * lam[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++) t = t + rows[r].u[j] * lam[r];
+#pragma unroll
             for (int i = 0; i < 6; i++) t = t - a.BK[j][i] * z[i];
             s.qd[j] = clampv<V>(s.qd[j] + t, -cap, cap);
         }

@@ -207,3 +207,36 @@ def test_trace_tap_rows():
         np.testing.assert_allclose(te[:, 26:38], to[:, 26:38], atol=2e-2)
         np.testing.assert_allclose(te[:, 38:62], to[:, 38:62], atol=5e-2)                       # torques follow q, qd (kp = 75)
         np.testing.assert_array_equal(te[:, 66:70], to[:, 66:70])
+
+
+def test_joint_limit_rows_all_joints():
+    """Raw torques push calves, then hips and thighs into their stops with the robots held in the air: every kind of limit row,
+    both sweep directions.  The reference here is the FLOAT32 build of the oracle: whether a joint that sits within rounding of
+    its stop gets a row depends on the rounding of the state itself (the float64 build differs from its own float32 build in 2 %
+    of the values of this scenario, by up to 3e-3), so both sides are given the same float32 state."""
+    from qs_amd.config import build_config as bc
+    n = 16
+    cfg, _ = bc(n_envs=n, noise=False, env_randomizer_mode="NONE", isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK",
+                observation_space_mode="ENCODER", enable_action_filter=False, enable_springs=False)
+    o, e = Oracle(cfg, "f32"), Emu(cfg)
+    o.reset(); e.reset()
+    rng = np.random.default_rng(4)
+    hit = np.zeros(3, bool)
+    for i in range(90):
+        tau = 2.0 * rng.normal(size=(n, 12)).astype(np.float32)
+        if i < 45:
+            tau[:, 2::3] = -30.0
+        else:
+            tau[:, 0::3] = np.array([-20.0, 20.0, -20.0, 20.0], np.float32)
+            tau[:, 1::3] = -20.0
+        s = o.get_state()
+        s[:, 2] = np.maximum(s[:, 2], 0.6)
+        s[:, 7:13] = 0
+        o.set_state(s); e.set_state(s)
+        o.step(tau); e.step(tau)
+        so, se = o.get_state(), e.get_state()
+        np.testing.assert_allclose(se[:, 13:25], so[:, 13:25], atol=1e-5, err_msg=f"q step {i}")
+        np.testing.assert_allclose(se[:, 25:], so[:, 25:], atol=5e-3, err_msg=f"qd step {i}")
+        q = so[:, 13:25]
+        hit |= np.array([(q[:, 2::3] < -2.70).any(), (np.abs(q[:, 0::3]) > 1.03).any(), (q[:, 1::3] < -0.65).any()])
+    assert hit.all(), hit

@@ -627,6 +627,40 @@ def test_reference_state_initialisation(torch_cuda, golden, name):
         env.close()
 
 
+def test_joint_limit_solver_path(torch_cuda):
+    """Raw torques drive joints into their stops (calves to the lower stop, then hips outwards and thighs back): the 6-rows-per-leg
+    solver path against the FLOAT32 build of the oracle on the same float32 states (see tests/test_emu_vs_oracle.py::
+    test_joint_limit_rows_all_joints for why float32); the telemetry counter shows the path was taken."""
+    from oracle.qso import Oracle
+    n = 32
+    _, v, cfg = make_pair(n, torch_cuda, oracle=False, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK",
+                          observation_space_mode="ENCODER", enable_action_filter=False, enable_springs=False)
+    o = Oracle(cfg, "f32")
+    o.reset(); v.reset()
+    c0 = v.counter("limit_path_substeps")
+    rng = np.random.default_rng(4)
+    hit = np.zeros(3, bool)
+    for i in range(90):
+        tau = 2.0 * rng.normal(size=(n, 12)).astype(np.float32)
+        if i < 45:
+            tau[:, 2::3] = -30.0                     # calves against the lower stop (-2.72 rad)
+        else:
+            tau[:, 0::3] = np.array([-20.0, 20.0, -20.0, 20.0], np.float32)   # hips outwards
+            tau[:, 1::3] = -20.0                     # thighs against their lower stop
+        s = o.get_state()
+        s[:, 2] = np.maximum(s[:, 2], 0.6)           # keep the robots in the air: only the joint stops act
+        s[:, 7:13] = 0
+        o.set_state(s); v.set_state(s)
+        o.step(tau); v.step(tau)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=2e-5, err_msg=f"q step {i}")
+        np.testing.assert_allclose(sv[:, 25:], so[:, 25:], atol=1e-2, err_msg=f"qd step {i}")
+        q = so[:, 13:25]
+        hit |= np.array([(q[:, 2::3] < -2.70).any(), (np.abs(q[:, 0::3]) > 1.03).any(), (q[:, 1::3] < -0.65).any()])
+    assert hit.all(), hit
+    assert v.counter("limit_path_substeps") - c0 > 200
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
