@@ -377,10 +377,13 @@ template <class T> struct Env {
     }
 
     // ---- sensors (sensors/robot_sensors.py, sensor.py:46-60) into obs[QS_MAX_OBS] of this environment
+    // `rpy`: roll, pitch, yaw of s if the caller has them already (task_on_step computes them for every task but NO_TASK)
     static QS_FN void write_obs(const qs_config& cfg, float* obs, const typename S::State& s, const typename S::Out& o, const Task& t,
-                                uint32_t env_id, uint32_t total_steps) {
+                                uint32_t env_id, uint32_t total_steps, const V* rpy = nullptr) {
         int n = 0;
-        V roll, pitch, yaw; quat_to_rpy(s.qx, s.qy, s.qz, s.qw, roll, pitch, yaw);
+        V roll, pitch, yaw;
+        if (rpy) { roll = rpy[0]; pitch = rpy[1]; yaw = rpy[2]; }
+        else quat_to_rpy(s.qx, s.qy, s.qz, s.qw, roll, pitch, yaw);
         for (int si = 0; si < cfg.n_sensors; si++) {
             switch (cfg.sensors[si]) {
             case QS_SENS_JOINT_POS: for (int j = 0; j < 3; j++) T::st_leg(obs, n + j, 3, s.q[j]); n += 12; break;
@@ -658,7 +661,7 @@ template <class T> struct Env {
 #pragma unroll
         for (int j = 0; j < 3; j++) T::st_leg(rec, R_NEW_TAU + j, 3, o.tau_pd[j]);
         T::st(rec, R_SIM_STEP, V(i2f(sim_step))); T::st(rec, R_ENV_STEP, V(i2f(env_step))); T::st(rec, R_TOTAL_STEPS, V(i2f(total)));
-        write_obs(cfg, obs, s, o, t, env_id, (uint32_t)total);
+        write_obs(cfg, obs, s, o, t, env_id, (uint32_t)total, cfg.task != QS_TASK_NO_TASK ? t.rpy : nullptr);
         return r;
     }
 
