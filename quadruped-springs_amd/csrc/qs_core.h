@@ -21,7 +21,7 @@
 // Optional cycle accounting per phase of the substep (build with -DQS_PROFILE_PHASES; tools/phase_profile.py): s_memtime at
 // the phase boundaries of workgroup 0, accumulated in a __device__ array.  Compiled out otherwise.
 #if defined(QS_PROFILE_PHASES) && defined(__HIPCC__)
-__device__ unsigned long long qs_phase_cycles[32];
+__device__ unsigned long long qs_phase_cycles[48];
 __device__ unsigned long long qs_phase_t0, qs_phase_sub0;   // written by one lane of workgroup 0 only
 #endif
 #if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)

@@ -48,9 +48,12 @@ template <class T> struct Env {
         V p = qasin(clampv<V>(sarg, V(-1.0f), V(1.0f)));
         V r = qatan2(V(2.0f) * (y * z + w * x), w * w - x * x - y * y + z * z);
         V yw = qatan2(V(2.0f) * (x * y + w * z), w * w + x * x - y * y - z * z);
-        pitch = qsel(lo, V(-0.5f * PI), qsel(hi, V(0.5f * PI), p));
-        roll = qsel(qor(lo, hi), V(0.0f), r);
-        yaw = qsel(lo, V(2.0f) * qatan2(x, -y), qsel(hi, V(2.0f) * qatan2(-x, y), yw));
+        pitch = p; roll = r; yaw = yw;
+        if (T::any(qor(lo, hi))) {   // gimbal lock (pitch = +-90 degrees): pybullet's special case
+            pitch = qsel(lo, V(-0.5f * PI), qsel(hi, V(0.5f * PI), p));
+            roll = qsel(qor(lo, hi), V(0.0f), r);
+            yaw = qsel(lo, V(2.0f) * qatan2(x, -y), qsel(hi, V(2.0f) * qatan2(-x, y), yw));
+        }
     }
     // ---- PitchBackFlip sensor (robot_sensors.py:333-340)
     static QS_FN V pitch_backflip(V x, V y, V z, V w, V switched) {
@@ -592,18 +595,22 @@ template <class T> struct Env {
             }
         }
         if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); return z; }
+        QS_PHASE(32)
         if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;
         Task t;
         load_task(rec, t);
         V now = V((float)((double)sim_step * cfg.dt));
+        QS_PHASE(33)
         task_on_step(cfg, t, s, o, old_tau, now);
+        QS_PHASE(34)
         V force = T::quad_sum(o.foot_force);
         V reward = task_reward(cfg, t, force, cfg.task == QS_TASK_BACKFLIP_PPO ? pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched) : V(0.0f));
         V term = task_terminated(cfg, t, s, o.n_invalid);
         bool timeout = sim_step > cfg.max_sim_steps;   // gym_env.py:245
         V done = timeout ? V(1.0f) : term;
         reward = reward + qsel(qgt(done, V(0.5f)), task_reward_end(cfg, t, term, now), V(0.0f));  // :250-251
+        QS_PHASE(35)
         StepOut r; r.reward = reward; r.done = done; r.trunc = qsel(qgt(term, V(0.5f)), V(0.0f), done);  // :246
         if (cfg.wrapper_mode != QS_WRAP_NONE) {
             float* w = rec + R_WRAP;
@@ -657,11 +664,14 @@ template <class T> struct Env {
             }
             T::st(w, W_PHASE, w_phase); T::st(w, W_TIMER, w_timer); T::st(w, W_END, w_end); T::st(w, W_TSTART, w_tstart);
         }
+        QS_PHASE(36)
         store_state(rec, s, o); store_task(rec, t);
 #pragma unroll
         for (int j = 0; j < 3; j++) T::st_leg(rec, R_NEW_TAU + j, 3, o.tau_pd[j]);
         T::st(rec, R_SIM_STEP, V(i2f(sim_step))); T::st(rec, R_ENV_STEP, V(i2f(env_step))); T::st(rec, R_TOTAL_STEPS, V(i2f(total)));
+        QS_PHASE(37)
         write_obs(cfg, obs, s, o, t, env_id, (uint32_t)total, cfg.task != QS_TASK_NO_TASK ? t.rpy : nullptr);
+        QS_PHASE(38)
         return r;
     }
 

@@ -653,8 +653,8 @@ int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets) {
 // debug builds only (tools/phase_profile.py): cycles of workgroup 0 per substep phase, summed over all substeps so far
 int qs_debug_phases(unsigned long long* out32, int reset) {
     QS_HIP(hipDeviceSynchronize());
-    QS_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(qs_phase_cycles), 32 * sizeof(unsigned long long)));
-    if (reset) { unsigned long long z[32] = {0}; QS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(qs_phase_cycles), z, sizeof(z))); }
+    QS_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(qs_phase_cycles), 48 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[48] = {0}; QS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(qs_phase_cycles), z, sizeof(z))); }
     return 0;
 }
 #endif

@@ -20,7 +20,7 @@ env.reset_tensor()
 a = torch.rand((16, 8192, 6), device="cuda") * 2 - 1
 for i in range(20):
     env.step_tensor(a[i % 16])
-out = (C.c_uint64 * 32)()
+out = (C.c_uint64 * 48)()
 env.lib.qs_debug_phases(out, 1)
 n = 200
 for i in range(n):
@@ -36,3 +36,5 @@ print(f"per env-step: tile load {out[13] / n:.0f}, E::step outside the substeps 
 print("cycles of substep k of the env step (k = 0 pays the cold instruction cache): " + ", ".join(f"{out[16 + k] / n:.0f}" for k in range(10)))
 print("kernel entry: config / kernarg reads %.0f, issue of the tile loads %.0f, action loads %.0f, wait + barrier %.0f, rest of the prologue %.0f cycles per env-step"
       % tuple(out[k] / n for k in (26, 27, 28, 29, 13)))
+print("epilogue of E::step: load task %.0f, task_on_step %.0f, reward + termination %.0f, wrapper machine %.0f, store state / task %.0f, "
+      "observations + noise %.0f cycles per env-step" % tuple(out[k] / n for k in (33, 34, 35, 36, 37, 38)))
