@@ -20,18 +20,19 @@ template <class T> struct Env {
         const float sh = cfg.leg_len[0], el = cfg.leg_len[1], wr = cfg.leg_len[2];
         V D = (y * y + z * z - sh * sh + x * x - el * el - wr * wr) * (1.0f / (2.0f * wr * el));
         D = clampv<V>(D, V(-1.0f), V(1.0f));
-        V wrist = qatan2(-qsqrt(V(1.0f) - D * D), D);
+        V sw = -qsqrt(V(1.0f) - D * D);          // sin(wrist); cos(wrist) = D: the point (D, sw) is on the unit circle
+        V wrist = qatan2(sw, D);
         V sc = qmax(y * y + z * z - sh * sh, V(0.0f));
         V rt = qsqrt(sc);
         V shoulder = -qatan2(z, y) - qatan2(rt, T::sy() * sh);
-        V elbow = qatan2(-x, rt) - qatan2(qsin(wrist) * wr, qcos(wrist) * wr + el);
+        V elbow = qatan2(-x, rt) - qatan2(sw * wr, D * wr + el);
         q[0] = -shoulder; q[1] = elbow; q[2] = wrist;
     }
     // ---- analytic leg FK + Jacobian (quadruped.py:348-392)
     static QS_FN void leg_fk(const qs_config& cfg, const V* q, V* J, V* p) {
         const float l1 = cfg.leg_len[0], l2 = cfg.leg_len[1], l3 = cfg.leg_len[2];
         V sg = T::sy();
-        V s1 = qsin(q[0]), s2 = qsin(q[1]), s3 = qsin(q[2]), c1 = qcos(q[0]), c2 = qcos(q[1]), c3 = qcos(q[2]);
+        V s1, s2, s3, c1, c2, c3; qsincos(q[0], s1, c1); qsincos(q[1], s2, c2); qsincos(q[2], s3, c3);
         V c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
         V zero = V(0.0f);
         J[0] = zero; J[3] = -sg * l1 * s1 + c2 * c1 * l2 + c23 * c1 * l3; J[6] = sg * l1 * c1 + c2 * s1 * l2 + c23 * s1 * l3;
@@ -206,7 +207,8 @@ template <class T> struct Env {
     }
     static QS_FN V jump_distance(const Task& t) {  // task_base.py:108-116
         V dx = t.pos[0] - t.pose_to[0], dy = t.pos[1] - t.pose_to[1];
-        return qmax(qcos(t.yaw_to) * dx - qsin(t.yaw_to) * dy, V(0.0f));
+        V sn, cs; qsincos(t.yaw_to, sn, cs);
+        return qmax(cs * dx - sn * dy, V(0.0f));
     }
     // `old_tau` is the record's R_NEW_TAU (own leg), `o.tau_pd` the torque of the last substep
     static QS_FN void task_on_step(const qs_config& cfg, Task& t, const typename S::State& s, const typename S::Out& o, const V* old_tau, V now) {
