@@ -25,21 +25,31 @@
 #endif
 
 // ------------------------------------------------------------------ scalar (device) flavour
-QS_FN float qsqrt(float x) { return sqrtf(x); }
 QS_FN float qabs(float x) { return fabsf(x); }
 QS_FN float qfloor(float x) { return floorf(x); }
 QS_FN float qmin(float a, float b) { return fminf(a, b); }
 QS_FN float qmax(float a, float b) { return fmaxf(a, b); }
 QS_FN float qsin(float x) { return sinf(x); }
 QS_FN float qcos(float x) { return cosf(x); }
+QS_FN float qexp(float x) { return expf(x); }
+QS_FN float qlog(float x) { return logf(x); }
+#if defined(__HIP_DEVICE_COMPILE__)
+QS_FN float qsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
+QS_FN float qrcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
+QS_FN float qrsqrt(float x) { return __builtin_amdgcn_rsqf(x); }    // v_rsq_f32, 1 ulp
+#else
+QS_FN float qsqrt(float x) { return sqrtf(x); }
+QS_FN float qrcp(float x) { return 1.0f / x; }
+QS_FN float qrsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
 // atan2 / asin for the Euler angles of the task and sensor epilogue: Cephes' single-precision arctangent polynomial on
 // min / max of the magnitudes (|error| < 2e-7 rad), branch-free; libm's versions cost ~5x the instructions
 QS_FN float qatan2(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float a = mx > 0.0f ? mn / mx : 0.0f;                       // in [0, 1]
+    float a = mx > 0.0f ? mn * qrcp(mx) : 0.0f;                 // in [0, 1]
     const bool mid = a > 0.4142135623730950f;                   // tan(pi/8): atan(a) = pi/4 + atan((a - 1) / (a + 1))
-    const float t = mid ? (a - 1.0f) / (a + 1.0f) : a;
+    const float t = mid ? (a - 1.0f) * qrcp(a + 1.0f) : a;
     const float z = t * t;
     float r = ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z) * t + t;
     r = mid ? r + 0.7853981633974483f : r;
@@ -47,16 +57,7 @@ QS_FN float qatan2(float y, float x) {
     r = x < 0.0f ? 3.141592653589793f - r : r;
     return y < 0.0f ? -r : r;
 }
-QS_FN float qasin(float x) { return qatan2(x, sqrtf(fmaxf(1.0f - x * x, 0.0f))); }
-QS_FN float qexp(float x) { return expf(x); }
-QS_FN float qlog(float x) { return logf(x); }
-#if defined(__HIP_DEVICE_COMPILE__)
-QS_FN float qrcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
-QS_FN float qrsqrt(float x) { return __builtin_amdgcn_rsqf(x); }    // v_rsq_f32, 1 ulp
-#else
-QS_FN float qrcp(float x) { return 1.0f / x; }
-QS_FN float qrsqrt(float x) { return 1.0f / sqrtf(x); }
-#endif
+QS_FN float qasin(float x) { return qatan2(x, qsqrt(fmaxf(1.0f - x * x, 0.0f))); }
 // sin and cos of a joint angle (|x| < ~10): 2-term Cody-Waite reduction by pi/2, degree-7/8 minimax polynomials on
 // [-pi/4, pi/4] (abs. error < 2e-7), a third of the instruction count of the libm pair
 QS_FN void qsincos(float x, float& s, float& c) {
