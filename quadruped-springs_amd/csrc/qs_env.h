@@ -58,7 +58,7 @@ template <class T> struct Env {
     }
     // ---- PitchBackFlip sensor (robot_sensors.py:333-340)
     static QS_FN V pitch_backflip(V x, V y, V z, V w, V switched) {
-        V d = x * x + y * y + z * z + w * w, sc = V(2.0f) / d;
+        V d = x * x + y * y + z * z + w * w, sc = V(2.0f) * qrcp(d);
         V r20 = (x * z - w * y) * sc, r22 = V(1.0f) - (x * x + y * y) * sc;
         V pitch = -qatan2(-r20, r22);
         return qsel(qand(qlt(pitch, V(0.0f)), qgt(switched, V(0.5f))), pitch + 2.0f * PI, pitch);
@@ -283,7 +283,7 @@ template <class T> struct Env {
         M bad = qgt(n_invalid, V(0.5f));                                          // :137-147
         if (cfg.task == QS_TASK_BACKFLIP) return qflag(qor(low, bad));            // robot_tasks.py:532-533
         V d = s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw;
-        V r22 = V(1.0f) - (s.qx * s.qx + s.qy * s.qy) * (V(2.0f) / d);
+        V r22 = V(1.0f) - (s.qx * s.qx + s.qy * s.qy) * (V(2.0f) * qrcp(d));
         return qflag(qor(qand(qlt(r22, V(0.85f)), low), bad));                    // task_base.py:126-135
     }
     static QS_FN V task_reward(const qs_config& cfg, const Task& t, V contact_force, V bf_pitch) {
@@ -400,7 +400,7 @@ template <class T> struct Env {
             case QS_SENS_LANDING: T::st(obs, n++, t.switched); break;
             case QS_SENS_JUMPING: T::st(obs, n++, t.is_jumping); break;
             case QS_SENS_PITCH_RATE: {  // quadruped.py:141-170: (R^T w_world)[1]
-                V d = s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw, sc = V(2.0f) / d;
+                V d = s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw, sc = V(2.0f) * qrcp(d);
                 V r01 = (s.qx * s.qy - s.qw * s.qz) * sc, r11 = V(1.0f) - (s.qx * s.qx + s.qz * s.qz) * sc, r21 = (s.qy * s.qz + s.qw * s.qx) * sc;
                 T::st(obs, n++, r01 * s.vang.x + r11 * s.vang.y + r21 * s.vang.z);
                 break;
