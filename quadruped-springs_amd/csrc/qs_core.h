@@ -165,7 +165,7 @@ template <class V> QS_FN void ltsolve6(const V* L, const V* dinv, V* b) {  // b 
         b[i] = t * dinv[i];
     }
 }
-template <class V> QS_FN V clampv(V x, V lo, V hi) { return qmin(qmax(x, lo), hi); }
+template <class V> QS_FN V clampv(V x, V lo, V hi) { return qmed3(x, lo, hi); }   // one v_med3_f32 on the device (no NaN canonicalisation of the three operands)
 
 // ------------------------------------------------------------------ Philox4x32-10 (same stream definition as oracle/qso_env.c)
 QS_FN void philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
