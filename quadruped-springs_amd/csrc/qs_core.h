@@ -411,7 +411,7 @@ template <class T> struct Sim {
         for (int c = 0; c < NR; c++)
             lam_own[c] = qsel(T::is_leg(0), lam_all[NR * 0 + c], qsel(T::is_leg(1), lam_all[NR * 1 + c], qsel(T::is_leg(2), lam_all[NR * 2 + c], lam_all[NR * 3 + c])));
         QS_PHASE_G(10)
-        o.foot_force = lam_own[0] * (1.0f / dt);   // getContactPoints()[9] = normal impulse / dt
+        o.foot_force = lam_own[0] * qrcp(dt);   // getContactPoints()[9] = normal impulse / dt
         s.warm = lam_own[0];
 
         // delta v = H^-1 J^T lambda :  dv_b = L^-T sum_i w_i lam_i ;  dqd = sum_own u_r lam_r - (B K)^T dv_b
@@ -528,7 +528,7 @@ template <class T> struct Sim {
 #undef QS_RLEG_FWD
 #undef QS_RLEG_BWD
 #undef QS_RROW
-        o.foot_force = lam[0] * (1.0f / dt);
+        o.foot_force = lam[0] * qrcp(dt);
         s.warm = lam[0];
         V z[6];
 #pragma unroll
@@ -761,7 +761,7 @@ template <class T> struct Sim {
         V3v rc = rf - Rz * V(FOOT_R);                   // contact point on the sphere, base coordinates
         V3v d1 = rc - p1, d2 = rc - p2, d3 = rc - p3;
         V3v g1 = cross(ax1, d1), g2 = cross(Y, d2), g3 = cross(Y, d3);  // d(point)/dq_j
-        const V inv_dt = V(1.0f / dt);
+        const V inv_dt = V(qrcp(dt));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
 #define QS_CONTACT_ROW(IDX, DIR, NORMAL)                                                                               \
     {                                                                                                                  \
         Row& r_ = rows[IDX];                                                                                           \
