@@ -93,6 +93,10 @@ class Oracle:
         self._check(self.lib.qso_get_obs(self.h, self._p(obs)))
         return obs
 
+    def set_threads(self, n):
+        """Spread the environments over n OpenMP threads (default 1)."""
+        self._check(self.lib.qso_set_threads(int(n)))
+
     def set_trace(self, env):
         """Per-substep rows of one environment (layout of qs_set_trace); returns the array the next step() calls fill."""
         self._trace = np.zeros((self.cfg.action_repeat, 70), self.real)

@@ -2,6 +2,9 @@
  * Restatement of the numpy half of the reference's hot path; every function cites the reference lines it follows
  * (paths relative to /root/reference/quadruped_spring/). Pinned by tests/golden/ (tests/golden/gen_golden.py). */
 #include "qso_internal.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static char g_err[256] = "";
 const char* qso_last_error(void) { return g_err; }
@@ -763,6 +766,15 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
     return 0;
 }
 
+/* threads the environment loops of THIS library spread over (OpenMP); 1 unless a test or bench.py's cpu_baseline asks for more */
+int qso_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+    return 0;
+}
 int qso_set_trace(qso_handle* h, int env, real* rows) { h->trace_env = env; h->trace = env >= 0 ? rows : NULL; return 0; }
 
 int qso_get_state(qso_handle* h, real* st) {

@@ -661,6 +661,47 @@ def test_joint_limit_solver_path(torch_cuda):
     assert v.counter("limit_path_substeps") - c0 > 200
 
 
+def test_free_running_statistics(torch_cuda):
+    """No resynchronisation: 512 environments run 150 env.steps (1500 substeps, several take-offs and landings each) on the kernel
+    and on the float64 oracle from the same settled states with the same actions.  Individual trajectories separate at contact-mode
+    changes (rounding decides which substep a foot lands in), so the comparison is (i) the part of the batch that has not separated
+    stays within loose trajectory bounds and is the large majority, (ii) the batch statistics -- height, pitch, return, episode ends --
+    agree: a systematic bias in the float32 path would show here and not in the resynchronised tests."""
+    from scipy.stats import ks_2samp
+    n, T = 512, 150
+    o, v, cfg = make_pair(n, torch_cuda, env_randomizer_mode="GROUND_RANDOMIZER", seed=21)
+    o.set_threads(min(32, os.cpu_count() or 1))
+    o.reset(); v.reset()
+    rng = np.random.default_rng(8)
+    period = rng.integers(25, 60, size=n)
+    depth = rng.uniform(0.3, 1.0, size=(n, 1))
+    ret_o, ret_v = np.zeros(n), np.zeros(n)
+    end_o, end_v = np.full(n, T), np.full(n, T)
+    zmax_o, zmax_v = np.zeros(n), np.zeros(n)
+    for i in range(T):
+        a = 0.3 * rng.uniform(-1, 1, size=(n, 6)).astype(np.float32)
+        crouch = ((i % period) < period // 2)[:, None]
+        a += np.where(crouch, depth * np.tile([0.0, 1.0, -1.0], 2), depth * np.tile([0.0, -1.0, 1.0], 2)).astype(np.float32)
+        _, ro, do, _ = o.step(a)
+        _, rv, dv, _ = v.step(a)
+        live_o, live_v = end_o == T, end_v == T
+        ret_o += np.where(live_o, ro, 0); ret_v += np.where(live_v, rv, 0)
+        end_o = np.where(live_o & do, i, end_o); end_v = np.where(live_v & dv, i, end_v)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        zmax_o = np.maximum(zmax_o, np.where(live_o, so[:, 2], 0)); zmax_v = np.maximum(zmax_v, np.where(live_v, sv[:, 2], 0))
+    assert np.isfinite(sv).all()
+    assert zmax_o.max() > 0.45 and (end_o < T).mean() > 0.05     # the script makes robots jump, and some episodes end
+    same = (end_o == end_v) & (np.abs(zmax_o - zmax_v) < 5e-3)
+    print("same outcome:", same.mean(), "ended:", (end_o < T).mean(), (end_v < T).mean(), "zmax:", zmax_o.mean(), zmax_v.mean(),
+          "return:", ret_o.mean(), ret_v.mean())
+    assert same.mean() > 0.8
+    assert abs((end_o < T).mean() - (end_v < T).mean()) < 0.05
+    for name, x, y in (("max height", zmax_o, zmax_v), ("return", ret_o, ret_v), ("episode end", end_o, end_v),
+                       ("final pitch rate", so[:, 11], sv[:, 11])):
+        assert ks_2samp(x, y).pvalue > 0.01, name
+    assert abs(zmax_o.mean() - zmax_v.mean()) < 5e-3
+
+
 def test_create_rejects_bad_config(torch_cuda):
     import ctypes as C
     from qs_amd import lib as L
