@@ -694,7 +694,7 @@ def test_free_running_statistics(torch_cuda):
     same = (end_o == end_v) & (np.abs(zmax_o - zmax_v) < 5e-3)
     print("same outcome:", same.mean(), "ended:", (end_o < T).mean(), (end_v < T).mean(), "zmax:", zmax_o.mean(), zmax_v.mean(),
           "return:", ret_o.mean(), ret_v.mean())
-    assert same.mean() > 0.8
+    assert same.mean() > 0.95      # measured on MI355X: 1.0 (no environment separated within 150 steps)
     assert abs((end_o < T).mean() - (end_v < T).mean()) < 0.05
     for name, x, y in (("max height", zmax_o, zmax_v), ("return", ret_o, ret_v), ("episode end", end_o, end_v),
                        ("final pitch rate", so[:, 11], sv[:, 11])):
