@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="jump_in_place_8192")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--total-envs", type=int, default=0, help="strong scaling: this many environments split over the ranks (SURVEY 8e: 65536)")
     ap.add_argument("--reset-pool", type=int, default=4096, help="pre-settled reset states per GPU (0 = settle inside the step)")
     ap.add_argument("--no-pool-streaming", action="store_true",
                     help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
@@ -105,8 +106,11 @@ def main():
     n_default, kw = workload(args.workload)
     kw["solver_residual_threshold"] = args.solver_residual_threshold
     n = args.envs_per_gpu or n_default
-    env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, env_id_offset=n * rank if sharded else 0,
-                          seed=1234 + (0 if sharded else 7919 * rank), **kw)
+    if args.total_envs:
+        assert args.total_envs % (16 * world) == 0, "--total-envs must split into whole waves (16 environments) per rank"
+        n = args.total_envs // world
+    env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, env_id_offset=n * rank,
+                          seed=1234, **kw)   # Philox streams keyed by the global environment id: one job of n x world environments
     env.reset_tensor()
     d = env.action_dim
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -190,13 +194,20 @@ def main():
         achieved = n * ALGO_BYTES_PER_ENV_STEP / kavg / 1e9
         # HBM bytes per launch from the committed PMC passes of this very configuration (rocprofv3 cannot run inside this
         # process); null when the run differs from the profiled one
-        traffic = None
+        traffic = valu = None
         try:
             import glob
             pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))[-1]   # the latest committed PMC passes
             pmc = json.load(open(pmc_file))
             if (pmc["workload"], pmc["envs_per_gpu"], pmc["reset_pool"], pmc["settle_lanes"]) == (args.workload, n, args.reset_pool, streaming):
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
+                if "sq_insts_valu" in pmc:
+                    # the roof that does bound this kernel: one wave64 fp32 VALU instruction per SIMD every 4 cycles (16 lanes per SIMD)
+                    prop = torch.cuda.get_device_properties(dev)
+                    peak = prop.multi_processor_count * 4 * getattr(prop, "clock_rate", 2.4e6) * 1e3 / 4 / 1e9
+                    valu = {"achieved": pmc["sq_insts_valu"] / kavg / 1e9, "peak": peak, "unit": "G wave-instructions/s",
+                            "frac": pmc["sq_insts_valu"] / kavg / 1e9 / peak,
+                            "note": f"SQ_INSTS_VALU per launch (same PMC passes) / k_step duration, against SIMDs x clock / 4; at N = {n} only {min(1.0, (n // 16) / (prop.multi_processor_count * 4)):.0%} of the SIMDs hold a stepping wave"}
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -208,7 +219,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_envs else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -225,7 +236,7 @@ def main():
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step, rollout buffer on rank 0" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_step", "kernel_ms": kavg * 1e3,
+                         "traffic": traffic, "valu_issue": valu, "kernel": "k_step", "kernel_ms": kavg * 1e3,
                          "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (latest profiles/r*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step (80 % VALU-active): latency/issue-bound, not HBM-bound"},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a property of the box, reported with the single-GPU line only
