@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "qs_hip.hip")
 SRC_NORM = os.path.join(HERE, "csrc", "qs_norm.hip")
-DEPS = [SRC, SRC_NORM] + [os.path.join(HERE, "csrc", f) for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h")] + \
+DEPS = [SRC, SRC_NORM] + [os.path.join(HERE, "csrc", f) for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h", "qs_host.h")] + \
        [os.path.join(REPO, "include", "qs_amd.h")]
 OUT = os.path.join(HERE, "qs_amd", "libqs_hip.so")
 

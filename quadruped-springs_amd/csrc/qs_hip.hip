@@ -12,6 +12,7 @@
 #include <string.h>
 #include <new>
 #include "qs_env.h"
+#include "qs_host.h"
 
 using qs::Env;
 using E = Env<LaneDev>;
@@ -352,6 +353,7 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h);
 int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (!cfg || !out) QS_FAIL(-1, "null argument");
     if (cfg->n_envs <= 0) QS_FAIL(-1, "n_envs must be positive");
+    if (cfg->n_envs > (1 << 24)) QS_FAIL(-1, "n_envs %d exceeds %d environments per handle (16 GB of records); shard over more handles", cfg->n_envs, 1 << 24);
     if (cfg->obs_dim <= 0 || cfg->obs_dim > QS_MAX_OBS || cfg->n_sensors > QS_MAX_SENSORS) QS_FAIL(-1, "observation bundle too large");
     if (cfg->action_dim != 12 && cfg->action_dim != 6 && cfg->action_dim != 4 && cfg->action_dim != 5) QS_FAIL(-1, "action_dim must be 12, 6, 4 or 5 (CPG)");
     if (cfg->wrapper_mode != QS_WRAP_NONE && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
@@ -366,7 +368,7 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (derr != hipSuccess || ndev <= 0)
         QS_FAIL(-3, "no HIP device available (hipGetDeviceCount: %s, %d devices): this library has no CPU path", hipGetErrorString(derr), ndev);
     if (device < 0 || device >= ndev) QS_FAIL(-3, "HIP device %d out of range (%d visible)", device, ndev);
-    QS_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
     qs_handle* h = new (std::nothrow) qs_handle();
     if (!h) QS_FAIL(-4, "out of host memory");
     memset(h, 0, sizeof(*h));
@@ -412,7 +414,7 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
 
 void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null members are skipped)
     if (!h) return;
-    hipSetDevice(h->device);
+    QS_ON_DEVICE(h);
     hipStreamSynchronize(h->stream);
     hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
     if (h->d_pool) hipFree(h->d_pool);
@@ -427,6 +429,7 @@ int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle");
 
 int qs_reset(qs_handle* h, const uint8_t* mask) {
     if (!h) QS_FAIL(-1, "null handle");
+    QS_ON_DEVICE(h);
     hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
     QS_HIP(hipGetLastError());
     return 0;
@@ -434,6 +437,7 @@ int qs_reset(qs_handle* h, const uint8_t* mask) {
 
 int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states) {
     if (!h || !states) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
     QS_HIP(hipGetLastError());
     return 0;
@@ -441,12 +445,14 @@ int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states) {
 
 int qs_get_obs(qs_handle* h, float* obs) {
     if (!h || !obs) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     QS_HIP(hipMemcpyAsync(obs, h->d_obs, (size_t)h->cfg.n_envs * h->cfg.obs_dim * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
 int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
     if (!h) QS_FAIL(-1, "null handle");
+    QS_ON_DEVICE(h);
     if (on && h->pool_size < QS_COHORTS * QS_ENVS_PER_WAVE) QS_FAIL(-1, "streaming refill needs a reset pool of at least %d entries (cfg.reset_pool)", QS_COHORTS * QS_ENVS_PER_WAVE);
     if (on && !h->d_pool_back) QS_HIP(hipMalloc(&h->d_pool_back, (size_t)h->pool_size * QS_REC * sizeof(float)));
     if (on && !h->streaming) {          // resets that happened while streaming was off are not owed
@@ -480,6 +486,7 @@ int qs_step_fused(qs_handle* h, const float* actions, float* fused) {
 }
 
 static int launch_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
+    QS_ON_DEVICE(h);
     PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
     SettleLanes lanes;
     memset(&lanes, 0, sizeof(lanes));
@@ -529,6 +536,7 @@ int qs_set_trace(qs_handle* h, int env, float* rows) {
 
 int qs_counter(qs_handle* h, int which, uint64_t* value) {
     if (!h || !value) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     QS_HIP(hipStreamSynchronize(h->stream));
     unsigned long long v = 0;
     switch (which) {
@@ -546,6 +554,7 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
 int qs_last_step_kernel_ms(qs_handle* h, float* ms) {
     if (!h || !ms) QS_FAIL(-1, "null argument");
     if (!h->timing) QS_FAIL(-1, "timing is off (qs_enable_timing)");
+    QS_ON_DEVICE(h);
     QS_HIP(hipEventSynchronize(h->ev1));
     QS_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return 0;
@@ -553,6 +562,7 @@ int qs_last_step_kernel_ms(qs_handle* h, float* ms) {
 
 int qs_refresh_pool(qs_handle* h) {  // redraw the pre-settled reset states (new parameter draws)
     if (!h) QS_FAIL(-1, "null handle");
+    QS_ON_DEVICE(h);
     if (h->pool_size <= 0) return 0;
     h->pool_generation++;
     hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
@@ -585,8 +595,8 @@ static int gather_wrapper(qs_handle* h, float* out) {
     return 0;
 }
 
-int qs_get_state(qs_handle* h, float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); return gather(h, R_POS, QS_STATE_DIM, st, 0); }
-int qs_set_state(qs_handle* h, const float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); return scatter(h, R_POS, QS_STATE_DIM, st, 1); }
+int qs_get_state(qs_handle* h, float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); QS_ON_DEVICE(h); return gather(h, R_POS, QS_STATE_DIM, st, 0); }
+int qs_set_state(qs_handle* h, const float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); QS_ON_DEVICE(h); return scatter(h, R_POS, QS_STATE_DIM, st, 1); }
 
 int qs_info_dim(const qs_handle* h, int which) {
     switch (which) {
@@ -604,6 +614,7 @@ int qs_info_dim(const qs_handle* h, int which) {
 
 int qs_get_info(qs_handle* h, int which, float* out) {
     if (!h || !out) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     switch (which) {
     case QS_INFO_FOOT_FORCE: return gather(h, R_FOOT_FORCE, 4, out, 0);
     case QS_INFO_FOOT_CONTACT: return gather(h, R_FOOT_CONTACT, 4, out, 0);
@@ -628,6 +639,7 @@ int qs_get_info(qs_handle* h, int which, float* out) {
 
 int qs_set_params(qs_handle* h, int which, const float* v) {
     if (!h || !v) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     switch (which) {
     case QS_PARAM_MU: return scatter(h, R_PARAMS + P_MU, 1, v, 0);
     case QS_PARAM_SPRING_K: return scatter(h, R_PARAMS + P_K, 3, v, 0);
@@ -641,6 +653,7 @@ int qs_set_params(qs_handle* h, int which, const float* v) {
 
 int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets) {
     if (!h) QS_FAIL(-1, "null handle");
+    QS_ON_DEVICE(h);
     unsigned long long v[2];
     QS_HIP(hipStreamSynchronize(h->stream));
     QS_HIP(hipMemcpy(v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost));

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include "qs_amd.h"
+#include "qs_host.h"
 
 extern thread_local char qs_g_err[512];
 #define QN_FAIL(code, ...) do { snprintf(qs_g_err, sizeof(qs_g_err), __VA_ARGS__); return (code); } while (0)
@@ -109,7 +110,7 @@ int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, f
     hipError_t derr = hipGetDeviceCount(&ndev);
     if (derr != hipSuccess || ndev <= 0) QN_FAIL(-3, "no HIP device available: this library has no CPU path");
     if (device < 0 || device >= ndev) QN_FAIL(-3, "HIP device %d out of range (%d visible)", device, ndev);
-    QN_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
     qs_norm* h = new (std::nothrow) qs_norm();
     if (!h) QN_FAIL(-4, "out of host memory");
     memset(h, 0, sizeof(*h));
@@ -130,7 +131,7 @@ int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, f
 
 void qs_norm_destroy(qs_norm* h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    QS_ON_DEVICE(h);
     hipStreamSynchronize(h->stream);
     hipFree(h->d_stat); hipFree(h->d_ret);
     delete h;
@@ -140,6 +141,7 @@ int qs_norm_set_stream(qs_norm* h, void* s) { if (!h) QN_FAIL(-1, "null handle")
 
 int qs_norm_set_stats(qs_norm* h, const double* obs_mean, const double* obs_var, double obs_count, double ret_mean, double ret_var, double ret_count) {
     if (!h || !obs_mean || !obs_var) QN_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     const int C = h->o + 1;
     double buf[2 * 256 + 2];
     for (int c = 0; c < h->o; c++) { buf[c] = obs_mean[c]; buf[C + c] = obs_var[c]; }
@@ -151,6 +153,7 @@ int qs_norm_set_stats(qs_norm* h, const double* obs_mean, const double* obs_var,
 
 int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs_count, double* ret_mean, double* ret_var, double* ret_count) {
     if (!h) QN_FAIL(-1, "null handle");
+    QS_ON_DEVICE(h);
     const int C = h->o + 1;
     double buf[2 * 256 + 2];
     QN_HIP(hipStreamSynchronize(h->stream));
@@ -166,6 +169,7 @@ int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs
 // VecNormalize.reset (vec_normalize.py): returns = 0; obs_rms.update(obs) when training; normalize
 int qs_norm_reset(qs_norm* h, float* obs, int training, int norm_obs) {
     if (!h || !obs) QN_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     QN_HIP(hipMemsetAsync(h->d_ret, 0, (size_t)h->n * sizeof(double), h->stream));
     const int upd = training && norm_obs;
     if (upd) {
@@ -182,6 +186,7 @@ int qs_norm_reset(qs_norm* h, float* obs, int training, int norm_obs) {
 // VecNormalize.step_wait on the arrays a step produced (all in place, device memory; term_obs may be NULL)
 int qs_norm_step(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward) {
     if (!h || !obs || !rew || !done) QN_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
     if (training) {
         hipLaunchKernelGGL(k_norm_moments, dim3(h->o + 1), dim3(256), 0, h->stream, obs, rew, h->d_ret, h->n, h->o, (double)h->gamma, norm_obs, 1, h->d_stat);
         hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(256), 0, h->stream, h->d_stat, h->o, (double)h->n, norm_obs, 1);

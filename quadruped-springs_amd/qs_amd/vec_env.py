@@ -98,6 +98,10 @@ class QuadrupedVecEnv(SB3VecEnv):
     def step_fused(self, actions, out):
         """One step with a single output: `out` [N, obs_dim + 2] float32 CUDA tensor = observation | reward | done + 2 * truncated
         (the row a sharded run all-gathers, qs_amd/sharded.py)."""
+        t = self.torch
+        for name, x, shape in (("actions", actions, (self.num_envs, self.action_dim)), ("out", out, (self.num_envs, self.obs_dim + 2))):
+            if tuple(x.shape) != shape or x.dtype != t.float32 or x.device != self.device or not x.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous float32 tensor of shape {shape} on {self.device}")
         self._stream()
         _lib.check(self.lib.qs_step_fused(self.h, self._ptr(actions), self._ptr(out)))
         return out
