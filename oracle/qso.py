@@ -93,6 +93,15 @@ class Oracle:
         self._check(self.lib.qso_get_obs(self.h, self._p(obs)))
         return obs
 
+    def set_demo(self, rows):
+        r = np.ascontiguousarray(rows, np.float32).reshape(-1, self.d + 38)
+        self._check(self.lib.qso_set_demo(self.h, self._p(r), int(r.shape[0])))
+
+    def set_demo_counter(self, values, mask=None):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values, np.int32), (self.n,)))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._check(self.lib.qso_set_demo_counter(self.h, None if m is None else self._p(m), self._p(v)))
+
     def set_threads(self, n):
         """Spread the environments over n OpenMP threads (default 1)."""
         self._check(self.lib.qso_set_threads(int(n)))

@@ -234,10 +234,12 @@ static real jump_distance(const qso_task* t) { /* task_base.py:108-116: (pos - p
 }
 static void max_fwd_update(qso_task* t) { real d = jump_distance(t); if (d > t->max_fwd) t->max_fwd = d; }
 static int task_family_continuous(int task) { return task == QSO_TASK_CONT_JUMPING_FORWARD || task == QSO_TASK_CONT_JUMPING_FORWARD2; }
-static int task_family_continuous2(int task) { return task == QSO_TASK_CONT_JUMPING_FORWARD3 || task == QSO_TASK_CONT_JUMPING_FORWARD_PPO; }
+static int task_family_continuous2(int task) { return task == QSO_TASK_CONT_JUMPING_FORWARD3 || task == QSO_TASK_CONT_JUMPING_FORWARD_PPO || task == QSO_TASK_CONT_JUMPING_FORWARD_DEMO; }
+static int task_family_demo(int task) { return task >= QSO_TASK_JUMPING_IN_PLACE_DEMO && task <= QSO_TASK_CONT_JUMPING_FORWARD_DEMO; }
 /* TaskContinuousJumping2 constants (task_base.py:286-290; robot_tasks.py:171-175, 559-561) */
 static void cj2_constants(int task, real* jump_limit, real* height_limit, real* bound) {
     if (task == QSO_TASK_CONT_JUMPING_FORWARD3) { *jump_limit = (real)0.6; *height_limit = (real)0.45; *bound = (real)0.7; }
+    else if (task == QSO_TASK_CONT_JUMPING_FORWARD_DEMO) { *jump_limit = (real)0.5; *height_limit = (real)0.5; *bound = (real)0.85; } /* the base class's */
     else { *jump_limit = (real)0.6; *height_limit = (real)0.5; *bound = (real)0.85; }
 }
 /* get_entropy_fwd (task_base.py:376-383) from the sums: -sum p log2 p = log2 S - (sum f log2 f) / S, over max(n, 3) entries */
@@ -344,10 +346,24 @@ static int task_terminated(const qso_config* cfg, const qso_env* e) {
     const qso_task* t = &e->task;
     if (cfg->task == QSO_TASK_NO_TASK) return 0;
     int low = t->pos[2] < cfg->fallen_height;
-    if (cfg->task == QSO_TASK_BACKFLIP) return low || e->n_invalid > 0; /* robot_tasks.py:532-533 */
+    /* the demonstration is used up: task_base.py:213-214, 446-447; robot_tasks.py:239-241 */
+    int demo_end = task_family_demo(cfg->task) && t->demo_counter >= e->demo_len;
+    if (cfg->task == QSO_TASK_BACKFLIP || cfg->task == QSO_TASK_BACKFLIP_DEMO) return low || e->n_invalid > 0 || demo_end; /* robot_tasks.py:532-533 */
     real R[3][3]; qso_quat_to_mat(e->s.quat, R);
     int tilted = R[2][2] < (real)0.85; /* task_base.py:126-130 */
-    return (tilted && low) || e->n_invalid > 0; /* :132-147 */
+    return (tilted && low) || e->n_invalid > 0 || demo_end; /* :132-147 */
+}
+/* TaskJumpingDemo._reward (task_base.py:194-211): distance between the demonstration's action (the FILTERED action the
+   demonstration recorded) and the action env.step was just given (get_last_action: the unfiltered one), shared out over
+   the rows that were left when the episode began; consumes one row */
+static real demo_reward(const qso_handle* h, qso_env* e) {
+    qso_task* t = &e->task;
+    const int d = h->cfg.action_dim, row = t->demo_counter < h->demo_len ? t->demo_counter : h->demo_len - 1;
+    const float* a = h->demo + (size_t)row * (d + 38);
+    real n2 = 0;
+    for (int k = 0; k < d; k++) { real x = (real)a[k] - e->last_action[k]; n2 += x * x; }
+    t->demo_counter++;
+    return exp(-(real)0.35 * sqrt(n2)) / (real)(h->demo_len - t->demo_start);
 }
 
 static real clipped_height(real z, real lo, real hi) { return (z < lo || z > hi) ? 0 : z; }
@@ -631,7 +647,25 @@ int qso_create(const qso_config* cfg, qso_handle** out) {
     *out = h;
     return 0;
 }
-void qso_destroy(qso_handle* h) { if (h) { free(h->env); free(h); } }
+void qso_destroy(qso_handle* h) { if (h) { free(h->demo); free(h->env); free(h); } }
+
+int qso_set_demo(qso_handle* h, const float* rows, int length) {
+    if (!rows || length <= 0) FAIL("a demonstration needs at least one row");
+    const size_t n = (size_t)length * (h->cfg.action_dim + 38);
+    float* copy = (float*)malloc(n * sizeof(float));
+    if (!copy) FAIL("out of memory");
+    memcpy(copy, rows, n * sizeof(float));
+    free(h->demo); h->demo = copy; h->demo_len = length;
+    for (int i = 0; i < h->cfg.n_envs; i++) h->env[i].demo_len = length;
+    return 0;
+}
+int qso_set_demo_counter(qso_handle* h, const uint8_t* mask, const int32_t* values) {
+    for (int i = 0; i < h->cfg.n_envs; i++) if (!mask || mask[i]) {
+        if (values[i] < 0 || values[i] >= (h->demo_len > 0 ? h->demo_len : 1)) FAIL("demo counter %d of environment %d outside the demonstration (%d rows)", values[i], i, h->demo_len);
+        h->env[i].task.demo_counter = h->env[i].task.demo_start = values[i];
+    }
+    return 0;
+}
 
 int qso_reset(qso_handle* h, const uint8_t* mask) {
 #ifdef _OPENMP
@@ -664,6 +698,7 @@ static wrap_traits wrap_traits_of(int mode) {
 
 int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     const qso_config* cfg = &h->cfg; int d = cfg->action_dim;
+    if (task_family_demo(cfg->task) && !h->demo) FAIL("the DEMO tasks need a demonstration: qso_set_demo first");
     /* environments are independent (gym_env.py:132-137): with -fopenmp they spread over OMP_NUM_THREADS host threads, which is
        what bench.py's cpu_baseline uses; the default is one thread */
 #ifdef _OPENMP
@@ -726,7 +761,7 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         }
         e->env_step++; e->total_steps++;
         task_on_step(cfg, e);
-        real r = task_reward(cfg, e);
+        real r = task_family_demo(cfg->task) ? demo_reward(h, e) : task_reward(cfg, e);
         int term = task_terminated(cfg, e);
         int dn = term || e->sim_step > cfg->max_sim_steps;
         if (dn) r += task_reward_end(cfg, e);
@@ -825,6 +860,7 @@ int qso_get_info(qso_handle* h, int which, real* out) {
             o[26] = t->max_perf; o[27] = t->last_perf; o[28] = t->max_jump_h; o[29] = t->first_jump; o[30] = t->end_jump;
             for (int k = 0; k < 3; k++) { o[32 + k] = t->pos[k]; o[35 + k] = t->vel[k]; o[38 + k] = t->rpy[k]; }
             o[41] = e->n_invalid; o[42] = e->foot_force[0] + e->foot_force[1] + e->foot_force[2] + e->foot_force[3]; o[43] = e->sim_step;
+            o[44] = t->demo_counter; o[45] = t->demo_start;
             break; }
         default: FAIL("unknown info id %d", which);
         }

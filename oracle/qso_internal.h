@@ -38,6 +38,8 @@ typedef struct {
     real bf_max_pitch;
     /* TaskContinuousJumping2: sufficient statistics of fwd_array / height_array / performance_array */
     real jump_count, good_jumps, sum_fwd, sum_flogf, sum_height, sum_perf, max_perf, last_perf, max_jump_h, first_jump, end_jump;
+    /* TaskJumpingDemo: row of the demonstration the next step is compared with, and its value when the episode began */
+    int demo_counter, demo_start;
 } qso_task;
 
 typedef struct {
@@ -60,6 +62,7 @@ typedef struct {
     real cpg[8];            /* Hopf oscillators: r[4], theta[4] */
     struct { int phase, scripted, armed; real timer, end, t_start, h_old, h_act, action[12]; } wrap; /* landing / go-to-rest machine */
     float obs[QSO_MAX_OBS], term_obs[QSO_MAX_OBS];
+    int demo_len;           /* rows of the handle's demonstration (copy, for the task functions) */
 } qso_env;
 
 struct qso_handle {
@@ -67,6 +70,7 @@ struct qso_handle {
     qso_env* env;
     real gravity;
     real* trace; int trace_env;
+    float* demo; int demo_len;   /* qso_set_demo */
 };
 
 /* qso_model.c */

@@ -44,9 +44,16 @@ TASKS = {
     "BACKFLIP_PPO": 10,
     "CONTINUOUS_JUMPING_FORWARD3": 11,
     "CONTINUOUS_JUMPING_FORWARD_PPO": 12,
+    # imitation tasks (task_base.py:169-220, 402-453): the demonstration comes in through the `demo` keyword
+    "JUMPING_IN_PLACE_DEMO": 13,
+    "JUMPING_FORWARD_DEMO": 14,
+    "BACKFLIP_DEMO": 15,
+    "CONTINUOUS_JUMPING_FORWARD_DEMO": 16,
 }
-# registry keys the reference defines but this build does not run: demo tasks need the absent demonstrations/*.npy
-TASKS_UNSUPPORTED = ("JUMPING_IN_PLACE_DEMO", "JUMPING_FORWARD_DEMO", "BACKFLIP_DEMO", "CONTINUOUS_JUMPING_FORWARD_DEMO")
+# the file each DEMO task of the reference loads from <package>/demonstrations/ (robot_tasks.py:224, 230, 236, 246); the
+# reference's repository does not hold them, so here the rows are given with `demo=` (array, or the path of such a .npy)
+DEMO_FILES = {"JUMPING_IN_PLACE_DEMO": "demo_list_jip_0.npy", "JUMPING_FORWARD_DEMO": "demo_list_jf_0.npy",
+              "BACKFLIP_DEMO": "backflip-1.npy", "CONTINUOUS_JUMPING_FORWARD_DEMO": "continuous-jf-1.npy"}
 
 # sensor ids (include/qs_amd.h QS_SENS_*): name, dim, (high, low, noise) attribute names, reference obs-dict key
 SENSORS = {
@@ -224,15 +231,13 @@ def build_config(
     solver_residual_threshold=0.0,
     wrapper=None,
     robot_config=None,
+    demo=None,
     **_ignored,
 ):
     """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
     if motor_control_mode == "TORQUE" and isRLGymInterface:
         # gym_env.py:167-168
         raise ValueError(f"the motor control mode {motor_control_mode} not" "implemented yet for RL Gym interface.")
-    if task_env in TASKS_UNSUPPORTED:
-        raise NotImplementedError(
-            f"task {task_env} exists in the reference registry but is outside this build's scope (see DESIGN.md)")
     rc = robot_config if robot_config is not None else go1_config.make_config(enable_springs)
     mode_id, action_dim = _lookup(ACTION_SPACE_MODES, action_space_mode, "action space mode")
     motor_id = _lookup(MOTOR_CONTROL_MODES, motor_control_mode, "motor control mode")
@@ -346,5 +351,15 @@ def build_config(
                 init_pose=np.array(init_pose, float), landing_pose=np.array(landing_pose, float),
                 settle_action=np.array(settle_action, float), landing_action=np.array(landing_action, float),
                 action_space_mode=action_space_mode, motor_control_mode=motor_control_mode, task_env=task_env,
-                observation_space_mode=observation_space_mode, env_randomizer_mode=env_randomizer_mode)
+                observation_space_mode=observation_space_mode, env_randomizer_mode=env_randomizer_mode, demo=None)
+    if task_env in DEMO_FILES:
+        if action_space_mode == "CPG" or not isRLGymInterface:
+            raise ValueError("the DEMO tasks compare the policy's action with a recorded one: they need an RL action space")
+        if demo is not None:
+            rows = np.load(demo) if isinstance(demo, (str, bytes)) or hasattr(demo, "__fspath__") else np.asarray(demo)
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            if rows.ndim != 2 or rows.shape[1] != action_dim + 38 or rows.shape[0] < 1:
+                raise ValueError(f"a demonstration for this action space has rows of {action_dim + 38} numbers "
+                                 f"(get_demonstration_wrapper.py:35-58), got an array of shape {rows.shape}")
+            meta["demo"] = rows
     return cfg, meta

@@ -891,6 +891,116 @@ def gen_wrappers():
     print("wrappers.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- DEMO tasks + reference-state initialisation
+def gen_demo():
+    """The imitation tasks (TaskJumpingDemo / TaskJumpingDemo2, task_base.py:169-220, 402-453; robot_tasks.py:222-247) and
+    ReferenceStateInitializationWrapper on top of them.  The reference's repository does not hold the demonstrations its DEMO tasks
+    load, so one is RECORDED here with the reference's own GetDemonstrationWrapper (a scripted jump under the matching plain task),
+    saved under the file name the DEMO task expects in a scratch directory, and robot_tasks' package handle is pointed there."""
+    import importlib
+    import tempfile
+    import types
+    from qs_amd.config import build_config
+    from oracle.qso import Oracle
+    from quadruped_spring.env.quadruped_gym_env import QuadrupedGymEnv
+    from quadruped_spring.env.wrappers.get_demonstration_wrapper import GetDemonstrationWrapper
+    from quadruped_spring.env.wrappers.reference_state_initialization_wrapper import ReferenceStateInitializationWrapper
+    import quadruped_spring.env.tasks.robot_tasks as rt
+
+    scratch = tempfile.mkdtemp(prefix="qs_demo_")
+    os.makedirs(os.path.join(scratch, "demonstrations"))
+    rt.qs = types.SimpleNamespace(__file__=os.path.join(scratch, "__init__.py"))
+    cases = [
+        dict(name="demo_jip", task_env="JUMPING_IN_PLACE_DEMO", record_task="JUMPING_IN_PLACE", file="demo_list_jip_0", rsi=5, plain=1,
+             kw=dict(observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC", motor_control_mode="PD")),
+        dict(name="demo_bf", task_env="BACKFLIP_DEMO", record_task="JUMPING_FORWARD", file="backflip-1", rsi=4, plain=1,
+             kw=dict(observation_space_mode="PPO_BACKFLIP", enable_springs=False, enable_action_filter=False, action_space_mode="SYMMETRIC", motor_control_mode="PD")),
+        dict(name="demo_jf12", task_env="JUMPING_FORWARD_DEMO", record_task="JUMPING_FORWARD", file="demo_list_jf_0", rsi=0, plain=2,
+             kw=dict(observation_space_mode="PPO_BASIC_CONTACT", enable_springs=True, enable_action_filter=True, action_space_mode="DEFAULT", motor_control_mode="PD")),
+        dict(name="demo_cjf", task_env="CONTINUOUS_JUMPING_FORWARD_DEMO", record_task="CONTINUOUS_JUMPING_FORWARD", file="continuous-jf-1", rsi=0, plain=2,
+             kw=dict(observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", enable_springs=True, enable_action_filter=True, action_space_mode="SYMMETRIC_NO_HIP",
+                     motor_control_mode="PD")),
+    ]
+    out = {}
+    for case in cases:
+        name, kw = case["name"], case["kw"]
+        mod = importlib.import_module("quadruped_spring.go1.configs_go1_with_springs" if kw["enable_springs"]
+                                      else "quadruped_spring.go1.configs_go1_without_springs")
+        saved = {}
+        for attr in dir(mod):
+            if attr.endswith("_NOISE"):
+                saved[attr] = getattr(mod, attr)
+                setattr(mod, attr, np.zeros_like(np.asarray(saved[attr], float)))
+
+        def factory(dt, iters, kw=kw):
+            cfg, _ = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", task_env="NO_TASK", **dict(kw, time_step=dt))
+            cfg.solver_iters = iters
+            cfg.randomizer_flags = 8
+            return Oracle(cfg)
+
+        FakeBulletClient.oracle_factory = factory
+        np.random.seed(99)
+        rng = np.random.default_rng(23)
+        # 1. record a demonstration: crouch, jump, land (get_demonstration_wrapper.py)
+        rec = GetDemonstrationWrapper(QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", task_env=case["record_task"], **kw),
+                                      path=os.path.join(scratch, "demonstrations"), name=case["file"])
+        rec.reset()
+        d = rec.env.action_dim
+        acts = scripted_actions(rng, 110, d, 70, ext=(-0.5, 0.6))
+        for t in range(110):
+            _, _, dn, _ = rec.step(acts[t])
+            if dn:
+                break
+        with contextlib_redirect():
+            rec.save_demo()
+        demo = np.load(os.path.join(scratch, "demonstrations", case["file"] + ".npy"))
+        L = demo.shape[0]
+        # 2. the DEMO task on it: plain episodes (settle, counter 0) first, then reference-state initialisation
+        env = QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", task_env=case["task_env"], **kw)
+        assert env.task.demo_length == L
+        wrapped = ReferenceStateInitializationWrapper(env)
+        assert wrapped.enable_wrapper == (case["task_env"] != "CONTINUOUS_JUMPING_FORWARD_DEMO")
+        if wrapped.enable_wrapper:
+            wrapped._rng.seed(7)
+        keys = None
+        A, O, R, D, TR, S, C = [], [], [], [], [], [], []
+        reset_at, reset_el, reset_obs, mus = [], [], [], []
+        for ep in range(case["plain"] + case["rsi"]):
+            if ep < case["plain"]:
+                o = env.reset(); el = -1
+            else:
+                o = wrapped.reset(); el = wrapped.random_el
+            keys = keys or list(o.keys())
+            flat = lambda ob: np.concatenate([np.atleast_1d(np.asarray(ob[k], float)).flatten() for k in keys])
+            client = env._pybullet_client
+            reset_at.append(len(A)); reset_el.append(el); reset_obs.append(flat(o)); mus.append(client.mu)
+            assert env.task.demo_counter == max(el, 0)
+            while True:
+                a = demo[env.task.demo_counter, :d] + (0.02 + 0.1 * (ep % 3)) * rng.standard_normal(d)
+                ob, r, dn, info = env.step(a)
+                A.append(a); O.append(flat(ob)); R.append(r); D.append(dn); TR.append(bool(info.get("TimeLimit.truncated", False)))
+                S.append(client.o.get_state()[0].copy()); C.append(env.task.demo_counter)
+                if dn:
+                    break
+        out[f"{name}_demo"], out[f"{name}_kwargs"] = demo, np.array(repr(dict(kw, task_env=case["task_env"])))
+        out[f"{name}_actions"], out[f"{name}_obs"], out[f"{name}_rew"] = np.array(A), np.array(O), np.array(R, float)
+        out[f"{name}_done"], out[f"{name}_trunc"], out[f"{name}_state"], out[f"{name}_counter"] = np.array(D), np.array(TR), np.array(S), np.array(C)
+        out[f"{name}_reset_at"], out[f"{name}_reset_el"], out[f"{name}_reset_obs"], out[f"{name}_mu"] = np.array(reset_at), np.array(reset_el), np.array(reset_obs), np.array(mus)
+        ends = [int(C[i]) for i in range(len(D)) if D[i]]
+        print(f"demo {name}: L={L} d={d} episodes={len(reset_at)} steps={len(A)} reset_el={reset_el} counters at done={ends} "
+              f"demo ends={sum(c == L for c in ends)} rew sum={np.sum(R):.3f}")
+        for attr, v in saved.items():
+            setattr(mod, attr, v)
+    np.savez_compressed(os.path.join(OUT, "demo.npz"), **out)
+    print("demo.npz:", len(out), "arrays")
+
+
+def contextlib_redirect():
+    import contextlib
+    import io
+    return contextlib.redirect_stdout(io.StringIO())
+
+
 # --------------------------------------------------------------------------------------------- G13 Hopf CPG
 def gen_cpg():
     from quadruped_spring.hopf_network import HopfNetwork
@@ -919,7 +1029,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf", "rsi"]
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf", "rsi", "demo"]
     for w in which:
         {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers,
-         "randomizers": gen_randomizers, "urdf": gen_urdf, "rsi": gen_rsi}[w]()
+         "randomizers": gen_randomizers, "urdf": gen_urdf, "rsi": gen_rsi, "demo": gen_demo}[w]()

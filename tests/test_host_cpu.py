@@ -78,8 +78,10 @@ def test_registries_and_errors_mirror_the_reference():
         build_config(motor_control_mode="TORQUE")            # gym_env.py:167-168
     with pytest.raises(KeyError):
         build_config(observation_space_mode="ARS_HEIGHT")    # the reference's broken gym default (quadruped_spring/__init__.py:9)
-    with pytest.raises(NotImplementedError):
-        build_config(task_env="JUMPING_IN_PLACE_DEMO")
+    with pytest.raises(ValueError):
+        build_config(task_env="JUMPING_IN_PLACE_DEMO", demo=np.zeros((5, 7)))   # rows of a demonstration are action_dim + 38 wide
+    c4, m4 = build_config(task_env="JUMPING_IN_PLACE_DEMO", demo=np.zeros((5, 44)))
+    assert c4.task == 13 and m4["demo"].shape == (5, 44) and m4["demo"].dtype == np.float32
     c2, _ = build_config(time_step=0.002, action_repeat=5, enable_springs=True)
     assert c2.solver_iters == 60 and c2.max_sim_steps == 5000
     # BACKFLIP widens two joint limits in place (motor_interface.py:17-22)

@@ -73,3 +73,41 @@ def test_reference_state_initialisation(golden, name):
         np.testing.assert_allclose(ob[0], g[f"{name}_obs"][t], atol=5e-4, rtol=1e-4, err_msg=f"obs step {t}")
         np.testing.assert_allclose(r[0], g[f"{name}_rew"][t], atol=2e-4, rtol=1e-4, err_msg=f"reward step {t}")
         assert bool(dn[0]) == bool(g[f"{name}_done"][t])
+
+
+def demo_state(row, d):
+    """get_demonstration_wrapper.py:61-70 -> the 37-float state row of get_state (pos3 quat4 vlin3 vang3 q12 qd12)."""
+    q, qd, pos, quat, vlin, vang = row[d:d + 12], row[d + 12:d + 24], row[d + 24:d + 27], row[d + 27:d + 31], row[d + 31:d + 34], row[d + 34:d + 37]
+    return np.concatenate([pos, quat, vlin, vang, q, qd])
+
+
+@pytest.mark.parametrize("name", ["demo_jip", "demo_bf", "demo_jf12", "demo_cjf"])
+def test_demo_tasks_and_rsi(golden, name):
+    """The imitation tasks on a demonstration the reference's GetDemonstrationWrapper recorded, plain resets and resets by its
+    ReferenceStateInitializationWrapper (a random row of the demonstration becomes the initial state and the demo counter)."""
+    g = golden("demo.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    cfg, meta = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", demo=g[f"{name}_demo"], **kw)
+    cfg.randomizer_flags = 8
+    o = Oracle(cfg)
+    d, demo, L = cfg.action_dim, g[f"{name}_demo"], len(g[f"{name}_demo"])
+    with pytest.raises(RuntimeError):     # no demonstration yet
+        o.step(np.zeros((1, d), np.float32))
+    o.set_demo(meta["demo"])
+    starts = list(g[f"{name}_reset_at"]) + [len(g[f"{name}_actions"])]
+    for ep, el in enumerate(g[f"{name}_reset_el"]):
+        o.set_params(0, np.array([float(g[f"{name}_mu"][ep])]))
+        if el < 0:
+            ob = o.reset()
+        else:
+            ob = o.reset_to(demo_state(demo[el], d)[None])
+            o.set_demo_counter(int(el))
+        np.testing.assert_allclose(ob[0], g[f"{name}_reset_obs"][ep], atol=5e-4, rtol=1e-4, err_msg=f"reset obs episode {ep}")
+        for t in range(starts[ep], starts[ep + 1]):
+            ob, r, dn, tr = o.step(g[f"{name}_actions"][t][None])
+            np.testing.assert_allclose(o.get_state()[0], g[f"{name}_state"][t], atol=5e-4, rtol=1e-4, err_msg=f"state step {t}")
+            np.testing.assert_allclose(ob[0], g[f"{name}_obs"][t], atol=5e-4, rtol=1e-4, err_msg=f"obs step {t}")
+            np.testing.assert_allclose(r[0], g[f"{name}_rew"][t], atol=1e-6, rtol=1e-4, err_msg=f"reward step {t}")
+            assert bool(dn[0]) == bool(g[f"{name}_done"][t]) and bool(tr[0]) == bool(g[f"{name}_trunc"][t]), t
+            assert int(o.get_info(4)[0, 44]) == int(g[f"{name}_counter"][t])
+        assert dn[0]
