@@ -42,6 +42,10 @@ enum {                                                                          
     QS_TASK_JUMPING_IN_PLACE_PPO = 5, QS_TASK_JUMPING_FORWARD_PPO = 6, QS_TASK_BACKFLIP = 7,
     QS_TASK_JUMPING_IN_PLACE_PPO_HP = 8, QS_TASK_JUMPING_FORWARD_PPO_HP = 9, QS_TASK_BACKFLIP_PPO = 10,
     QS_TASK_CONT_JUMPING_FORWARD3 = 11, QS_TASK_CONT_JUMPING_FORWARD_PPO = 12,
+    /* imitation tasks (TaskJumpingDemo task_base.py:169-220, TaskJumpingDemo2 :402-453; robot_tasks.py:222-247): the rows come
+     * through qs_set_demo, not from the demonstrations/<name>.npy files the reference loads (its repository does not hold them) */
+    QS_TASK_JUMPING_IN_PLACE_DEMO = 13, QS_TASK_JUMPING_FORWARD_DEMO = 14, QS_TASK_BACKFLIP_DEMO = 15,
+    QS_TASK_CONT_JUMPING_FORWARD_DEMO = 16,
 };
 enum {                                                                          /* sensors/robot_sensors.py */
     QS_SENS_JOINT_POS = 0, QS_SENS_JOINT_VEL = 1, QS_SENS_PITCH = 2, QS_SENS_HEIGHT = 3, QS_SENS_VEL_Z = 4,
@@ -131,6 +135,16 @@ int qs_reset(qs_handle* h, const uint8_t* mask);
  * qs_get_state) instead of spawning and settling it, then resets task, sensors and filter as every reset does. */
 int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states);
 int qs_get_obs(qs_handle* h, float* obs /*[N,obs_dim]*/);
+/* The demonstration of the DEMO tasks: rows[length][action_dim + 38] (device memory; copied) in the layout
+ * GetDemonstrationWrapper._get_demo records (get_demonstration_wrapper.py:35-58: filtered action, q 12, qd 12, base position 3,
+ * quaternion 4, linear velocity 3, angular velocity 3, landing flag).  Replaces `np.load(self.demo_path)` (task_base.py:173);
+ * qs_step fails for a DEMO task until it was called.  Row `demo counter` is compared with the action of each step; the counter
+ * and its value at the start of the episode are slots 44 and 45 of QS_INFO_TASK. */
+int qs_set_demo(qs_handle* h, const float* rows, int length);
+/* task.set_demo_counter(value) (task_base.py:219-220) for the masked environments (mask NULL = all), as
+ * ReferenceStateInitializationWrapper.reset does after set_robot_desired_state (reference_state_initialization_wrapper.py:25-33):
+ * call it after qs_reset_to.  values[N] int32, device memory. */
+int qs_set_demo_counter(qs_handle* h, const uint8_t* mask, const int32_t* values);
 int qs_step(qs_handle* h, const float* actions /*[N,action_dim]*/, float* obs /*[N,obs_dim]*/, float* rew /*[N]*/,
             uint8_t* done /*[N]*/, uint8_t* truncated /*[N]*/);
 int qs_get_state(qs_handle* h, float* state /*[N,37]*/);

@@ -196,7 +196,8 @@ template <class T> struct Env {
         T::st(p, T_MAX_JUMP_H, t.max_jump_h); T::st(p, T_FIRST_JUMP, t.first_jump); T::st(p, T_END_JUMP, t.end_jump);
     }
     static QS_FN bool continuous(int task) { return task == QS_TASK_CONT_JUMPING_FORWARD || task == QS_TASK_CONT_JUMPING_FORWARD2; }
-    static QS_FN bool continuous2(int task) { return task == QS_TASK_CONT_JUMPING_FORWARD3 || task == QS_TASK_CONT_JUMPING_FORWARD_PPO; }
+    static QS_FN bool continuous2(int task) { return task == QS_TASK_CONT_JUMPING_FORWARD3 || task == QS_TASK_CONT_JUMPING_FORWARD_PPO || task == QS_TASK_CONT_JUMPING_FORWARD_DEMO; }
+    static QS_FN bool demo_task(int task) { return task >= QS_TASK_JUMPING_IN_PLACE_DEMO && task <= QS_TASK_CONT_JUMPING_FORWARD_DEMO; }
     // get_entropy_fwd (task_base.py:376-383) from the sums: -sum p log2 p = log2 S - (sum f log2 f) / S over max(n, 3) entries
     static QS_FN V cj2_entropy(const Task& t) {
         const float il2 = 1.4426950408889634f;
@@ -240,7 +241,8 @@ template <class T> struct Env {
         V fwd_upd = qmax(dist, t.max_fwd);
         V flight_upd = qmax(now - t_takeoff0, t.max_flight);
         if (continuous2(cfg.task)) {  // TaskContinuousJumping2, task_base.py:321-355
-            const float jump_limit = 0.6f, height_limit = cfg.task == QS_TASK_CONT_JUMPING_FORWARD3 ? 0.45f : 0.5f;
+            const float jump_limit = cfg.task == QS_TASK_CONT_JUMPING_FORWARD_DEMO ? 0.5f : 0.6f;   // the base class's (task_base.py:286-290)
+            const float height_limit = cfg.task == QS_TASK_CONT_JUMPING_FORWARD3 ? 0.45f : 0.5f;
             const float bound = cfg.task == QS_TASK_CONT_JUMPING_FORWARD3 ? 0.7f : 0.85f;
             M in_flight = qand(flying, air);
             t.is_jumping = qsel(take, qflag(takeoff_v), qsel(land, zero, t.is_jumping));
@@ -277,11 +279,11 @@ template <class T> struct Env {
         if (cfg.task == QS_TASK_BACKFLIP) t.bf_max_pitch = qmax(t.bf_max_pitch, pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched));   // :527-530
         if (cfg.task == QS_TASK_BACKFLIP_PPO) t.max_pitch = qmax(t.max_pitch, pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched));  // :752-754
     }
-    static QS_FN V task_terminated(const qs_config& cfg, const Task& t, const typename S::State& s, V n_invalid) {
+    static QS_FN V task_terminated(const qs_config& cfg, const Task& t, const typename S::State& s, V n_invalid, M demo_end) {
         if (cfg.task == QS_TASK_NO_TASK) return V(0.0f);
         M low = qlt(t.pos[2], V(cfg.fallen_height));                              // task_base.py:123-124
-        M bad = qgt(n_invalid, V(0.5f));                                          // :137-147
-        if (cfg.task == QS_TASK_BACKFLIP) return qflag(qor(low, bad));            // robot_tasks.py:532-533
+        M bad = qor(qgt(n_invalid, V(0.5f)), demo_end);                           // :137-147; demonstration used up: :213-214, 446-447
+        if (cfg.task == QS_TASK_BACKFLIP || cfg.task == QS_TASK_BACKFLIP_DEMO) return qflag(qor(low, bad));   // robot_tasks.py:532-533, 239-241
         V d = s.qx * s.qx + s.qy * s.qy + s.qz * s.qz + s.qw * s.qw;
         V r22 = V(1.0f) - (s.qx * s.qx + s.qy * s.qy) * (V(2.0f) * qrcp(d));
         return qflag(qor(qand(qlt(r22, V(0.85f)), low), bad));                    // task_base.py:126-135
@@ -478,7 +480,7 @@ template <class T> struct Env {
         T::st_leg(row, TR_FOOT_FORCE, 1, o.foot_force); T::st_leg(row, TR_FOOT_CONTACT, 1, o.foot_contact);
     }
     static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0,
-                              float* trace = nullptr, bool any_trace = false) {
+                              float* trace = nullptr, bool any_trace = false, const float* demo_rows = nullptr, int demo_len = 0) {
         typename S::State s; typename S::Par P; typename S::Out o;
         load_state(rec, s); load_par(rec, P);
         const int d = settle_n > 0 ? 0 : cfg.action_dim;
@@ -539,6 +541,8 @@ template <class T> struct Env {
             for (int j = 0; j < 3; j++) { P.kp[j] = qsel(scripted_gain, gkp, P.kp[j]); P.kd[j] = qsel(scripted_gain, gkd, P.kd[j]); }
             T::st(rec, R_WRAP + W_SCRIPTED, qflag(qgt(w_phase, V(0.5f))));
         }
+        V act_last[15];   // what env.step was given (after the scripted phases): _last_action, gym_env.py:230
+        for (int k = 0; k < 15; k++) act_last[k] = act[k];
         if (d == 12) {  // DEFAULT space / raw commands: every lane filters the 3 entries of its own leg
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -607,8 +611,31 @@ template <class T> struct Env {
         task_on_step(cfg, t, s, o, old_tau, now);
         QS_PHASE(34)
         V force = T::quad_sum(o.foot_force);
-        V reward = task_reward(cfg, t, force, cfg.task == QS_TASK_BACKFLIP_PPO ? pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched) : V(0.0f));
-        V term = task_terminated(cfg, t, s, o.n_invalid);
+        V reward;
+        M demo_end = qlt(V(1.0f), V(0.0f));
+        if (demo_task(cfg.task)) {
+            // TaskJumpingDemo._reward (task_base.py:194-211): distance between the demonstration's (filtered) action of row `counter`
+            // and the action this step was given (get_last_action: before the filter), over the rows left when the episode began
+            V cnt = T::ld(rec, R_DEMO), start = T::ld(rec, R_DEMO + 1);
+            int row = (int)T::first(cnt);
+            row = row < demo_len ? row : demo_len - 1;
+            const float* a = demo_rows + (size_t)row * (size_t)(d + 38);
+            V n2 = V(0.0f);
+            if (d == 12) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) { V e = T::ld_leg(a, j, 3) - act_last[12 + j]; n2 = n2 + e * e; }
+                n2 = T::quad_sum(n2);
+            } else {
+                for (int k = 0; k < d; k++) { V e = T::ld(a, k) - act_last[k]; n2 = n2 + e * e; }
+            }
+            reward = qexp(qsqrt(n2) * (-0.35f)) / (V((float)demo_len) - start);
+            cnt = cnt + 1.0f;
+            T::st(rec, R_DEMO, cnt);
+            demo_end = qge(cnt, V((float)demo_len));
+        } else {
+            reward = task_reward(cfg, t, force, cfg.task == QS_TASK_BACKFLIP_PPO ? pitch_backflip(s.qx, s.qy, s.qz, s.qw, t.switched) : V(0.0f));
+        }
+        V term = task_terminated(cfg, t, s, o.n_invalid, demo_end);
         bool timeout = sim_step > cfg.max_sim_steps;   // gym_env.py:245
         V done = timeout ? V(1.0f) : term;
         reward = reward + qsel(qgt(done, V(0.5f)), task_reward_end(cfg, t, term, now), V(0.0f));  // :250-251
@@ -764,6 +791,7 @@ template <class T> struct Env {
             for (int k = 0; k < 20; k++) T::st(rec, R_WRAP + k, V(0.0f));
             T::st(rec, R_WRAP + W_HOLD, s.pos.z); T::st(rec, R_WRAP + W_HACT, s.pos.z);   // go_to_rest_wrapper.py:86-90
         }
+        if (demo_task(cfg.task)) { T::st(rec, R_DEMO, V(0.0f)); T::st(rec, R_DEMO + 1, V(0.0f)); }   // task_base.py:177-183 (set_demo_counter comes after)
         task_reset(cfg, t, s, o, V(0.0f));
         store_task(rec, t);
 #pragma unroll

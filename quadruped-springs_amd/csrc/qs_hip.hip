@@ -45,6 +45,7 @@ struct PoolView { const float* pool; int size; };
 #define QS_COHORTS 5
 struct SettleLanes { float* staging; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], settle_n[QS_COHORTS], generation[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
+struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_REFILLED = 4, CTL_CURSOR = 5, CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
 
 // settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
@@ -77,7 +78,7 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, PoolView pool,
-                                                 unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap) {
+                                                 unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
@@ -114,7 +115,7 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
-    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace);
+    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace, demo.rows, demo.length);
     QS_PHASE(14)
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
@@ -170,8 +171,8 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
 
 #define QS_STEP_ARGS const qs_config* __restrict__ cfgp, float* __restrict__ recs, const float* __restrict__ actions, float* __restrict__ obs_out,    \
                      float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep, \
-                     float* __restrict__ term_obs, PoolView pool, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap
-#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap
+                     float* __restrict__ term_obs, PoolView pool, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo
+#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap, demo
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
 __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body(QS_STEP_PASS); }
@@ -293,7 +294,7 @@ __global__ void k_scatter(float* __restrict__ recs, int n, int off, int dim, con
     recs[(size_t)(i / dim) * QS_REC + off + i % dim] = in[i];
     if (zero_warm && i % dim < 4) recs[(size_t)(i / dim) * QS_REC + R_WARM + i % dim] = 0.0f;
 }
-__global__ void k_task_info(const float* __restrict__ recs, int n, float* __restrict__ out) {
+__global__ void k_task_info(const float* __restrict__ recs, int n, float* __restrict__ out, int demo) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const float* r = recs + (size_t)e * QS_REC;
@@ -303,7 +304,8 @@ __global__ void k_task_info(const float* __restrict__ recs, int n, float* __rest
     o[41] = r[R_N_INVALID];
     o[42] = r[R_FOOT_FORCE] + r[R_FOOT_FORCE + 1] + r[R_FOOT_FORCE + 2] + r[R_FOOT_FORCE + 3];
     o[43] = (float)qs::f2i(r[R_SIM_STEP]);
-    for (int k = 44; k < QS_TASK_DIM; k++) o[k] = 0.0f;
+    o[44] = demo ? r[R_DEMO] : 0.0f; o[45] = demo ? r[R_DEMO + 1] : 0.0f;   // demo counter, and at the start of the episode
+    for (int k = 46; k < QS_TASK_DIM; k++) o[k] = 0.0f;
 }
 
 // ------------------------------------------------------------------ host side of the C ABI
@@ -327,6 +329,7 @@ struct qs_handle {
     long long tick;         // qs_step launches since streaming was switched on
     int cohort_generation[QS_COHORTS];
     float* trace_rows; int trace_env;
+    float* d_demo; int demo_len;   // qs_set_demo
     int n_simd, step_variant;   // SIMDs of the device; 0 = pick k_step / k_step_dense by grid size, 1 / 2 = forced (QS_STEP_VARIANT)
     unsigned long long* d_stats;
     hipEvent_t ev0, ev1;
@@ -358,6 +361,9 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (cfg->action_dim != 12 && cfg->action_dim != 6 && cfg->action_dim != 4 && cfg->action_dim != 5) QS_FAIL(-1, "action_dim must be 12, 6, 4 or 5 (CPG)");
     if (cfg->wrapper_mode != QS_WRAP_NONE && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
         QS_FAIL(-1, "the landing / go-to-rest phase machine needs an RL action space (not CPG, not raw commands)");
+    if (cfg->task >= QS_TASK_JUMPING_IN_PLACE_DEMO && cfg->task <= QS_TASK_CONT_JUMPING_FORWARD_DEMO && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
+        QS_FAIL(-1, "the DEMO tasks compare the policy's action with a recorded one: they need an RL action space (not CPG, not raw commands)");
+    if (cfg->task < 0 || cfg->task > QS_TASK_CONT_JUMPING_FORWARD_DEMO) QS_FAIL(-1, "unknown task id %d", cfg->task);
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
     int od = 0;
@@ -419,6 +425,7 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
     if (h->d_pool) hipFree(h->d_pool);
     if (h->d_pool_back) hipFree(h->d_pool_back);
+    if (h->d_demo) hipFree(h->d_demo);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     delete h;
@@ -492,6 +499,8 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     memset(&lanes, 0, sizeof(lanes));
     lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.waves_per_cohort = 1; lanes.slice = 0;
     TraceTap tap; tap.rows = h->trace_rows; tap.env = h->trace_env;
+    DemoTab demo; demo.rows = h->d_demo; demo.length = h->demo_len;
+    if (E::demo_task(h->cfg.task) && !h->d_demo) QS_FAIL(-1, "the DEMO tasks need a demonstration: qs_set_demo first");
     int grid = lanes.n_env_waves;
     if (h->streaming) {
         // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder);
@@ -519,10 +528,44 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     // more waves than 1.5 x the SIMDs of the device: the two-waves-per-SIMD build of the same body wins (see k_step_dense)
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && 2 * grid > 3 * h->n_simd);
     if (dense) hipLaunchKernelGGL(k_step_dense, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap);
+                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo);
     else hipLaunchKernelGGL(k_step, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                            h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap);
+                            h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo);
     if (h->timing) hipEventRecord(h->ev1, h->stream);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_set_demo_counter(float* __restrict__ recs, int n, const uint8_t* __restrict__ mask, const int32_t* __restrict__ values, int length) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || (mask && !mask[e])) return;
+    int v = values[e];
+    v = v < 0 ? 0 : (v >= length ? length - 1 : v);
+    float* r = recs + (size_t)e * QS_REC + R_DEMO;
+    r[0] = (float)v; r[1] = (float)v;
+}
+
+int qs_set_demo(qs_handle* h, const float* rows, int length) {
+    if (!h || !rows) QS_FAIL(-1, "null argument");
+    if (!E::demo_task(h->cfg.task)) QS_FAIL(-1, "task %d is not a DEMO task", h->cfg.task);
+    if (length <= 0 || length >= (1 << 24)) QS_FAIL(-1, "a demonstration has between 1 and 2^24 rows (got %d)", length);
+    QS_ON_DEVICE(h);
+    const size_t bytes = (size_t)length * (size_t)(h->cfg.action_dim + 38) * sizeof(float);
+    float* copy = nullptr;
+    QS_HIP(hipMalloc(&copy, bytes));
+    hipError_t e = hipMemcpyAsync(copy, rows, bytes, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // also: no step still reads the table that is about to go
+    if (e != hipSuccess) { hipFree(copy); QS_FAIL(-2, "copying the demonstration failed: %s", hipGetErrorString(e)); }
+    if (h->d_demo) hipFree(h->d_demo);
+    h->d_demo = copy; h->demo_len = length;
+    return 0;
+}
+
+int qs_set_demo_counter(qs_handle* h, const uint8_t* mask, const int32_t* values) {
+    if (!h || !values) QS_FAIL(-1, "null argument");
+    if (!h->d_demo) QS_FAIL(-1, "no demonstration (qs_set_demo)");
+    QS_ON_DEVICE(h);
+    hipLaunchKernelGGL(k_set_demo_counter, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, mask, values, h->demo_len);
     QS_HIP(hipGetLastError());
     return 0;
 }
@@ -627,7 +670,7 @@ int qs_get_info(qs_handle* h, int which, float* out) {
     case QS_INFO_WRAPPER: return gather_wrapper(h, out);
     case QS_INFO_FILTERED_ACTION: return gather(h, R_YHIST, 12, out, 0);
     case QS_INFO_TASK:
-        hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out);
+        hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out, (int)E::demo_task(h->cfg.task));
         QS_HIP(hipGetLastError());
         return 0;
     case QS_INFO_TERMINAL_OBS:

@@ -25,6 +25,8 @@ enum {
     R_POSE_CACHE = 206,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
     R_FLAGS = 215,
     R_CPG = 216,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
+    R_DEMO = 216,         // 2: demo counter and its value at the start of the episode (task_base.py:177-183); shares the CPG slots,
+                          //    the DEMO tasks do not take the CPG action layer (qs_create refuses the combination)
     R_WRAP = 224,         // 18: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
                           //     h_actual, held or ramp-start action [12]
     QS_REC = 244,         // multiple of 4 (16-byte vector moves)

@@ -17,6 +17,9 @@ def __getattr__(name):  # lazy: importing the package must not need torch / a GP
     if name == "ShardedVecEnv":
         from .sharded import ShardedVecEnv
         return ShardedVecEnv
+    if name == "ReferenceStateInitVecEnv":
+        from .rsi import ReferenceStateInitVecEnv
+        return ReferenceStateInitVecEnv
     raise AttributeError(name)
 
 

@@ -157,6 +157,22 @@ class _TaskView:
     def enable_rest_mode(self):   # robot_tasks.py:346-347: sets a flag the reference never reads
         pass
 
+    # DEMO tasks (task_base.py:169-220): what ReferenceStateInitializationWrapper reads and sets
+    @property
+    def demo_list(self):
+        return self._env._vec.demo_list
+
+    @property
+    def demo_length(self):
+        return self._env._vec.demo_length
+
+    @property
+    def demo_counter(self):
+        return int(self._scalars()[44])
+
+    def set_demo_counter(self, value):
+        self._env._vec.set_demo_counter(int(value))
+
     def _scalars(self):
         return self._env._vec.get_info("task")[0].cpu().numpy()
 
@@ -204,6 +220,7 @@ class QuadrupedGymEnv(GymEnv):
         device=0,
         seed=0,
         noise=True,   # extensions (not in the reference's signature): device, seed of the counter-based RNG, sensor noise on / off
+        demo=None,    # DEMO tasks: the demonstration rows (array or .npy path) the reference would np.load (task_base.py:173)
     ):
         if on_rack or render:
             raise NotImplementedError("on_rack / render need the PyBullet GUI path, which this build does not provide")
@@ -213,7 +230,7 @@ class QuadrupedGymEnv(GymEnv):
             action_repeat=action_repeat, motor_control_mode=motor_control_mode, task_env=task_env,
             observation_space_mode=observation_space_mode, action_space_mode=action_space_mode, enable_springs=enable_springs,
             enable_action_interpolation=enable_action_interpolation, enable_action_filter=enable_action_filter,
-            env_randomizer_mode=env_randomizer_mode, seed=seed, noise=noise)
+            env_randomizer_mode=env_randomizer_mode, seed=seed, noise=noise, demo=demo)
         meta = self._vec.meta
         self._robot_config = meta["robot_config"]
         self._enable_springs = enable_springs
@@ -259,7 +276,10 @@ class QuadrupedGymEnv(GymEnv):
         if self.robot_desired_state is not None:   # gym_env.py:289-290, quadruped.py:521-525: no settle, _last_action stays zero
             _, q, qd, pos, quat, lin, ang, _ = self.robot_desired_state
             st = np.concatenate([pos, quat, lin, ang, q, qd]).astype(np.float32)[None]
+            keep = self.task.demo_counter if self._vec.demo_list is not None else None   # task_base.py:177-179: the counter survives this reset
             flat = self._vec.reset_tensor(states=st)[0].cpu().numpy()
+            if keep is not None:
+                self._vec.set_demo_counter(keep)
             self._last_action = np.zeros(self.action_dim)
             return self._as_dict(flat)
         flat = self._vec.reset()[0]

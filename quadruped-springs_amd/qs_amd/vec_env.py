@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .config import OBSERVATION_EPS, build_config
+from .config import DEMO_FILES, OBSERVATION_EPS, build_config
 from .spaces import Box, SB3VecEnv
 
 INFO = dict(foot_force=0, foot_contact=1, torque=2, spring_torque=3, task=4, n_invalid=5, params=6, counters=7,
@@ -48,6 +48,13 @@ class QuadrupedVecEnv(SB3VecEnv):
         self._trace = None
         self._closed = False
         self.render_mode = None
+        self.demo_list, self.demo_length = None, 0
+        if self.meta["task_env"] in DEMO_FILES:
+            if self.meta["demo"] is None:
+                self.close()
+                raise ValueError(f"task {self.meta['task_env']} imitates a demonstration: pass demo=<array [L, action_dim + 38] or path of the "
+                                 f".npy> (the reference loads demonstrations/{DEMO_FILES[self.meta['task_env']]}, task_base.py:173)")
+            self.set_demo(self.meta["demo"])
 
     # ---- plumbing
     def _stream(self):
@@ -179,6 +186,35 @@ class QuadrupedVecEnv(SB3VecEnv):
         out = {k: rows[:, a:b] for k, (a, b) in self.TRACE_FIELDS.items()}
         out["time"] = out["time"][:, 0]
         return out
+
+    # ---- DEMO tasks (task_base.py:169-220)
+    def set_demo(self, rows):
+        """The demonstration the DEMO task imitates: [L, action_dim + 38] rows as demo_rows() / GetDemonstrationWrapper record them."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.action_dim + 38:
+            raise ValueError(f"demonstration rows have {self.action_dim + 38} entries, got shape {rows.shape}")
+        t = self.torch.from_numpy(rows).to(self.device)
+        self._stream()
+        _lib.check(self.lib.qs_set_demo(self.h, self._ptr(t), int(rows.shape[0])))   # synchronises: `t` may go
+        self.demo_list, self.demo_length = rows, int(rows.shape[0])
+
+    def set_demo_counter(self, values, mask=None):
+        """task.set_demo_counter (task_base.py:219-220) of the masked environments; after reset_tensor(mask, states=...)."""
+        t = self.torch
+        v = t.as_tensor(values, device=self.device).to(t.int32).expand(self.num_envs).contiguous()
+        m = None if mask is None else t.as_tensor(mask, device=self.device).to(t.uint8).contiguous()
+        self._stream()
+        _lib.check(self.lib.qs_set_demo_counter(self.h, None if m is None else self._ptr(m), self._ptr(v)))
+
+    def demo_counter(self):
+        return self.get_info("task")[:, 44].to(self.torch.int64)
+
+    @staticmethod
+    def demo_states(rows, action_dim):
+        """[K, 37] rigid-body states (layout of get_state) of demonstration rows (read_demo order: a, q, qd, pos, quat, vlin, vang, flag)."""
+        r = np.atleast_2d(np.asarray(rows, dtype=np.float32))
+        d = action_dim
+        return np.concatenate([r[:, d + 24:d + 37], r[:, d:d + 24]], axis=1)
 
     # ---- demonstration rows (get_demonstration_wrapper.py:35-70)
     def demo_rows(self, done=None):

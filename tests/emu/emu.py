@@ -82,3 +82,18 @@ class Emu:
 
     def set_mu(self, mu):
         self.records()[:, self.field("R_PARAMS")] = mu
+
+    def reset_to(self, states, mask=None):
+        st = np.ascontiguousarray(states, np.float32).reshape(self.n, 37)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.lib.qse_reset_to(self.h, None if m is None else self._p(m), self._p(st))
+        return self.get_obs()
+
+    def set_demo(self, rows):
+        r = np.ascontiguousarray(rows, np.float32).reshape(-1, self.d + 38)
+        self.lib.qse_set_demo(self.h, self._p(r), int(r.shape[0]))
+
+    def set_demo_counter(self, values, mask=None):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values, np.int32), (self.n,)))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.lib.qse_set_demo_counter(self.h, None if m is None else self._p(m), self._p(v))

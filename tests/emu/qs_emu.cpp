@@ -12,6 +12,7 @@ struct Emu {
     qs_config cfg;
     std::vector<float> rec, obs, term_obs;
     float* trace = nullptr; int trace_env = -1;
+    std::vector<float> demo; int demo_len = 0;
 };
 
 static void init_record(const qs_config& cfg, float* r, int env) {
@@ -40,6 +41,35 @@ int qse_reset(void* h, const uint8_t* mask) {
         if (!mask || mask[i]) E::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)(i + e->cfg.env_id_offset), true);
     return 0;
 }
+// qs_reset_to (k_reset with states): randomizers, the given rigid-body state, task / sensor / filter reset, zero action history
+int qse_reset_to(void* h, const uint8_t* mask, const float* states) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++) {
+        if (mask && !mask[i]) continue;
+        float* rec = &e->rec[(size_t)i * QS_REC];
+        const uint32_t gid = (uint32_t)(i + e->cfg.env_id_offset);
+        E::randomize(e->cfg, rec, gid, qs::f2i(rec[R_EPISODE]) + 1, false);
+        memcpy(rec + R_POS, states + (size_t)i * 37, 37 * sizeof(float));
+        for (int k = 0; k < 4; k++) { rec[R_WARM + k] = 0.0f; rec[R_FOOT_FORCE + k] = 0.0f; rec[R_FOOT_CONTACT + k] = 0.0f; }
+        rec[R_N_INVALID] = 0.0f;
+        for (int k = 0; k < 24; k++) rec[R_TAU_PD + k] = 0.0f;
+        E::reset(e->cfg, rec, &e->obs[(size_t)i * QS_MAX_OBS], gid, false);
+        for (int k = 0; k < 12 + 24 + 24; k++) rec[R_LAST_ACTION + k] = 0.0f;
+    }
+    return 0;
+}
+int qse_set_demo(void* h, const float* rows, int length) {
+    Emu* e = (Emu*)h;
+    e->demo.assign(rows, rows + (size_t)length * (e->cfg.action_dim + 38));
+    e->demo_len = length;
+    return 0;
+}
+int qse_set_demo_counter(void* h, const uint8_t* mask, const int32_t* values) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++)
+        if (!mask || mask[i]) { float* r = &e->rec[(size_t)i * QS_REC + R_DEMO]; r[0] = r[1] = (float)values[i]; }
+    return 0;
+}
 int qse_get_obs(void* h, float* obs) {
     Emu* e = (Emu*)h;
     for (int i = 0; i < e->cfg.n_envs; i++) memcpy(obs + (size_t)i * e->cfg.obs_dim, &e->obs[(size_t)i * QS_MAX_OBS], e->cfg.obs_dim * sizeof(float));
@@ -52,7 +82,7 @@ int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* don
         float* rec = &e->rec[(size_t)i * QS_REC];
         float* ob = &e->obs[(size_t)i * QS_MAX_OBS];
         float* tr = (e->trace && i == e->trace_env) ? e->trace : nullptr;
-        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset), 0, tr, tr != nullptr);
+        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset), 0, tr, tr != nullptr, e->demo.data(), e->demo_len);
         rew[i] = r.reward.v[0]; done[i] = r.done.v[0] > 0.5f; trunc[i] = r.trunc.v[0] > 0.5f;
         if (done[i] && e->cfg.auto_reset) {
             memcpy(&e->term_obs[(size_t)i * QS_MAX_OBS], ob, QS_MAX_OBS * sizeof(float));
@@ -82,7 +112,7 @@ int qse_field(const char* name) {
 #define F(n) if (!strcmp(name, #n)) return n;
     F(R_POS) F(R_QUAT) F(R_VLIN) F(R_VANG) F(R_Q) F(R_QD) F(R_WARM) F(R_LAST_ACTION) F(R_XHIST) F(R_YHIST) F(R_SIM_STEP) F(R_ENV_STEP)
     F(R_EPISODE) F(R_TOTAL_STEPS) F(R_TASK) F(R_NEW_TAU) F(R_PARAMS) F(R_FOOT_FORCE) F(R_FOOT_CONTACT) F(R_N_INVALID) F(R_TAU_PD)
-    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_FLAGS) F(R_CPG) F(R_WRAP)
+    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_FLAGS) F(R_CPG) F(R_DEMO) F(R_WRAP)
 #undef F
     return -1;
 }

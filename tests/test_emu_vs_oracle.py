@@ -240,3 +240,36 @@ def test_joint_limit_rows_all_joints():
         q = so[:, 13:25]
         hit |= np.array([(q[:, 2::3] < -2.70).any(), (np.abs(q[:, 0::3]) > 1.03).any(), (q[:, 1::3] < -0.65).any()])
     assert hit.all(), hit
+
+
+@pytest.mark.parametrize("name", ["demo_jip", "demo_bf", "demo_jf12", "demo_cjf"])
+def test_demo_tasks_and_rsi(golden, name):
+    """Imitation tasks + reference-state initialisation of the kernel code against the reference's own run (tests/golden/demo.npz:
+    its DEMO tasks on a demonstration its GetDemonstrationWrapper recorded, resets by its ReferenceStateInitializationWrapper),
+    free-running inside an episode."""
+    import ast
+    from test_oracle_traces import demo_state
+    g = golden("demo.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    cfg, meta = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", demo=g[f"{name}_demo"], **kw)
+    cfg.randomizer_flags = 8
+    e = Emu(cfg)
+    e.set_demo(meta["demo"])
+    d, demo = cfg.action_dim, g[f"{name}_demo"]
+    starts = list(g[f"{name}_reset_at"]) + [len(g[f"{name}_actions"])]
+    for ep, el in enumerate(g[f"{name}_reset_el"]):
+        e.set_mu(float(g[f"{name}_mu"][ep]))
+        if el < 0:
+            ob = e.reset()
+        else:
+            ob = e.reset_to(demo_state(demo[el], d)[None])
+            e.set_demo_counter(int(el))
+        np.testing.assert_allclose(ob[0], g[f"{name}_reset_obs"][ep], atol=2e-3, rtol=1e-3, err_msg=f"reset obs episode {ep}")
+        for t in range(starts[ep], starts[ep + 1]):
+            ob, r, dn, tr = e.step(g[f"{name}_actions"][t][None])
+            np.testing.assert_allclose(r[0], g[f"{name}_rew"][t], atol=1e-6, rtol=2e-4, err_msg=f"reward step {t}")
+            assert bool(dn[0]) == bool(g[f"{name}_done"][t]) and bool(tr[0]) == bool(g[f"{name}_trunc"][t]), t
+            assert int(e.get("R_DEMO", 2)[0, 0]) == int(g[f"{name}_counter"][t])
+            np.testing.assert_allclose(e.get_state()[0][13:25], g[f"{name}_state"][t][13:25], atol=2e-2, err_msg=f"q step {t}")
+            e.set_state(g[f"{name}_state"][t][None])     # float32 vs the float64 run: re-seat the rigid-body state
+        assert dn[0]

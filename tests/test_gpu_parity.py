@@ -627,6 +627,95 @@ def test_reference_state_initialisation(torch_cuda, golden, name):
         env.close()
 
 
+@pytest.mark.parametrize("name", ["demo_jip", "demo_bf", "demo_jf12", "demo_cjf"])
+def test_demo_tasks_and_rsi(torch_cuda, golden, name):
+    """Imitation tasks + reference-state initialisation through the C ABI against the REFERENCE's run (tests/golden/demo.npz: its DEMO
+    tasks on a demonstration its GetDemonstrationWrapper recorded, resets by its ReferenceStateInitializationWrapper)."""
+    from test_oracle_traces import demo_state
+    g = golden("demo.npz")
+    kw = ast.literal_eval(str(g[f"{name}_kwargs"]))
+    _, v, cfg = make_pair(1, torch_cuda, oracle=False, keep_params=True, demo=g[f"{name}_demo"], **kw)
+    d, demo = cfg.action_dim, g[f"{name}_demo"]
+    with pytest.raises(RuntimeError, match="qs_set_demo"):
+        v.step(np.zeros((1, d), np.float32))
+    v.set_demo(v.meta["demo"])
+    starts = list(g[f"{name}_reset_at"]) + [len(g[f"{name}_actions"])]
+    for ep, el in enumerate(g[f"{name}_reset_el"]):
+        if ep == 0:
+            v.reset()
+        v.set_params("mu", np.array([[float(g[f"{name}_mu"][ep])]], np.float32))
+        if el < 0:
+            ob = v.reset()
+        else:
+            ob = v.reset_tensor(states=demo_state(demo[el], d)[None].astype(np.float32)).cpu().numpy()
+            v.set_demo_counter(int(el))
+        np.testing.assert_allclose(ob[0], g[f"{name}_reset_obs"][ep], atol=2e-3, rtol=1e-3, err_msg=f"reset obs episode {ep}")
+        for t in range(starts[ep], starts[ep + 1]):
+            ob, r, dn, infos = v.step(g[f"{name}_actions"][t][None].astype(np.float32))
+            np.testing.assert_allclose(r[0], g[f"{name}_rew"][t], atol=1e-6, rtol=2e-4, err_msg=f"reward step {t}")
+            assert bool(dn[0]) == bool(g[f"{name}_done"][t]), t
+            assert bool(infos[0].get("TimeLimit.truncated", False)) == bool(g[f"{name}_trunc"][t])
+            assert int(v.demo_counter()[0]) == int(g[f"{name}_counter"][t])
+            np.testing.assert_allclose(v.get_state().cpu().numpy()[0][13:25], g[f"{name}_state"][t][13:25], atol=2e-2, err_msg=f"q step {t}")
+            np.testing.assert_allclose(ob[0], g[f"{name}_obs"][t], atol=5e-2, rtol=1e-2, err_msg=f"obs step {t}")
+            v.set_state(g[f"{name}_state"][t][None].astype(np.float32))   # float32 vs the float64 run: re-seat the rigid-body state
+        assert dn[0]
+
+
+def test_rsi_vec_env_and_gym_view(torch_cuda, golden):
+    """ReferenceStateInitVecEnv (N environments re-seated in random rows of the demonstration by masked qs_reset_to +
+    qs_set_demo_counter) and the reference's wrapper flow on the N = 1 view (task.demo_list / set_demo_counter + set_robot_desired_state)."""
+    from qs_amd import QuadrupedVecEnv, ReferenceStateInitVecEnv
+    from qs_amd.env.quadruped_gym_env import QuadrupedGymEnv
+    torch = torch_cuda
+    g = golden("demo.npz")
+    kw = ast.literal_eval(str(g["demo_jip_kwargs"]))
+    demo = g["demo_jip_demo"]
+    L, n, d = len(demo), 64, 6
+    with pytest.raises(ValueError, match="demo="):
+        QuadrupedVecEnv(num_envs=4, **kw)
+    venv = ReferenceStateInitVecEnv(QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_pool=64, demo=demo, noise=False, seed=3, **kw), seed=11)
+    obs = venv.reset_tensor()
+    st = venv.get_state().cpu().numpy()
+    np.testing.assert_allclose(st, venv.demo_states(demo[venv.random_el], d), atol=1e-6)
+    assert np.array_equal(venv.demo_counter().cpu().numpy(), venv.random_el) and venv.random_el.max() < L - 5
+    resets, firsts = np.ones(n, int), []
+    for i in range(260):
+        c = venv.demo_counter().cpu().numpy()
+        a = torch.as_tensor(demo[np.minimum(c, L - 1), :d], device=venv.device)
+        el0 = venv.random_el.copy()
+        obs, rew, done, trunc = venv.step_tensor(a)
+        dn = done.bool().cpu().numpy()
+        r = rew.cpu().numpy()
+        # the demonstration's own actions are its filtered ones, the comparison is with the unfiltered input: distance 0 here
+        np.testing.assert_allclose(r, 1.0 / (L - el0), rtol=1e-5)
+        assert np.array_equal(dn, (c + 1 == L) | dn) and not trunc.any()
+        if dn.any():
+            idx = np.nonzero(dn)[0]
+            np.testing.assert_allclose(venv.get_state().cpu().numpy()[idx], venv.demo_states(demo[venv.random_el[idx]], d), atol=1e-6)
+            assert np.array_equal(venv.demo_counter().cpu().numpy()[idx], venv.random_el[idx])
+            firsts += [(resets[j] % 6 == 5, venv.random_el[j]) for j in idx]   # every sixth reset draws from the first fifth
+            resets[idx] += 1
+    assert len(firsts) > 100 and all(el < L // 5 for short, el in firsts if short) and any(el >= L // 5 for short, el in firsts if not short)
+    venv.close()
+    # N = 1 view driven the way reference_state_initialization_wrapper.py:25-33 drives the reference's environment
+    env = QuadrupedGymEnv(env_randomizer_mode="GROUND_RANDOMIZER", seed=1, noise=False, demo=demo, **kw)
+    assert env.task.demo_length == L and env.task.demo_list.shape == demo.shape
+    ep = 1
+    el = int(g["demo_jip_reset_el"][ep])
+    env.set_robot_desired_state(QuadrupedVecEnv.read_demo(env.task.demo_list[el]))
+    env.task.set_demo_counter(value=el)
+    env.reset()
+    assert env.task.demo_counter == el
+    t0 = int(g["demo_jip_reset_at"][ep])
+    _, r, dn, _ = env.step(g["demo_jip_actions"][t0])
+    np.testing.assert_allclose(r, g["demo_jip_rew"][t0], rtol=2e-4)
+    assert env.task.demo_counter == el + 1
+    env.reset()                                   # the desired state stays set: the counter survives (task_base.py:177-179)
+    assert env.task.demo_counter == el + 1
+    env.close()
+
+
 def test_joint_limit_solver_path(torch_cuda):
     """Raw torques drive joints into their stops (calves to the lower stop, then hips outwards and thighs back): the 6-rows-per-leg
     solver path against the FLOAT32 build of the oracle on the same float32 states (see tests/test_emu_vs_oracle.py::
