@@ -153,6 +153,8 @@ enum {
     QS_INFO_FOOT_FORCE = 0, QS_INFO_FOOT_CONTACT = 1, QS_INFO_TORQUE = 2, QS_INFO_SPRING_TORQUE = 3, QS_INFO_TASK = 4,
     QS_INFO_N_INVALID = 5, QS_INFO_PARAMS = 6, QS_INFO_COUNTERS = 7, QS_INFO_LAST_ACTION = 8, QS_INFO_TERMINAL_OBS = 9,
     QS_INFO_FILTERED_ACTION = 11,  /* [N,12]: output of the action filter at the last step (get_last_filtered_action, gym_env.py:385-387) */
+    QS_INFO_REWARD_END = 12,  /* [N,1]: get_reward_end_episode() (gym_env.py:363-365): the end-of-episode bonus / malus the task would add
+                               * if the episode ended in the current state */
     QS_INFO_WRAPPER = 10,  /* [N,4]: phase after the step (0 policy, 1 take-off hold, 2 landing, 3 rest), scripted (the step just
                             * made ignored the caller's action), timer, end time */
 };

@@ -626,6 +626,17 @@ static int scatter(qs_handle* h, int off, int dim, const float* in, int zero_war
     return 0;
 }
 
+// get_reward_end_episode (gym_env.py:363-365 -> task._reward_end_episode()) on the task state the records hold
+__global__ __launch_bounds__(QS_WAVE) void k_reward_end(const qs_config* __restrict__ cfgp, const float* __restrict__ recs, float* __restrict__ out) {
+    const qs_config& cfg = *cfgp;
+    const int env = blockIdx.x * QS_ENVS_PER_WAVE + (threadIdx.x >> 2);
+    const float* rec = recs + (size_t)(env < cfg.n_envs ? env : 0) * QS_REC;
+    typename E::S::State s; E::Task t;
+    E::load_state(rec, s); E::load_task(rec, t);
+    float term = E::task_terminated(cfg, t, s, rec[R_N_INVALID], false);
+    float r = E::task_reward_end(cfg, t, term, (float)((double)qs::f2i(rec[R_SIM_STEP]) * cfg.dt));
+    if (env < cfg.n_envs && (threadIdx.x & 3) == 0) out[env] = r;
+}
 __global__ void k_wrapper_info(const float* __restrict__ recs, int n, float* __restrict__ out) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -651,6 +662,7 @@ int qs_info_dim(const qs_handle* h, int which) {
     case QS_INFO_TERMINAL_OBS: return h ? h->cfg.obs_dim : -1;
     case QS_INFO_WRAPPER: return 4;
     case QS_INFO_FILTERED_ACTION: return 12;
+    case QS_INFO_REWARD_END: return 1;
     default: return -1;
     }
 }
@@ -669,6 +681,10 @@ int qs_get_info(qs_handle* h, int which, float* out) {
     case QS_INFO_LAST_ACTION: return gather(h, R_LAST_ACTION, 12, out, 0);
     case QS_INFO_WRAPPER: return gather_wrapper(h, out);
     case QS_INFO_FILTERED_ACTION: return gather(h, R_YHIST, 12, out, 0);
+    case QS_INFO_REWARD_END:
+        hipLaunchKernelGGL(k_reward_end, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, out);
+        QS_HIP(hipGetLastError());
+        return 0;
     case QS_INFO_TASK:
         hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out, (int)E::demo_task(h->cfg.task));
         QS_HIP(hipGetLastError());

@@ -286,6 +286,10 @@ class QuadrupedGymEnv(GymEnv):
         self._last_action = np.asarray(self._settling_action, float)
         return self._as_dict(flat)
 
+    def get_reward_end_episode(self):
+        """gym_env.py:363-365: the task's end-of-episode bonus / malus for the current state."""
+        return float(self._vec.get_info("reward_end")[0, 0])
+
     def set_robot_desired_state(self, state):
         """gym_env.py:400-402: the 8-tuple of GetDemonstrationWrapper.read_demo (action, q, qd, base position, base quaternion, linear
         velocity, angular velocity, landing flag), or None; the next reset() places the robot there instead of settling it."""

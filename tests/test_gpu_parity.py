@@ -124,6 +124,8 @@ def test_env_step_parity_resynced(torch_cuda, kw):
         np.testing.assert_allclose(v.get_info("foot_force").cpu().numpy(), o.get_info(0), rtol=2e-2, atol=0.5)
         np.testing.assert_array_equal(v.get_info("foot_contact").cpu().numpy(), o.get_info(1))
         np.testing.assert_allclose(v.get_info("torque").cpu().numpy(), o.get_info(2), atol=5e-3)
+        np.testing.assert_allclose(v.get_info("reward_end").cpu().numpy()[:, 0], o.eval_reward(1), atol=2e-4, rtol=1e-3,
+                                   err_msg=f"get_reward_end_episode step {i}")
         if do.any():
             o.reset(do.astype(np.uint8)); v.reset_tensor(do.astype(np.uint8))
 
