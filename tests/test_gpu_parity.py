@@ -303,6 +303,49 @@ def test_streaming_pool_refill(torch_cuda):
     v.close()
 
 
+@pytest.mark.parametrize("n", [1, 15, 17, 100])
+def test_ragged_batch_sizes_stay_inside_their_arrays(torch_cuda, n):
+    """N not a multiple of the 16 environments of a wave: the tail quads of the last wave compute on a replayed record and must
+    neither write past row N of any caller array nor disturb the others; results equal those of the first N environments of a
+    larger batch.  Every output array is allocated with guard rows behind it."""
+    import ctypes as C
+    from qs_amd import lib as L
+    from qs_amd.vec_env import QuadrupedVecEnv
+    torch = torch_cuda
+    kw = dict(auto_reset=True, reset_pool=96, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+              enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=9, noise=True, settle_steps=200)
+    v, w = QuadrupedVecEnv(num_envs=n, **kw), QuadrupedVecEnv(num_envs=n + 23, **kw)
+    v.pool_streaming(True); w.pool_streaming(True)
+    o, G = v.obs_dim, 8
+    guard = dict(obs=torch.full((n + G, o), 777.0, device=v.device), rew=torch.full((n + G,), 777.0, device=v.device),
+                 done=torch.full((n + G,), 77, dtype=torch.uint8, device=v.device), trunc=torch.full((n + G,), 77, dtype=torch.uint8, device=v.device),
+                 fused=torch.full((n + G, o + 2), 777.0, device=v.device), state=torch.full((n + G, 37), 777.0, device=v.device),
+                 info=torch.full((n + G, 48), 777.0, device=v.device))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    v.reset_tensor(); w.reset_tensor()
+    rng = np.random.default_rng(n)
+    for i in range(60):
+        a = rng.uniform(-1, 1, size=(n + 23, 6)).astype(np.float32)
+        a[:, 1::3] = -1.0; a[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5       # falls: auto-resets from the pool happen
+        av = torch.as_tensor(a[:n].copy(), device=v.device)
+        v._stream()
+        if i % 2:
+            L.check(v.lib.qs_step(v.h, p(av), p(guard["obs"]), p(guard["rew"]), p(guard["done"]), p(guard["trunc"])))
+            got = guard["obs"][:n]
+        else:
+            L.check(v.lib.qs_step_fused(v.h, p(av), p(guard["fused"])))
+            got = guard["fused"][:n, :o]
+        ref = w.step_tensor(torch.as_tensor(a, device=w.device))[0][:n]
+        assert torch.equal(got, ref), f"step {i}"
+        L.check(v.lib.qs_get_state(v.h, p(guard["state"])))
+        L.check(v.lib.qs_get_info(v.h, 4, p(guard["info"])))
+    for k, t in guard.items():
+        tail = t[n:]
+        assert bool((tail == (77 if t.dtype == torch.uint8 else 777.0)).all()), f"guard rows of {k} were written"
+    assert v.stats()["resets"] > n        # more than the initial reset of every environment
+    v.close(); w.close()
+
+
 def test_trace_tap(torch_cuda):
     """qs_set_trace: one row per physics substep of the chosen environment (evaluation_wrapper.py / monitor_state.py taps)."""
     n = 48
