@@ -65,8 +65,9 @@ class QuadrupedVecEnv(SB3VecEnv):
         return C.c_void_p(t.data_ptr())
 
     def close(self):
-        if not self._closed and self.h:
-            self.lib.qs_destroy(self.h)
+        if not getattr(self, "_closed", True) and self.h:
+            h, self.h = self.h, C.c_void_p()     # later calls reach the library with a null handle and fail with its error text
+            self.lib.qs_destroy(h)
             self._closed = True
 
     def __del__(self):
