@@ -30,7 +30,11 @@ def build(force=False, verbose=False):
     # -fno-slp-vectorize: packed fp32 (v_pk_*) costs more moves than it saves here.  iterative-ilp: with one wave per SIMD
     # there is no other wave to hide a dependent instruction's latency, so the scheduler should chase ILP, not occupancy
     # (measured +6.5 % env-steps/s over the default strategy, same instructions, same results).
+    # -ffinite-math-only -fno-signed-zeros -fno-trapping-math: the step produces no NaN / infinity and tests for none, so the
+    # v_max_f32 x, x canonicalisations in front of every fmin / fmax / med3 can go (+5 % measured); reassociation and the rest of
+    # -ffast-math are NOT enabled (measured slower, and the summation order is part of the parity with the host emulation).
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
+           "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math",
            "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] + os.environ.get("QS_HIPCC_EXTRA", "").split() + [
            "-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
     if verbose:
