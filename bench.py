@@ -246,9 +246,16 @@ def main():
             if child.returncode != 0:
                 raise SystemExit("cpu_baseline child failed:\n" + child.stderr[-2000:])
             out["cpu_baseline"] = json.loads(child.stdout.strip().splitlines()[-1])
-        print(json.dumps(out))
+    env.close()
     if world > 1 or sharded:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which (piped) would otherwise
+        # be flushed at process exit, after anything printed here
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
