@@ -17,6 +17,7 @@ CASES = [
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER"),
     dict(task_env="JUMPING_FORWARD_PPO", observation_space_mode="CARTESIAN_NO_IMU", motor_control_mode="CARTESIAN_PD", action_space_mode="DEFAULT",
          wrapper="LANDING2", enable_springs=False),
+    dict(task_env="JUMPING_FORWARD_DEMO", observation_space_mode="PPO_BASIC_CONTACT", action_space_mode="DEFAULT"),   # the drivers install a synthetic demonstration
 ]
 SAN = ["-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]   # no -g: variable tracking makes g++ take minutes on the templates
 
