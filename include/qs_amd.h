@@ -211,9 +211,11 @@ int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs
 /* VecNormalize.reset: returns <- 0, obs_rms.update(obs) if training && norm_obs, obs <- normalize_obs(obs) */
 int qs_norm_reset(qs_norm* h, float* obs /* [N,o] */, int training, int norm_obs);
 /* VecNormalize.step_wait: obs_rms.update(obs); obs <- normalize_obs(obs); returns <- returns*gamma + rew; ret_rms.update(returns);
- * rew <- normalize_reward(rew); term_obs (may be NULL) <- normalize_obs(term_obs); returns[done] <- 0 */
+ * rew <- normalize_reward(rew); term_obs (may be NULL) <- normalize_obs(term_obs); returns[done] <- 0.
+ * raw_obs [N,o] / raw_rew [N] (either may be NULL) receive the values before normalisation: VecNormalize.old_obs / old_reward
+ * (get_original_obs / get_original_reward), written by the same pass */
 int qs_norm_step(qs_norm* h, float* obs /* [N,o] */, float* rew /* [N] */, const uint8_t* done /* [N] */, float* term_obs /* [N,o] or NULL */,
-                 int training, int norm_obs, int norm_reward);
+                 int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
 
 const char* qs_last_error(void);
 const char* qs_version(void);

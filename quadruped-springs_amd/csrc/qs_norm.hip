@@ -22,8 +22,11 @@ struct qs_norm {
     int n, o, device;
     float clip_obs, clip_rew, gamma, eps;
     hipStream_t stream;
-    // [0, C) mean, [C, 2C) var, [2C, 2C+2) count (obs, returns), [2C+2, 3C+2) batch mean, [3C+2, 4C+2) batch var; C = o + 1, column o = returns
+    // [0, C) mean, [C, 2C) var, [2C, 2C+2) count (obs, returns), [2C+2, 3C+2) batch mean, [3C+2, 4C+2) batch var,
+    // [4C+2, 5C+2) 1 / sqrt(var + eps); C = o + 1, column o = returns
     double* d_stat;
+    void* d_part;    // per-block moments of the batch [n_parts][C] (k_norm_partial -> k_norm_update)
+    int n_parts, rows_per_block;
     double* d_ret;   // discounted return of every environment (VecNormalize.returns)
 };
 
@@ -37,61 +40,87 @@ __device__ inline Moments merge(Moments a, Moments b) {   // Chan et al. pairwis
     return r;
 }
 
-// one block per column (obs_dim observation columns + the returns column): batch mean and population variance over the N rows
-__global__ void k_norm_moments(const float* __restrict__ obs, const float* __restrict__ rew, double* __restrict__ ret, int n, int o, double gamma,
-                               int with_obs, int with_ret, double* __restrict__ stat) {
-    const int c = blockIdx.x, C = o + 1;
-    if ((c < o && !with_obs) || (c == o && !with_ret)) return;
-    Moments m; m.n = 0.0; m.mean = 0.0; m.m2 = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        double x;
-        if (c < o) x = (double)obs[(size_t)i * o + c];
-        else { x = ret[i] * gamma + (double)rew[i]; ret[i] = x; }   // vec_normalize.py:_update_reward
-        m.n += 1.0;
-        double d = x - m.mean;
-        m.mean += d / m.n;
-        m.m2 += d * (x - m.mean);
-    }
-    __shared__ Moments sh[256];
-    sh[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = merge(sh[threadIdx.x], sh[threadIdx.x + s]);
+// Batch moments, stage 1: a block reduces `rows_per_block` consecutive rows, every column at once -- thread (cx, ry) takes column
+// c0 + cx of rows ry, ry + 8, ...: a wavefront reads two whole rows (coalesced), not one column with a stride of a row.  The
+// returns column (index o) also advances VecNormalize.returns (vec_normalize.py:_update_reward).
+#define QN_MAX_PARTS 1024
+__global__ __launch_bounds__(256) void k_norm_partial(const float* __restrict__ obs, const float* __restrict__ rew, double* __restrict__ ret, int n, int o,
+                                                      double gamma, int with_obs, int with_ret, int rows_per_block, Moments* __restrict__ part) {
+    const int C = o + 1, cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    __shared__ Moments sh[8][32];
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int c = c0 + cx;
+        const bool act = c < C && ((c < o && with_obs) || (c == o && with_ret));
+        double pivot = 0.0, s1 = 0.0, s2 = 0.0, cnt = 0.0;       // sums about the first value: no cancellation in s2 - s1^2 / cnt
+        if (act)
+            for (int i = r0 + ry; i < r1; i += 8) {
+                double x;
+                if (c < o) x = (double)obs[(size_t)i * o + c];
+                else { x = ret[i] * gamma + (double)rew[i]; ret[i] = x; }
+                if (cnt == 0.0) pivot = x;
+                const double d = x - pivot;
+                s1 += d; s2 += d * d; cnt += 1.0;
+            }
+        Moments m; m.n = cnt; m.mean = cnt > 0.0 ? pivot + s1 / cnt : 0.0; m.m2 = cnt > 0.0 ? s2 - s1 * s1 / cnt : 0.0;
+        sh[ry][cx] = m;
+        __syncthreads();
+        if (ry == 0 && c < C) {
+            for (int k = 1; k < 8; k++) m = merge(m, sh[k][cx]);
+            part[(size_t)blockIdx.x * C + c] = m;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stat[2 * C + 2 + c] = sh[0].mean; stat[3 * C + 2 + c] = sh[0].m2 / sh[0].n; }
 }
 
-// running_mean_std.py: update_from_moments
-__global__ void k_norm_update(double* __restrict__ stat, int o, double batch_count, int with_obs, int with_ret) {
-    const int c = threadIdx.x, C = o + 1;
-    const bool active = c < C && ((c < o && with_obs) || (c == o && with_ret));
-    double new_mean = 0.0, new_var = 0.0, tot = 0.0;
-    if (active) {
-        const double count = stat[2 * C + (c == o ? 1 : 0)];
-        const double mean = stat[c], var = stat[C + c], bm = stat[2 * C + 2 + c], bv = stat[3 * C + 2 + c];
-        const double delta = bm - mean;
-        tot = count + batch_count;
-        new_mean = mean + delta * batch_count / tot;
-        new_var = (var * count + bv * batch_count + delta * delta * count * batch_count / (count + batch_count)) / (count + batch_count);
+// Stage 2 + running_mean_std.py update_from_moments: one block merges the per-block moments of every column (Chan's pairwise
+// merge, the formula RunningMeanStd itself uses), folds the batch into the running statistics and refreshes 1 / sqrt(var + eps).
+__global__ __launch_bounds__(1024) void k_norm_update(double* __restrict__ stat, int o, double batch_count, int with_obs, int with_ret,
+                                                      const Moments* __restrict__ part, int n_parts, double eps) {
+    const int C = o + 1, cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+    __shared__ Moments sh[32][33];
+    __shared__ double old_count[2];
+    if (threadIdx.x < 2) old_count[threadIdx.x] = stat[2 * C + threadIdx.x];
+    __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int c = c0 + cx;
+        Moments m; m.n = 0.0; m.mean = 0.0; m.m2 = 0.0;
+        if (c < C)
+            for (int g = gy; g < n_parts; g += 32) m = merge(m, part[(size_t)g * C + c]);
+        sh[gy][cx] = m;
+        __syncthreads();
+        for (int s = 16; s > 0; s >>= 1) {
+            if (gy < s) sh[gy][cx] = merge(sh[gy][cx], sh[gy + s][cx]);
+            __syncthreads();
+        }
+        if (gy == 0 && c < C && ((c < o && with_obs) || (c == o && with_ret))) {
+            const Moments b = sh[0][cx];
+            const double bm = b.mean, bv = b.m2 / b.n;
+            const double count = old_count[c == o ? 1 : 0], mean = stat[c], var = stat[C + c];
+            const double delta = bm - mean, tot = count + batch_count;
+            const double new_var = (var * count + bv * batch_count + delta * delta * count * batch_count / (count + batch_count)) / (count + batch_count);
+            stat[c] = mean + delta * batch_count / tot;
+            stat[C + c] = new_var;
+            stat[2 * C + 2 + c] = bm; stat[3 * C + 2 + c] = bv;
+            stat[4 * C + 2 + c] = 1.0 / sqrt(new_var + eps);
+        }
+        __syncthreads();
     }
-    __syncthreads();   // every column has read the old count
-    if (active) {
-        stat[c] = new_mean; stat[C + c] = new_var;
-        if (c == 0) stat[2 * C] = tot;
-        if (c == o) stat[2 * C + 1] = tot;
-    }
+    if (threadIdx.x == 0 && with_obs) stat[2 * C] = old_count[0] + batch_count;
+    if (threadIdx.x == 0 && with_ret) stat[2 * C + 1] = old_count[1] + batch_count;
 }
 
 // vec_normalize.py: normalize_obs (incl. terminal observations), normalize_reward, returns[dones] = 0
 __global__ void k_norm_apply(float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ rew, const uint8_t* __restrict__ done,
                              double* __restrict__ ret, int n, int o, const double* __restrict__ stat, double eps, double clip_obs, double clip_rew,
-                             int norm_obs, int norm_rew) {
+                             int norm_obs, int norm_rew, float* __restrict__ raw_obs, float* __restrict__ raw_rew) {
     const int C = o + 1;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (raw_obs && i < (size_t)n * o) raw_obs[i] = obs[i];
+    if (raw_rew && i < (size_t)n) raw_rew[i] = rew[i];
     if (i < (size_t)n * o && norm_obs) {
         const int c = (int)(i % o);
-        const double mean = stat[c], inv = 1.0 / sqrt(stat[C + c] + eps);
+        const double mean = stat[c], inv = stat[4 * C + 2 + c];   // 1 / sqrt(var + eps), refreshed by k_norm_update / qs_norm_set_stats
         obs[i] = (float)fmin(fmax(((double)obs[i] - mean) * inv, -clip_obs), clip_obs);
         if (term_obs) term_obs[i] = (float)fmin(fmax(((double)term_obs[i] - mean) * inv, -clip_obs), clip_obs);
     }
@@ -117,13 +146,17 @@ int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, f
     h->n = n_envs; h->o = obs_dim; h->device = device; h->clip_obs = clip_obs; h->clip_rew = clip_reward; h->gamma = gamma; h->eps = epsilon;
     const int C = obs_dim + 1;
 #define QN_HIP_H(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(qs_g_err, sizeof(qs_g_err), "%s failed: %s", #call, hipGetErrorString(e_)); qs_norm_destroy(h); return -2; } } while (0)
-    QN_HIP_H(hipMalloc(&h->d_stat, (size_t)(4 * C + 2) * sizeof(double)));
+    QN_HIP_H(hipMalloc(&h->d_stat, (size_t)(5 * C + 2) * sizeof(double)));
+    h->rows_per_block = ((n_envs + QN_MAX_PARTS - 1) / QN_MAX_PARTS + 7) / 8 * 8;
+    if (h->rows_per_block < 64) h->rows_per_block = 64;
+    h->n_parts = (n_envs + h->rows_per_block - 1) / h->rows_per_block;
+    QN_HIP_H(hipMalloc(&h->d_part, (size_t)h->n_parts * C * 3 * sizeof(double)));
     QN_HIP_H(hipMalloc(&h->d_ret, (size_t)n_envs * sizeof(double)));
     QN_HIP_H(hipMemset(h->d_ret, 0, (size_t)n_envs * sizeof(double)));
-    double init[4 * 256 + 2];
-    for (int c = 0; c < C; c++) { init[c] = 0.0; init[C + c] = 1.0; init[2 * C + 2 + c] = 0.0; init[3 * C + 2 + c] = 0.0; }
+    double init[5 * 256 + 2];
+    for (int c = 0; c < C; c++) { init[c] = 0.0; init[C + c] = 1.0; init[2 * C + 2 + c] = 0.0; init[3 * C + 2 + c] = 0.0; init[4 * C + 2 + c] = 1.0 / sqrt(1.0 + (double)epsilon); }
     init[2 * C] = init[2 * C + 1] = 1e-4;   // RunningMeanStd(epsilon=1e-4)
-    QN_HIP_H(hipMemcpy(h->d_stat, init, (size_t)(4 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
+    QN_HIP_H(hipMemcpy(h->d_stat, init, (size_t)(5 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
 #undef QN_HIP_H
     *out = h;
     return 0;
@@ -133,7 +166,7 @@ void qs_norm_destroy(qs_norm* h) {
     if (!h) return;
     QS_ON_DEVICE(h);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d_stat); hipFree(h->d_ret);
+    hipFree(h->d_stat); hipFree(h->d_ret); hipFree(h->d_part);
     delete h;
 }
 
@@ -148,6 +181,9 @@ int qs_norm_set_stats(qs_norm* h, const double* obs_mean, const double* obs_var,
     buf[h->o] = ret_mean; buf[C + h->o] = ret_var; buf[2 * C] = obs_count; buf[2 * C + 1] = ret_count;
     QN_HIP(hipStreamSynchronize(h->stream));
     QN_HIP(hipMemcpy(h->d_stat, buf, (size_t)(2 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
+    double inv[256];
+    for (int c = 0; c < C; c++) inv[c] = 1.0 / sqrt(buf[C + c] + (double)h->eps);
+    QN_HIP(hipMemcpy(h->d_stat + 4 * C + 2, inv, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -173,27 +209,30 @@ int qs_norm_reset(qs_norm* h, float* obs, int training, int norm_obs) {
     QN_HIP(hipMemsetAsync(h->d_ret, 0, (size_t)h->n * sizeof(double), h->stream));
     const int upd = training && norm_obs;
     if (upd) {
-        hipLaunchKernelGGL(k_norm_moments, dim3(h->o + 1), dim3(256), 0, h->stream, obs, (const float*)nullptr, h->d_ret, h->n, h->o, (double)h->gamma, 1, 0, h->d_stat);
-        hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(256), 0, h->stream, h->d_stat, h->o, (double)h->n, 1, 0);
+        hipLaunchKernelGGL(k_norm_partial, dim3(h->n_parts), dim3(256), 0, h->stream, obs, (const float*)nullptr, h->d_ret, h->n, h->o, (double)h->gamma, 1, 0,
+                           h->rows_per_block, (Moments*)h->d_part);
+        hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(1024), 0, h->stream, h->d_stat, h->o, (double)h->n, 1, 0, (const Moments*)h->d_part, h->n_parts, (double)h->eps);
     }
     const size_t total = (size_t)h->n * h->o;
     hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, obs, (float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr,
-                       h->d_ret, h->n, h->o, h->d_stat, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew, norm_obs, 0);
+                       h->d_ret, h->n, h->o, h->d_stat, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew, norm_obs, 0, (float*)nullptr, (float*)nullptr);
     QN_HIP(hipGetLastError());
     return 0;
 }
 
 // VecNormalize.step_wait on the arrays a step produced (all in place, device memory; term_obs may be NULL)
-int qs_norm_step(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward) {
+int qs_norm_step(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward,
+                 float* raw_obs, float* raw_rew) {
     if (!h || !obs || !rew || !done) QN_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);
     if (training) {
-        hipLaunchKernelGGL(k_norm_moments, dim3(h->o + 1), dim3(256), 0, h->stream, obs, rew, h->d_ret, h->n, h->o, (double)h->gamma, norm_obs, 1, h->d_stat);
-        hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(256), 0, h->stream, h->d_stat, h->o, (double)h->n, norm_obs, 1);
+        hipLaunchKernelGGL(k_norm_partial, dim3(h->n_parts), dim3(256), 0, h->stream, obs, rew, h->d_ret, h->n, h->o, (double)h->gamma, norm_obs, 1,
+                           h->rows_per_block, (Moments*)h->d_part);
+        hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(1024), 0, h->stream, h->d_stat, h->o, (double)h->n, norm_obs, 1, (const Moments*)h->d_part, h->n_parts, (double)h->eps);
     }
     const size_t total = (size_t)h->n * h->o;
     hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, obs, term_obs, rew, done, h->d_ret, h->n, h->o,
-                       h->d_stat, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew, norm_obs, norm_reward);
+                       h->d_stat, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew, norm_obs, norm_reward, raw_obs, raw_rew);
     QN_HIP(hipGetLastError());
     return 0;
 }

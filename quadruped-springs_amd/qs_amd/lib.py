@@ -64,7 +64,7 @@ def load():
     lib.qs_norm_set_stats.argtypes = [vp, vp, vp, f64, f64, f64, f64]
     lib.qs_norm_get_stats.argtypes = [vp, vp, vp, pd, pd, pd, pd]
     lib.qs_norm_reset.argtypes = [vp, vp, i32, i32]
-    lib.qs_norm_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
+    lib.qs_norm_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.qs_last_error.restype = C.c_char_p
     lib.qs_version.restype = C.c_char_p
     _lib = lib

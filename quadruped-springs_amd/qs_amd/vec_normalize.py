@@ -47,11 +47,9 @@ class DeviceVecNormalize:
         """-> (obs, rew, done, truncated): normalised in place in the environment's reused buffers; the raw values of this step
         stay in `old_obs` / `old_reward` (VecNormalize.get_original_obs / get_original_reward)."""
         obs, rew, done, trunc = self.venv.step_tensor(actions)
-        self.old_obs.copy_(obs)
-        self.old_reward.copy_(rew)
         self._stream()
         _lib.check(self.lib.qs_norm_step(self.h, self._p(obs), self._p(rew), self._p(done), None, int(self.training), int(self.norm_obs),
-                                         int(self.norm_reward)))
+                                         int(self.norm_reward), self._p(self.old_obs), self._p(self.old_reward)))
         return obs, rew, done, trunc
 
     def normalize_obs(self, obs):
