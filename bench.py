@@ -194,12 +194,13 @@ def main():
         achieved = n * ALGO_BYTES_PER_ENV_STEP / kavg / 1e9
         # HBM bytes per launch from the committed PMC passes of this very configuration (rocprofv3 cannot run inside this
         # process); null when the run differs from the profiled one
-        traffic = valu = None
+        traffic = valu = pmc = None
         try:
             import glob
-            pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))[-1]   # the latest committed PMC passes
-            pmc = json.load(open(pmc_file))
-            if (pmc["workload"], pmc["envs_per_gpu"], pmc["reset_pool"], pmc["settle_lanes"]) == (args.workload, n, args.reset_pool, streaming):
+            # the latest committed PMC passes of this very configuration
+            pmcs = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True)]
+            pmc = next((p for p in pmcs if (p["workload"], p["envs_per_gpu"], p["reset_pool"], p["settle_lanes"]) == (args.workload, n, args.reset_pool, streaming)), None)
+            if pmc is not None:
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
                 if "sq_insts_valu" in pmc:
                     # the roof that does bound this kernel: one wave64 fp32 VALU instruction per SIMD every 4 cycles (16 lanes per SIMD)
@@ -207,9 +208,11 @@ def main():
                     peak = prop.multi_processor_count * 4 * getattr(prop, "clock_rate", 2.4e6) * 1e3 / 4 / 1e9
                     valu = {"achieved": pmc["sq_insts_valu"] / kavg / 1e9, "peak": peak, "unit": "G wave-instructions/s",
                             "frac": pmc["sq_insts_valu"] / kavg / 1e9 / peak,
-                            "note": f"SQ_INSTS_VALU per launch (same PMC passes) / k_step duration, against SIMDs x clock / 4; at N = {n} only {min(1.0, (n // 16) / (prop.multi_processor_count * 4)):.0%} of the SIMDs hold a stepping wave"}
+                            "note": "SQ_INSTS_VALU per launch (same PMC passes) / step-kernel duration, against SIMDs x clock / 4; " +
+                                    (f"at N = {n} only {(n // 16) / (prop.multi_processor_count * 4):.0%} of the SIMDs hold a stepping wave"
+                                     if n // 16 < prop.multi_processor_count * 4 else f"at N = {n} every SIMD holds {(n // 16) / (prop.multi_processor_count * 4):.0f} stepping waves")}
         except (OSError, KeyError, ValueError):
-            pass
+            pmc = None
         out = {
             "metric": "env-steps/sec (whole node), Go1+PEA jump-in-place, N=8192 envs",
             "value": total_steps / elapsed,
@@ -236,7 +239,7 @@ def main():
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step, rollout buffer on rank 0" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "valu_issue": valu, "kernel": "k_step", "kernel_ms": kavg * 1e3,
+                         "traffic": traffic, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
                          "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (latest profiles/r*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step (80 % VALU-active): latency/issue-bound, not HBM-bound"},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a property of the box, reported with the single-GPU line only
