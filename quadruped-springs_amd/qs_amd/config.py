@@ -232,6 +232,9 @@ def build_config(
     wrapper=None,
     robot_config=None,
     demo=None,
+    contact_erp=0.2,
+    joint_erp=0.2,
+    warmstart=0.1,
     **_ignored,
 ):
     """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
@@ -326,7 +329,9 @@ def build_config(
         cfg.filt_b[i], cfg.filt_a[i] = fb[i], fa[i]
     cfg.fallen_height = rc.IS_FALLEN_HEIGHT
     # engine constants assumed for PyBullet defaults (DESIGN.md "contact model")
-    cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = 0.2, 0.2, 0.1, rc.VELOCITY_LIMITS[0]
+    # Bullet solver constants assumed for PyBullet's defaults: keywords so that they can follow
+    # what tools/pin_against_pybullet.py finds on a machine that has PyBullet
+    cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = float(contact_erp), float(joint_erp), float(warmstart), rc.VELOCITY_LIMITS[0]
     cfg.solver_residual_threshold = float(solver_residual_threshold)
     for i, s in enumerate(lay["std"]):
         cfg.obs_noise_std[i] = s

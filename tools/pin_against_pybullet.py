@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--substeps", type=int, default=2600)
     ap.add_argument("--springs", type=int, default=1)
     ap.add_argument("--mu", type=float, default=1.0, help="ground lateralFriction (env_randomizer.py:287-289 draws 0.5 .. 1)")
+    ap.add_argument("--contact-erp", type=float, nargs="+", default=[0.2, 0.08],
+                    help="contact error-reduction values to try in the oracle (hypothesis: PyBullet solves shallow contacts with its erp2; 0.2 is Bullet's "
+                         "default, 0.08 a value PyBullet may set): the table is printed once per value")
     ap.add_argument("--write", default="", help="save the compared rows as an .npz fixture")
     args = ap.parse_args()
     try:
@@ -103,10 +106,12 @@ def main():
 
     from oracle.qso import Oracle
     from qs_amd.config import build_config
-    cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
-                          enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False)
-    o = Oracle(cfg)
-    o.set_params(0, np.array([[args.mu]]))
+    oracles = []
+    for erp in args.contact_erp:
+        cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                              enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False, contact_erp=erp)
+        oracles.append(Oracle(cfg))
+        oracles[-1].set_params(0, np.array([[args.mu]]))
 
     p = bullet_client.BulletClient(connection_mode=pybullet.DIRECT)
     p.resetSimulation()
@@ -129,9 +134,10 @@ def main():
         p.resetJointState(robot, j, a, targetVelocity=0)
 
     rows = dict(state=[], tau=[], next_state=[], foot_force=[])
-    worst = dict(pos=0.0, quat=0.0, v=0.0, w=0.0, q=0.0, qd=0.0, force_rel=0.0)
+    keys = ("pos", "quat", "v", "w", "q", "qd", "force_rel")
+    worst = [dict.fromkeys(keys, 0.0) for _ in oracles]
     phase_of = lambda i: "stand" if i < 1000 else "crouch" if i < 1400 else "push" if i < 1430 else "flight+landing"
-    by_phase = {}
+    by_phase = [dict() for _ in oracles]
     for i in range(args.substeps):
         s = bullet_state(p, robot)
         q, qd = s[13:25], s[25:37]
@@ -141,8 +147,9 @@ def main():
             p.setJointMotorControl2(robot, j, p.TORQUE_CONTROL, force=tm)
             if args.springs:
                 p.setJointMotorControl2(robot, j, p.TORQUE_CONTROL, force=ts)
-        o.set_state(s[None])
-        o.phys_step(0, tau_m + tau_s)
+        for o in oracles:
+            o.set_state(s[None])
+            o.phys_step(0, tau_m + tau_s)
         p.stepSimulation()
         other = [c[3] for c in p.getContactPoints(bodyA=robot) if c[3] not in FOOT_IDS]
         if other:
@@ -150,22 +157,24 @@ def main():
             # contact force to them: the comparison is meaningless from here on
             print(f"substep {i}: PyBullet reports contact on non-foot link(s) {sorted(set(other))}; stopping the comparison here")
             break
-        sb, so = bullet_state(p, robot), o.get_state()[0]
-        fb, fo = foot_forces(p, robot, plane), o.get_info(0)[0]
-        d = dict(pos=np.abs(sb[:3] - so[:3]).max(), quat=min(np.abs(sb[3:7] - so[3:7]).max(), np.abs(sb[3:7] + so[3:7]).max()),
-                 v=np.abs(sb[7:10] - so[7:10]).max(), w=np.abs(sb[10:13] - so[10:13]).max(),
-                 q=np.abs(sb[13:25] - so[13:25]).max(), qd=np.abs(sb[25:] - so[25:]).max(),
-                 force_rel=np.abs(fb - fo).max() / max(1.0, fb.max()))
-        ph = by_phase.setdefault(phase_of(i), dict.fromkeys(d, 0.0))
-        for k, x in d.items():
-            worst[k] = max(worst[k], x)
-            ph[k] = max(ph[k], x)
+        sb, fb = bullet_state(p, robot), foot_forces(p, robot, plane)
+        for k_o, o in enumerate(oracles):
+            so, fo = o.get_state()[0], o.get_info(0)[0]
+            d = dict(pos=np.abs(sb[:3] - so[:3]).max(), quat=min(np.abs(sb[3:7] - so[3:7]).max(), np.abs(sb[3:7] + so[3:7]).max()),
+                     v=np.abs(sb[7:10] - so[7:10]).max(), w=np.abs(sb[10:13] - so[10:13]).max(),
+                     q=np.abs(sb[13:25] - so[13:25]).max(), qd=np.abs(sb[25:] - so[25:]).max(),
+                     force_rel=np.abs(fb - fo).max() / max(1.0, fb.max()))
+            ph = by_phase[k_o].setdefault(phase_of(i), dict.fromkeys(d, 0.0))
+            for k, x in d.items():
+                worst[k_o][k] = max(worst[k_o][k], x)
+                ph[k] = max(ph[k], x)
         rows["state"].append(s); rows["tau"].append(tau_m + tau_s); rows["next_state"].append(sb); rows["foot_force"].append(fb)
 
-    print("one-substep deviation oracle vs PyBullet (max over the script; oracle re-seated in PyBullet's state every substep)")
-    for name, ph in by_phase.items():
-        print(f"  {name:16s} " + "  ".join(f"{k} {x:.3e}" for k, x in ph.items()))
-    print("  overall          " + "  ".join(f"{k} {x:.3e}" for k, x in worst.items()))
+    for erp, phases, w in zip(args.contact_erp, by_phase, worst):
+        print(f"one-substep deviation oracle (contact_erp = {erp}) vs PyBullet (max over the script; oracle re-seated in PyBullet's state every substep)")
+        for name, ph in phases.items():
+            print(f"  {name:16s} " + "  ".join(f"{k} {x:.3e}" for k, x in ph.items()))
+        print("  overall          " + "  ".join(f"{k} {x:.3e}" for k, x in w.items()))
     if args.write:
         np.savez_compressed(args.write, mu=args.mu, springs=args.springs, pybullet_api_version=pybullet.getAPIVersion(),
                             **{k: np.asarray(v) for k, v in rows.items()})
