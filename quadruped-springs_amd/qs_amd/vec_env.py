@@ -267,12 +267,10 @@ class QuadrupedVecEnv(SB3VecEnv):
         done, trunc = flags > 0.5, flags > 1.5
         infos = [{} for _ in range(self.num_envs)]
         if done.any():
-            idx = np.nonzero(done)[0]
-            # only the rows of the finished environments cross the bus
-            term = self.get_info("terminal_obs")[self.torch.as_tensor(idx, device=self.device)].cpu().numpy() if self.cfg.auto_reset else obs[idx]
-            for k, i in enumerate(idx):
+            term = self.get_info("terminal_obs").cpu().numpy() if self.cfg.auto_reset else obs
+            for i in np.nonzero(done)[0]:
                 infos[i]["TimeLimit.truncated"] = bool(trunc[i])  # gym_env.py:246
-                infos[i]["terminal_observation"] = term[k].copy()
+                infos[i]["terminal_observation"] = term[i].copy()
         if self.cfg.wrapper_mode:
             # the reference's LandingWrapper / GoToRestWrapper loop over env.step inside one wrapper.step; here every inner
             # step is one launch and the ones whose action was scripted are flagged, so a learner can mask them out.  Only the
