@@ -198,23 +198,39 @@ def test_reference_wrapper_traces(torch_cuda, golden, name):
     assert phases == expect.get(name, {"policy", "take_off", "landing"})
 
 
-def test_full_size_properties(torch_cuda):
-    """BASELINE.json size (N = 8192): size-independent properties instead of the (slow) oracle."""
+FULL_SIZE = {   # BASELINE.json configs[0..4] at their full sizes (configs[3] = 8 x 8192: its per-GPU share)
+    "jump_in_place_8192": (8192, dict(env_randomizer_mode="GROUND_RANDOMIZER")),
+    "config2_4096": (4096, dict(time_step=0.002, action_repeat=5, env_randomizer_mode="NONE")),
+    "config3_8192": (8192, dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", env_randomizer_mode="SPRING_RANDOMIZER")),
+    "config4_8192": (8192, dict(task_env="JUMPING_FORWARD", env_randomizer_mode="GROUND_RANDOMIZER")),
+    "config5_8192": (8192, dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER")),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+def test_full_size_properties(torch_cuda, name):
+    """BASELINE.json sizes: size-independent properties instead of the (slow) oracle."""
     torch = torch_cuda
-    n = 8192
-    _, v, cfg = make_pair(n, torch, oracle=False, env_randomizer_mode="GROUND_RANDOMIZER", seed=7, noise=True)
-    _, w, _ = make_pair(64, torch, oracle=False, env_randomizer_mode="GROUND_RANDOMIZER", seed=7, noise=True)
+    n, kw = FULL_SIZE[name]
+    kw = dict(kw, seed=7, noise=True)
+    _, v, cfg = make_pair(n, torch, oracle=False, **kw)
+    _, w, _ = make_pair(64, torch, oracle=False, **kw)
     ov, ow = v.reset(), w.reset()
     assert np.array_equal(ov[:64], ow)                       # batch-size invariance (counter-based RNG, no cross-env state)
     f = v.get_info("foot_force").cpu().numpy()
+    par = v.get_info("params").cpu().numpy()
+    # also under the mass randomizer: it takes the payload and the leg-mass changes out of the trunk (env_randomizer.py:61-65)
     np.testing.assert_allclose(f.sum(axis=1), 12.01301 * 9.8, rtol=1e-2)
-    mu = v.get_info("params").cpu().numpy()[:, 0]
-    assert mu.min() >= 0.5 and mu.max() <= 1.0 and 0.70 < mu.mean() < 0.80   # env_randomizer.py:287-289
-    _, v2, _ = make_pair(n, torch, oracle=False, env_randomizer_mode="GROUND_RANDOMIZER", seed=7, noise=True)
+    if kw["env_randomizer_mode"] == "TEST_RANDOMIZER":
+        assert 0.3 < par[:, 20].mean() < 0.7 and par[:, 20].max() <= 1.0          # payload U(0, 1) kg (:78-83)
+    mu = par[:, 0]
+    if kw["env_randomizer_mode"] != "NONE":
+        assert mu.min() >= 0.5 and mu.max() <= 1.0 and 0.70 < mu.mean() < 0.80   # env_randomizer.py:287-289
+    _, v2, _ = make_pair(n, torch, oracle=False, **kw)
     assert torch.equal(v2.reset_tensor(), v._obs)
     gg = torch.Generator(device="cpu").manual_seed(0)
     for i in range(20):
-        a = (torch.rand((n, 6), generator=gg) * 2 - 1).to(v.device)
+        a = (torch.rand((n, cfg.action_dim), generator=gg) * 2 - 1).to(v.device)
         o, r, d, t = v.step_tensor(a)
         o2, r2, d2, t2 = v2.step_tensor(a)
         # determinism: two handles, same inputs -> bitwise identical outputs (K11)
