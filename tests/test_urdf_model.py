@@ -218,3 +218,62 @@ def test_collision_geometry_matches_the_urdf(model, seed):
     o.phys_step(0, np.zeros(12))
     n_pen = sum(1 for k, v in low.items() if k not in feet and v + p[2] < -1e-3)
     assert n_pen >= 1 and o.get_info(5)[0, 0] >= 1
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_contact_step_balances_impulse_and_momentum(model, seed):
+    """One oracle substep from rest on the ground under random joint torques, checked against first principles only: with the mass
+    matrix M, the gravity force G and the foot-point Jacobians J all derived from the URDF tables by finite differences,
+    M nu+ = dt (tau - G) + J^T p must hold for SOME contact impulses p (18 equations, 12 unknowns), whose normal parts are the foot
+    forces the oracle reports, which push (p_n >= 0), stay inside the friction pyramid, and leave no foot approaching the ground
+    faster than its gap allows.  Pins the constrained half of the step (contact Jacobians incl. the 0.08 m hip offset of the URDF,
+    H^-1 J^T lambda, force read-out) the way test_mass_matrix_and_gravity_from_first_principles pins the unconstrained half."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    mu, dt, r_foot = 0.7, 1e-3, 0.02
+    cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False)
+    o = Oracle(cfg)
+    o.reset()
+    hold = o.get_info(2)[0].copy()                         # the joint torques that carry the settled stance
+    o.set_params(0, np.array([[mu]]))
+    s = o.get_state()
+    s[0, 13:25] += 0.0007 * rng.normal(size=12)            # the feet end up at slightly different heights (fractions of a millimetre)
+    s[0, 3:7] = quat_xyzw(Rotation.from_quat(s[0, 3:7]).as_matrix() @ Rotation.from_rotvec(0.0004 * rng.normal(size=3)).as_matrix())
+    s[0, 7:13], s[0, 25:] = 0.0, 0.0                       # at rest: the bias force is gravity alone
+    p, R, q = s[0, :3].copy(), Rotation.from_quat(s[0, 3:7]).as_matrix(), s[0, 13:25].copy()
+    feet = [model.link_frames(p, R, q)[f"{leg}_foot"] for leg in ("FR", "FL", "RR", "RL")]
+    p[2] -= min(pf[2] for _, pf in feet) - r_foot + 2e-4   # lowest foot 0.2 mm into the ground
+    s[0, :3] = p
+    o.set_state(s)
+    tau = hold + 2.0 * rng.normal(size=12)
+    tau[0::3] += rng.choice([-6.0, 6.0])                   # all hips pushed the same way: some feet reach the edge of the friction pyramid
+    o.phys_step(0, tau)
+    s1, f_n = o.get_state()[0], o.get_info(0)[0]
+    nu = np.concatenate([R.T @ s1[10:13], R.T @ s1[7:10], s1[25:]])        # [w_b, v_b (base frame), qd], the coordinates of H
+    M, G = model.mass_matrix(p, R, q), model.gravity_force(p, R, q, 9.8)
+
+    def contact_points(cfgn):                                                # material points of the four feet that touch down first
+        fr = model.link_frames(*cfgn)
+        return np.array([fr[f"{leg}_foot"][1] + fr[f"{leg}_foot"][0] @ (Rf0.T @ np.array([0, 0, -r_foot]))
+                         for leg, (Rf0, _) in zip(("FR", "FL", "RR", "RL"), feet)])
+
+    eps, J = 1e-6, np.zeros((12, 18))
+    for i in range(18):
+        e = np.zeros(18); e[i] = 1.0
+        d = (contact_points(model.displaced(p, R, q, e, eps)) - contact_points(model.displaced(p, R, q, e, -eps))) / (2 * eps)   # [4, 3] world
+        for k in range(4):
+            J[3 * k: 3 * k + 3, i] = d[k]                                    # rows: x, y, z velocity of foot k's contact point
+    rhs = M @ nu - dt * (np.concatenate([np.zeros(6), tau]) - G)
+    imp, res, *_ = np.linalg.lstsq(J.T, rhs, rcond=None)
+    assert np.linalg.norm(J.T @ imp - rhs) < 2e-6 * max(1.0, np.linalg.norm(rhs)) + 2e-8, "the velocity change is not a sum of foot impulses"
+    imp = imp.reshape(4, 3)
+    gap = contact_points((p, R, q))[:, 2]
+    np.testing.assert_allclose(imp[:, 2] / dt, f_n, rtol=1e-4, atol=1e-3)    # getContactPoints()[9] = normal impulse / dt
+    assert np.all(imp[:, 2] >= -1e-9) and f_n.sum() > 30.0 and (f_n > 0).sum() >= 2   # they push, several feet at once, a good part of the 118 N
+    touching = f_n > 0
+    assert np.all(np.abs(imp[touching, 0]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)      # friction pyramid, x and y separately
+    assert np.all(np.abs(imp[touching, 1]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)
+    assert np.all(np.abs(imp[~touching]) < 1e-9)
+    vz = (J @ nu).reshape(4, 3)[:, 2]
+    assert np.all(vz[touching] >= -np.maximum(gap[touching], 0) / dt - 2e-3), "a touching foot still moves into the ground"
