@@ -33,9 +33,11 @@ def build(force=False, verbose=False):
     # -ffinite-math-only -fno-signed-zeros -fno-trapping-math: the step produces no NaN / infinity and tests for none, so the
     # v_max_f32 x, x canonicalisations in front of every fmin / fmax / med3 can go (+5 % measured); reassociation and the rest of
     # -ffast-math are NOT enabled (measured slower, and the summation order is part of the parity with the host emulation).
+    # -amdgpu-mfma-vgpr-form: the 4x4x1 MFMAs of the Delassus block write VGPRs, no v_accvgpr_read per result (+1 % at N = 8192).
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
            "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math",
-           "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] + os.environ.get("QS_HIPCC_EXTRA", "").split() + [
+           "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+           "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("QS_HIPCC_EXTRA", "").split() + [
            "-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
