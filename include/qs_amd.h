@@ -115,7 +115,10 @@ typedef struct qs_config {
     float cpg_clearance, cpg_penetration, cpg_coupling, cpg_alpha;  /* :42-43, :35, :142 */
     float solver_residual_threshold; /* PyBullet setPhysicsEngineParameter(solverResidualThreshold): a sweep whose largest
                                       * squared velocity change is <= this ends the solve; 0 = always `solver_iters` sweeps */
-    float reserved_g[1];
+    int32_t friction_cone;     /* 0: friction pyramid, each direction clamped on its own and left alone while its normal impulse is zero
+                                * (btMultiBodyConstraintSolver::solveSingleIteration without implicit cone friction); 1: the two friction
+                                * rows of a contact are updated together and projected onto the disc of radius mu x normal impulse
+                                * (resolveConeFrictionConstraintRows, PyBullet's enableConeFriction) */
     /* scripted phases of env/wrappers/landing_wrapper.py:18-69 and go_to_rest_wrapper.py:22-95 */
     float landing_action[12];  /* get_landing_action(), gym_env.py:375-379 */
     float landing_kp, landing_kd; /* landing_wrapper.py:22-27 */

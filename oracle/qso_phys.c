@@ -374,6 +374,26 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             if (jj < nlim) r = &lim[(it & 1) ? jj : nlim - 1 - jj];
             else if (jj < nlim + nn) r = &nor[jj - nlim];
             else r = &fr[jj - nlim - nn];
+            if (r->fric_of >= 0 && cfg->friction_cone) {
+                /* btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows (SOLVER_USE_2_FRICTION_DIRECTIONS without
+                   SOLVER_DISABLE_IMPLICIT_CONE_FRICTION): both rows of the contact from the same velocities, the summed impulse
+                   scaled back onto the disc of radius mu x normal impulse (its atan2 / sin / cos form is this radial projection) */
+                row* a = r; row* b = &fr[jj + 1 - nlim - nn];
+                jj++;
+                real lim = a->mu * nor[a->fric_of].lam;
+                real ja = 0, jb = 0;
+                for (int k = 0; k < NV; k++) { ja += a->J[k] * dv[k]; jb += b->J[k] * dv[k]; }
+                real sa = a->lam + (a->rhs - ja * a->dinv), sb = b->lam + (b->rhs - jb * b->dinv);
+                real r2 = sa * sa + sb * sb;
+                if (r2 > lim * lim) { real sc = lim / sqrt(r2); sa *= sc; sb *= sc; }
+                real da = sa - a->lam, db = sb - b->lam;
+                a->lam = sa; b->lam = sb;
+                for (int k = 0; k < NV; k++) dv[k] += a->W[k] * da + b->W[k] * db;
+                real ra = da / a->dinv, rb = db / b->dinv;
+                if (ra * ra > maxres2) maxres2 = ra * ra;
+                if (rb * rb > maxres2) maxres2 = rb * rb;
+                continue;
+            }
             if (r->fric_of >= 0) {
                 real tot = nor[r->fric_of].lam;
                 if (!(tot > 0)) continue;

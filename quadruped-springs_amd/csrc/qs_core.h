@@ -392,9 +392,27 @@ template <class T> struct Sim {
         else { _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk; }                     \
         if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
+            // Implicit cone friction (cfg.friction_cone; resolveConeFrictionConstraintRows): the two friction rows of foot K from the same
+            // state, their summed impulse scaled back onto the disc of radius mu x normal impulse, both deltas applied together.
+#define QS_PAIR_UPDATE(K)                                                                                              \
+    {                                                                                                                  \
+        constexpr int ia_ = NR * (K) + 1, ib_ = NR * (K) + 2;                                                          \
+        V lim = mu * lam_all[NR * (K)];                                                                                \
+        V r2 = res[1] * res[1] + res[2] * res[2];                                                                      \
+        V sc = qsel(qgt(r2, lim * lim), lim * qrsqrt(r2), V(1.0f));                                                    \
+        V da = T::template bcast<K>(res[1] * sc) - lam_all[ia_], db = T::template bcast<K>(res[2] * sc) - lam_all[ib_]; \
+        lam_all[ia_] = lam_all[ia_] + da; lam_all[ib_] = lam_all[ib_] + db;                                             \
+        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + (Ap[ia_][c] * da + Ap[ib_][c] * db);          \
+        if (TRACK) dvmax = qmax(dvmax, qmax(qabs(da * diag_all[TRACK ? ia_ : 0]), qabs(db * diag_all[TRACK ? ib_ : 0]))); \
+    }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
-            QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
-            QS_ROW_UPDATE(2, 1, 1) QS_ROW_UPDATE(2, 2, 1) QS_ROW_UPDATE(3, 1, 1) QS_ROW_UPDATE(3, 2, 1)
+            if (NR == 3 && cfg.friction_cone) {
+                QS_PAIR_UPDATE(0) QS_PAIR_UPDATE(1) QS_PAIR_UPDATE(2) QS_PAIR_UPDATE(3)
+            } else {
+                QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
+                QS_ROW_UPDATE(2, 1, 1) QS_ROW_UPDATE(2, 2, 1) QS_ROW_UPDATE(3, 1, 1) QS_ROW_UPDATE(3, 2, 1)
+            }
+#undef QS_PAIR_UPDATE
 #undef QS_ROW_UPDATE
             if (TRACK) {
                 M conv = qle(dvmax, thr);
@@ -508,6 +526,19 @@ template <class T> struct Sim {
         _Pragma("unroll") for (int c = 0; c < 6; c++) res[c] = res[c] - ApB[(6 * (K) + (R)) * 6 + c] * dk;             \
         if (track) dvmax = qmax(dvmax, qabs(dk * T::template bcast<K>(rows[R].diag)));                                 \
     }
+        // implicit cone friction: both friction rows of foot K together (see solve_and_integrate)
+#define QS_RPAIR(K)                                                                                                    \
+    {                                                                                                                  \
+        V ca = lam[1] + res[1], cb = lam[2] + res[2], lim = mu * lam[0];                                               \
+        V r2 = ca * ca + cb * cb;                                                                                      \
+        V sc = qsel(qgt(r2, lim * lim), lim * qrsqrt(r2), V(1.0f));                                                    \
+        ca = ca * sc; cb = cb * sc;                                                                                    \
+        V da = T::template bcast<K>(ca - lam[1]), db = T::template bcast<K>(cb - lam[2]);                              \
+        lam[1] = qsel(T::is_leg(K), ca, lam[1]); lam[2] = qsel(T::is_leg(K), cb, lam[2]);                              \
+        _Pragma("unroll") for (int c = 0; c < 6; c++)                                                                  \
+            res[c] = res[c] - (ApB[(6 * (K) + 1) * 6 + c] * da + ApB[(6 * (K) + 2) * 6 + c] * db);                      \
+        if (track) dvmax = qmax(dvmax, qmax(qabs(da * T::template bcast<K>(rows[1].diag)), qabs(db * T::template bcast<K>(rows[2].diag)))); \
+    }
 #define QS_RLEG_FWD(K) QS_RROW(K, 3, 0) QS_RROW(K, 4, 0) QS_RROW(K, 5, 0) T::sched_fence();
 #define QS_RLEG_BWD(K) QS_RROW(K, 5, 0) QS_RROW(K, 4, 0) QS_RROW(K, 3, 0) T::sched_fence();
         for (int it = 0; it < cfg.solver_iters; it++) {
@@ -516,8 +547,12 @@ template <class T> struct Sim {
             if (it & 1) { QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3) }
             else { QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0) }
             QS_RROW(0, 0, 0) QS_RROW(1, 0, 0) T::sched_fence(); QS_RROW(2, 0, 0) QS_RROW(3, 0, 0) T::sched_fence();
-            QS_RROW(0, 1, 1) QS_RROW(0, 2, 1) T::sched_fence(); QS_RROW(1, 1, 1) QS_RROW(1, 2, 1) T::sched_fence();
-            QS_RROW(2, 1, 1) QS_RROW(2, 2, 1) T::sched_fence(); QS_RROW(3, 1, 1) QS_RROW(3, 2, 1) T::sched_fence();
+            if (cfg.friction_cone) {
+                QS_RPAIR(0) T::sched_fence(); QS_RPAIR(1) T::sched_fence(); QS_RPAIR(2) T::sched_fence(); QS_RPAIR(3) T::sched_fence();
+            } else {
+                QS_RROW(0, 1, 1) QS_RROW(0, 2, 1) T::sched_fence(); QS_RROW(1, 1, 1) QS_RROW(1, 2, 1) T::sched_fence();
+                QS_RROW(2, 1, 1) QS_RROW(2, 2, 1) T::sched_fence(); QS_RROW(3, 1, 1) QS_RROW(3, 2, 1) T::sched_fence();
+            }
             if (track) {
                 M conv = qle(dvmax, thr);
 #pragma unroll
@@ -527,6 +562,7 @@ template <class T> struct Sim {
         }
 #undef QS_RLEG_FWD
 #undef QS_RLEG_BWD
+#undef QS_RPAIR
 #undef QS_RROW
         o.foot_force = lam[0] * qrcp(dt);
         s.warm = lam[0];

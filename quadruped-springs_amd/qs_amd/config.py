@@ -126,7 +126,7 @@ class QsConfig(C.Structure):
         ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("reserved_f", C.c_float * 8),
         ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
         ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
-        ("solver_residual_threshold", C.c_float), ("reserved_g", C.c_float * 1),
+        ("solver_residual_threshold", C.c_float), ("friction_cone", C.c_int32),
         ("landing_action", C.c_float * 12), ("landing_kp", C.c_float), ("landing_kd", C.c_float),
         ("rest_kp", C.c_float), ("rest_kd", C.c_float), ("rest_time", C.c_float), ("reserved_h", C.c_float * 3),
     ]
@@ -235,6 +235,7 @@ def build_config(
     contact_erp=0.2,
     joint_erp=0.2,
     warmstart=0.1,
+    friction_model="pyramid",
     **_ignored,
 ):
     """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
@@ -332,6 +333,7 @@ def build_config(
     # Bullet solver constants assumed for PyBullet's defaults: keywords so that they can follow
     # what tools/pin_against_pybullet.py finds on a machine that has PyBullet
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = float(contact_erp), float(joint_erp), float(warmstart), rc.VELOCITY_LIMITS[0]
+    cfg.friction_cone = {"pyramid": 0, "cone": 1}[friction_model]   # PyBullet's enableConeFriction off / on (see include/qs_amd.h)
     cfg.solver_residual_threshold = float(solver_residual_threshold)
     for i, s in enumerate(lay["std"]):
         cfg.obs_noise_std[i] = s

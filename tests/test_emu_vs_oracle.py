@@ -65,6 +65,8 @@ def test_reset_settle_matches():
     dict(task_env="BACKFLIP_PPO", observation_space_mode="PPO_BACKFLIP"),
     dict(task_env="CONTINUOUS_JUMPING_FORWARD3", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
     dict(task_env="CONTINUOUS_JUMPING_FORWARD_PPO", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD"),
+    dict(friction_model="cone"),                                        # PyBullet's implicit cone friction instead of the pyramid
+    dict(friction_model="cone", solver_residual_threshold=1e-7, task_env="JUMPING_FORWARD", action_space_mode="DEFAULT"),
 ])
 def test_env_step_parity_resynced(kw):
     """Every step starts from the oracle's state, so chaotic divergence cannot accumulate."""
@@ -240,6 +242,37 @@ def test_joint_limit_rows_all_joints():
         q = so[:, 13:25]
         hit |= np.array([(q[:, 2::3] < -2.70).any(), (np.abs(q[:, 0::3]) > 1.03).any(), (q[:, 1::3] < -0.65).any()])
     assert hit.all(), hit
+
+
+@pytest.mark.parametrize("model", ["pyramid", "cone"])
+def test_joint_limits_together_with_sliding_contacts(model):
+    """The 6-rows-per-leg path with ground contact: raw torques fold the calves to their stops while the robots stand and push
+    sideways, so limit rows, normals and (saturating) friction rows are all active at once; both friction models; float32 oracle on
+    the same float32 state, as in test_joint_limit_rows_all_joints."""
+    from qs_amd.config import build_config as bc
+    n = 8
+    cfg, _ = bc(n_envs=n, noise=False, env_randomizer_mode="NONE", isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK",
+                observation_space_mode="ENCODER", enable_action_filter=False, enable_springs=False, friction_model=model)
+    o, e = Oracle(cfg, "f32"), Emu(cfg)
+    o.reset(); e.reset()
+    o.set_params(0, np.full((n, 1), 0.5)); e.set_mu(0.5)
+    rng = np.random.default_rng(6)
+    at_stop = sliding = False
+    for i in range(120):
+        tau = 2.0 * rng.normal(size=(n, 12)).astype(np.float32)
+        tau[:, 2::3] -= 12.0                                                        # calves fold
+        tau[:, 0::3] += 10.0 * np.sign(np.sin(0.2 * i))                             # hips push sideways, both ways
+        s = o.get_state()
+        o.set_state(s); e.set_state(s)
+        o.step(tau); e.step(tau)
+        so, se = o.get_state(), e.get_state()
+        np.testing.assert_allclose(se[:, 13:25], so[:, 13:25], atol=2e-5, err_msg=f"q step {i}")
+        np.testing.assert_allclose(se[:, 25:], so[:, 25:], atol=1e-2, err_msg=f"qd step {i}")
+        np.testing.assert_allclose(se[:, 7:13], so[:, 7:13], atol=2e-3, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(e.get("R_FOOT_FORCE", 4), o.get_info(0), rtol=3e-2, atol=1.0, err_msg=f"foot force step {i}")
+        at_stop |= bool(((so[:, 15:25:3] < -2.715) & (o.get_info(1) > 0)).any())      # a calf at its stop on a foot that touches the ground
+        sliding |= bool((np.abs(so[:, 8]) > 0.05).any())
+    assert at_stop and sliding
 
 
 @pytest.mark.parametrize("name", ["demo_jip", "demo_bf", "demo_jf12", "demo_cjf"])

@@ -90,6 +90,8 @@ CASES = [
     dict(time_step=0.002, action_repeat=5),   # BASELINE.json config 2: dt = 1/500 s, 60 solver sweeps
     dict(task_env="CONTINUOUS_JUMPING_FORWARD", observation_space_mode="PPO_CONTINUOUS_JUMPING_FORWARD", env_randomizer_mode="SPRING_RANDOMIZER", seed=9),  # config 3
     dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER", seed=4),  # config 5
+    dict(friction_model="cone"),                                              # PyBullet's implicit cone friction (enableConeFriction)
+    dict(friction_model="cone", task_env="JUMPING_FORWARD", action_space_mode="DEFAULT", env_randomizer_mode="GROUND_RANDOMIZER", seed=2),
 ]
 
 
@@ -850,6 +852,38 @@ def test_free_running_statistics(torch_cuda):
                        ("final pitch rate", so[:, 11], sv[:, 11])):
         assert ks_2samp(x, y).pvalue > 0.01, name
     assert abs(zmax_o.mean() - zmax_v.mean()) < 5e-3
+
+
+@pytest.mark.parametrize("model", ["pyramid", "cone"])
+def test_joint_limits_together_with_sliding_contacts(torch_cuda, model):
+    """The 6-rows-per-leg solver path with ground contact (calves folded to their stops while the robots stand and are pushed sideways),
+    both friction models, against the float32 oracle on the same float32 state; see tests/test_emu_vs_oracle.py for the CPU twin."""
+    from oracle.qso import Oracle
+    n = 32
+    _, v, cfg = make_pair(n, torch_cuda, oracle=False, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK",
+                          observation_space_mode="ENCODER", enable_action_filter=False, enable_springs=False, friction_model=model)
+    o = Oracle(cfg, "f32")
+    o.reset(); v.reset()
+    mu = np.full((n, 1), 0.5, np.float32)
+    o.set_params(0, mu); v.set_params("mu", mu)
+    c0 = v.counter("limit_path_substeps")
+    rng = np.random.default_rng(6)
+    at_stop = sliding = False
+    for i in range(120):
+        tau = 2.0 * rng.normal(size=(n, 12)).astype(np.float32)
+        tau[:, 2::3] -= 12.0
+        tau[:, 0::3] += 10.0 * np.sign(np.sin(0.2 * i))
+        s = o.get_state()
+        o.set_state(s); v.set_state(s)
+        o.step(tau); v.step(tau)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=2e-5, err_msg=f"q step {i}")
+        np.testing.assert_allclose(sv[:, 25:], so[:, 25:], atol=1e-2, err_msg=f"qd step {i}")
+        np.testing.assert_allclose(sv[:, 7:13], so[:, 7:13], atol=2e-3, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(v.get_info("foot_force").cpu().numpy(), o.get_info(0), rtol=3e-2, atol=1.0, err_msg=f"foot force step {i}")
+        at_stop |= bool(((so[:, 15:25:3] < -2.715) & (o.get_info(1) > 0)).any())
+        sliding |= bool((np.abs(so[:, 8]) > 0.05).any())
+    assert at_stop and sliding and v.counter("limit_path_substeps") - c0 > 100
 
 
 def test_create_rejects_bad_config(torch_cuda):

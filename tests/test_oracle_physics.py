@@ -138,6 +138,35 @@ def test_k7_coulomb_cone():
     assert abs(o.get_state()[0, 7]) < 5e-2
 
 
+@pytest.mark.parametrize("model,expect", [("pyramid", np.sqrt(2.0)), ("cone", 1.0)])
+def test_k7b_friction_model_on_a_diagonal_slide(model, expect):
+    """All four feet sliding along the diagonal x = y: the pyramid clamps each tangent direction at mu N on its own, so the friction
+    force is sqrt(2) mu N; the implicit cone (PyBullet's enableConeFriction) projects the pair onto the disc: mu N, opposite to
+    the sliding direction."""
+    mu = 0.5
+    cfg, _ = build_config(n_envs=1, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
+                          env_randomizer_mode="NONE", friction_model=model)
+    cfg.randomizer_flags = 8
+    o = Oracle(cfg)
+    o.set_params(0, np.array([mu]))
+    o.reset()
+    s = o.get_state()
+    s[0, 7], s[0, 8] = 2.0, 2.0
+    o.set_state(s)
+    tau_hold = o.get_info(2)[0] + o.get_info(3)[0]
+    for _ in range(5):
+        p0 = o.energy(0)["p"][:2].copy()
+        o.phys_step(0, tau_hold)
+        dp = o.energy(0)["p"][:2] - p0
+        fn = o.get_info(0)[0].sum()
+        assert fn > 50
+        assert np.linalg.norm(dp) == pytest.approx(expect * mu * fn * cfg.dt, rel=3e-3)
+        d = dp / np.linalg.norm(dp)
+        # against the motion; the cone projects the IMPULSE that would stop the feet, whose direction follows the (anisotropic) contact
+        # inertia, so it is only roughly opposite to the sliding velocity
+        assert d[0] < -0.5 and d[1] < -0.5, d
+
+
 def test_k8_joint_limit_stop():
     o, cfg = make()
     o.set_gravity(0.0)

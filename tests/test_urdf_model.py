@@ -220,8 +220,8 @@ def test_collision_geometry_matches_the_urdf(model, seed):
     assert n_pen >= 1 and o.get_info(5)[0, 0] >= 1
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
-def test_contact_step_balances_impulse_and_momentum(model, seed):
+@pytest.mark.parametrize("seed,friction", [(0, "pyramid"), (1, "pyramid"), (2, "pyramid"), (3, "pyramid"), (0, "cone"), (3, "cone")])
+def test_contact_step_balances_impulse_and_momentum(model, seed, friction):
     """One oracle substep from rest on the ground under random joint torques, checked against first principles only: with the mass
     matrix M, the gravity force G and the foot-point Jacobians J all derived from the URDF tables by finite differences,
     M nu+ = dt (tau - G) + J^T p must hold for SOME contact impulses p (18 equations, 12 unknowns), whose normal parts are the foot
@@ -232,7 +232,7 @@ def test_contact_step_balances_impulse_and_momentum(model, seed):
     rng = np.random.default_rng(seed)
     mu, dt, r_foot = 0.7, 1e-3, 0.02
     cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
-                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False)
+                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False, friction_model=friction)
     o = Oracle(cfg)
     o.reset()
     hold = o.get_info(2)[0].copy()                         # the joint torques that carry the settled stance
@@ -272,8 +272,12 @@ def test_contact_step_balances_impulse_and_momentum(model, seed):
     np.testing.assert_allclose(imp[:, 2] / dt, f_n, rtol=1e-4, atol=1e-3)    # getContactPoints()[9] = normal impulse / dt
     assert np.all(imp[:, 2] >= -1e-9) and f_n.sum() > 30.0 and (f_n > 0).sum() >= 2   # they push, several feet at once, a good part of the 118 N
     touching = f_n > 0
-    assert np.all(np.abs(imp[touching, 0]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)      # friction pyramid, x and y separately
-    assert np.all(np.abs(imp[touching, 1]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)
+    if friction == "pyramid":                                                                 # x and y separately
+        assert np.all(np.abs(imp[touching, 0]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)
+        assert np.all(np.abs(imp[touching, 1]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)
+    else:                                                                                     # the disc of PyBullet's implicit cone
+        assert np.all(np.hypot(imp[touching, 0], imp[touching, 1]) <= mu * imp[touching, 2] * (1 + 1e-6) + 1e-9)
+        assert np.any(np.hypot(imp[touching, 0], imp[touching, 1]) >= mu * imp[touching, 2] * (1 - 1e-6))   # and some foot is on its rim
     assert np.all(np.abs(imp[~touching]) < 1e-9)
     vz = (J @ nu).reshape(4, 3)[:, 2]
     assert np.all(vz[touching] >= -np.maximum(gap[touching], 0) / dt - 2e-3), "a touching foot still moves into the ground"

@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--contact-erp", type=float, nargs="+", default=[0.2, 0.08],
                     help="contact error-reduction values to try in the oracle (hypothesis: PyBullet solves shallow contacts with its erp2; 0.2 is Bullet's "
                          "default, 0.08 a value PyBullet may set): the table is printed once per value")
+    ap.add_argument("--friction", nargs="+", default=["pyramid", "cone"], choices=["pyramid", "cone"],
+                    help="friction models to try in the oracle: the pyramid with Bullet's skip rule, or the implicit cone of "
+                         "resolveConeFrictionConstraintRows (PyBullet's enableConeFriction, which its documentation calls the default)")
     ap.add_argument("--write", default="", help="save the compared rows as an .npz fixture")
     args = ap.parse_args()
     try:
@@ -106,12 +109,15 @@ def main():
 
     from oracle.qso import Oracle
     from qs_amd.config import build_config
-    oracles = []
+    oracles, labels = [], []
     for erp in args.contact_erp:
-        cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
-                              enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False, contact_erp=erp)
-        oracles.append(Oracle(cfg))
-        oracles[-1].set_params(0, np.array([[args.mu]]))
+        for fm in args.friction:
+            cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                                  enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False, contact_erp=erp,
+                                  friction_model=fm)
+            oracles.append(Oracle(cfg))
+            oracles[-1].set_params(0, np.array([[args.mu]]))
+            labels.append(f"contact_erp = {erp}, friction = {fm}")
 
     p = bullet_client.BulletClient(connection_mode=pybullet.DIRECT)
     p.resetSimulation()
@@ -170,8 +176,8 @@ def main():
                 ph[k] = max(ph[k], x)
         rows["state"].append(s); rows["tau"].append(tau_m + tau_s); rows["next_state"].append(sb); rows["foot_force"].append(fb)
 
-    for erp, phases, w in zip(args.contact_erp, by_phase, worst):
-        print(f"one-substep deviation oracle (contact_erp = {erp}) vs PyBullet (max over the script; oracle re-seated in PyBullet's state every substep)")
+    for label, phases, w in zip(labels, by_phase, worst):
+        print(f"one-substep deviation oracle ({label}) vs PyBullet (max over the script; oracle re-seated in PyBullet's state every substep)")
         for name, ph in phases.items():
             print(f"  {name:16s} " + "  ".join(f"{k} {x:.3e}" for k, x in ph.items()))
         print("  overall          " + "  ".join(f"{k} {x:.3e}" for k, x in w.items()))
