@@ -78,12 +78,15 @@ def main():
                     help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
+    ap.add_argument("--friction-model", default="pyramid", choices=["pyramid", "cone"],
+                    help="pyramid with Bullet's skip rule (default) or PyBullet's implicit cone (enableConeFriction)")
     ap.add_argument("--solver-residual-threshold", type=float, default=0.0,
                     help="PyBullet solverResidualThreshold (its default is 1e-7); 0 = always int(300/action_repeat) sweeps")
     args = ap.parse_args()
     if args.cpu_baseline_only:   # runs in a child process that never touches the GPU or torch: its OpenMP runtime starts with the settings below
         _, kw = workload(args.workload)
         kw["solver_residual_threshold"] = args.solver_residual_threshold
+        kw["friction_model"] = args.friction_model
         print(json.dumps(cpu_baseline(kw)))
         return
 
@@ -105,6 +108,7 @@ def main():
     from qs_amd.vec_env import QuadrupedVecEnv
     n_default, kw = workload(args.workload)
     kw["solver_residual_threshold"] = args.solver_residual_threshold
+    kw["friction_model"] = args.friction_model
     n = args.envs_per_gpu or n_default
     if args.total_envs:
         assert args.total_envs % (16 * world) == 0, "--total-envs must split into whole waves (16 environments) per rank"
@@ -199,7 +203,8 @@ def main():
             import glob
             # the latest committed PMC passes of this very configuration
             pmcs = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True)]
-            pmc = next((p for p in pmcs if (p["workload"], p["envs_per_gpu"], p["reset_pool"], p["settle_lanes"]) == (args.workload, n, args.reset_pool, streaming)), None)
+            pmc = next((p for p in pmcs if (p["workload"], p["envs_per_gpu"], p["reset_pool"], p["settle_lanes"], p.get("friction_model", "pyramid")) ==
+                        (args.workload, n, args.reset_pool, streaming, args.friction_model)), None)
             if pmc is not None:
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
                 if "sq_insts_valu" in pmc:
@@ -227,7 +232,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
-                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
+                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True,
                        "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
                                   ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))
@@ -245,7 +250,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a property of the box, reported with the single-GPU line only
             import subprocess
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
-                                    "--solver-residual-threshold", str(args.solver_residual_threshold)], capture_output=True, text=True, timeout=300)
+                                    "--solver-residual-threshold", str(args.solver_residual_threshold), "--friction-model", args.friction_model], capture_output=True, text=True, timeout=300)
             if child.returncode != 0:
                 raise SystemExit("cpu_baseline child failed:\n" + child.stderr[-2000:])
             out["cpu_baseline"] = json.loads(child.stdout.strip().splitlines()[-1])

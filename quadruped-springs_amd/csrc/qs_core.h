@@ -213,7 +213,9 @@ template <> struct Rng<LaneEmu> {
 #endif
 
 // ------------------------------------------------------------------ rigid-body substep
-template <class T> struct Sim {
+// CONE: friction model of the contact rows, a compile-time choice so that neither variant costs the other registers or a branch:
+// false = pyramid with Bullet's skip rule, true = implicit cone (qs_config::friction_cone; the kernels are built for both).
+template <class T, bool CONE = false> struct Sim {
     using V = typename T::V;
     using M = typename T::M;
     using V3v = V3<V>;
@@ -392,7 +394,7 @@ template <class T> struct Sim {
         else { _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk; }                     \
         if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
-            // Implicit cone friction (cfg.friction_cone; resolveConeFrictionConstraintRows): the two friction rows of foot K from the same
+            // Implicit cone friction (CONE; resolveConeFrictionConstraintRows): the two friction rows of foot K from the same
             // state, their summed impulse scaled back onto the disc of radius mu x normal impulse, both deltas applied together.
 #define QS_PAIR_UPDATE(K)                                                                                              \
     {                                                                                                                  \
@@ -406,7 +408,7 @@ template <class T> struct Sim {
         if (TRACK) dvmax = qmax(dvmax, qmax(qabs(da * diag_all[TRACK ? ia_ : 0]), qabs(db * diag_all[TRACK ? ib_ : 0]))); \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
-            if (NR == 3 && cfg.friction_cone) {
+            if (NR == 3 && CONE) {
                 QS_PAIR_UPDATE(0) QS_PAIR_UPDATE(1) QS_PAIR_UPDATE(2) QS_PAIR_UPDATE(3)
             } else {
                 QS_ROW_UPDATE(0, 1, 1) QS_ROW_UPDATE(0, 2, 1) QS_ROW_UPDATE(1, 1, 1) QS_ROW_UPDATE(1, 2, 1)
@@ -547,7 +549,7 @@ template <class T> struct Sim {
             if (it & 1) { QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3) }
             else { QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0) }
             QS_RROW(0, 0, 0) QS_RROW(1, 0, 0) T::sched_fence(); QS_RROW(2, 0, 0) QS_RROW(3, 0, 0) T::sched_fence();
-            if (cfg.friction_cone) {
+            if (CONE) {
                 QS_RPAIR(0) T::sched_fence(); QS_RPAIR(1) T::sched_fence(); QS_RPAIR(2) T::sched_fence(); QS_RPAIR(3) T::sched_fence();
             } else {
                 QS_RROW(0, 1, 1) QS_RROW(0, 2, 1) T::sched_fence(); QS_RROW(1, 1, 1) QS_RROW(1, 2, 1) T::sched_fence();

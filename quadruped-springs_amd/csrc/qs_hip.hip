@@ -73,12 +73,13 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
 
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
 // The body is compiled twice (k_step / k_step_dense below) under different register budgets.
-static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+template <bool CONE> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                  const float* __restrict__ actions, float* __restrict__ obs_out,
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, PoolView pool,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
+    using E = Env<LaneDev, CONE>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
@@ -115,7 +116,7 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
     if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
-    E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace, demo.rows, demo.length);
+    typename E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace, demo.rows, demo.length);
     QS_PHASE(14)
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
@@ -175,11 +176,11 @@ static __device__ __forceinline__ void step_body(const qs_config* __restrict__ c
 #define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap, demo
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
-__global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body(QS_STEP_PASS); }
+template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE>(QS_STEP_PASS); }
 // Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
 // issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
 // (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
-__global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body(QS_STEP_PASS); }
+template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE>(QS_STEP_PASS); }
 
 // Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
 // settling into the pool (they replace the entries at the rotating cursor) ...
@@ -214,9 +215,10 @@ __global__ void k_pool_plan(unsigned long long* __restrict__ ctl, int pool_size,
 }
 
 // QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297); all settles run side by side.
-__global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ obs_keep,
                                                       unsigned long long* __restrict__ stats, const float* __restrict__ states) {
+    using E = Env<LaneDev, CONE>;
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     const qs_config& cfg = *cfgp;
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restric
 }
 
 // Pre-settled reset states: entry p = reset of a virtual environment id 0x40000000 + p (its own parameter draw).
-__global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(const qs_config* __restrict__ cfgp, float* __restrict__ pool, int first, int size, int generation) {
+template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(const qs_config* __restrict__ cfgp, float* __restrict__ pool, int first, int size, int generation) {
+    using E = Env<LaneDev, CONE>;
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     const qs_config& cfg = *cfgp;
@@ -364,6 +367,7 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (cfg->task >= QS_TASK_JUMPING_IN_PLACE_DEMO && cfg->task <= QS_TASK_CONT_JUMPING_FORWARD_DEMO && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
         QS_FAIL(-1, "the DEMO tasks compare the policy's action with a recorded one: they need an RL action space (not CPG, not raw commands)");
     if (cfg->task < 0 || cfg->task > QS_TASK_CONT_JUMPING_FORWARD_DEMO) QS_FAIL(-1, "unknown task id %d", cfg->task);
+    if (cfg->friction_cone != 0 && cfg->friction_cone != 1) QS_FAIL(-1, "friction_cone must be 0 (pyramid) or 1 (implicit cone), got %d", cfg->friction_cone);
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
     int od = 0;
@@ -411,7 +415,8 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
     if (cfg->reset_pool > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
         h->pool_size = cfg->reset_pool;
         QS_HIP(hipMalloc(&h->d_pool, (size_t)h->pool_size * QS_REC * sizeof(float)));
-        hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, 0);
+        if (cfg->friction_cone) hipLaunchKernelGGL((k_pool_fill<true>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, 0);
+        else hipLaunchKernelGGL((k_pool_fill<false>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, 0);
         QS_HIP(hipGetLastError());
     }
     QS_HIP(hipStreamSynchronize(h->stream));
@@ -437,7 +442,8 @@ int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle");
 int qs_reset(qs_handle* h, const uint8_t* mask) {
     if (!h) QS_FAIL(-1, "null handle");
     QS_ON_DEVICE(h);
-    hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
+    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_reset<true>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
+    else hipLaunchKernelGGL((k_reset<false>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
     QS_HIP(hipGetLastError());
     return 0;
 }
@@ -445,7 +451,8 @@ int qs_reset(qs_handle* h, const uint8_t* mask) {
 int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states) {
     if (!h || !states) QS_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);
-    hipLaunchKernelGGL(k_reset, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
+    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_reset<true>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
+    else hipLaunchKernelGGL((k_reset<false>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
     QS_HIP(hipGetLastError());
     return 0;
 }
@@ -527,10 +534,11 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     if (h->timing) hipEventRecord(h->ev0, h->stream);
     // more waves than 1.5 x the SIMDs of the device: the two-waves-per-SIMD build of the same body wins (see k_step_dense)
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && 2 * grid > 3 * h->n_simd);
-    if (dense) hipLaunchKernelGGL(k_step_dense, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo);
-    else hipLaunchKernelGGL(k_step, dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc,
-                            h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo);
+#define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
+                                                 h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo)
+    if (h->cfg.friction_cone) { if (dense) QS_LAUNCH_STEP(k_step_dense<true>); else QS_LAUNCH_STEP(k_step<true>); }
+    else { if (dense) QS_LAUNCH_STEP(k_step_dense<false>); else QS_LAUNCH_STEP(k_step<false>); }
+#undef QS_LAUNCH_STEP
     if (h->timing) hipEventRecord(h->ev1, h->stream);
     QS_HIP(hipGetLastError());
     return 0;
@@ -608,7 +616,8 @@ int qs_refresh_pool(qs_handle* h) {  // redraw the pre-settled reset states (new
     QS_ON_DEVICE(h);
     if (h->pool_size <= 0) return 0;
     h->pool_generation++;
-    hipLaunchKernelGGL(k_pool_fill, dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
+    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_pool_fill<true>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
+    else hipLaunchKernelGGL((k_pool_fill<false>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
     QS_HIP(hipGetLastError());
     return 0;
 }

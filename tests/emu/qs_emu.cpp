@@ -6,7 +6,8 @@
 #include <vector>
 #include "../../quadruped-springs_amd/csrc/qs_env.h"
 
-using E = qs::Env<LaneEmu>;
+using E = qs::Env<LaneEmu>;            // friction pyramid
+using EC = qs::Env<LaneEmu, true>;     // implicit cone (cfg.friction_cone): the kernels are built for both, so is this harness
 
 struct Emu {
     qs_config cfg;
@@ -21,6 +22,16 @@ static void init_record(const qs_config& cfg, float* r, int env) {
     r[R_QUAT + 3] = 1.0f; r[R_POS + 2] = 0.32f; r[R_TASK + T_FIRST_JUMP] = 1.0f;
     for (int L = 0; L < 4; L++) { r[R_Q + 3 * L + 1] = 0.78539816339f; r[R_Q + 3 * L + 2] = -1.57079632679f; }
     E::randomize(cfg, r, (uint32_t)(env + cfg.env_id_offset), -1, true);
+}
+
+template <class EV> static void phys_step_impl(Emu* e, int i, const float* tau12) {
+    float* rec = &e->rec[(size_t)i * QS_REC];
+    typename EV::S::State s; typename EV::S::Par P; typename EV::S::Out o;
+    EV::load_state(rec, s); EV::load_par(rec, P);
+    V4 tau[3];
+    for (int j = 0; j < 3; j++) { tau[j] = LaneEmu::ld_leg(tau12, j, 3); o.tau_pd[j] = V4(0.0f); o.tau_spring[j] = V4(0.0f); }
+    EV::S::substep(e->cfg, P, s, tau, o);
+    EV::store_state(rec, s, o);
 }
 
 extern "C" {
@@ -38,7 +49,10 @@ int qse_set_trace(void* h, int env, float* rows) { Emu* e = (Emu*)h; e->trace_en
 int qse_reset(void* h, const uint8_t* mask) {
     Emu* e = (Emu*)h;
     for (int i = 0; i < e->cfg.n_envs; i++)
-        if (!mask || mask[i]) E::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)(i + e->cfg.env_id_offset), true);
+        if (!mask || mask[i]) {
+            if (e->cfg.friction_cone) EC::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)(i + e->cfg.env_id_offset), true);
+            else E::reset(e->cfg, &e->rec[(size_t)i * QS_REC], &e->obs[(size_t)i * QS_MAX_OBS], (uint32_t)(i + e->cfg.env_id_offset), true);
+        }
     return 0;
 }
 // qs_reset_to (k_reset with states): randomizers, the given rigid-body state, task / sensor / filter reset, zero action history
@@ -82,11 +96,14 @@ int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* don
         float* rec = &e->rec[(size_t)i * QS_REC];
         float* ob = &e->obs[(size_t)i * QS_MAX_OBS];
         float* tr = (e->trace && i == e->trace_env) ? e->trace : nullptr;
-        E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset), 0, tr, tr != nullptr, e->demo.data(), e->demo_len);
-        rew[i] = r.reward.v[0]; done[i] = r.done.v[0] > 0.5f; trunc[i] = r.trunc.v[0] > 0.5f;
+        float rw, dn, tc;
+        if (e->cfg.friction_cone) { EC::StepOut r = EC::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset), 0, tr, tr != nullptr, e->demo.data(), e->demo_len); rw = r.reward.v[0]; dn = r.done.v[0]; tc = r.trunc.v[0]; }
+        else { E::StepOut r = E::step(e->cfg, rec, actions + (size_t)i * d, ob, (uint32_t)(i + e->cfg.env_id_offset), 0, tr, tr != nullptr, e->demo.data(), e->demo_len); rw = r.reward.v[0]; dn = r.done.v[0]; tc = r.trunc.v[0]; }
+        rew[i] = rw; done[i] = dn > 0.5f; trunc[i] = tc > 0.5f;
         if (done[i] && e->cfg.auto_reset) {
             memcpy(&e->term_obs[(size_t)i * QS_MAX_OBS], ob, QS_MAX_OBS * sizeof(float));
-            E::reset(e->cfg, rec, ob, (uint32_t)(i + e->cfg.env_id_offset), true);
+            if (e->cfg.friction_cone) EC::reset(e->cfg, rec, ob, (uint32_t)(i + e->cfg.env_id_offset), true);
+            else E::reset(e->cfg, rec, ob, (uint32_t)(i + e->cfg.env_id_offset), true);
         }
         memcpy(obs + (size_t)i * e->cfg.obs_dim, ob, e->cfg.obs_dim * sizeof(float));
     }
@@ -119,13 +136,8 @@ int qse_field(const char* name) {
 // one physics substep of env `i` under given joint torques (KATs on the kernel arithmetic)
 int qse_phys_step(void* h, int i, const float* tau12) {
     Emu* e = (Emu*)h;
-    float* rec = &e->rec[(size_t)i * QS_REC];
-    typename E::S::State s; typename E::S::Par P; typename E::S::Out o;
-    E::load_state(rec, s); E::load_par(rec, P);
-    V4 tau[3];
-    for (int j = 0; j < 3; j++) { tau[j] = LaneEmu::ld_leg(tau12, j, 3); o.tau_pd[j] = V4(0.0f); o.tau_spring[j] = V4(0.0f); }
-    E::S::substep(e->cfg, P, s, tau, o);
-    E::store_state(rec, s, o);
+    if (e->cfg.friction_cone) phys_step_impl<EC>(e, i, tau12);
+    else phys_step_impl<E>(e, i, tau12);
     return 0;
 }
 }
