@@ -401,7 +401,7 @@ template <class T, bool CONE = false> struct Sim {
         constexpr int ia_ = NR * (K) + 1, ib_ = NR * (K) + 2;                                                          \
         V lim = mu * lam_all[NR * (K)];                                                                                \
         V r2 = res[1] * res[1] + res[2] * res[2];                                                                      \
-        V sc = qsel(qgt(r2, lim * lim), lim * qrsqrt(r2), V(1.0f));                                                    \
+        V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));   /* min(1, mu lambda_n / |c|) */                      \
         V da = T::template bcast<K>(res[1] * sc) - lam_all[ia_], db = T::template bcast<K>(res[2] * sc) - lam_all[ib_]; \
         lam_all[ia_] = lam_all[ia_] + da; lam_all[ib_] = lam_all[ib_] + db;                                             \
         _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + (Ap[ia_][c] * da + Ap[ib_][c] * db);          \
@@ -533,7 +533,7 @@ template <class T, bool CONE = false> struct Sim {
     {                                                                                                                  \
         V ca = lam[1] + res[1], cb = lam[2] + res[2], lim = mu * lam[0];                                               \
         V r2 = ca * ca + cb * cb;                                                                                      \
-        V sc = qsel(qgt(r2, lim * lim), lim * qrsqrt(r2), V(1.0f));                                                    \
+        V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));                                                       \
         ca = ca * sc; cb = cb * sc;                                                                                    \
         V da = T::template bcast<K>(ca - lam[1]), db = T::template bcast<K>(cb - lam[2]);                              \
         lam[1] = qsel(T::is_leg(K), ca, lam[1]); lam[2] = qsel(T::is_leg(K), cb, lam[2]);                              \
