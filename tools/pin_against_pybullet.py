@@ -91,12 +91,11 @@ def main():
     ap.add_argument("--substeps", type=int, default=2600)
     ap.add_argument("--springs", type=int, default=1)
     ap.add_argument("--mu", type=float, default=1.0, help="ground lateralFriction (env_randomizer.py:287-289 draws 0.5 .. 1)")
-    ap.add_argument("--contact-erp", type=float, nargs="+", default=[0.2, 0.08],
-                    help="contact error-reduction values to try in the oracle (hypothesis: PyBullet solves shallow contacts with its erp2; 0.2 is Bullet's "
-                         "default, 0.08 a value PyBullet may set): the table is printed once per value")
-    ap.add_argument("--friction", nargs="+", default=["pyramid", "cone"], choices=["pyramid", "cone"],
-                    help="friction models to try in the oracle: the pyramid with Bullet's skip rule, or the implicit cone of "
-                         "resolveConeFrictionConstraintRows (PyBullet's enableConeFriction, which its documentation calls the default)")
+    ap.add_argument("--grid", nargs="+", default=["friction_model=pyramid,cone", "contact_erp=0.2,0.08"],
+                    help="solver settings of the oracle to try, key=v1,v2,... each (keywords of qs_amd.config.build_config: friction_model, "
+                         "contact_erp, joint_erp, warmstart, solver_residual_threshold); every combination gets its own table.  Defaults: the "
+                         "friction pyramid with Bullet's skip rule vs the implicit cone PyBullet's documentation calls its default "
+                         "(enableConeFriction), and Bullet's contact ERP 0.2 vs the erp2 = 0.08 PyBullet may set")
     ap.add_argument("--write", default="", help="save the compared rows as an .npz fixture")
     args = ap.parse_args()
     try:
@@ -109,15 +108,18 @@ def main():
 
     from oracle.qso import Oracle
     from qs_amd.config import build_config
+    import itertools
+    axes = []
+    for item in args.grid:
+        key, _, vals = item.partition("=")
+        axes.append([(key, v if key == "friction_model" else float(v)) for v in vals.split(",")])
     oracles, labels = [], []
-    for erp in args.contact_erp:
-        for fm in args.friction:
-            cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
-                                  enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False, contact_erp=erp,
-                                  friction_model=fm)
-            oracles.append(Oracle(cfg))
-            oracles[-1].set_params(0, np.array([[args.mu]]))
-            labels.append(f"contact_erp = {erp}, friction = {fm}")
+    for combo in itertools.product(*axes):
+        cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                              enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False, **dict(combo))
+        oracles.append(Oracle(cfg))
+        oracles[-1].set_params(0, np.array([[args.mu]]))
+        labels.append(", ".join(f"{k} = {v}" for k, v in combo))
 
     p = bullet_client.BulletClient(connection_mode=pybullet.DIRECT)
     p.resetSimulation()
