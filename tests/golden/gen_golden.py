@@ -24,7 +24,7 @@ import types
 import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("QS_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")   # QS_GOLDEN_OUT: regenerate elsewhere, e.g. to check reproducibility
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "quadruped-springs_amd"))
 sys.path.insert(0, "/root/reference")
