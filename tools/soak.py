@@ -16,6 +16,9 @@ CASES = [
     dict(task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", env_randomizer_mode="MASS_RANDOMIZER", action_space_mode="DEFAULT", wrapper="GO_TO_REST",
          enable_springs=False),
     dict(task_env="NO_TASK", observation_space_mode="ENCODER", env_randomizer_mode="GROUND_RANDOMIZER", motor_control_mode="CARTESIAN_PD"),
+    dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="TEST_RANDOMIZER", friction_model="cone", wrapper="LANDING"),
+    dict(task_env="NO_TASK", observation_space_mode="ENCODER", env_randomizer_mode="GROUND_RANDOMIZER", friction_model="cone", isRLGymInterface=False,
+         motor_control_mode="TORQUE", enable_action_filter=False),     # raw torques in [-1.2, 1.2] Nm: the robots sag onto their joint stops
     dict(task_env="JUMPING_FORWARD_DEMO", observation_space_mode="PPO_BASIC", env_randomizer_mode="SPRING_RANDOMIZER", action_space_mode="DEFAULT",
          demo=np.random.default_rng(0).uniform(-1, 1, size=(137, 50)).astype(np.float32)),     # an arbitrary "demonstration": only its action columns matter here
 ]
