@@ -221,16 +221,20 @@ class QuadrupedGymEnv(GymEnv):
         seed=0,
         noise=True,   # extensions (not in the reference's signature): device, seed of the counter-based RNG, sensor noise on / off
         demo=None,    # DEMO tasks: the demonstration rows (array or .npy path) the reference would np.load (task_base.py:173)
+        **solver_settings,   # friction_model, contact_erp, joint_erp, warmstart, solver_residual_threshold (qs_amd.config.build_config)
     ):
         if on_rack or render:
             raise NotImplementedError("on_rack / render need the PyBullet GUI path, which this build does not provide")
+        unknown = set(solver_settings) - {"friction_model", "contact_erp", "joint_erp", "warmstart", "solver_residual_threshold"}
+        if unknown:
+            raise TypeError(f"unexpected keyword argument(s) {sorted(unknown)}")
         self.verbose = verbose
         self._vec = QuadrupedVecEnv(
             num_envs=1, device=device, auto_reset=False, isRLGymInterface=isRLGymInterface, time_step=time_step,
             action_repeat=action_repeat, motor_control_mode=motor_control_mode, task_env=task_env,
             observation_space_mode=observation_space_mode, action_space_mode=action_space_mode, enable_springs=enable_springs,
             enable_action_interpolation=enable_action_interpolation, enable_action_filter=enable_action_filter,
-            env_randomizer_mode=env_randomizer_mode, seed=seed, noise=noise, demo=demo)
+            env_randomizer_mode=env_randomizer_mode, seed=seed, noise=noise, demo=demo, **solver_settings)
         meta = self._vec.meta
         self._robot_config = meta["robot_config"]
         self._enable_springs = enable_springs
