@@ -2,6 +2,8 @@
 """Headline benchmark: env-steps/sec of the batched Go1 + PEA step (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 1000 --warmup 50
+    python bench.py --gpus 8 --steps 1000 --warmup 50                       # starts the 8 ranks itself (one fresh child per GPU)
+    python bench.py --gpus 8 --total-envs 65536 --steps 1000 --warmup 50    # strong scaling: SURVEY.md 8e's N = 65536 split over the ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one QuadrupedGymEnv.step() of every environment (10 physics substeps x 30 solver sweeps + task / reward /
@@ -18,7 +20,6 @@ for p in (REPO, os.path.join(REPO, "quadruped-springs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-ALGO_BYTES_PER_ENV_STEP = 1112  # SURVEY.md 8(d), d = 6, o = 28
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -65,7 +66,7 @@ def cpu_baseline(cfg_kwargs, budget_s=12.0):
                 sample=f"{n} envs x {steps} env-steps of the same workload on {cores} host threads (OpenMP over environments), auto-reset incl. 2500-substep settles ({dt:.1f} s)")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -78,30 +79,101 @@ def main():
                     help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
-    ap.add_argument("--friction-model", default="pyramid", choices=["pyramid", "cone"],
-                    help="pyramid with Bullet's skip rule (default) or PyBullet's implicit cone (enableConeFriction)")
-    ap.add_argument("--solver-residual-threshold", type=float, default=0.0,
-                    help="PyBullet solverResidualThreshold (its default is 1e-7); 0 = always int(300/action_repeat) sweeps")
-    args = ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the --gpus N children exactly as a real run does, but each only prints its rank environment (one JSON line) and exits; touches no GPU")
+    ap.add_argument("--friction-model", default="cone", choices=["pyramid", "cone"],
+                    help="PyBullet's implicit cone (its default, and this build's) or the friction pyramid with Bullet's skip rule")
+    ap.add_argument("--solver-residual-threshold", type=float, default=1e-7,
+                    help="PyBullet solverResidualThreshold (its default 1e-7 is this build's default); 0 = always int(300/action_repeat) sweeps")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh children, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    set), BEFORE anything in this process touches a GPU; rank 0's child prints the JSON line.  Returns the exit code."""
+    import subprocess
+    port = free_port()
+    envs = []
+    for r in range(args.gpus):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks
+        envs.append(e)
+    import torch
+    visible = torch.cuda.device_count()   # counting devices does not initialise the GPU runtime in this process
+    if visible < args.gpus and not args.dry_launch:
+        print(f"bench.py: --gpus {args.gpus} but {visible} GPU(s) visible on this box; refusing to report a {args.gpus}-GPU line from fewer devices",
+              file=sys.stderr)
+        return 2
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e) for e in envs]
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):      # one rank failed: stop exactly the children started here
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.2)
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def metric_name(workload_name, kw, n, world, total_envs):
+    if workload_name == "jump_in_place_8192" and n == 8192 and not total_envs:
+        return "env-steps/sec (whole node), Go1+PEA jump-in-place, N=8192 envs"     # BASELINE.json's metric, verbatim
+    task = kw["task_env"].lower().replace("_", "-")
+    return f"env-steps/sec (whole node), Go1+PEA {task} ({workload_name}), N={n} envs per GPU x {world} GPU(s)"
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
     if args.cpu_baseline_only:   # runs in a child process that never touches the GPU or torch: its OpenMP runtime starts with the settings below
         _, kw = workload(args.workload)
         kw["solver_residual_threshold"] = args.solver_residual_threshold
         kw["friction_model"] = args.friction_model
         print(json.dumps(cpu_baseline(kw)))
         return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if under_launcher and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; they must agree")
+    if not under_launcher and (args.gpus > 1 or args.dry_launch):
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_launch:   # a child of `--dry-launch`: report the rank environment it was started with and stop before any GPU call
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"pid": os.getpid(), "ppid": os.getppid()}), flush=True)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus
     sharded = args.workload == "config4_sharded"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the simulation step has no CPU path")
     if world > 1 or sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the simulation step has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -122,25 +194,22 @@ def main():
     acts = torch.rand((n_act, n, d), generator=gen, device=dev) * 2 - 1
     local_step = step_fn = env.step_tensor
     if sharded:
-        # the centralised-learner exchange of SURVEY.md 8e on top of the same local step: rank 0 owns the global action batch
-        # and an SB3-PPO-shaped rollout buffer (n_steps = 128) that every gathered step is written into
+        # the centralised-learner exchange of SURVEY.md 8e on top of the same local step.  Rank 0 owns an SB3-PPO-shaped rollout
+        # buffer (n_steps = 128): its action rows ARE the broadcast source and its result rows [N, o + 2] (observation | reward |
+        # done + 2 truncated) ARE the all-gather destination, so a step adds no copy kernel: broadcast (world > 1 only), the step
+        # kernel writing this rank's rows in place, one in-place all-gather (world > 1 only).
         from qs_amd.sharded import ShardedVecEnv
         shard = ShardedVecEnv(env, learner_rank=0)
         n_glob, o_dim = n * world, env.obs_dim
-        g_acts = (torch.rand((8, n_glob, d), generator=gen, device=dev) * 2 - 1) if rank == 0 else None
-        if rank == 0:
-            buf = dict(obs=torch.zeros((128, n_glob, o_dim), device=dev), act=torch.zeros((128, n_glob, d), device=dev),
-                       rew=torch.zeros((128, n_glob), device=dev), start=torch.zeros((128, n_glob), device=dev))
+        n_roll = 128
+        roll_act = torch.rand((n_roll, n_glob, d), generator=gen, device=dev) * 2 - 1   # stands in for the policy's outputs
+        roll_res = torch.zeros((n_roll if rank == 0 else 1, n_glob, o_dim + 2), device=dev)
         state = dict(t=0)
 
         def sharded_step(_unused):
-            t = state["t"]
-            a = g_acts[t % 8] if rank == 0 else None
-            obs, rew, done, trunc = shard.step(a)
-            if rank == 0:
-                k = t % 128
-                buf["obs"][k].copy_(obs); buf["act"][k].copy_(a); buf["rew"][k].copy_(rew); buf["start"][k].copy_(done)
-            state["t"] = t + 1
+            k = state["t"] % n_roll
+            shard.step(roll_act[k] if rank == 0 else None, out=roll_res[k if rank == 0 else 0])
+            state["t"] += 1
 
         step_fn = sharded_step
 
@@ -151,7 +220,8 @@ def main():
 
     # Auto-reset draws pre-settled states from a pool; with streaming on, as many entries as were consumed are re-settled by
     # extra workgroups of the step kernel (2500 substeps per state, new randomizer draws, action_repeat substeps per launch),
-    # so the settle work of the resets consumed in the timed region is done in the timed region, next to the stepping.
+    # so in the steady state the settle work of the resets consumed in the timed region is done in the timed region, next to the
+    # stepping (config.settle_work_ratio says how much of it this particular run did).
     streaming = bool(args.reset_pool) and not args.no_pool_streaming
     if streaming:
         env.pool_streaming(True)
@@ -179,6 +249,14 @@ def main():
     stats1 = env.stats()
     limit1 = env.counter("limit_path_substeps")
     refills1 = env.pool_streaming(True) if streaming else 0
+    local_elapsed = None
+    if sharded:   # the same number of steps without the exchange, to price it (reported as config.exchange_us; not the headline)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            local_step(acts[i % n_act])
+        barrier()
+        local_elapsed = time.perf_counter() - t1
     env.enable_timing(True)
     # per-launch duration of the step kernel from HIP events on the kernel's own stream (separate short loop so that
     # the event synchronisation does not sit inside the timed region)
@@ -188,38 +266,44 @@ def main():
     env.enable_timing(False)
     if streaming:
         env.pool_streaming(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, local_elapsed or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, local_elapsed = float(t[0].item()), (float(t[1].item()) if sharded else None)
     total_steps = n * world * args.steps
     if rank == 0:
         kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
-        achieved = n * ALGO_BYTES_PER_ENV_STEP / kavg / 1e9
-        # HBM bytes per launch from the committed PMC passes of this very configuration (rocprofv3 cannot run inside this
-        # process); null when the run differs from the profiled one
-        traffic = valu = pmc = None
+        algo_bytes = 736 + 44 * d + 4 * env.obs_dim + (64 if kw["action_space_mode"] == "CPG" else 0)   # B(d, o); 1112 for d = 6, o = 28
+        achieved = n * algo_bytes / kavg / 1e9
+        # HBM bytes per launch: rocprofv3 cannot run inside this process, so the figure is the PMC byte count of the committed
+        # passes of this very configuration (roofline.traffic_source names the file); null when the run differs from every profiled one
+        traffic = valu = pmc = pmc_file = None
         try:
             import glob
-            # the latest committed PMC passes of this very configuration
-            pmcs = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True)]
-            pmc = next((p for p in pmcs if (p["workload"], p["envs_per_gpu"], p["reset_pool"], p["settle_lanes"], p.get("friction_model", "pyramid")) ==
-                        (args.workload, n, args.reset_pool, streaming, args.friction_model)), None)
+            for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True):
+                p = json.load(open(f))
+                if (p["workload"], p["envs_per_gpu"], p["reset_pool"], p["settle_lanes"], p.get("friction_model", "pyramid"),
+                        float(p.get("solver_residual_threshold", 0.0))) == (args.workload, n, args.reset_pool, streaming, args.friction_model,
+                                                                            float(args.solver_residual_threshold)):
+                    pmc, pmc_file = p, os.path.relpath(f, REPO)
+                    break
             if pmc is not None:
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
                 if "sq_insts_valu" in pmc:
-                    # the roof that does bound this kernel: one wave64 fp32 VALU instruction per SIMD every 4 cycles (16 lanes per SIMD)
+                    # the roof that does bound this kernel: one wave64 fp32 VALU instruction per SIMD every 4 cycles (one wave's issue rate)
                     prop = torch.cuda.get_device_properties(dev)
                     peak = prop.multi_processor_count * 4 * getattr(prop, "clock_rate", 2.4e6) * 1e3 / 4 / 1e9
                     valu = {"achieved": pmc["sq_insts_valu"] / kavg / 1e9, "peak": peak, "unit": "G wave-instructions/s",
                             "frac": pmc["sq_insts_valu"] / kavg / 1e9 / peak,
-                            "note": "SQ_INSTS_VALU per launch (same PMC passes) / step-kernel duration, against SIMDs x clock / 4; " +
+                            "note": "SQ_INSTS_VALU per launch (committed PMC passes) / live step-kernel duration, against SIMDs x clock / 4; " +
                                     (f"at N = {n} only {(n // 16) / (prop.multi_processor_count * 4):.0%} of the SIMDs hold a stepping wave"
                                      if n // 16 < prop.multi_processor_count * 4 else f"at N = {n} every SIMD holds {(n // 16) / (prop.multi_processor_count * 4):.0f} stepping waves")}
         except (OSError, KeyError, ValueError):
             pmc = None
+        resets = int(stats1["resets"] - stats0["resets"])
+        settle_sub = int(stats1["settle_substeps"] - stats0["settle_substeps"])
         out = {
-            "metric": "env-steps/sec (whole node), Go1+PEA jump-in-place, N=8192 envs",
+            "metric": metric_name(args.workload, kw, n, world, args.total_envs),
             "value": total_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -237,16 +321,23 @@ def main():
                        "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
                                   ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))
                                  if args.reset_pool else "2500-substep settle inside the step"),
-                       "resets_in_timed_region": int(stats1["resets"] - stats0["resets"]),
+                       "resets_in_timed_region": resets,
                        "pool_states_settled_in_timed_region": int(refills1 - refills0),
-                       "settle_substeps_in_timed_region": int(stats1["settle_substeps"] - stats0["settle_substeps"]),
+                       "settle_substeps_in_timed_region": settle_sub,
+                       # settle work executed inside the timed region / the settle work its resets are worth (1.0 = every reset paid for
+                       # inside the region; short runs see less because an entry takes settle_steps / action_repeat launches to settle)
+                       "settle_work_ratio": (settle_sub / (resets * env.cfg.settle_steps)) if resets else None,
                        "joint_limit_path_wave_substeps": int(limit1 - limit0),
-                       "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step, rollout buffer on rank 0" if sharded
+                       "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step (both skipped on one rank), results land in rank 0's rollout buffer" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
-                         "note": "achieved = N x 1112 algorithmic bytes per env-step (SURVEY 8d) / k_step duration; traffic = PMC bytes per launch (latest profiles/r*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step (80 % VALU-active): latency/issue-bound, not HBM-bound"},
+                         "traffic": traffic, "traffic_source": pmc_file, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
+                         "algorithmic_bytes_per_env_step": algo_bytes,
+                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / live k_step duration (HIP events on the kernel's stream; the events add ~1.5 % to a 0.1 ms launch); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same live duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
         }
+        if sharded:
+            out["config"]["local_ms_per_step"] = 1e3 * local_elapsed / args.steps
+            out["config"]["exchange_us"] = 1e6 * (elapsed - local_elapsed) / args.steps
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a property of the box, reported with the single-GPU line only
             import subprocess
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,

@@ -5,11 +5,20 @@ Environments are independent, so the simulation data path needs no collective: r
 of the number of ranks.  What a centralised learner needs per step is:
   * actions:  broadcast of the global [N, d] batch from the learner rank (each rank keeps its slice), and
   * results:  ONE all-gather of a fused [n, o+2] float32 buffer (obs | reward | done+2*truncated) per rank.
+Nothing else is launched: the step kernel writes this rank's rows straight into its slice of the gathered buffer (which may be
+the learner's own rollout row, `out=`), the all-gather runs in place on that buffer, and on one rank both collectives are skipped.
 Backend "nccl" is RCCL over xGMI on the GPU box; the same code runs on "gloo" for the CPU tests, where the local
 environment is any object with `step_tensor` / `reset_tensor` (tests plug in the CPU oracle).
 """
 import torch
 import torch.distributed as dist
+
+
+def decode_flags(flags):
+    """The last column of a fused result row is done + 2 * truncated (include/qs_amd.h, qs_step_fused): 0 running, 1 terminated,
+    3 truncated (gym_env.py:245-246: truncation is a done without termination).  Returns (done, truncated) as booleans; works on
+    torch tensors and numpy arrays alike.  The one decoder for QuadrupedVecEnv.step_wait and ShardedVecEnv."""
+    return flags > 0.5, flags > 2.5
 
 
 class ShardedVecEnv:
@@ -23,44 +32,58 @@ class ShardedVecEnv:
         self.num_envs = self.n_local * self.world
         self.action_dim, self.obs_dim = local_env.action_dim, local_env.obs_dim
         self.device = local_env.device
-        self._fused = torch.zeros((self.n_local, self.obs_dim + 2), dtype=torch.float32, device=self.device)
         self._gathered = torch.zeros((self.num_envs, self.obs_dim + 2), dtype=torch.float32, device=self.device)
         self._actions = torch.zeros((self.num_envs, self.action_dim), dtype=torch.float32, device=self.device)
+        self.lo = self.rank * self.n_local
 
     @staticmethod
     def env_id_offset(n_local, rank=None):
         return n_local * (dist.get_rank() if rank is None else rank)
 
-    def _unpack(self):
-        g = self._gathered
-        flags = g[:, self.obs_dim + 1]
-        # done = flag 1 or 3, truncated = flag 3 (done without termination, gym_env.py:246); obs / reward are views, not copies
-        return g[:, : self.obs_dim], g[:, self.obs_dim], flags > 0.5, flags > 2.5
+    def _unpack(self, g):
+        done, trunc = decode_flags(g[:, self.obs_dim + 1])
+        return g[:, : self.obs_dim], g[:, self.obs_dim], done, trunc   # obs / reward are views of the gathered buffer, not copies
 
-    def _gather(self, obs, rew=None, done=None, trunc=None):
-        f = self._fused
-        f[:, : self.obs_dim] = obs
-        f[:, self.obs_dim] = 0 if rew is None else rew
-        f[:, self.obs_dim + 1] = 0 if done is None else done.to(torch.float32) + 2 * trunc.to(torch.float32)
-        dist.all_gather_into_tensor(self._gathered, f, group=self.group)
-        return self._unpack()
+    def _all_gather(self, g):
+        if self.world > 1:   # in place: this rank's rows already sit in its slice of g
+            dist.all_gather_into_tensor(g, g[self.lo: self.lo + self.n_local], group=self.group)
+
+    def _check_out(self, out):
+        if out is None:
+            return self._gathered
+        if tuple(out.shape) != (self.num_envs, self.obs_dim + 2) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self._gathered.device:
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {(self.num_envs, self.obs_dim + 2)} on {self._gathered.device}")
+        return out
 
     def reset(self):
-        return self._gather(self.env.reset_tensor())[0]
+        g = self._gathered
+        mine = g[self.lo: self.lo + self.n_local]
+        mine[:, : self.obs_dim] = self.env.reset_tensor()
+        mine[:, self.obs_dim:] = 0
+        self._all_gather(g)
+        return self._unpack(g)[0]
 
-    def step(self, actions=None):
-        """`actions`: the global [N, d] batch on the learner rank (ignored elsewhere).  Returns the global
-        (obs [N,o], rew [N], done [N], truncated [N]) on every rank (views of the gathered buffer, valid until the next call)."""
-        buf = actions if (self.rank == self.learner_rank and actions.is_contiguous() and actions.dtype == torch.float32
-                          and actions.device == self._actions.device) else self._actions
-        if self.rank == self.learner_rank and buf is self._actions:
+    def step(self, actions=None, out=None):
+        """`actions`: the global [N, d] batch on the learner rank (ignored elsewhere).  `out` (optional): a contiguous float32
+        [N, o + 2] tensor that receives the gathered rows (e.g. one row block of the learner's rollout buffer) instead of the
+        internal buffer.  Returns the global (obs [N,o], rew [N], done [N], truncated [N]) on every rank: views of / computed
+        from that buffer, valid until it is written again."""
+        g = self._check_out(out)
+        learner = self.rank == self.learner_rank
+        direct = learner and actions.is_contiguous() and actions.dtype == torch.float32 and actions.device == self._actions.device
+        buf = actions if direct else self._actions
+        if learner and not direct:
             self._actions.copy_(actions)
-        dist.broadcast(buf, src=self.learner_rank, group=self.group)
-        lo = self.rank * self.n_local
-        mine = buf[lo: lo + self.n_local]          # a row slice: contiguous
-        if hasattr(self.env, "step_fused"):        # the step kernel writes the fused row itself (qs_step_fused)
-            self.env.step_fused(mine, self._fused)
-            dist.all_gather_into_tensor(self._gathered, self._fused, group=self.group)
-            return self._unpack()
-        obs, rew, done, trunc = self.env.step_tensor(mine.contiguous())
-        return self._gather(obs, rew, done, trunc)
+        if self.world > 1:
+            dist.broadcast(buf, src=self.learner_rank, group=self.group)
+        mine = buf[self.lo: self.lo + self.n_local]          # a row slice: contiguous
+        rows = g[self.lo: self.lo + self.n_local]
+        if hasattr(self.env, "step_fused"):        # the step kernel writes the fused rows itself (qs_step_fused), in place
+            self.env.step_fused(mine, rows)
+        else:
+            obs, rew, done, trunc = self.env.step_tensor(mine.contiguous())
+            rows[:, : self.obs_dim] = obs
+            rows[:, self.obs_dim] = rew
+            rows[:, self.obs_dim + 1] = done.to(torch.float32) + 2 * trunc.to(torch.float32)
+        self._all_gather(g)
+        return self._unpack(g)

@@ -10,6 +10,7 @@ import numpy as np
 
 from . import lib as _lib
 from .config import DEMO_FILES, OBSERVATION_EPS, build_config
+from .sharded import decode_flags
 from .spaces import Box, SB3VecEnv
 
 INFO = dict(foot_force=0, foot_contact=1, torque=2, spring_torque=3, task=4, n_invalid=5, params=6, counters=7,
@@ -263,8 +264,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         self._act.copy_(self.torch.from_numpy(self._actions))
         res = self.step_fused(self._act, self._d_fused).cpu().numpy()
         obs, rew = res[:, : self.obs_dim].copy(), res[:, self.obs_dim].copy()
-        flags = res[:, self.obs_dim + 1]
-        done, trunc = flags > 0.5, flags > 1.5
+        done, trunc = decode_flags(res[:, self.obs_dim + 1])
         infos = [{} for _ in range(self.num_envs)]
         if done.any():
             term = self.get_info("terminal_obs").cpu().numpy() if self.cfg.auto_reset else obs
