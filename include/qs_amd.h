@@ -108,7 +108,13 @@ typedef struct qs_config {
     float contact_erp, joint_erp, warmstart, vel_cap;
     float obs_noise_std[QS_MAX_OBS];
     float task_p[16];
-    float reserved_f[8];
+    float contact_slop;        /* btContactSolverInfo::m_linearSlop (PhysicsServerCommandProcessor sets 1e-5): added to a contact's distance
+                                * before the positional / speculative error terms of its normal row */
+    int32_t body_contacts;     /* 1: trunk / hip / thigh / calf primitives that touch the plane push back (normal + friction rows on the
+                                * rare path, at most two support points per leg); 0: they only count as invalid contacts (quadruped.py:243-249) */
+    int32_t self_collision;    /* 1: link-link contacts that involve a calf are detected and counted as invalid contacts
+                                * (URDF_USE_SELF_COLLISION quadruped.py:533-539, rule :237-241); 0: no link-link test */
+    float reserved_f[5];
     /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
     float cpg_lo[5], cpg_hi[5];/* action -> (omega_swing, omega_stance, mu, des_step_len, robot_height) */
@@ -124,6 +130,11 @@ typedef struct qs_config {
     float landing_kp, landing_kd; /* landing_wrapper.py:22-27 */
     float rest_kp, rest_kd, rest_time; /* go_to_rest_wrapper.py:16-19, 26-32 */
     float reserved_h[3];
+    /* Inertia tensors about the centre of mass PER UNIT MASS (xx, xy, xz, yy, yz, zz; link axes, sign convention of the FR leg) of
+     * hip, thigh, calf and trunk: a link of mass m has the tensor m * unit_inertia.  mass_inertia_rule = "scale": the URDF tensor over the
+     * URDF mass.  "collision_shape": what Bullet's changeDynamics(mass=...) (quadruped.py:761,776) leaves behind -- the box inertia of the
+     * collision compound's AABB in the link's principal frame.  The host fills the table (qs_amd/config.py). */
+    float unit_inertia[4][6];
 } qs_config;
 
 typedef struct qs_handle qs_handle;

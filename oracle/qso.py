@@ -130,6 +130,17 @@ class Oracle:
         t = np.ascontiguousarray(tau, self.real)
         self._check(self.lib.qso_phys_step(self.h, env, self._p(t)))
 
+    def contacts(self, env=0, max_n=64):
+        """[(bodyA, bodyB, linkA, linkB, distance, normal force)] of the last substep, PyBullet numbering (qso.h)."""
+        ids = np.zeros((max_n, 4), np.int32)
+        df = np.zeros((max_n, 2), self.real)
+        n = self.lib.qso_get_contacts(self.h, int(env), self._p(ids), self._p(df), max_n)
+        return [(int(a), int(b), int(c), int(d), float(x), float(f)) for (a, b, c, d), (x, f) in zip(ids[:min(n, max_n)], df[:min(n, max_n)])]
+
+    def boxes_overlap(self, ca, Ra, ha, cb, Rb, hb):
+        args = [np.ascontiguousarray(x, self.real) for x in (ca, Ra, ha, cb, Rb, hb)]
+        return bool(self.lib.qso_geom_boxes_overlap(*[self._p(x) for x in args]))
+
     def set_gravity(self, g):
         self.lib.qso_phys_set_gravity(self.h, self._creal(g))
 

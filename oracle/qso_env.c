@@ -582,7 +582,7 @@ static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
         /* :43-47,61-65: total_mass sums EVERY URDF link, so the imu (0.001) and floating-base (1e-5) masses end up in the trunk too */
         e->m_trunk = QSO_M_TRUNK + (real)0.00101 + legs0 - legs - e->m_pay;
     }
-    qso_model_build(&e->model, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
+    qso_model_build(&e->model, cfg->unit_inertia, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
 }
 
 static void reset_env_to(qso_handle* h, int i, const real* st37);
@@ -882,7 +882,7 @@ int qso_set_params(qso_handle* h, int which, const real* v) {
             e->mu = o[0];
             for (int k = 0; k < 3; k++) { e->k[k] = o[1 + k]; e->b[k] = o[4 + k]; e->rest[k] = o[7 + k]; e->kp[k] = o[10 + k]; e->kd[k] = o[13 + k]; e->m_leg[k] = o[17 + k]; e->r_pay[k] = o[21 + k]; }
             e->m_trunk = o[16]; e->m_pay = o[20];
-            qso_model_build(&e->model, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
+            qso_model_build(&e->model, h->cfg.unit_inertia, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
             break; }
         default: FAIL("unknown param id %d", which);
         }

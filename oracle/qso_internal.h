@@ -9,7 +9,8 @@
 
 #define NB 13   /* rigid bodies after merging fixed joints: 0 = base+trunk+imu(+payload), 1+3L+j = leg L link j */
 #define NJ 12
-#define NV 18   /* generalized velocity: [w_b(3) v_b(3)] in base coordinates, then qd(12) */
+#define NV 18
+#define QSO_MAX_CONTACTS 64   /* generalized velocity: [w_b(3) v_b(3)] in base coordinates, then qd(12) */
 
 /* Go1 rigid-body model, restated from go1/go1_description/urdf/go1.urdf (see qso_model.c). */
 typedef struct {
@@ -52,6 +53,10 @@ typedef struct {
     real foot_force[4];
     int foot_contact[4];
     int n_invalid;
+    /* every contact point of the last substep as getContactPoints() would list it (PyBullet ids: body 0 plane, 1 robot, 2 payload block;
+       link -1 base / plane, 0 trunk, 2/6/10/14 hips, 3/7/11/15 thighs, 4/8/12/16 calves, 5/9/13/17 feet) */
+    struct { int body_a, body_b, link_a, link_b; real dist, force; } contacts[QSO_MAX_CONTACTS];
+    int n_contacts;
     real warm[4];
     real tau_pd[NJ], tau_spring[NJ];
     /* env-level */
@@ -74,7 +79,8 @@ struct qso_handle {
 };
 
 /* qso_model.c */
-void qso_model_build(qso_model* M, real m_trunk, const real* m_leg3, real m_pay, const real* r_pay);
+void qso_model_build(qso_model* M, const float (*unit)[6], real m_trunk, const real* m_leg3, real m_pay, const real* r_pay);
+extern const real QSO_TRUNK_I[6], QSO_HIP_I[6], QSO_THIGH_I[6], QSO_CALF_I[6];   /* URDF tensors (FR-leg magnitudes) */
 extern const real QSO_M_TRUNK, QSO_M_LEG[3];
 extern const real QSO_JOINT_LO[3], QSO_JOINT_HI[3];
 

@@ -8,7 +8,7 @@
 /* trunk :80-85 */
 const real QSO_M_TRUNK = 5.204;
 static const real TRUNK_COM[3] = {0.0223, 0.0, -0.0005};
-static const real TRUNK_I[6] = {0.0168352186, 0.0004636141, 0.0002367952, 0.0656071082, 3.6671e-05, 0.0742720659};
+const real QSO_TRUNK_I[6] = {0.0168352186, 0.0004636141, 0.0002367952, 0.0656071082, 3.6671e-05, 0.0742720659};
 /* base :55-59, imu :87-97 */
 static const real BASE_M = 0.00001, BASE_I = 1e-5;
 static const real IMU_M = 0.001, IMU_I = 0.0001;
@@ -16,13 +16,13 @@ static const real IMU_POS[3] = {-0.01592, -0.06659, -0.00617};
 /* hip :134-136 (FR), mirrored :294-296 :454-456 :614-616 */
 const real QSO_M_LEG[3] = {0.591, 0.92, 0.131};
 static const real HIP_COM[3] = {0.00541, 0.00074, 6e-06};
-static const real HIP_I[6] = {0.000374268192, 3.6844422e-05, 9.86754e-07, 0.000635923669, 1.172894e-06, 0.000457647394};
+const real QSO_HIP_I[6] = {0.000374268192, 3.6844422e-05, 9.86754e-07, 0.000635923669, 1.172894e-06, 0.000457647394};
 /* thigh :186-188 (FR/RR), :346-348 (FL/RL) */
 static const real THIGH_COM[3] = {-0.003468, 0.018947, -0.032736};
-static const real THIGH_I[6] = {0.005851561134, 1.783284e-06, 0.000328291374, 0.005596155105, 2.1430713e-05, 0.00107157026};
+const real QSO_THIGH_I[6] = {0.005851561134, 1.783284e-06, 0.000328291374, 0.005596155105, 2.1430713e-05, 0.00107157026};
 /* calf :212-216, identical on all legs */
 static const real CALF_COM[3] = {0.006286, 0.001307, -0.122269};
-static const real CALF_I[6] = {0.002939186297, 1.440899e-06, -0.00010535955, 0.00295576935, -2.4397752e-05, 3.0273372e-05};
+const real QSO_CALF_I[6] = {0.002939186297, 1.440899e-06, -0.00010535955, 0.00295576935, -2.4397752e-05, 3.0273372e-05};
 /* foot :218-240 */
 static const real FOOT_M = 0.06, FOOT_I = 9.6e-06;
 static const real FOOT_POS[3] = {0, 0, -0.213};
@@ -66,9 +66,11 @@ static void spatial_inertia(real m, const real* c, const real Ic[3][3], real I6[
         }
 }
 
-/* Mass randomisation (env_randomizer.py:56-83): link masses change; this oracle scales each link's
- * inertia tensor with its mass (DESIGN.md "deviations": Bullet would recompute a box inertia). */
-void qso_model_build(qso_model* M, real m_trunk, const real* m_leg3, real m_pay, const real* r_pay) {
+/* Mass randomisation (env_randomizer.py:56-83): link masses change; a link of mass m gets the inertia m x unit[link], the table
+ * of inertia per unit mass that the host fills by the chosen rule (config.py unit_inertia_table: the URDF tensor scaled with the
+ * mass, or what Bullet's changeDynamics(mass=...) leaves: the box inertia of the collision compound's AABB in the principal frame).
+ * unit = float[4][6] for hip, thigh, calf, trunk: magnitudes in the FR-leg convention of the tables above. */
+void qso_model_build(qso_model* M, const float (*unit)[6], real m_trunk, const real* m_leg3, real m_pay, const real* r_pay) {
     memset(M, 0, sizeof(*M));
     real Idiag[3][3];
     /* body 0 */
@@ -76,8 +78,9 @@ void qso_model_build(qso_model* M, real m_trunk, const real* m_leg3, real m_pay,
     real z3[3] = {0, 0, 0};
     memset(Idiag, 0, sizeof(Idiag)); Idiag[0][0] = Idiag[1][1] = Idiag[2][2] = BASE_I;
     acc_add(&a, BASE_M, z3, Idiag);
-    real It[3][3]; sym6_to_mat(TRUNK_I, It);
-    real sc = m_trunk / QSO_M_TRUNK;
+    real ut[6]; for (int i = 0; i < 6; i++) ut[i] = (real)unit[3][i];
+    real It[3][3]; sym6_to_mat(ut, It);
+    real sc = m_trunk;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) It[i][j] *= sc;
     acc_add(&a, m_trunk, TRUNK_COM, It);
     memset(Idiag, 0, sizeof(Idiag)); Idiag[0][0] = Idiag[1][1] = Idiag[2][2] = IMU_I;
@@ -95,26 +98,29 @@ void qso_model_build(qso_model* M, real m_trunk, const real* m_leg3, real m_pay,
         int ih = 1 + 3 * L, it = ih + 1, ic = ih + 2;
         /* hip */
         real hc[3] = {-fx * HIP_COM[0], -sy * HIP_COM[1], HIP_COM[2]};
-        real hs[6] = {HIP_I[0], fx * sy * HIP_I[1], -fx * HIP_I[2], HIP_I[3], -sy * HIP_I[4], HIP_I[5]};
+        const float* uh = unit[0];
+        real hs[6] = {uh[0], fx * sy * uh[1], -fx * uh[2], uh[3], -sy * uh[4], uh[5]};
         real Ih[3][3]; sym6_to_mat(hs, Ih);
-        sc = m_leg3[0] / QSO_M_LEG[0];
+        sc = m_leg3[0];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M->Ic[ih][i][j] = Ih[i][j] * sc;
         M->mass[ih] = m_leg3[0]; memcpy(M->com[ih], hc, sizeof(hc));
         M->jpos[ih][0] = fx * HIP_X; M->jpos[ih][1] = sy * HIP_Y; M->jpos[ih][2] = 0;
         M->jaxis[ih] = 0; M->parent[ih] = 0;
         /* thigh */
         real tc[3] = {THIGH_COM[0], -sy * THIGH_COM[1], THIGH_COM[2]};
-        real ts[6] = {THIGH_I[0], sy * THIGH_I[1], THIGH_I[2], THIGH_I[3], sy * THIGH_I[4], THIGH_I[5]};
+        const float* uth = unit[1];
+        real ts[6] = {uth[0], sy * uth[1], uth[2], uth[3], sy * uth[4], uth[5]};
         real Ith[3][3]; sym6_to_mat(ts, Ith);
-        sc = m_leg3[1] / QSO_M_LEG[1];
+        sc = m_leg3[1];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M->Ic[it][i][j] = Ith[i][j] * sc;
         M->mass[it] = m_leg3[1]; memcpy(M->com[it], tc, sizeof(tc));
         M->jpos[it][0] = 0; M->jpos[it][1] = sy * THIGH_Y; M->jpos[it][2] = 0;
         M->jaxis[it] = 1; M->parent[it] = ih;
         /* calf + foot */
         memset(&a, 0, sizeof(a));
-        real Icf[3][3]; sym6_to_mat(CALF_I, Icf);
-        sc = m_leg3[2] / QSO_M_LEG[2];
+        real uc[6]; for (int i = 0; i < 6; i++) uc[i] = (real)unit[2][i];
+        real Icf[3][3]; sym6_to_mat(uc, Icf);
+        sc = m_leg3[2];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Icf[i][j] *= sc;
         acc_add(&a, m_leg3[2], CALF_COM, Icf);
         memset(Idiag, 0, sizeof(Idiag)); Idiag[0][0] = Idiag[1][1] = Idiag[2][2] = FOOT_I;

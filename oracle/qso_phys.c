@@ -239,22 +239,104 @@ static real box_min_z(const real R[3][3], const real* o, const real* centre, con
     return mn;
 }
 
-/* number of non-foot links touching the ground: trunk box :74-79, hip cylinder :128-131,
- * thigh box :180-183, calf box :207-210 (classification quadruped.py:243-249) */
-static int count_invalid(const phys_cache* C) {
+static const real TRUNK_HALF[3] = {0.1881, 0.04675, 0.057};          /* go1.urdf:74-79 */
+static const real LINK_BOX_C[3] = {0, 0, -0.1065};                     /* thigh :180-183, calf :207-210 */
+static const real THIGH_HALF[3] = {0.017, 0.01225, 0.1065}, CALF_HALF[3] = {0.008, 0.008, 0.1065};
+#define HIP_CYL_R ((real)0.046)
+#define HIP_CYL_H ((real)0.02)
+#define HIP_SELF_R ((real)0.046)   /* link-link tests treat the hip housing as a sphere of its cylinder's radius */
+#define PAYLOAD_HALF ((real)0.05)  /* quadruped.py:793 */
+#define THR_PAYLOAD ((real)0.00173)
+
+static void push_contact(qso_env* e, int body_a, int body_b, int link_a, int link_b, real dist) {
+    if (e->n_contacts >= QSO_MAX_CONTACTS) return;
+    e->contacts[e->n_contacts].body_a = body_a; e->contacts[e->n_contacts].body_b = body_b;
+    e->contacts[e->n_contacts].link_a = link_a; e->contacts[e->n_contacts].link_b = link_b;
+    e->contacts[e->n_contacts].dist = dist; e->contacts[e->n_contacts].force = 0;
+    e->n_contacts++;
+}
+
+/* ---- link-link contacts (URDF_USE_SELF_COLLISION, quadruped.py:533-539).  Box / box pairs: Bullet's btBoxBoxDetector reports a contact
+ * iff the boxes overlap; decided here by clipping the twelve edges of each box against the other (two convex polyhedra meet iff an
+ * edge of one meets the other, or one lies inside the other -- then its edges do).  The product uses the separating-axis test. */
+typedef struct { real c[3]; real R[3][3]; real h[3]; } obox;   /* centre, axes as COLUMNS of R (world), half extents */
+static void link_box(const phys_cache* C, int body, const real* centre_local, const real* half, obox* B) {
+    real t[3]; m3v(C->Rw[body], centre_local, t);
+    for (int k = 0; k < 3; k++) { B->c[k] = C->ow[body][k] + t[k]; B->h[k] = half[k]; }
+    memcpy(B->R, C->Rw[body], sizeof(B->R));
+}
+static int segment_hits_box(const real* a, const real* d, const real* h) { /* segment a + t d, t in [0,1], box |x_k| <= h_k (local frame) */
+    real t0 = 0, t1 = 1;
+    for (int k = 0; k < 3; k++) {
+        if (fabs(d[k]) < (real)1e-30) { if (fabs(a[k]) > h[k]) return 0; continue; }
+        real ta = (-h[k] - a[k]) / d[k], tb = (h[k] - a[k]) / d[k];
+        if (ta > tb) { real t = ta; ta = tb; tb = t; }
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+        if (t0 > t1) return 0;
+    }
+    return 1;
+}
+static int edges_hit(const obox* A, const obox* B) { /* does an edge of A meet B? */
+    for (int ax = 0; ax < 3; ax++)
+        for (int s1 = -1; s1 <= 1; s1 += 2)
+            for (int s2 = -1; s2 <= 1; s2 += 2) {
+                int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+                real pl[3]; pl[ax] = -A->h[ax]; pl[a1] = s1 * A->h[a1]; pl[a2] = s2 * A->h[a2];
+                real dl[3] = {0, 0, 0}; dl[ax] = 2 * A->h[ax];
+                real pw[3], dw[3]; m3v(A->R, pl, pw); m3v(A->R, dl, dw);
+                for (int k = 0; k < 3; k++) pw[k] += A->c[k] - B->c[k];
+                real pb[3], db[3]; m3tv(B->R, pw, pb); m3tv(B->R, dw, db);
+                if (segment_hits_box(pb, db, B->h)) return 1;
+            }
+    return 0;
+}
+static int boxes_overlap(const obox* A, const obox* B) { return edges_hit(A, B) || edges_hit(B, A); }
+static real sphere_box_dist(const real* c, real r, const obox* B) {
+    real d[3] = {c[0] - B->c[0], c[1] - B->c[1], c[2] - B->c[2]}, l[3], e2 = 0;
+    m3tv(B->R, d, l);
+    for (int k = 0; k < 3; k++) { real q = l[k] > B->h[k] ? B->h[k] : (l[k] < -B->h[k] ? -B->h[k] : l[k]); e2 += (l[k] - q) * (l[k] - q); }
+    return sqrt(e2) - r;
+}
+
+/* Contacts that the reference counts as invalid (quadruped.py:237-249): non-foot links and the payload block on the ground, and
+ * link-link contacts that involve a calf.  Fills the contact list; returns the count. */
+static int collect_invalid(const qso_config* cfg, qso_env* e, const phys_cache* C, const qso_dyn* s) {
     int n = 0;
-    static const real zc[3] = {0, 0, 0}, th[3] = {0.1881, 0.04675, 0.057};
-    if (box_min_z(C->Rw[0], C->ow[0], zc, th) < THR_TRUNK) n++;
-    static const real lc[3] = {0, 0, -0.1065}, hh[3] = {0.017, 0.01225, 0.1065}, ch[3] = {0.008, 0.008, 0.1065};
+    static const real zc[3] = {0, 0, 0};
+    real d;
+    if ((d = box_min_z(C->Rw[0], C->ow[0], zc, TRUNK_HALF)) < THR_TRUNK) { n++; push_contact(e, 1, 0, 0, -1, d); }
     for (int L = 0; L < 4; L++) {
         int ih = 1 + 3 * L;
         real az = C->Rw[ih][2][1]; /* z component of the cylinder axis (link y) */
         real s2 = 1 - az * az; if (s2 < 0) s2 = 0;
-        real zmin = C->ow[ih][2] - (real)0.02 * fabs(az) - (real)0.046 * sqrt(s2);
-        if (zmin < THR_HIP) n++;
-        if (box_min_z(C->Rw[ih + 1], C->ow[ih + 1], lc, hh) < THR_THIGH) n++;
-        if (box_min_z(C->Rw[ih + 2], C->ow[ih + 2], lc, ch) < THR_CALF) n++;
+        real zmin = C->ow[ih][2] - HIP_CYL_H * fabs(az) - HIP_CYL_R * sqrt(s2);
+        if (zmin < THR_HIP) { n++; push_contact(e, 1, 0, 2 + 4 * L, -1, zmin); }
+        if ((d = box_min_z(C->Rw[ih + 1], C->ow[ih + 1], LINK_BOX_C, THIGH_HALF)) < THR_THIGH) { n++; push_contact(e, 1, 0, 3 + 4 * L, -1, d); }
+        if ((d = box_min_z(C->Rw[ih + 2], C->ow[ih + 2], LINK_BOX_C, CALF_HALF)) < THR_CALF) { n++; push_contact(e, 1, 0, 4 + 4 * L, -1, d); }
     }
+    if (e->m_pay > 0) { /* the block is a second body bolted to the base (quadruped.py:778-819); its box is aligned with the base frame */
+        static const real ph[3] = {PAYLOAD_HALF, PAYLOAD_HALF, PAYLOAD_HALF};
+        if ((d = box_min_z(C->Rw[0], C->ow[0], e->r_pay, ph)) < THR_PAYLOAD) { n++; push_contact(e, 2, 0, -1, -1, d); }
+    }
+    if (cfg->self_collision) {
+        obox trunk, thigh[4], calf[4];
+        link_box(C, 0, zc, TRUNK_HALF, &trunk);
+        for (int L = 0; L < 4; L++) { link_box(C, 2 + 3 * L, LINK_BOX_C, THIGH_HALF, &thigh[L]); link_box(C, 3 + 3 * L, LINK_BOX_C, CALF_HALF, &calf[L]); }
+        for (int i = 0; i < 4; i++) {
+            if (boxes_overlap(&calf[i], &trunk)) { n++; push_contact(e, 1, 1, 4 + 4 * i, 0, 0); }
+            for (int j = 0; j < 4; j++) {
+                if (j == i) continue;
+                if (boxes_overlap(&calf[i], &thigh[j])) { n++; push_contact(e, 1, 1, 4 + 4 * i, 3 + 4 * j, 0); }
+                if (j > i && boxes_overlap(&calf[i], &calf[j])) { n++; push_contact(e, 1, 1, 4 + 4 * i, 4 + 4 * j, 0); }
+                if ((d = sphere_box_dist(C->ow[1 + 3 * j], HIP_SELF_R, &calf[i])) < THR_HIP) { n++; push_contact(e, 1, 1, 4 + 4 * i, 2 + 4 * j, d); }
+                real fc[3]; m3v(C->Rw[3 + 3 * j], FOOT_OFF, fc);
+                for (int k = 0; k < 3; k++) fc[k] += C->ow[3 + 3 * j][k];
+                if ((d = sphere_box_dist(fc, FOOT_R, &calf[i])) < THR_FOOT) { n++; push_contact(e, 1, 1, 4 + 4 * i, 5 + 4 * j, d); }
+            }
+        }
+    }
+    (void)s;
     return n;
 }
 
@@ -267,6 +349,49 @@ typedef struct {
 } row;
 
 static void clamp_vel(real* v, real cap) { if (*v > cap) *v = cap; if (*v < -cap) *v = -cap; }
+
+/* rows (normal, t1, t2) of a contact at world point p of body `body` (0 = base, 1 + 3 L + j = link j of leg L), `dist` above the plane.
+ * Directions: normal +z; friction t1 = (0,-1,0), t2 = (1,0,0) (btPlaneSpace1 of +z). */
+static void contact_rows(const qso_config* cfg, const qso_model* M, const phys_cache* C, const qso_dyn* s, const real* v, real mu, int body,
+                         const real* p, real dist, real warm, row* nr, row* f1, row* f2, int nor_index) {
+    static const real dirs[3][3] = {{0, 0, 1}, {0, -1, 0}, {1, 0, 0}};
+    real dt = cfg->dt;
+    for (int rr = 0; rr < 3; rr++) {
+        row* r = rr == 0 ? nr : (rr == 1 ? f1 : f2);
+        memset(r, 0, sizeof(*r));
+        const real* d = dirs[rr];
+        real rb[3], pw[3] = {p[0] - s->pos[0], p[1] - s->pos[1], p[2] - s->pos[2]};
+        m3tv(C->R0, pw, rb);
+        real db[3]; m3tv(C->R0, d, db);
+        real ang[3]; v3cross(rb, db, ang);
+        for (int k = 0; k < 3; k++) { r->J[k] = ang[k]; r->J[3 + k] = db[k]; }
+        if (body > 0) {
+            int L = (body - 1) / 3, depth = (body - 1) % 3;
+            for (int j = 0; j <= depth; j++) {
+                int b = 1 + 3 * L + j;
+                real ax[3] = {C->Rw[b][0][M->jaxis[b]], C->Rw[b][1][M->jaxis[b]], C->Rw[b][2][M->jaxis[b]]};
+                real rp[3] = {p[0] - C->ow[b][0], p[1] - C->ow[b][1], p[2] - C->ow[b][2]};
+                real t[3]; v3cross(ax, rp, t);
+                r->J[6 + 3 * L + j] = v3dot(d, t);
+            }
+        }
+        minv_apply(M, C, r->J, r->W);
+        real dd = 0; for (int k = 0; k < NV; k++) dd += r->J[k] * r->W[k];
+        r->dinv = 1 / dd;
+        real rel = 0; for (int k = 0; k < NV; k++) rel += r->J[k] * v[k];
+        if (rr == 0) {
+            /* btMultiBodyConstraintSolver::setupMultiBodyContactConstraint: penetration = distance + m_linearSlop */
+            real pen = dist + (real)cfg->contact_slop, pos_err = 0, vel_err = -rel;
+            if (pen > 0) vel_err -= pen / dt; else pos_err = -pen * cfg->contact_erp / dt;
+            r->rhs = (pos_err + vel_err) * r->dinv;
+            r->lo = 0; r->hi = 1e10; r->fric_of = -1;
+            r->lam = warm * cfg->warmstart;
+        } else {
+            r->rhs = -rel * r->dinv;
+            r->fric_of = nor_index; r->mu = mu;
+        }
+    }
+}
 
 void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, real g) {
     const qso_model* M = &e->model;
@@ -295,9 +420,11 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
     }
 
     /* ---- constraint rows ---- */
-    row rows[12 + 24]; int nlim = 0, nn = 0, nf = 0;
-    row* lim = rows; row* nor = rows + 24; row* fr = rows + 28;
-    int nor_foot[4];
+    row rows[24 + 12 + 24]; int nlim = 0, nn = 0, nf = 0;
+    row* lim = rows; row* nor = rows + 24; row* fr = rows + 36;
+    int nor_foot[12];    /* foot index of a normal row, -1 for the other links' support points */
+    int nor_contact[12]; /* contact-list entry that receives the row's force */
+    e->n_contacts = 0;
     /* joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint) */
     for (int j = 0; j < NJ; j++) {
         real lo = QSO_JOINT_LO[j % 3], hi = QSO_JOINT_HI[j % 3];
@@ -315,54 +442,62 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             r->lo = 0; r->hi = 1e10; r->fric_of = -1;
         }
     }
-    /* foot contacts */
+    /* contacts, leg by leg: the foot, then (cfg->body_contacts) up to two more support points of the leg -- the lowest of
+       {the trunk corner on the leg's side, hip housing, the two ends of the thigh box, knee end of the calf box} within contact range */
     for (int L = 0; L < 4; L++) {
-        int ic = 3 + 3 * L;
+        int ih = 1 + 3 * L, it = ih + 1, ic = ih + 2;
         real c3[3]; m3v(C.Rw[ic], FOOT_OFF, c3);
         real centre[3] = {C.ow[ic][0] + c3[0], C.ow[ic][1] + c3[1], C.ow[ic][2] + c3[2]};
         real dist = centre[2] - FOOT_R;
         e->foot_contact[L] = 0; e->foot_force[L] = 0;
-        if (!(dist < THR_FOOT)) { e->warm[L] = 0; continue; }
-        e->foot_contact[L] = 1;
-        real p[3] = {centre[0], centre[1], centre[2] - FOOT_R}; /* contact point on the sphere */
-        /* directions: normal +z; friction t1 = (0,-1,0), t2 = (1,0,0) (btPlaneSpace1 of +z) */
-        static const real dirs[3][3] = {{0, 0, 1}, {0, -1, 0}, {1, 0, 0}};
-        for (int rr = 0; rr < 3; rr++) {
-            row* r = rr == 0 ? &nor[nn] : &fr[nf + rr - 1];
-            memset(r, 0, sizeof(*r));
-            const real* d = dirs[rr];
-            real rb[3], pw[3] = {p[0] - s->pos[0], p[1] - s->pos[1], p[2] - s->pos[2]};
-            m3tv(C.R0, pw, rb);
-            real db[3]; m3tv(C.R0, d, db);
-            real ang[3]; v3cross(rb, db, ang);
-            for (int k = 0; k < 3; k++) { r->J[k] = ang[k]; r->J[3 + k] = db[k]; }
-            for (int j = 0; j < 3; j++) {
-                int b = 1 + 3 * L + j;
-                real ax[3] = {C.Rw[b][0][M->jaxis[b]], C.Rw[b][1][M->jaxis[b]], C.Rw[b][2][M->jaxis[b]]};
-                real rp[3] = {p[0] - C.ow[b][0], p[1] - C.ow[b][1], p[2] - C.ow[b][2]};
-                real t[3]; v3cross(ax, rp, t);
-                r->J[6 + 3 * L + j] = v3dot(d, t);
-            }
-            minv_apply(M, &C, r->J, r->W);
-            real dd = 0; for (int k = 0; k < NV; k++) dd += r->J[k] * r->W[k];
-            r->dinv = 1 / dd;
-            real rel = 0; for (int k = 0; k < NV; k++) rel += r->J[k] * v[k];
-            if (rr == 0) {
-                real pos_err = 0, vel_err = -rel;
-                if (dist > 0) vel_err -= dist / dt; else pos_err = -dist * cfg->contact_erp / dt;
-                r->rhs = (pos_err + vel_err) * r->dinv;
-                r->lo = 0; r->hi = 1e10; r->fric_of = -1;
-                r->lam = e->warm[L] * cfg->warmstart;
-            } else {
-                r->rhs = -rel * r->dinv;
-                r->fric_of = nn; r->mu = e->mu;
-            }
+        if (!(dist < THR_FOOT)) e->warm[L] = 0;
+        else {
+            e->foot_contact[L] = 1;
+            real p[3] = {centre[0], centre[1], centre[2] - FOOT_R}; /* contact point on the sphere */
+            contact_rows(cfg, M, &C, s, v, e->mu, ic, p, dist, e->warm[L], &nor[nn], &fr[nf], &fr[nf + 1], nn);
+            nor_foot[nn] = L; nor_contact[nn] = e->n_contacts;
+            push_contact(e, 1, 0, 5 + 4 * L, -1, dist);
+            nn++; nf += 2;
         }
-        nor_foot[nn] = L;
-        nn++; nf += 2;
+        if (!cfg->body_contacts) continue;
+        real fx = (L < 2) ? 1 : -1, sy = (L & 1) ? 1 : -1;
+        real cand[5][3], ch[5]; int cbody[5] = {0, ih, it, it, ic}, clink[5] = {0, 2 + 4 * L, 3 + 4 * L, 3 + 4 * L, 4 + 4 * L};
+        real cthr[5] = {THR_TRUNK, THR_HIP, THR_THIGH, THR_THIGH, THR_CALF};
+        {   /* 0: trunk corner */
+            real zsign = C.R0[2][2] < 0 ? 1 : -1;   /* the vertex on the side the plane normal points away from */
+            real pb[3] = {fx * TRUNK_HALF[0], sy * TRUNK_HALF[1], zsign * TRUNK_HALF[2]}, pw[3];
+            m3v(C.R0, pb, pw);
+            for (int k = 0; k < 3; k++) cand[0][k] = s->pos[k] + pw[k];
+        }
+        {   /* 1: hip cylinder (axis = link y), lowest point of its rim */
+            real a[3] = {C.Rw[ih][0][1], C.Rw[ih][1][1], C.Rw[ih][2][1]};
+            real az = a[2], s2 = 1 - az * az; if (s2 < (real)1e-12) s2 = (real)1e-12;
+            real sg = az < 0 ? -1 : 1, inv = HIP_CYL_R / sqrt(s2);
+            for (int k = 0; k < 3; k++) cand[1][k] = C.ow[ih][k] - sg * HIP_CYL_H * a[k] - ((k == 2 ? 1 : 0) - az * a[k]) * inv;
+        }
+        {   /* 2, 3: lowest vertex of the thigh box at its hip end and at its knee end; 4: of the calf box at its knee end */
+            real X[3] = {C.Rw[it][0][0], C.Rw[it][1][0], C.Rw[it][2][0]}, Y[3] = {C.Rw[it][0][1], C.Rw[it][1][1], C.Rw[it][2][1]};
+            real sx = X[2] < 0 ? -1 : 1, sgy = Y[2] < 0 ? -1 : 1;
+            for (int k = 0; k < 3; k++) {
+                real off = sx * THIGH_HALF[0] * X[k] + sgy * THIGH_HALF[1] * Y[k];
+                cand[2][k] = C.ow[it][k] - off; cand[3][k] = C.ow[ic][k] - off;
+            }
+            real X3[3] = {C.Rw[ic][0][0], C.Rw[ic][1][0], C.Rw[ic][2][0]};
+            real s3 = X3[2] < 0 ? -1 : 1;
+            for (int k = 0; k < 3; k++) cand[4][k] = C.ow[ic][k] - s3 * CALF_HALF[0] * X3[k] - sgy * CALF_HALF[1] * Y[k];
+        }
+        for (int i = 0; i < 5; i++) ch[i] = cand[i][2] < cthr[i] ? cand[i][2] : (real)1e9;
+        for (int slot = 0; slot < 2; slot++) {
+            int bi = 0;
+            for (int i = 1; i < 5; i++) if (ch[i] < ch[bi]) bi = i;
+            if (!(ch[bi] < (real)1e8)) break;
+            contact_rows(cfg, M, &C, s, v, e->mu, cbody[bi], cand[bi], ch[bi], 0, &nor[nn], &fr[nf], &fr[nf + 1], nn);
+            nor_foot[nn] = -1; nor_contact[nn] = -1 - clink[bi];
+            ch[bi] = (real)1e9;
+            nn++; nf += 2;
+        }
     }
-    e->n_invalid = count_invalid(&C);
-
+    e->n_invalid = collect_invalid(cfg, e, &C, s);
     /* ---- projected Gauss-Seidel in velocity space (btMultiBodyConstraintSolver::solveSingleIteration order) ---- */
     real dv[NV]; memset(dv, 0, sizeof(dv));
     for (int i = 0; i < nn; i++)
@@ -414,8 +549,14 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
         if (maxres2 <= (real)cfg->solver_residual_threshold) break;
     }
     for (int i = 0; i < nn; i++) {
-        e->foot_force[nor_foot[i]] = nor[i].lam / dt;
-        e->warm[nor_foot[i]] = nor[i].lam;
+        if (nor_foot[i] >= 0) {
+            e->foot_force[nor_foot[i]] = nor[i].lam / dt;
+            e->warm[nor_foot[i]] = nor[i].lam;
+            e->contacts[nor_contact[i]].force = nor[i].lam / dt;
+        } else {   /* support point of another link: its force goes to that link's entry of the contact list */
+            for (int c = 0; c < e->n_contacts; c++)
+                if (e->contacts[c].body_a == 1 && e->contacts[c].body_b == 0 && e->contacts[c].link_a == -1 - nor_contact[i]) { e->contacts[c].force += nor[i].lam / dt; break; }
+        }
     }
     /* apply constraint impulses, clamp, integrate positions */
     {
@@ -514,6 +655,22 @@ int qso_phys_step(qso_handle* h, int env, const real* tau) {
     return 0;
 }
 int qso_phys_set_gravity(qso_handle* h, real g) { h->gravity = g; return 0; }
+int qso_get_contacts(qso_handle* h, int env, int32_t* ids /*[max][4]*/, real* dist_force /*[max][2]*/, int max) {
+    const qso_env* e = &h->env[env];
+    int n = e->n_contacts < max ? e->n_contacts : max;
+    for (int i = 0; i < n; i++) {
+        ids[4 * i] = e->contacts[i].body_a; ids[4 * i + 1] = e->contacts[i].body_b; ids[4 * i + 2] = e->contacts[i].link_a; ids[4 * i + 3] = e->contacts[i].link_b;
+        dist_force[2 * i] = e->contacts[i].dist; dist_force[2 * i + 1] = e->contacts[i].force;
+    }
+    return e->n_contacts;
+}
+/* geometry hooks for the known-answer tests: box / box overlap by edge clipping, sphere / box distance */
+int qso_geom_boxes_overlap(const real* ca, const real* Ra /*row-major, columns = axes*/, const real* ha, const real* cb, const real* Rb, const real* hb) {
+    obox A, B;
+    memcpy(A.c, ca, sizeof(A.c)); memcpy(A.R, Ra, sizeof(A.R)); memcpy(A.h, ha, sizeof(A.h));
+    memcpy(B.c, cb, sizeof(B.c)); memcpy(B.R, Rb, sizeof(B.R)); memcpy(B.h, hb, sizeof(B.h));
+    return boxes_overlap(&A, &B);
+}
 
 int qso_phys_energy(qso_handle* h, int env, real* out) {
     const qso_model* M = &h->env[env].model; const qso_dyn* s = &h->env[env].s;

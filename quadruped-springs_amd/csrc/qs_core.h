@@ -76,6 +76,8 @@ constexpr float TRUNK_HALF[3] = {0.1881f, 0.04675f, 0.057f};                    
 constexpr float HIP_CYL_HALF_LEN = 0.02f, HIP_CYL_R = 0.046f;                              // cylinder :128-131
 constexpr float LINK_BOX_Z = -0.1065f, THIGH_HALF[3] = {0.017f, 0.01225f, 0.1065f}, CALF_HALF[3] = {0.008f, 0.008f, 0.1065f};
 constexpr float PAYLOAD_I = 0.1f * 0.1f / 6.0f;                                            // cube of half extent 0.05, quadruped.py:793
+constexpr float PAYLOAD_HALF = 0.05f, THR_PAYLOAD = 0.00173f;                              // its box against the plane (0.02 x |half extents|)
+constexpr float HIP_SELF_R = 0.046f;   // link-link tests treat the hip's motor housing (cylinder r 0.046, half length 0.02) as a sphere
 }  // namespace go1
 
 // ------------------------------------------------------------------ small linear algebra on lane values
@@ -231,6 +233,7 @@ template <class T, bool CONE = false> struct Sim {
         V m_leg[3];
         SI<V> I0;                                   // base + trunk + imu (+ payload) about the base origin
         V mtot;
+        V m_pay; V3v r_pay;                         // payload block (quadruped.py:778-819): its box can touch the ground
     };
     struct Model {          // link constants of the own leg (mirror signs, mass scaling), rebuilt inside every substep
         V m_hip, m_thigh, m_calf;
@@ -240,12 +243,13 @@ template <class T, bool CONE = false> struct Sim {
         V tau_pd[3], tau_spring[3], foot_force, foot_contact, n_invalid;
     };
 
-    // per-env model from the randomizable masses (env_randomizer.py:56-83); link inertias scale with link mass
-    static QS_FN void build_base(Par& P, V m_trunk, V m_pay, V3v r_pay) {
+    // per-env model from the randomizable masses (env_randomizer.py:56-83); a link of mass m has the inertia m x cfg.unit_inertia
+    // (the host picks the rule: URDF tensor scaled with the mass, or Bullet's collision-shape inertia; qs_amd/config.py)
+    static QS_FN void build_base(const qs_config& cfg, Par& P, V m_trunk, V m_pay, V3v r_pay) {
         using namespace go1;
-        V st = m_trunk * (1.0f / TRUNK_M);
+        const float* U = cfg.unit_inertia[3];
         SI<V> I0 = point_inertia<V>(V(BASE_M), V(BASE_I), mk3<V>(V(0.0f), V(0.0f), V(0.0f)));
-        S3<V> It; It.xx = st * TRUNK_I[0]; It.xy = st * TRUNK_I[1]; It.xz = st * TRUNK_I[2]; It.yy = st * TRUNK_I[3]; It.yz = st * TRUNK_I[4]; It.zz = st * TRUNK_I[5];
+        S3<V> It; It.xx = m_trunk * U[0]; It.xy = m_trunk * U[1]; It.xz = m_trunk * U[2]; It.yy = m_trunk * U[3]; It.yz = m_trunk * U[4]; It.zz = m_trunk * U[5];
         V3v ex = mk3<V>(V(1.0f), V(0.0f), V(0.0f)), ey = mk3<V>(V(0.0f), V(1.0f), V(0.0f)), ez = mk3<V>(V(0.0f), V(0.0f), V(1.0f));
         V3v zero = mk3<V>(V(0.0f), V(0.0f), V(0.0f));
         I0 = I0 + part_inertia<V>(m_trunk, mk3<V>(V(TRUNK_CX), V(0.0f), V(TRUNK_CZ)), It, zero, ex, ey, ez);
@@ -253,20 +257,22 @@ template <class T, bool CONE = false> struct Sim {
         I0 = I0 + point_inertia<V>(m_pay, m_pay * PAYLOAD_I, r_pay);
         P.I0 = I0;
         P.mtot = I0.m + 4.0f * (P.m_leg[0] + P.m_leg[1] + P.m_leg[2] + FOOT_M);
+        P.m_pay = m_pay; P.r_pay = r_pay;
     }
-    static QS_FN void build_model(Model& P, const V* m_leg) {
+    static QS_FN void build_model(const qs_config& cfg, Model& P, const V* m_leg) {
         using namespace go1;
         V fx = T::fx(), sy = T::sy();
-        V s1 = m_leg[0] * (1.0f / HIP_M), s2 = m_leg[1] * (1.0f / THIGH_M), s3 = m_leg[2] * (1.0f / CALF_M);
+        const float* H = cfg.unit_inertia[0]; const float* Th = cfg.unit_inertia[1]; const float* Cf = cfg.unit_inertia[2];
+        V s1 = m_leg[0], s2 = m_leg[1], s3 = m_leg[2];
         P.m_hip = m_leg[0]; P.m_thigh = m_leg[1]; P.m_calf = m_leg[2];
         P.c_hip = mk3<V>(fx * (-HIP_C[0]), sy * (-HIP_C[1]), V(HIP_C[2]));
-        P.I_hip.xx = s1 * HIP_I[0]; P.I_hip.xy = s1 * (fx * sy) * HIP_I[1]; P.I_hip.xz = s1 * fx * (-HIP_I[2]);
-        P.I_hip.yy = s1 * HIP_I[3]; P.I_hip.yz = s1 * sy * (-HIP_I[4]); P.I_hip.zz = s1 * HIP_I[5];
+        P.I_hip.xx = s1 * H[0]; P.I_hip.xy = s1 * (fx * sy) * H[1]; P.I_hip.xz = s1 * fx * (-H[2]);
+        P.I_hip.yy = s1 * H[3]; P.I_hip.yz = s1 * sy * (-H[4]); P.I_hip.zz = s1 * H[5];
         P.c_thigh = mk3<V>(V(THIGH_C[0]), sy * (-THIGH_C[1]), V(THIGH_C[2]));
-        P.I_thigh.xx = s2 * THIGH_I[0]; P.I_thigh.xy = s2 * sy * THIGH_I[1]; P.I_thigh.xz = s2 * THIGH_I[2];
-        P.I_thigh.yy = s2 * THIGH_I[3]; P.I_thigh.yz = s2 * sy * THIGH_I[4]; P.I_thigh.zz = s2 * THIGH_I[5];
-        P.I_calf.xx = s3 * CALF_I[0]; P.I_calf.xy = s3 * CALF_I[1]; P.I_calf.xz = s3 * CALF_I[2];
-        P.I_calf.yy = s3 * CALF_I[3]; P.I_calf.yz = s3 * CALF_I[4]; P.I_calf.zz = s3 * CALF_I[5];
+        P.I_thigh.xx = s2 * Th[0]; P.I_thigh.xy = s2 * sy * Th[1]; P.I_thigh.xz = s2 * Th[2];
+        P.I_thigh.yy = s2 * Th[3]; P.I_thigh.yz = s2 * sy * Th[4]; P.I_thigh.zz = s2 * Th[5];
+        P.I_calf.xx = s3 * Cf[0]; P.I_calf.xy = s3 * Cf[1]; P.I_calf.xz = s3 * Cf[2];
+        P.I_calf.yy = s3 * Cf[3]; P.I_calf.yz = s3 * Cf[4]; P.I_calf.zz = s3 * Cf[5];
     }
 
     // PD law + torque clip (quadruped_motor.py:45-99) and unilateral PEA (quadruped_motor.py:101-104, springs.py:34-74)
@@ -462,106 +468,116 @@ template <class T, bool CONE = false> struct Sim {
         s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
     }
 
-    // The joint-limit path (6 rows per leg: contact rows + one row per violated limit) is rare (falls).  It is written
-    // with its 24 x 6 Delassus block and row data in private (scratch) memory instead of ~300 extra registers: the common path
-    // then needs no spills at all, and the scratch traffic exists only in waves that actually take this branch.  Same arithmetic
-    // as solve_and_integrate<3>.
-    struct RareArgs { Row rows[6]; V Sm[21], Ld[6], BK[3][6], R[9]; };
-    static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs& a) {
+    // The rare path: rows beyond the three foot-contact rows of a leg -- one row per violated joint limit (falls) and, with NCP = 3,
+    // normal + friction rows of up to two more support points of the leg (trunk corner, hip housing, thigh ends, knee end of the calf:
+    // a fallen robot rests on them).  It is written with its (4 NRW) x NRW Delassus block and row data in private (scratch) memory
+    // instead of hundreds of extra registers: the common path then needs no spills at all, and the scratch traffic exists only in waves
+    // that actually take this branch.  Same arithmetic as solve_and_integrate<3>.  Row layout of a leg: contact point c = 0 .. NCP-1
+    // (0 = the foot) at rows 3c (normal), 3c + 1, 3c + 2 (friction), joint limits at rows 3 NCP + j.
+    template <int NCP> struct RareArgs { Row rows[3 * NCP + 3]; V Sm[21], Ld[6], BK[3][6], R[9]; };
+    template <int NCP> static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs<NCP>& a) {
+        constexpr int NRW = 3 * NCP + 3, LIM = 3 * NCP;
         const float dt = (float)cfg.dt;
         const V zero = V(0.0f), big = V(1e10f);
-        // Everything that is indexed below goes through a runtime zero, so the 24 x 6 Delassus block and the row data live in
+        // Everything that is indexed below goes through a runtime zero, so the Delassus block and the row data live in
         // private memory and are fetched row by row with constant offsets; the loops are unrolled, the impulses and residuals of
-        // the own six rows stay in registers and every broadcast is a DPP quad_perm.
+        // the own rows stay in registers and every broadcast is a DPP quad_perm.
         const int z0 = T::opaque_zero();
         const Row* rows = a.rows + z0;
-        V Ap[24 * 6], wcs[6 * 6];
+        V Ap[4 * NRW * NRW], wcs[NRW * 6];
         V* ApB = Ap + z0; V* wc = wcs + z0;
 #pragma clang loop unroll(disable)
-        for (int c = 0; c < 6; c++) {
+        for (int c = 0; c < NRW; c++) {
             V di = rows[c].dinv;
 #pragma unroll
             for (int i = 0; i < 6; i++) wc[6 * c + i] = rows[c].w[i] * di;
         }
         const V own0 = qflag(T::is_leg(0)), own1 = qflag(T::is_leg(1)), own2 = qflag(T::is_leg(2)), own3 = qflag(T::is_leg(3));
-        // the 36 (row kind, column kind) blocks: rolled, six MFMAs each (built once per substep; only the sweeps below are unrolled)
+        // the NRW^2 (row kind, column kind) blocks: rolled, six MFMAs each (built once per substep; only the sweeps below are unrolled)
 #pragma clang loop unroll(disable)
-        for (int r = 0; r < 6; r++) {
+        for (int r = 0; r < NRW; r++) {
             V wr[6], jr[3];
 #pragma unroll
             for (int i = 0; i < 6; i++) wr[i] = rows[r].w[i];
 #pragma unroll
             for (int j = 0; j < 3; j++) jr[j] = rows[r].jq[j];
 #pragma clang loop unroll(disable)
-            for (int c = 0; c < 6; c++) {
+            for (int c = 0; c < NRW; c++) {
                 typename T::Acc4 acc = T::acc4_zero();
 #pragma unroll
                 for (int i = 0; i < 6; i++) T::outer_fma(wr[i], wc[6 * c + i], acc);
                 V locs = (jr[0] * rows[c].u[0] + jr[1] * rows[c].u[1] + jr[2] * rows[c].u[2]) * rows[c].dinv;
-                ApB[(6 * 0 + r) * 6 + c] = T::template acc4_get<0>(acc) + own0 * locs;
-                ApB[(6 * 1 + r) * 6 + c] = T::template acc4_get<1>(acc) + own1 * locs;
-                ApB[(6 * 2 + r) * 6 + c] = T::template acc4_get<2>(acc) + own2 * locs;
-                ApB[(6 * 3 + r) * 6 + c] = T::template acc4_get<3>(acc) + own3 * locs;
+                ApB[(NRW * 0 + r) * NRW + c] = T::template acc4_get<0>(acc) + own0 * locs;
+                ApB[(NRW * 1 + r) * NRW + c] = T::template acc4_get<1>(acc) + own1 * locs;
+                ApB[(NRW * 2 + r) * NRW + c] = T::template acc4_get<2>(acc) + own2 * locs;
+                ApB[(NRW * 3 + r) * NRW + c] = T::template acc4_get<3>(acc) + own3 * locs;
             }
         }
-        V lam[6], res[6];
+        V lam[NRW], res[NRW];
 #pragma unroll
-        for (int r = 0; r < 6; r++) { lam[r] = zero; res[r] = rows[r].rhs; }
+        for (int r = 0; r < NRW; r++) { lam[r] = zero; res[r] = rows[r].rhs; }
         lam[0] = s.warm * cfg.warmstart * rows[0].act;
 #define QS_RWARM(K)                                                                                                    \
     {                                                                                                                  \
         V lk = T::template bcast<K>(lam[0]);                                                                           \
-        _Pragma("unroll") for (int c = 0; c < 6; c++) res[c] = res[c] - ApB[(6 * (K)) * 6 + c] * lk;                   \
+        _Pragma("unroll") for (int c = 0; c < NRW; c++) res[c] = res[c] - ApB[(NRW * (K)) * NRW + c] * lk;             \
     }
         QS_RWARM(0) QS_RWARM(1) QS_RWARM(2) QS_RWARM(3)
 #undef QS_RWARM
         const bool track = cfg.solver_residual_threshold > 0.0f;
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
-        // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the own normal impulse
-#define QS_RROW(K, R, KIND)                                                                                            \
+        // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the normal impulse
+        // of its contact point (row N0 of the same leg)
+#define QS_RROW(K, R, KIND, N0)                                                                                        \
     {                                                                                                                  \
         V cand = lam[R] + res[R];                                                                                      \
         if (KIND == 0) cand = qmin(qmax(cand, zero), big);                                                             \
-        else { V tot = lam[0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[R]); }   \
+        else { V tot = lam[N0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[R]); }  \
         V dk = T::template bcast<K>(cand - lam[R]);                                                                    \
         lam[R] = qsel(T::is_leg(K), cand, lam[R]);                                                                     \
-        _Pragma("unroll") for (int c = 0; c < 6; c++) res[c] = res[c] - ApB[(6 * (K) + (R)) * 6 + c] * dk;             \
+        _Pragma("unroll") for (int c = 0; c < NRW; c++) res[c] = res[c] - ApB[(NRW * (K) + (R)) * NRW + c] * dk;       \
         if (track) dvmax = qmax(dvmax, qabs(dk * T::template bcast<K>(rows[R].diag)));                                 \
     }
-        // implicit cone friction: both friction rows of foot K together (see solve_and_integrate)
-#define QS_RPAIR(K)                                                                                                    \
+        // implicit cone friction: both friction rows of a contact point of leg K together (see solve_and_integrate)
+#define QS_RPAIR(K, N0)                                                                                                \
     {                                                                                                                  \
-        V ca = lam[1] + res[1], cb = lam[2] + res[2], lim = mu * lam[0];                                               \
+        V ca = lam[(N0) + 1] + res[(N0) + 1], cb = lam[(N0) + 2] + res[(N0) + 2], lim = mu * lam[N0];                  \
         V r2 = ca * ca + cb * cb;                                                                                      \
         V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));                                                       \
         ca = ca * sc; cb = cb * sc;                                                                                    \
-        V da = T::template bcast<K>(ca - lam[1]), db = T::template bcast<K>(cb - lam[2]);                              \
-        lam[1] = qsel(T::is_leg(K), ca, lam[1]); lam[2] = qsel(T::is_leg(K), cb, lam[2]);                              \
-        _Pragma("unroll") for (int c = 0; c < 6; c++)                                                                  \
-            res[c] = res[c] - (ApB[(6 * (K) + 1) * 6 + c] * da + ApB[(6 * (K) + 2) * 6 + c] * db);                      \
-        if (track) dvmax = qmax(dvmax, qmax(qabs(da * T::template bcast<K>(rows[1].diag)), qabs(db * T::template bcast<K>(rows[2].diag)))); \
+        V da = T::template bcast<K>(ca - lam[(N0) + 1]), db = T::template bcast<K>(cb - lam[(N0) + 2]);                \
+        lam[(N0) + 1] = qsel(T::is_leg(K), ca, lam[(N0) + 1]); lam[(N0) + 2] = qsel(T::is_leg(K), cb, lam[(N0) + 2]);  \
+        _Pragma("unroll") for (int c = 0; c < NRW; c++)                                                                \
+            res[c] = res[c] - (ApB[(NRW * (K) + (N0) + 1) * NRW + c] * da + ApB[(NRW * (K) + (N0) + 2) * NRW + c] * db); \
+        if (track) dvmax = qmax(dvmax, qmax(qabs(da * T::template bcast<K>(rows[(N0) + 1].diag)), qabs(db * T::template bcast<K>(rows[(N0) + 2].diag)))); \
     }
-#define QS_RLEG_FWD(K) QS_RROW(K, 3, 0) QS_RROW(K, 4, 0) QS_RROW(K, 5, 0) T::sched_fence();
-#define QS_RLEG_BWD(K) QS_RROW(K, 5, 0) QS_RROW(K, 4, 0) QS_RROW(K, 3, 0) T::sched_fence();
+#define QS_RLEG_FWD(K) QS_RROW(K, LIM + 0, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 2, 0, 0) T::sched_fence();
+#define QS_RLEG_BWD(K) QS_RROW(K, LIM + 2, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 0, 0, 0) T::sched_fence();
+#define QS_RNORMALS(K) { QS_RROW(K, 0, 0, 0) if constexpr (NCP == 3) { QS_RROW(K, 3, 0, 3) QS_RROW(K, 6, 0, 6) } T::sched_fence(); }
+#define QS_RFRICTION(K)                                                                                               \
+    {                                                                                                                  \
+        if (CONE) { QS_RPAIR(K, 0) T::sched_fence(); if constexpr (NCP == 3) { QS_RPAIR(K, 3) T::sched_fence(); QS_RPAIR(K, 6) T::sched_fence(); } } \
+        else {                                                                                                         \
+            QS_RROW(K, 1, 1, 0) QS_RROW(K, 2, 1, 0) T::sched_fence();                                                  \
+            if constexpr (NCP == 3) { QS_RROW(K, 4, 1, 3) QS_RROW(K, 5, 1, 3) T::sched_fence(); QS_RROW(K, 7, 1, 6) QS_RROW(K, 8, 1, 6) T::sched_fence(); } \
+        }                                                                                                              \
+    }
         for (int it = 0; it < cfg.solver_iters; it++) {
             V dvmax = zero;
-            // 24 row updates per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), 4 normals, 8 frictions
+            // per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), the normal rows (leg by leg, foot first), the friction rows
             if (it & 1) { QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3) }
             else { QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0) }
-            QS_RROW(0, 0, 0) QS_RROW(1, 0, 0) T::sched_fence(); QS_RROW(2, 0, 0) QS_RROW(3, 0, 0) T::sched_fence();
-            if (CONE) {
-                QS_RPAIR(0) T::sched_fence(); QS_RPAIR(1) T::sched_fence(); QS_RPAIR(2) T::sched_fence(); QS_RPAIR(3) T::sched_fence();
-            } else {
-                QS_RROW(0, 1, 1) QS_RROW(0, 2, 1) T::sched_fence(); QS_RROW(1, 1, 1) QS_RROW(1, 2, 1) T::sched_fence();
-                QS_RROW(2, 1, 1) QS_RROW(2, 2, 1) T::sched_fence(); QS_RROW(3, 1, 1) QS_RROW(3, 2, 1) T::sched_fence();
-            }
+            QS_RNORMALS(0) QS_RNORMALS(1) QS_RNORMALS(2) QS_RNORMALS(3)
+            QS_RFRICTION(0) QS_RFRICTION(1) QS_RFRICTION(2) QS_RFRICTION(3)
             if (track) {
                 M conv = qle(dvmax, thr);
 #pragma unroll
-                for (int c = 0; c < 6; c++) res[c] = qsel(conv, zero, res[c]);
+                for (int c = 0; c < NRW; c++) res[c] = qsel(conv, zero, res[c]);
                 if (!T::any(qnot(conv))) break;
             }
         }
+#undef QS_RFRICTION
+#undef QS_RNORMALS
 #undef QS_RLEG_FWD
 #undef QS_RLEG_BWD
 #undef QS_RPAIR
@@ -573,7 +589,7 @@ template <class T, bool CONE = false> struct Sim {
         for (int i = 0; i < 6; i++) {
             V t = zero;
 #pragma unroll
-            for (int r = 0; r < 6; r++) t = t + rows[r].w[i] * lam[r];
+            for (int r = 0; r < NRW; r++) t = t + rows[r].w[i] * lam[r];
             z[i] = T::quad_sum(t);
         }
         ltsolve6<V>(a.Sm, a.Ld, z);
@@ -582,7 +598,7 @@ template <class T, bool CONE = false> struct Sim {
         for (int j = 0; j < 3; j++) {
             V t = zero;
 #pragma unroll
-            for (int r = 0; r < 6; r++) t = t + rows[r].u[j] * lam[r];
+            for (int r = 0; r < NRW; r++) t = t + rows[r].u[j] * lam[r];
 #pragma unroll
             for (int i = 0; i < 6; i++) t = t - a.BK[j][i] * z[i];
             s.qd[j] = clampv<V>(s.qd[j] + t, -cap, cap);
@@ -596,6 +612,72 @@ template <class T, bool CONE = false> struct Sim {
         s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
     }
 
+    // ---- link-link tests of the self-collision rule (rare path)
+    // Do two boxes (centre, orthonormal axes, half extents) overlap?  Separating-axis test over the 15 candidate axes -- what Bullet's
+    // btBoxBoxDetector (dBoxBox2) decides the contact of a box / box pair by (no contact while any axis separates).
+    struct H3 { float v[3]; QS_FN float operator[](int i) const { return v[i]; } };
+    static QS_FN M obb_overlap(V3v ca, V3v a0, V3v a1, V3v a2, H3 ha, V3v cb, V3v b0, V3v b1, V3v b2, H3 hb) {
+        V3v t0 = cb - ca;
+        V3v A[3] = {a0, a1, a2}, B[3] = {b0, b1, b2};
+        V t[3] = {dot(t0, a0), dot(t0, a1), dot(t0, a2)};
+        V R[3][3], AR[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) { R[i][j] = dot(A[i], B[j]); AR[i][j] = qabs(R[i][j]) + 1e-6f; }
+        M sep = qlt(V(1.0f), V(0.0f));
+#pragma unroll
+        for (int i = 0; i < 3; i++) sep = qor(sep, qgt(qabs(t[i]), V(ha[i]) + (AR[i][0] * hb[0] + AR[i][1] * hb[1] + AR[i][2] * hb[2])));
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            sep = qor(sep, qgt(qabs(t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j]), (AR[0][j] * ha[0] + AR[1][j] * ha[1] + AR[2][j] * ha[2]) + hb[j]));
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+                V ra = AR[i2][j] * ha[i1] + AR[i1][j] * ha[i2], rb = AR[i][j2] * hb[j1] + AR[i][j1] * hb[j2];
+                sep = qor(sep, qgt(qabs(t[i2] * R[i1][j] - t[i1] * R[i2][j]), ra + rb));
+            }
+        return qnot(sep);
+    }
+    // distance from a sphere's surface to a box (negative inside)
+    static QS_FN V sphere_box_dist(V3v c, float r, V3v cb, V3v b0, V3v b1, V3v b2, H3 hb) {
+        V3v d = c - cb;
+        V l0 = dot(d, b0), l1 = dot(d, b1), l2 = dot(d, b2);
+        V e0 = l0 - clampv<V>(l0, V(-hb[0]), V(hb[0])), e1 = l1 - clampv<V>(l1, V(-hb[1]), V(hb[1])), e2 = l2 - clampv<V>(l2, V(-hb[2]), V(hb[2]));
+        return qsqrt(e0 * e0 + e1 * e1 + e2 * e2) - r;
+    }
+    struct LegGeom { V3v p1, ct, X2, Y, Z2, cc, X3, Z3, rf; };   // hip centre; thigh box; calf box; foot centre (base coordinates)
+    template <int K> static QS_FN LegGeom partner(const LegGeom& g) {
+        LegGeom r;
+#define QS_X3(f) r.f = mk3<V>(T::template xorl<K>(g.f.x), T::template xorl<K>(g.f.y), T::template xorl<K>(g.f.z));
+        QS_X3(p1) QS_X3(ct) QS_X3(X2) QS_X3(Y) QS_X3(Z2) QS_X3(cc) QS_X3(X3) QS_X3(Z3) QS_X3(rf)
+#undef QS_X3
+        return r;
+    }
+    // contacts of the own calf with the links of leg (own ^ K): thigh and calf boxes, hip housing and foot as spheres; a calf / calf pair
+    // is seen from both of its lanes and counts one half in each
+    template <int K> static QS_FN V calf_vs_leg(const LegGeom& g) {
+        using namespace go1;
+        const LegGeom p = partner<K>(g);
+        const H3 CALF_H = {{CALF_HALF[0], CALF_HALF[1], CALF_HALF[2]}}, THIGH_H = {{THIGH_HALF[0], THIGH_HALF[1], THIGH_HALF[2]}};
+        V n = qflag(obb_overlap(g.cc, g.X3, g.Y, g.Z3, CALF_H, p.ct, p.X2, p.Y, p.Z2, THIGH_H));
+        n = n + qflag(obb_overlap(g.cc, g.X3, g.Y, g.Z3, CALF_H, p.cc, p.X3, p.Y, p.Z3, CALF_H)) * 0.5f;
+        n = n + qflag(qlt(sphere_box_dist(p.p1, HIP_SELF_R, g.cc, g.X3, g.Y, g.Z3, CALF_H), V(THR_HIP)));
+        n = n + qflag(qlt(sphere_box_dist(p.rf, FOOT_R, g.cc, g.X3, g.Y, g.Z3, CALF_H), V(THR_FOOT)));
+        return n;
+    }
+    // number of link-link contacts that involve a calf (quadruped.py:237-241), own-lane share; c1..c3, ct: broad-phase flags
+    static QS_FN V self_contacts(const LegGeom& g, V c1, V c2, V c3, V ctr) {
+        using namespace go1;
+        V n = calf_vs_leg<1>(g) * c1 + calf_vs_leg<2>(g) * c2 + calf_vs_leg<3>(g) * c3;
+        V3v o = mk3<V>(V(0.0f), V(0.0f), V(0.0f)), ex = mk3<V>(V(1.0f), V(0.0f), V(0.0f)), ey = mk3<V>(V(0.0f), V(1.0f), V(0.0f)), ez = mk3<V>(V(0.0f), V(0.0f), V(1.0f));
+        const H3 CALF_H = {{CALF_HALF[0], CALF_HALF[1], CALF_HALF[2]}}, TRUNK_H = {{TRUNK_HALF[0], TRUNK_HALF[1], TRUNK_HALF[2]}};
+        n = n + qflag(obb_overlap(g.cc, g.X3, g.Y, g.Z3, CALF_H, o, ex, ey, ez, TRUNK_H)) * ctr;
+        return n;
+    }
+
     static QS_FN void substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o) {
         using namespace go1;
         Model P;
@@ -603,7 +685,7 @@ template <class T, bool CONE = false> struct Sim {
             // occupy registers for the whole env step); rebuilding them is ~40 multiplications per substep
             V ml[3] = {Pr.m_leg[0], Pr.m_leg[1], Pr.m_leg[2]};
             T::opaque(ml[0]); T::opaque(ml[1]); T::opaque(ml[2]);
-            build_model(P, ml);
+            build_model(cfg, P, ml);
         }
         QS_PHASE_BEGIN
         const float dt = (float)cfg.dt;
@@ -752,26 +834,51 @@ template <class T, bool CONE = false> struct Sim {
         vs.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
 
         QS_PHASE(7)
-        // ---- collision: foot sphere vs plane z = 0 ; other link primitives only flag invalid contacts (quadruped.py:243-249)
-        V dist = s.pos.z + dot(Rz, rf) - FOOT_R;
+        // ---- collision: foot sphere vs plane z = 0 ; the other link primitives (trunk box, hip cylinder, thigh and calf boxes, payload
+        // block) count as invalid contacts (quadruped.py:243-249) and, with cfg.body_contacts, push back on the rare path below
+        const V zc = s.pos.z;
+        const V grf = dot(Rz, rf);
+        V dist = zc + grf - FOOT_R;
         M act_m = qlt(dist, V(THR_FOOT));
         V active = qflag(act_m);
         o.foot_contact = active;
+        // height of the lowest vertex of each primitive (this lane: the trunk corner on its own side, its hip, the two ends of its
+        // thigh box, the two ends of its calf box)
+        const V az = dot(Rz, Y), gx2 = dot(Rz, X2), gx3 = dot(Rz, X3), gp2 = dot(Rz, p2), gp3 = dot(Rz, p3);
+        const V h_trunk = zc + Rz.x * (fx * TRUNK_HALF[0]) + Rz.y * (sy * TRUNK_HALF[1]) - qabs(Rz.z) * TRUNK_HALF[2];
+        const V h_hip = zc + dot(Rz, p1) - HIP_CYL_HALF_LEN * qabs(az) - HIP_CYL_R * qsqrt(qmax(one - az * az, zero));
+        const V th_off = qabs(gx2) * THIGH_HALF[0] + qabs(az) * THIGH_HALF[1], cf_off = (qabs(gx3) + qabs(az)) * CALF_HALF[0];
+        const V h_th_hi = zc + gp2 - th_off, h_th_lo = zc + gp3 - th_off, h_cf_hi = zc + gp3 - cf_off, h_cf_lo = zc + grf - cf_off;
+        M any_extra = qlt(one, zero);
         {
-            V zc = s.pos.z;
-            // trunk box: this lane tests the two corners on its own side
-            V tz = zc + Rz.x * (fx * TRUNK_HALF[0]) + Rz.y * (sy * TRUNK_HALF[1]) - qabs(Rz.z) * TRUNK_HALF[2];
-            V trunk = qflag(qgt(T::quad_sum(qflag(qlt(tz, V(THR_TRUNK)))), zero));
-            // hip cylinder, axis = link y
-            V az = dot(Rz, Y);
-            V hz = zc + dot(Rz, p1) - HIP_CYL_HALF_LEN * qabs(az) - HIP_CYL_R * qsqrt(qmax(one - az * az, zero));
-            V n = qflag(qlt(hz, V(THR_HIP)));
-            // thigh / calf boxes centred at (0,0,-0.1065) of their frames
-            V3v ct = p2 + Z2 * V(LINK_BOX_Z), cc = p3 + Z3 * V(LINK_BOX_Z);
-            V tzm = zc + dot(Rz, ct) - qabs(dot(Rz, X2)) * THIGH_HALF[0] - qabs(az) * THIGH_HALF[1] - qabs(dot(Rz, Z2)) * THIGH_HALF[2];
-            V czm = zc + dot(Rz, cc) - qabs(dot(Rz, X3)) * CALF_HALF[0] - qabs(az) * CALF_HALF[1] - qabs(dot(Rz, Z3)) * CALF_HALF[2];
-            n = n + qflag(qlt(tzm, V(THR_THIGH))) + qflag(qlt(czm, V(THR_CALF)));
-            o.n_invalid = T::quad_sum(n) + trunk;
+            M m_trunk = qlt(h_trunk, V(THR_TRUNK)), m_hip = qlt(h_hip, V(THR_HIP));
+            M m_thigh = qlt(qmin(h_th_hi, h_th_lo), V(THR_THIGH)), m_calf = qlt(qmin(h_cf_hi, h_cf_lo), V(THR_CALF));
+            V trunk = qflag(qgt(T::quad_sum(qflag(m_trunk)), zero));
+            V n = qflag(m_hip) + qflag(m_thigh) + qflag(m_calf);
+            // payload block (a second body in the reference, quadruped.py:778-819: a plane / block contact is an invalid one, :248-249)
+            V h_pay = zc + dot(Rz, Pr.r_pay) - (qabs(Rz.x) + qabs(Rz.y) + qabs(Rz.z)) * PAYLOAD_HALF;
+            V pay = qflag(qand(qgt(Pr.m_pay, zero), qlt(h_pay, V(THR_PAYLOAD))));
+            o.n_invalid = T::quad_sum(n) + trunk + pay;
+            if (cfg.body_contacts) any_extra = qor(qor(m_trunk, m_hip), qor(m_thigh, qlt(h_cf_hi, V(THR_CALF))));
+        }
+        if (cfg.self_collision) {
+            // Link-link contacts count only when a calf is involved (quadruped.py:237-241).  Broad phase, every substep: extents of
+            // the own calf and of the own whole leg towards the robot's centre planes, in mirrored coordinates (sy y: towards the own
+            // side, fx x: towards the own end); thigh within 0.021 of its axis, calf and foot within 0.02, hip housing within 0.046.
+            const float MARGIN = 0.005f;
+            V y2 = sy * p2.y, y3 = sy * p3.y, yf = sy * rf.y, x3 = fx * p3.x, xf = fx * rf.x;
+            V mc = qmin(y3, yf) - 0.02f, nc = qmin(x3, xf) - 0.02f;
+            V ml = qmin(qmin(qmin(y2, y3) - 0.021f, yf - 0.02f), V(HIP_Y - HIP_SELF_R));
+            V nl = qmin(qmin(x3 - 0.021f, xf - 0.02f), V(HIP_X - HIP_SELF_R));
+            M cy1 = qlt(mc + T::template xorl<1>(ml), V(MARGIN));                                   // other side, same end
+            M cx2 = qlt(nc + T::template xorl<2>(nl), V(MARGIN));                                   // same side, other end
+            M c3 = qand(qlt(mc + T::template xorl<3>(ml), V(MARGIN)), qlt(nc + T::template xorl<3>(nl), V(MARGIN)));   // diagonal
+            M ctr = qand(qand(qlt(mc, V(TRUNK_HALF[1] + MARGIN)), qgt(qmax(p3.z, rf.z) + 0.02f, V(-TRUNK_HALF[2] - MARGIN))), qlt(nc, V(TRUNK_HALF[0] + MARGIN)));
+            if (T::any(qor(qor(cy1, cx2), qor(c3, ctr)))) {
+                LegGeom lg;
+                lg.p1 = p1; lg.ct = p2 + Z2 * V(LINK_BOX_Z); lg.X2 = X2; lg.Y = Y; lg.Z2 = Z2; lg.cc = p3 + Z3 * V(LINK_BOX_Z); lg.X3 = X3; lg.Z3 = Z3; lg.rf = rf;
+                o.n_invalid = o.n_invalid + T::quad_sum(self_contacts(lg, qflag(cy1), qflag(cx2), qflag(c3), qflag(ctr)));
+            }
         }
 
         // joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint)
@@ -790,7 +897,7 @@ template <class T, bool CONE = false> struct Sim {
         // Nothing to solve when no foot of the wave's 16 environments is within contact range and no joint sits at a stop:
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
-        if (T::any(qor(act_m, any_lim))) {
+        if (T::any(qor(qor(act_m, any_lim), any_extra))) {
         QS_PHASE(8)
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
         Row rows[6];
@@ -800,74 +907,125 @@ template <class T, bool CONE = false> struct Sim {
         V3v d1 = rc - p1, d2 = rc - p2, d3 = rc - p3;
         V3v g1 = cross(ax1, d1), g2 = cross(Y, d2), g3 = cross(Y, d3);  // d(point)/dq_j
         const V inv_dt = V(qrcp(dt));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
-#define QS_CONTACT_ROW(IDX, DIR, NORMAL)                                                                               \
+        // one row of a contact at the point RC (base coordinates) of a link whose point moves by G1, G2, G3 per unit joint velocity,
+        // DIST above the plane; btMultiBodyConstraintSolver::setupMultiBodyContactConstraint: penetration = distance + linear slop
+#define QS_CONTACT_ROW_AT(ROW, DIR, NORMAL, RC, G1, G2, G3, DIST, ACT)                                                 \
     {                                                                                                                  \
-        Row& r_ = rows[IDX];                                                                                           \
+        Row& r_ = ROW;                                                                                                 \
         V3v d_ = DIR;                                                                                                  \
-        V3v ja = cross(rc, d_);                                                                                        \
-        r_.jq[0] = dot(d_, g1); r_.jq[1] = dot(d_, g2); r_.jq[2] = dot(d_, g3);                                        \
+        V3v ja = cross(RC, d_);                                                                                        \
+        r_.jq[0] = dot(d_, G1); r_.jq[1] = dot(d_, G2); r_.jq[2] = dot(d_, G3);                                        \
         r_.u[0] = K11 * r_.jq[0] + K12 * r_.jq[1] + K13 * r_.jq[2];                                                    \
         r_.u[1] = K12 * r_.jq[0] + K22 * r_.jq[1] + K23 * r_.jq[2];                                                    \
         r_.u[2] = K13 * r_.jq[0] + K23 * r_.jq[1] + K33 * r_.jq[2];                                                    \
         V jb[6] = {ja.x, ja.y, ja.z, d_.x, d_.y, d_.z};                                                                \
         _Pragma("unroll") for (int i = 0; i < 6; i++)                                                                  \
-            r_.w[i] = (jb[i] - (Bm[0][i] * r_.u[0] + Bm[1][i] * r_.u[1] + Bm[2][i] * r_.u[2])) * active;               \
+            r_.w[i] = (jb[i] - (Bm[0][i] * r_.u[0] + Bm[1][i] * r_.u[1] + Bm[2][i] * r_.u[2])) * (ACT);                \
         lsolve6<V>(Sm, Ld, r_.w);                                                                                      \
         V diag = r_.jq[0] * r_.u[0] + r_.jq[1] * r_.u[1] + r_.jq[2] * r_.u[2];                                         \
         _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
         r_.dinv = qrcp(diag); r_.diag = diag;                                                                          \
         V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
         if (NORMAL) {                                                                                                  \
-            V pos_err = qsel(qgt(dist, zero), zero, (-dist) * (cfg.contact_erp * inv_dt));                       \
-            V vel_err = (-rel) - qsel(qgt(dist, zero), dist * inv_dt, zero);                                     \
-            r_.rhs = (pos_err + vel_err) * r_.dinv * active;                                                           \
+            V pen_ = (DIST) + cfg.contact_slop;                                                                        \
+            V pos_err = qsel(qgt(pen_, zero), zero, (-pen_) * (cfg.contact_erp * inv_dt));                             \
+            V vel_err = (-rel) - qsel(qgt(pen_, zero), pen_ * inv_dt, zero);                                           \
+            r_.rhs = (pos_err + vel_err) * r_.dinv * (ACT);                                                            \
         } else {                                                                                                       \
-            r_.rhs = (-rel) * r_.dinv * active;                                                                  \
+            r_.rhs = (-rel) * r_.dinv * (ACT);                                                                         \
         }                                                                                                              \
-        r_.act = active;                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < 3; j++) { r_.jq[j] = r_.jq[j] * active; r_.u[j] = r_.u[j] * active; }    \
+        r_.act = (ACT);                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) { r_.jq[j] = r_.jq[j] * (ACT); r_.u[j] = r_.u[j] * (ACT); }      \
     }
+#define QS_CONTACT_ROW(IDX, DIR, NORMAL) QS_CONTACT_ROW_AT(rows[IDX], DIR, NORMAL, rc, g1, g2, g3, dist, active)
         QS_CONTACT_ROW(0, Rz, true)
         QS_CONTACT_ROW(1, (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false)
         QS_CONTACT_ROW(2, Rx, false)
 #undef QS_CONTACT_ROW
         V Kc[3][3] = {{K11, K12, K13}, {K12, K22, K23}, {K13, K23, K33}};
-        if (T::any(any_lim)) {
+        // joint-limit rows of this leg into dst[0..2]
+#define QS_LIMIT_ROWS(DST)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                    \
+        Row& r_ = (DST)[j];                                                                                            \
+        r_.act = lim_act[j];                                                                                           \
+        V a_ = r_.act * lim_sgn[j];                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) { r_.jq[c] = c == j ? a_ : zero; r_.u[c] = Kc[c][j] * a_; }      \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) r_.w[i] = -BK[j][i] * a_;                                        \
+        lsolve6<V>(Sm, Ld, r_.w);                                                                                      \
+        V diag = Kc[j][j];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
+        r_.dinv = qrcp(diag); r_.diag = diag;                                                                          \
+        V rel = lim_sgn[j] * s.qd[j];                                                                                  \
+        r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;                                  \
+    }
+#define QS_RARE_COMMON(A)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 21; i++) (A).Sm[i] = Sm[i];                                                  \
+    _Pragma("unroll") for (int i = 0; i < 6; i++) (A).Ld[i] = Ld[i];                                                   \
+    _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int i = 0; i < 6; i++) (A).BK[j][i] = BK[j][i]; \
+    _Pragma("unroll") for (int i = 0; i < 9; i++) (A).R[i] = R[i];
+        if (T::any(any_extra)) {
+            // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
+            // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
             T::count_rare_path();
+            RareArgs<3> a;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                Row& r_ = rows[3 + j];
-                V a_ = r_.act * lim_sgn[j];
+            for (int r = 0; r < 3; r++) a.rows[r] = rows[r];
+            const V bigh = V(1e9f);
+            V hh[5] = {qsel(qlt(h_trunk, V(THR_TRUNK)), h_trunk, bigh), qsel(qlt(h_hip, V(THR_HIP)), h_hip, bigh), qsel(qlt(h_th_hi, V(THR_THIGH)), h_th_hi, bigh),
+                       qsel(qlt(h_th_lo, V(THR_THIGH)), h_th_lo, bigh), qsel(qlt(h_cf_hi, V(THR_CALF)), h_cf_hi, bigh)};
+            if (!cfg.body_contacts) { for (int i = 0; i < 5; i++) hh[i] = bigh; }
+            // candidate points (base coordinates): lowest vertex of each primitive
+            V sgz = qsel(qlt(Rz.z, zero), -one, one), sga = qsel(qlt(az, zero), -one, one);
+            V sg2 = qsel(qlt(gx2, zero), -one, one), sg3 = qsel(qlt(gx3, zero), -one, one);
+            V rad = HIP_CYL_R * qrsqrt(qmax(one - az * az, V(1e-12f)));
+            V3v pc[5];
+            pc[0] = mk3<V>(fx * TRUNK_HALF[0], sy * TRUNK_HALF[1], sgz * (-TRUNK_HALF[2]));
+            pc[1] = p1 - Y * (sga * HIP_CYL_HALF_LEN) - (Rz - Y * az) * rad;
+            V3v toff = X2 * (sg2 * THIGH_HALF[0]) + Y * (sga * THIGH_HALF[1]);
+            pc[2] = p2 - toff; pc[3] = p3 - toff;
+            pc[4] = p3 - X3 * (sg3 * CALF_HALF[0]) - Y * (sga * CALF_HALF[1]);
+            const float depth[5] = {0.0f, 1.0f, 2.0f, 2.0f, 3.0f};   // joints of the leg that move the point
 #pragma unroll
-                for (int c = 0; c < 3; c++) { r_.jq[c] = c == j ? a_ : zero; r_.u[c] = Kc[c][j] * a_; }
+            for (int slot = 0; slot < 2; slot++) {
+                V best = hh[0], bi = zero;
 #pragma unroll
-                for (int i = 0; i < 6; i++) r_.w[i] = -BK[j][i] * a_;
-                lsolve6<V>(Sm, Ld, r_.w);
-                V diag = Kc[j][j];
+                for (int i = 1; i < 5; i++) { M m = qlt(hh[i], best); best = qsel(m, hh[i], best); bi = qsel(m, V((float)i), bi); }
+                bi = qsel(qlt(best, V(1e8f)), bi, V(4.0f));   // empty slot: any point that the joints move (an all-zero Jacobian has no 1 / diag)
+                V3v pt = pc[0]; V dep = V(depth[0]);
 #pragma unroll
-                for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];
-                r_.dinv = qrcp(diag); r_.diag = diag;
-                V rel = lim_sgn[j] * s.qd[j];
-                r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;
+                for (int i = 1; i < 5; i++) {
+                    M m = qgt(bi, V(i - 0.5f));   // bi >= i: later candidates overwrite
+                    pt = mk3<V>(qsel(m, pc[i].x, pt.x), qsel(m, pc[i].y, pt.y), qsel(m, pc[i].z, pt.z));
+                    dep = qsel(m, V(depth[i]), dep);
+                }
+#pragma unroll
+                for (int i = 0; i < 5; i++) hh[i] = qsel(qand(qgt(bi, V(i - 0.5f)), qlt(bi, V(i + 0.5f))), bigh, hh[i]);   // taken
+                V act_x = qflag(qlt(best, V(1e8f)));
+                V dist_x = qsel(qlt(best, V(1e8f)), best, zero);
+                V f1 = qflag(qgt(dep, V(0.5f))), f2 = qflag(qgt(dep, V(1.5f))), f3 = qflag(qgt(dep, V(2.5f)));
+                V3v e1 = cross(ax1, pt - p1) * f1, e2 = cross(Y, pt - p2) * f2, e3 = cross(Y, pt - p3) * f3;
+                QS_CONTACT_ROW_AT(a.rows[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
+                QS_CONTACT_ROW_AT(a.rows[4 + 3 * slot], (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
+                QS_CONTACT_ROW_AT(a.rows[5 + 3 * slot], Rx, false, pt, e1, e2, e3, dist_x, act_x)
             }
-            RareArgs a;
+            QS_LIMIT_ROWS(a.rows + 9)
+            QS_RARE_COMMON(a)
+            solve_with_limits<3>(cfg, Pr.mu, s, o, a);
+        } else if (T::any(any_lim)) {
+            T::count_rare_path();
+            QS_LIMIT_ROWS(rows + 3)
+            RareArgs<1> a;
 #pragma unroll
             for (int r = 0; r < 6; r++) a.rows[r] = rows[r];
-#pragma unroll
-            for (int i = 0; i < 21; i++) a.Sm[i] = Sm[i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) a.Ld[i] = Ld[i];
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int i = 0; i < 6; i++) a.BK[j][i] = BK[j][i];
-#pragma unroll
-            for (int i = 0; i < 9; i++) a.R[i] = R[i];
-            solve_with_limits(cfg, Pr.mu, s, o, a);
+            QS_RARE_COMMON(a)
+            solve_with_limits<1>(cfg, Pr.mu, s, o, a);
         } else {
             if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
             else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
         }
+#undef QS_RARE_COMMON
+#undef QS_LIMIT_ROWS
+#undef QS_CONTACT_ROW_AT
         } else {
             o.foot_force = zero; s.warm = zero;
         }

@@ -149,7 +149,7 @@ template <class T, bool CONE = false> struct Env {
         T::st_leg(rec, R_FOOT_FORCE, 1, o.foot_force); T::st_leg(rec, R_FOOT_CONTACT, 1, o.foot_contact);
         T::st(rec, R_N_INVALID, o.n_invalid);
     }
-    static QS_FN void load_par(const float* rec, typename S::Par& P) {
+    static QS_FN void load_par(const qs_config& cfg, const float* rec, typename S::Par& P) {
         const float* p = rec + R_PARAMS;
         P.mu = T::ld(p, P_MU);
 #pragma unroll
@@ -157,7 +157,7 @@ template <class T, bool CONE = false> struct Env {
             P.k[j] = T::ld(p, P_K + j); P.b[j] = T::ld(p, P_B + j); P.rest[j] = T::ld(p, P_REST + j);
             P.kp[j] = T::ld(p, P_KP + j); P.kd[j] = T::ld(p, P_KD + j); P.m_leg[j] = T::ld(p, P_M_LEG + j);
         }
-        S::build_base(P, T::ld(p, P_M_TRUNK), T::ld(p, P_M_PAY), mk3<V>(T::ld(p, P_R_PAY), T::ld(p, P_R_PAY + 1), T::ld(p, P_R_PAY + 2)));
+        S::build_base(cfg, P, T::ld(p, P_M_TRUNK), T::ld(p, P_M_PAY), mk3<V>(T::ld(p, P_R_PAY), T::ld(p, P_R_PAY + 1), T::ld(p, P_R_PAY + 2)));
     }
 
     // ---- task state machine (tasks/task_base.py:61-166, 222-280) on replicated values
@@ -482,7 +482,7 @@ template <class T, bool CONE = false> struct Env {
     static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0,
                               float* trace = nullptr, bool any_trace = false, const float* demo_rows = nullptr, int demo_len = 0) {
         typename S::State s; typename S::Par P; typename S::Out o;
-        load_state(rec, s); load_par(rec, P);
+        load_state(rec, s); load_par(cfg, rec, P);
         const int d = settle_n > 0 ? 0 : cfg.action_dim;
         // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
         // raw action: d == 12 -> every lane holds the 3 entries of its own leg in act[12..14];
@@ -764,7 +764,7 @@ template <class T, bool CONE = false> struct Env {
             typename S::Par P;
             o.foot_force = zero; o.foot_contact = zero; o.n_invalid = zero;
             for (int j = 0; j < 3; j++) { o.tau_pd[j] = zero; o.tau_spring[j] = zero; }
-            load_par(rec, P);
+            load_par(cfg, rec, P);
             V cmd[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);

@@ -150,11 +150,34 @@ template <bool CONE> static __device__ __forceinline__ void step_body(const qs_c
                 LaneDev::sync();
                 if (do_reset) E::reset(cfg, rec, ob, gid, false);
             } else {
-                // exact mode: the whole wave walks through the 2500-substep settle (lanes of running environments idle)
-                if (do_reset) {
-                    E::reset(cfg, rec, ob, gid, true);
-                    if ((threadIdx.x & 3) == 0) atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps);
+                // exact mode: the whole wave walks through the 2500-substep settle.  The settle's solver uses v_mfma_f32_4x4x1, which
+                // ignores EXEC, so it must not run under a divergent branch: what the step produced is published first, then EVERY quad
+                // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
+                __syncthreads();
+                tile_store(s_rec, recs, first, cfg.n_envs);
+                {
+                    const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
+                    for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
+                        float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
+                        if (rew_out) obs_out[(size_t)first * od + i] = v;
+                        else obs_out[(size_t)(first + i / od) * (od + 2) + (i % od)] = v;
+                        obs_keep[(size_t)first * od + i] = v;
+                    }
                 }
+                __syncthreads();
+                E::reset(cfg, rec, ob, gid, true);
+                if (do_reset && (threadIdx.x & 3) == 0) atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps);
+                LaneDev::sync();
+                if (do_reset) {
+                    float* g = recs + (size_t)env * QS_REC;
+                    for (int i = threadIdx.x & 3; i < QS_REC; i += 4) g[i] = rec[i];
+                    for (int i = threadIdx.x & 3; i < od; i += 4) {
+                        if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
+                        else obs_out[(size_t)env * (od + 2) + i] = ob[i];
+                        obs_keep[(size_t)env * od + i] = ob[i];
+                    }
+                }
+                return;
             }
         }
     }
@@ -467,7 +490,8 @@ int qs_get_obs(qs_handle* h, float* obs) {
 int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
     if (!h) QS_FAIL(-1, "null handle");
     QS_ON_DEVICE(h);
-    if (on && h->pool_size < QS_COHORTS * QS_ENVS_PER_WAVE) QS_FAIL(-1, "streaming refill needs a reset pool of at least %d entries (cfg.reset_pool)", QS_COHORTS * QS_ENVS_PER_WAVE);
+    // a cohort settles whole pairs of waves (k_pool_plan: at least 32 records), so each of the QS_COHORTS slices must hold that many
+    if (on && h->pool_size < QS_COHORTS * 2 * QS_ENVS_PER_WAVE) QS_FAIL(-1, "streaming refill needs a reset pool of at least %d entries (cfg.reset_pool)", QS_COHORTS * 2 * QS_ENVS_PER_WAVE);
     if (on && !h->d_pool_back) QS_HIP(hipMalloc(&h->d_pool_back, (size_t)h->pool_size * QS_REC * sizeof(float)));
     if (on && !h->streaming) {          // resets that happened while streaming was off are not owed
         QS_HIP(hipMemcpyAsync(&h->d_stats[CTL_BACKED], &h->d_stats[CTL_CONSUMED], sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));

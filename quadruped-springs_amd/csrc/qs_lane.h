@@ -103,6 +103,8 @@ struct LaneDev {
         return x;
     }
     template <int K> static QS_DEV float bcast(float x) { return dpp<K * 0x55>(x); }
+    // value of lane (l ^ K) of the quad, K = 1..3: quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
+    template <int K> static QS_DEV float xorl(float x) { return dpp<K == 1 ? 0xB1 : (K == 2 ? 0x4E : 0x1B)>(x); }
     // acc + bcast<K>(d) * a as ONE v_fmac_f32_dpp: the DPP move is given the accumulator as its (ignored, bound_ctrl) old
     // value so that the three uses per row are not merged into one shared v_mov_dpp, which the DPP combiner could not fold
     template <int K> static QS_DEV float fma_bcast(float d, float a, float acc) {
@@ -193,6 +195,7 @@ struct LaneEmu {
         return r;
     }
     template <int K> static V4 bcast(V4 x) { return V4(x.v[K]); }
+    template <int K> static V4 xorl(V4 x) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = x.v[i ^ K]; return r; }
     static V4 bcast_dyn(V4 x, int k) { return V4(x.v[k]); }
     template <int K> static V4 fma_bcast(V4 d, V4 a, V4 acc) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = acc.v[i] + d.v[K] * a.v[i]; return r; }
     static V4 fx() { return V4(1, 1, -1, -1); }

@@ -123,12 +123,12 @@ class QsConfig(C.Structure):
         ("spring_k", C.c_float * 3), ("spring_b", C.c_float * 3), ("spring_rest", C.c_float * 3),
         ("fallen_height", C.c_float), ("leg_len", C.c_float * 3),
         ("contact_erp", C.c_float), ("joint_erp", C.c_float), ("warmstart", C.c_float), ("vel_cap", C.c_float),
-        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("reserved_f", C.c_float * 8),
+        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("contact_slop", C.c_float), ("body_contacts", C.c_int32), ("self_collision", C.c_int32), ("reserved_f", C.c_float * 5),
         ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
         ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
         ("solver_residual_threshold", C.c_float), ("friction_cone", C.c_int32),
         ("landing_action", C.c_float * 12), ("landing_kp", C.c_float), ("landing_kd", C.c_float),
-        ("rest_kp", C.c_float), ("rest_kd", C.c_float), ("rest_time", C.c_float), ("reserved_h", C.c_float * 3),
+        ("rest_kp", C.c_float), ("rest_kd", C.c_float), ("rest_time", C.c_float), ("reserved_h", C.c_float * 3), ("unit_inertia", (C.c_float * 6) * 4),
     ]
 
 
@@ -209,6 +209,48 @@ def to_actual_action_space(a12, mode, symm_idx):
     return np.concatenate((np.delete(fr, symm_idx), np.delete(rr, symm_idx)))
 
 
+# Link inertials and collision primitives of go1.urdf that the mass-to-inertia rule needs (FR leg; mirror signs are applied on the
+# device).  mass, inertia (ixx, ixy, ixz, iyy, iyz, izz) about the centre of mass, collision box extents in link axes (the hip's
+# cylinder enters Bullet's compound AABB as its bounding box: btCylinderShape::getAabb).  go1.urdf lines: trunk :74-85, hip :121-136,
+# thigh :173-188, calf :200-216.  Pinned against tests/golden/urdf_tables.npz by tests/test_host_cpu.py.
+URDF_LINKS = {
+    "hip": (0.591, (0.000374268192, -3.6844422e-05, -9.86754e-07, 0.000635923669, 1.172894e-06, 0.000457647394), (0.092, 0.04, 0.092)),
+    "thigh": (0.92, (0.005851561134, -1.783284e-06, 0.000328291374, 0.005596155105, -2.1430713e-05, 0.00107157026), (0.034, 0.0245, 0.213)),
+    "calf": (0.131, (0.002939186297, 1.440899e-06, -0.00010535955, 0.00295576935, -2.4397752e-05, 3.0273372e-05), (0.016, 0.016, 0.213)),
+    "trunk": (5.204, (0.0168352186, 0.0004636141, 0.0002367952, 0.0656071082, 3.6671e-05, 0.0742720659), (0.3762, 0.0935, 0.114)),
+}
+# sign of each FR tensor entry relative to the magnitudes the device mirrors per leg (csrc/qs_core.h build_model): the device
+# tables hold |FR| for the hip and the FR value itself elsewhere
+_DEVICE_SIGN = {"hip": (1, -1, -1, 1, 1, 1), "thigh": (1, -1, 1, 1, -1, 1), "calf": (1, 1, 1, 1, 1, 1), "trunk": (1, 1, 1, 1, 1, 1)}
+
+
+def unit_inertia_table(rule):
+    """[4][6] inertia per unit mass of hip, thigh, calf, trunk (device sign convention) under a mass-to-inertia rule.
+
+    "scale": I_urdf / m_urdf, i.e. the tensor scales with the mass.
+    "collision_shape": Bullet's changeDynamics(mass=m) on a multibody link (quadruped.py:761, 776) replaces the link's inertia by
+    collisionShape->calculateLocalInertia(m); the shape is the btCompoundShape the URDF importer wraps every link's collision in, whose
+    calculateLocalInertia is the solid-box formula on the compound's AABB, m/12 (ly^2 + lz^2, lx^2 + lz^2, lx^2 + ly^2), taken in the
+    link's inertial frame = the principal axes of the URDF tensor (the importer diagonalises it).  Rotated back to link axes here."""
+    out = np.zeros((4, 6))
+    for k, name in enumerate(("hip", "thigh", "calf", "trunk")):
+        m0, i6, ext = URDF_LINKS[name]
+        I = np.array([[i6[0], i6[1], i6[2]], [i6[1], i6[3], i6[4]], [i6[2], i6[4], i6[5]]])
+        if rule == "scale":
+            T = I / m0
+        elif rule == "collision_shape":
+            _, R = np.linalg.eigh(I)                       # columns: principal axes in link coordinates
+            half = 0.5 * np.asarray(ext)
+            l = 2.0 * (np.abs(R.T) @ half)                 # AABB extents of the (link-axis aligned) box seen from the principal frame
+            d = np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2]) / 12.0
+            T = R @ np.diag(d) @ R.T
+        else:
+            raise KeyError(f"the mass inertia rule {rule} is not implemented yet.")
+        t6 = np.array([T[0, 0], T[0, 1], T[0, 2], T[1, 1], T[1, 2], T[2, 2]])
+        out[k] = t6 * np.array(_DEVICE_SIGN[name])
+    return out
+
+
 def build_config(
     n_envs=1,
     isRLGymInterface=True,
@@ -228,14 +270,18 @@ def build_config(
     settle_steps=2500,
     env_id_offset=0,
     cpg_gait="BOUND",
-    solver_residual_threshold=0.0,
+    solver_residual_threshold=1e-7,
     wrapper=None,
     robot_config=None,
     demo=None,
-    contact_erp=0.2,
+    contact_erp=0.08,
+    contact_slop=1e-5,
     joint_erp=0.2,
     warmstart=0.1,
-    friction_model="pyramid",
+    friction_model="cone",
+    body_contacts=True,
+    self_collision=True,
+    mass_inertia_rule="collision_shape",
     **_ignored,
 ):
     """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
@@ -333,6 +379,15 @@ def build_config(
     # Bullet solver constants assumed for PyBullet's defaults: keywords so that they can follow
     # what tools/pin_against_pybullet.py finds on a machine that has PyBullet
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = float(contact_erp), float(joint_erp), float(warmstart), rc.VELOCITY_LIMITS[0]
+    cfg.contact_slop = float(contact_slop)
+    cfg.body_contacts, cfg.self_collision = int(bool(body_contacts)), int(bool(self_collision))
+    # changeDynamics(mass=...) is only ever called by the mass randomizer (env_randomizer.py:56-83 -> quadruped.py:761, 776), at every
+    # reset and for every randomised link, also when the drawn mass equals the URDF's: without it the URDF tensors stay
+    rule = mass_inertia_rule if (rand & RAND_MASSES) else "scale"
+    tab = unit_inertia_table(rule)
+    for k in range(4):
+        for i in range(6):
+            cfg.unit_inertia[k][i] = tab[k][i]
     cfg.friction_cone = {"pyramid": 0, "cone": 1}[friction_model]   # PyBullet's enableConeFriction off / on (see include/qs_amd.h)
     cfg.solver_residual_threshold = float(solver_residual_threshold)
     for i, s in enumerate(lay["std"]):

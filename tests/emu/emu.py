@@ -76,6 +76,10 @@ class Emu:
         t = np.ascontiguousarray(tau, np.float32)
         self.lib.qse_phys_step(self.h, env, self._p(t))
 
+    def obb_overlap(self, ca, Ra, ha, cb, Rb, hb):
+        a = [np.ascontiguousarray(x, np.float32) for x in (ca, Ra, ha, cb, Rb, hb)]
+        return bool(self.lib.qse_obb_overlap(*[self._p(x) for x in a]))
+
     def get(self, name, dim):
         f = self.field(name)
         return self.records()[:, f:f + dim].copy()

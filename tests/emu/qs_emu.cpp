@@ -27,7 +27,7 @@ static void init_record(const qs_config& cfg, float* r, int env) {
 template <class EV> static void phys_step_impl(Emu* e, int i, const float* tau12) {
     float* rec = &e->rec[(size_t)i * QS_REC];
     typename EV::S::State s; typename EV::S::Par P; typename EV::S::Out o;
-    EV::load_state(rec, s); EV::load_par(rec, P);
+    EV::load_state(rec, s); EV::load_par(e->cfg, rec, P);
     V4 tau[3];
     for (int j = 0; j < 3; j++) { tau[j] = LaneEmu::ld_leg(tau12, j, 3); o.tau_pd[j] = V4(0.0f); o.tau_spring[j] = V4(0.0f); }
     EV::S::substep(e->cfg, P, s, tau, o);
@@ -132,6 +132,15 @@ int qse_field(const char* name) {
     F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_FLAGS) F(R_CPG) F(R_DEMO) F(R_WRAP)
 #undef F
     return -1;
+}
+// the separating-axis box / box test of the self-collision rule (qs_core.h obb_overlap); R row-major with the axes as COLUMNS
+int qse_obb_overlap(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb, const float* hb) {
+    using S = E::S;
+    auto col = [](const float* R, int j) { return qs::mk3<V4>(V4(R[j]), V4(R[3 + j]), V4(R[6 + j])); };
+    S::H3 HA = {{ha[0], ha[1], ha[2]}}, HB = {{hb[0], hb[1], hb[2]}};
+    M4 m = S::obb_overlap(qs::mk3<V4>(V4(ca[0]), V4(ca[1]), V4(ca[2])), col(Ra, 0), col(Ra, 1), col(Ra, 2), HA,
+                          qs::mk3<V4>(V4(cb[0]), V4(cb[1]), V4(cb[2])), col(Rb, 0), col(Rb, 1), col(Rb, 2), HB);
+    return m.v[0] ? 1 : 0;
 }
 // one physics substep of env `i` under given joint torques (KATs on the kernel arithmetic)
 int qse_phys_step(void* h, int i, const float* tau12) {

@@ -263,15 +263,11 @@ class FakeBulletClient:
         return tuple(s[7:10]), tuple(s[10:13])
 
     def getContactPoints(self, *a, **k):
-        pts = []
-        force = self.o.get_info(0)[0]
-        flag = self.o.get_info(1)[0]
-        for f in range(4):
-            if flag[f]:
-                pts.append((0, 1, 0, _FOOT_IDS[f], -1, (0, 0, 0), (0, 0, 0), (0, 0, 1), 0.0, float(force[f])))
-        for _ in range(int(self.o.get_info(5)[0, 0])):
-            pts.append((0, 1, 0, 0, -1, (0, 0, 0), (0, 0, 0), (0, 0, 1), 0.0, 0.0))  # trunk-ground: invalid
-        return pts
+        # every contact point of the last substep with PyBullet's body / link numbering (oracle/qso.h qso_get_contacts), so that the
+        # reference's own GetContactInfo (quadruped.py:224-258) does the classification: feet valid; thighs, other links on the plane,
+        # the payload block, and self-contacts that involve a calf invalid
+        return [(0, ba, bb, la, lb, (0, 0, 0), (0, 0, 0), (0, 0, 1), float(dist), float(force))
+                for (ba, bb, la, lb, dist, force) in self.o.contacts(0)]
 
     # maths helpers (independent of the oracle's C versions: scipy)
     def getEulerFromQuaternion(self, q):
@@ -1025,11 +1021,62 @@ def gen_cpg():
     print("cpg.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------- contact classification rule
+def gen_contacts():
+    """The reference's GetContactInfo (quadruped.py:224-258) applied to contact lists that the oracle produces in scenarios with feet,
+    non-foot links, the payload block and link-link contacts; the fixture holds the lists and what the reference made of them."""
+    from qs_amd.config import build_config
+    from oracle.qso import Oracle
+    from quadruped_spring.env.quadruped import Quadruped
+    from scipy.spatial.transform import Rotation as Rot
+    rob = object.__new__(Quadruped)
+    rob._calf_ids, rob._thigh_ids, rob._foot_link_ids = [4, 8, 12, 16], [3, 7, 11, 15], [5, 9, 13, 17]
+    kw = dict(task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True, enable_action_filter=False, isRLGymInterface=False,
+              motor_control_mode="TORQUE", noise=False)
+    rng = np.random.default_rng(11)
+    lists, outs, states, params, warms = [], [], [], [], []
+    for k in range(160):
+        cfg, _ = build_config(n_envs=1, env_randomizer_mode="MASS_RANDOMIZER" if k % 4 == 3 else "NONE", seed=k, **kw)
+        o = Oracle(cfg)
+        o.reset()
+        s = o.get_state()
+        s[0, 7:] = 0
+        if k % 4 == 0:      # standing / crouching on the feet
+            s[0, 2] = rng.uniform(0.12, 0.32); s[0, 13:25] = np.tile([0.0, rng.uniform(0.6, 1.3), rng.uniform(-2.5, -1.3)], 4)
+        elif k % 4 == 1:    # lying in random orientations
+            s[0, 2] = rng.uniform(0.05, 0.15); s[0, 3:7] = Rot.random(random_state=k).as_quat()
+            s[0, 13:25] = rng.uniform(np.tile([-0.5, -0.6, -2.7], 4), np.tile([0.5, 2.0, -0.9], 4))
+        elif k % 4 == 2:    # legs tangled in the air
+            s[0, 2] = 1.0
+            q = np.tile([0.0, 0.8, -1.6], 4) + 0.25 * rng.normal(size=12)
+            q[0], q[3] = 0.55, -0.55
+            s[0, 13:25] = q
+        else:               # payload hanging low
+            p = o.get_info(6); p[0, 21:24] = [rng.uniform(-0.1, 0.1), 0.0, -0.1]; o.set_params(5, p)
+            s[0, 2] = rng.uniform(0.13, 0.2); s[0, 13:25] = np.tile([0.0, 1.2, -2.4], 4)
+        o.set_state(s)
+        for _ in range(2):
+            o.phys_step(0, np.zeros(12))
+        state_in, warm_in = o.get_state()[0].copy(), o.get_info(0)[0].copy() * cfg.dt     # state (and contact warm start) before the recorded substep
+        o.phys_step(0, np.zeros(12))
+        cl = o.contacts(0)
+        rob._pybullet_client = types.SimpleNamespace(getContactPoints=lambda cl=cl: [(0, a, b, c, d, (0, 0, 0), (0, 0, 0), (0, 0, 1), x, f) for (a, b, c, d, x, f) in cl])
+        nv, ni, ff, fb = rob.GetContactInfo()
+        row = np.full((64, 6), np.nan); row[:len(cl)] = np.array(cl, float).reshape(-1, 6)
+        lists.append(row); outs.append([nv, ni] + list(ff) + list(fb))
+        states.append(state_in); params.append(o.get_info(6)[0]); warms.append(warm_in)
+        assert int(o.get_info(5)[0, 0]) == ni, (k, ni, o.get_info(5))       # the oracle's own count follows the same rule
+    out = dict(contacts=np.array(lists), reference=np.array(outs, float), states=np.array(states), params=np.array(params), warm=np.array(warms))
+    np.savez_compressed(os.path.join(OUT, "contacts.npz"), **out)
+    kinds = np.array(outs)
+    print("contacts.npz:", len(lists), "scenarios;", int((kinds[:, 1] > 0).sum()), "with invalid contacts,", int((kinds[:, 0] > 0).sum()), "with feet on the ground")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     logging.disable(logging.CRITICAL)
-    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf", "rsi", "demo"]
+    which = sys.argv[1:] or ["stateless", "rewards", "traces", "cpg", "wrappers", "randomizers", "urdf", "rsi", "demo", "contacts"]
     for w in which:
         {"stateless": gen_stateless, "rewards": gen_rewards, "traces": gen_traces, "cpg": gen_cpg, "wrappers": gen_wrappers,
-         "randomizers": gen_randomizers, "urdf": gen_urdf, "rsi": gen_rsi, "demo": gen_demo}[w]()
+         "randomizers": gen_randomizers, "urdf": gen_urdf, "rsi": gen_rsi, "demo": gen_demo, "contacts": gen_contacts}[w]()

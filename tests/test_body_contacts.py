@@ -1,0 +1,283 @@
+"""Bullet behaviour that needs no PyBullet to restate (VERDICT r01 "missing" 1, 2, 4): contact response of the non-foot links, the
+calf self-collision rule (quadruped.py:237-241), the payload block on the ground, the mass-to-inertia rule.  Oracle known answers,
+then the kernel arithmetic (host lane emulation) against the oracle."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rot
+
+from emu.emu import Emu
+from oracle.qso import Oracle
+from qs_amd.config import build_config, unit_inertia_table, URDF_LINKS
+
+TOTAL_MASS = 12.01301
+KW = dict(task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True, enable_action_filter=False, env_randomizer_mode="NONE",
+          isRLGymInterface=False, motor_control_mode="TORQUE", noise=False)
+
+
+def make(n=1, **kw):
+    cfg, _ = build_config(n_envs=n, **dict(KW, **kw))
+    return cfg
+
+
+def fallen_state(o, roll=0.0, pitch=0.0, z=0.12, q=(0.0, 1.2, -2.4)):
+    s = o.get_state()
+    s[:, :3] = [0, 0, z]
+    s[:, 3:7] = Rot.from_euler("xyz", [roll, pitch, 0]).as_quat()
+    s[:, 7:] = 0
+    s[:, 13:25] = np.tile(q, 4)
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ oracle known answers
+@pytest.mark.parametrize("roll,pitch", [(0.0, 0.0), (1.45, 0.0), (0.0, 0.5)])
+def test_fallen_robot_rests_on_the_floor(roll, pitch):
+    """NO_TASK, no torques: the robot is dropped from a few centimetres in a folded pose (on its belly, on its side, nose down) and
+    must come to rest ON the floor, carried by whatever touches it: the sum of all normal forces is m g and nothing sinks in."""
+    cfg = make(solver_residual_threshold=0.0)
+    o = Oracle(cfg)
+    o.reset()
+    o.set_state(fallen_state(o, roll, pitch, z=0.16))
+    tau = np.zeros(12)
+    for _ in range(1500):
+        o.phys_step(0, tau)
+    s = o.get_state()[0]
+    assert np.abs(s[7:13]).max() < 2e-2 and np.abs(s[25:]).max() < 0.2, "not at rest"
+    cs = o.contacts()
+    ground = [c for c in cs if c[1] == 0]
+    assert any(c[2] not in (5, 9, 13, 17) for c in ground), "no non-foot link on the ground"
+    total = sum(c[5] for c in ground)
+    assert total == pytest.approx(TOTAL_MASS * 9.8, rel=2e-2)
+    assert min(c[4] for c in ground) > -2e-3, "a link sank into the floor"
+    assert o.get_info(5)[0, 0] >= 1                                    # and they still count as invalid contacts
+
+
+def test_without_body_contacts_the_fallen_robot_sinks():
+    """The switch: body_contacts=False is round 1's behaviour (non-foot links only flag)."""
+    cfg = make(body_contacts=False)
+    o = Oracle(cfg)
+    o.reset()
+    o.set_state(fallen_state(o, 1.45, 0.0, z=0.16))
+    for _ in range(600):
+        o.phys_step(0, np.zeros(12))
+    assert min(c[4] for c in o.contacts() if c[1] == 0) < -2e-2
+
+
+def crossed_calves_state(o):
+    """Front legs: hips rolled inwards and knees bent so that the two front calves cross under the trunk."""
+    s = o.get_state()
+    s[:, :3] = [0, 0, 0.6]
+    s[:, 3:7] = [0, 0, 0, 1]
+    s[:, 7:] = 0
+    q = np.tile([0.0, 0.8, -1.6], 4).astype(float)
+    q[0], q[3] = 0.55, -0.55        # FR hip +, FL hip -: both front legs swing towards the centre plane
+    s[:, 13:25] = q
+    return s
+
+
+def test_crossed_calves_are_an_invalid_contact():
+    cfg = make(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", isRLGymInterface=True, motor_control_mode="PD")
+    o = Oracle(cfg)
+    o.reset()
+    o.set_state(crossed_calves_state(o))
+    o.phys_step(0, np.zeros(12))
+    cs = o.contacts()
+    assert any(c[0] == 1 and c[1] == 1 and c[2] == 4 and c[3] == 8 for c in cs), cs       # FR calf (4) x FL calf (8)
+    assert o.get_info(5)[0, 0] >= 1
+    a = np.zeros((1, 6), np.float32)
+    _, _, done, trunc = o.step(a)
+    assert done[0] and not trunc[0]                                                        # task_base.py:137-147 -> terminated
+    cfg2 = make(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", isRLGymInterface=True, motor_control_mode="PD", self_collision=False)
+    o2 = Oracle(cfg2)
+    o2.reset()
+    o2.set_state(crossed_calves_state(o2))
+    o2.phys_step(0, np.zeros(12))
+    assert o2.get_info(5)[0, 0] == 0
+
+
+def test_self_contacts_without_a_calf_do_not_count():
+    """quadruped.py:237-241: only self-contacts that involve a calf are invalid.  Thighs pressed together (hips rolled inwards,
+    legs straight enough that the calves stay apart) leave the count at zero."""
+    cfg = make()
+    o = Oracle(cfg)
+    o.reset()
+    s = o.get_state()
+    s[:, :3] = [0, 0, 0.8]; s[:, 3:7] = [0, 0, 0, 1]; s[:, 7:] = 0
+    q = np.tile([0.0, 0.0, -0.9], 4).astype(float)
+    q[0], q[3] = 1.0, -1.0
+    s[:, 13:25] = q
+    o.set_state(s)
+    o.phys_step(0, np.zeros(12))
+    assert all(not (c[0] == 1 and c[1] == 1) for c in o.contacts()) or all(c[2] in (4, 8, 12, 16) for c in o.contacts() if c[0] == c[1] == 1)
+
+
+def test_payload_block_on_the_ground_is_invalid():
+    cfg = make(env_randomizer_mode="MASS_RANDOMIZER", seed=3)
+    o = Oracle(cfg)
+    o.reset()
+    p = o.get_info(6)
+    assert p[0, 20] > 0                                       # a payload was drawn
+    p[0, 21:24] = [0.0, 0.0, -0.1]                            # hang it 10 cm below the base origin
+    o.set_params(5, p)
+    s = o.get_state()
+    s[:, 2] = 0.148; s[:, 7:] = 0; s[:, 13:25] = np.tile([0.0, 1.2, -2.4], 4)
+    o.set_state(s)
+    o.phys_step(0, np.zeros(12))
+    assert any(c[0] == 2 and c[1] == 0 for c in o.contacts())
+    assert o.get_info(5)[0, 0] >= 1
+
+
+# ------------------------------------------------------------------------------------------------ geometry of the link-link tests
+def brute_overlap(ca, Ra, ha, cb, Rb, hb, n=14):
+    """Sampling answer: a lattice of points of A (incl. its surface) tested for membership of B and vice versa."""
+    g = np.linspace(-1, 1, n)
+    P = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    def inside(c1, R1, h1, c2, R2, h2):
+        pw = c1 + (P * h1) @ R1.T
+        pl = (pw - c2) @ R2
+        return bool(np.any(np.all(np.abs(pl) <= h2 + 1e-12, axis=1)))
+    return inside(ca, Ra, ha, cb, Rb, hb) or inside(cb, Rb, hb, ca, Ra, ha)
+
+
+def test_box_overlap_sat_equals_edge_clipping():
+    """The kernel decides box / box contact by the separating-axis test, the oracle by clipping edges: both are exact, so they must agree
+    on random rod-like boxes; where a sampling lattice finds a common point both must say overlap."""
+    cfg = make()
+    o, e = Oracle(cfg), Emu(cfg)
+    rng = np.random.default_rng(0)
+    ha, hb = np.array([0.008, 0.008, 0.1065]), np.array([0.017, 0.01225, 0.1065])
+    n_yes = 0
+    for k in range(600):
+        Ra, Rb = Rot.random(random_state=rng.integers(1 << 30)).as_matrix(), Rot.random(random_state=rng.integers(1 << 30)).as_matrix()
+        ca = np.zeros(3)
+        cb = rng.normal(size=3) * [0.03, 0.03, 0.08]
+        a, b = o.boxes_overlap(ca, Ra, ha, cb, Rb, hb), e.obb_overlap(ca, Ra, ha, cb, Rb, hb)
+        # float32 SAT against float64 clipping: skip configurations within a hair of touching
+        shrink, grow = o.boxes_overlap(ca, Ra, ha * 0.995, cb, Rb, hb * 0.995), o.boxes_overlap(ca, Ra, ha * 1.005, cb, Rb, hb * 1.005)
+        if shrink == grow:
+            assert a == b, (k, a, b)
+        if brute_overlap(ca, Ra, ha, cb, Rb, hb):
+            assert a
+        n_yes += a
+    assert 100 < n_yes < 500
+
+
+# ------------------------------------------------------------------------------------------------ mass -> inertia
+def test_unit_inertia_tables():
+    sc, cs = unit_inertia_table("scale"), unit_inertia_table("collision_shape")
+    m, i6, _ = URDF_LINKS["trunk"]
+    np.testing.assert_allclose(sc[3] * m, i6, rtol=1e-6)
+    # trunk: the principal frame is within 0.6 degrees of the link frame, so Bullet's rule is close to the solid box 0.3762 x 0.0935 x 0.114
+    # -- from above: the AABB of the 0.38 m long box seen from the slightly rotated frame is a few millimetres wider
+    lx, ly, lz = 0.3762, 0.0935, 0.114
+    box = np.array([ly**2 + lz**2, lx**2 + lz**2, lx**2 + ly**2]) / 12
+    assert np.all(cs[3][[0, 3, 5]] >= box * (1 - 1e-6)) and np.all(cs[3][[0, 3, 5]] <= box * 1.07)
+    # the calf's box is a 16 mm rod: the shape rule makes its long-axis inertia tiny, the URDF's is 3e-5 / 0.131
+    assert cs[2][5] < 0.5 * abs(sc[2][5]) or cs[2][5] > 0
+    for k in range(4):                                                     # both are positive definite tensors
+        for t in (sc[k], cs[k]):
+            T = np.array([[t[0], t[1], t[2]], [t[1], t[3], t[4]], [t[2], t[4], t[5]]])
+            assert np.all(np.linalg.eigvalsh(T) > 0)
+
+
+def test_mass_randomizer_uses_the_shape_inertia_and_the_switch_changes_the_dynamics():
+    """changeDynamics(mass=...) is called by the mass randomizer only: without it both rules give the URDF tensors."""
+    base = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", isRLGymInterface=True, motor_control_mode="PD")
+    c0, c1 = make(**base, mass_inertia_rule="scale"), make(**base, mass_inertia_rule="collision_shape")
+    assert np.array_equal(np.array(c0.unit_inertia), np.array(c1.unit_inertia))
+    m0, m1 = make(**base, env_randomizer_mode="MASS_RANDOMIZER", mass_inertia_rule="scale"), make(**base, env_randomizer_mode="MASS_RANDOMIZER")
+    assert not np.array_equal(np.array(m0.unit_inertia), np.array(m1.unit_inertia))
+    accs = []
+    for c in (m0, m1):
+        o = Oracle(c)
+        o.reset()
+        s = o.get_state(); s[:, 2] = 1.0; s[:, 10:13] = [1.0, 2.0, -1.0]
+        o.set_state(s)
+        accs.append(o.aba(0, np.tile([1.0, -2.0, 0.5], 4)))
+    assert np.abs(accs[0] - accs[1]).max() > 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ kernel arithmetic vs oracle
+@pytest.mark.parametrize("model", ["cone", "pyramid"])
+def test_emu_matches_oracle_on_fallen_robots(model):
+    """Robots lying on their side / belly / nose, flailing under random torques: support points of trunk, hips, thighs and calves,
+    joint limits and feet all at once (the 12-rows-per-leg rare path).  Float32 oracle on the same float32 state, re-seated every step."""
+    n = 6
+    cfg = make(n, friction_model=model, solver_residual_threshold=0.0)
+    o, e = Oracle(cfg, "f32"), Emu(cfg)
+    o.reset(); e.reset()
+    s = fallen_state(o)
+    for i, (r, p) in enumerate([(1.45, 0.0), (0.0, 0.0), (0.0, 0.5), (-1.45, 0.2), (3.0, 0.0), (0.7, -0.4)]):
+        s[i, 3:7] = Rot.from_euler("xyz", [r, p, 0]).as_quat()
+    s[:, 2] = 0.2
+    o.set_state(s); e.set_state(s)
+    rng = np.random.default_rng(5)
+    extra = 0
+    for i in range(80):
+        tau = (4.0 * rng.normal(size=(n, 12))).astype(np.float32) if i > 20 else np.zeros((n, 12), np.float32)
+        st = o.get_state()
+        o.set_state(st); e.set_state(st)
+        o.step(tau); e.step(tau)
+        so, se = o.get_state(), e.get_state()
+        np.testing.assert_allclose(se[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(se[:, 7:13], so[:, 7:13], atol=2e-2, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(se[:, 13:25], so[:, 13:25], atol=2e-4, err_msg=f"q step {i}")
+        np.testing.assert_allclose(se[:, 25:], so[:, 25:], atol=1e-1, err_msg=f"qd step {i}")
+        np.testing.assert_array_equal(e.get("R_N_INVALID", 1)[:, 0] > 0, o.get_info(5)[:, 0] > 0)
+        extra += sum(1 for k in range(n) for c in o.contacts(k) if c[1] == 0 and c[2] not in (5, 9, 13, 17) and c[5] > 1.0)
+    assert extra > 200, extra                                   # the scenario does load non-foot links
+    assert so[:, 2].min() > 0.03                                # and nobody fell through the floor
+
+
+def test_emu_counts_the_same_self_contacts():
+    cfg = make(4)
+    o, e = Oracle(cfg), Emu(cfg)
+    o.reset(); e.reset()
+    rng = np.random.default_rng(2)
+    hits = 0
+    for i in range(300):
+        s = o.get_state()
+        s[:, :3] = [0, 0, 1.0]; s[:, 3:7] = Rot.random(4, random_state=i).as_quat(); s[:, 7:] = 0
+        lo, hi = np.tile([-1.04, -0.66, -2.72], 4), np.tile([1.04, 2.96, -0.84], 4)
+        s[:, 13:25] = rng.uniform(lo, hi, size=(4, 12))
+        if i % 3 == 0:
+            s[:, 13:25] = crossed_calves_state(o)[:, 13:25] + 0.15 * rng.normal(size=(4, 12))
+        o.set_state(s); e.set_state(s)
+        for k in range(4):
+            o.phys_step(k, np.zeros(12)); e.phys_step(k, np.zeros(12))
+        no, ne = o.get_info(5)[:, 0], e.get("R_N_INVALID", 1)[:, 0]
+        hits += int((no > 0).sum())
+        np.testing.assert_array_equal(ne > 0, no > 0, err_msg=f"config {i}: {no} {ne}")
+    assert hits > 100
+
+
+# ------------------------------------------------------------------------------------------------ the reference's classification rule
+def test_contacts_are_classified_as_the_reference_does():
+    """tests/golden/contacts.npz: 160 states (standing, lying in random orientations, legs tangled in the air, payload block hanging low)
+    with the contact list one substep produces (PyBullet's body / link numbering) and what the reference's own Quadruped.GetContactInfo
+    (quadruped.py:224-258) made of that list.  From the recorded state the oracle must reproduce list and verdict, and the kernel
+    arithmetic (lane emulation) the verdict: invalid or not, which feet stand, with what force."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "contacts.npz"))
+    kinds = set()
+    for k in range(len(g["states"])):
+        cfg, _ = build_config(n_envs=1, **dict(KW, env_randomizer_mode="MASS_RANDOMIZER" if k % 4 == 3 else "NONE", seed=k))
+        cfg.randomizer_flags |= 8          # keep the parameters given below
+        o, e = Oracle(cfg), Emu(cfg)
+        o.set_params(5, g["params"][k][None])
+        e.records()[0, e.field("R_PARAMS"):e.field("R_PARAMS") + 24] = g["params"][k]
+        o.set_state(g["states"][k][None]); e.set_state(g["states"][k][None])
+        o.phys_step(0, np.zeros(12)); e.phys_step(0, np.zeros(12))
+        ref = g["reference"][k]
+        rows = g["contacts"][k]
+        rows = rows[~np.isnan(rows[:, 0])]
+        got = o.contacts(0)
+        assert [c[:4] for c in got] == [tuple(int(x) for x in r[:4]) for r in rows], k
+        for ba, bb, la, lb, dist, force in rows:
+            kinds.add((int(ba), int(bb), "foot" if la in (5, 9, 13, 17) else "calf" if la in (4, 8, 12, 16) else "thigh" if la in (3, 7, 11, 15) else "other"))
+        assert o.get_info(5)[0, 0] == ref[1], (k, o.get_info(5), ref[1])
+        np.testing.assert_array_equal(o.get_info(1)[0], ref[6:10])
+        np.testing.assert_allclose(o.get_info(0)[0], ref[2:6], rtol=0.25, atol=2.0)     # the recorded substep had a warm start, this one has none
+        assert (e.get("R_N_INVALID", 1)[0, 0] > 0) == (ref[1] > 0), (k, e.get("R_N_INVALID", 1), ref[1])
+        np.testing.assert_array_equal(e.get("R_FOOT_CONTACT", 4)[0], ref[6:10])
+        np.testing.assert_allclose(e.get("R_FOOT_FORCE", 4)[0], o.get_info(0)[0], rtol=3e-2, atol=0.5)
+    assert {(1, 0, "foot"), (1, 0, "calf"), (1, 0, "thigh"), (1, 0, "other"), (2, 0, "other"), (1, 1, "calf")} <= kinds, kinds

@@ -1,0 +1,301 @@
+"""Round-2 GPU tests (through the C ABI): contact response of the non-foot links, the calf self-collision rule, the device noise
+stream, the sharded exchange on RCCL, exact-mode auto-reset in partial waves, reuse of pooled reset states."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch
+
+
+def vec_env(n, **kw):
+    from qs_amd.vec_env import QuadrupedVecEnv
+    kw.setdefault("task_env", "JUMPING_IN_PLACE")
+    kw.setdefault("observation_space_mode", "PPO_BASIC")
+    kw.setdefault("enable_springs", True)
+    kw.setdefault("enable_action_filter", True)
+    kw.setdefault("env_randomizer_mode", "NONE")
+    kw.setdefault("noise", False)
+    kw.setdefault("auto_reset", False)
+    return QuadrupedVecEnv(num_envs=n, **kw)
+
+
+RAW = dict(task_env="NO_TASK", observation_space_mode="ENCODER", enable_action_filter=False, isRLGymInterface=False, motor_control_mode="TORQUE")
+
+
+def fallen_states(s, rng):
+    from scipy.spatial.transform import Rotation as Rot
+    n = len(s)
+    s = s.copy()
+    s[:, :3] = [0, 0, 0.2]
+    eul = np.stack([rng.choice([0.0, 1.45, -1.45, 3.0, 0.7], n), rng.uniform(-0.5, 0.5, n), np.zeros(n)], 1)
+    s[:, 3:7] = Rot.from_euler("xyz", eul).as_quat()
+    s[:, 7:] = 0
+    s[:, 13:25] = np.tile([0.0, 1.2, -2.4], 4)
+    return s
+
+
+@pytest.mark.parametrize("model", ["cone", "pyramid"])
+def test_fallen_robots_parity(torch_cuda, model):
+    """Waves that mix standing robots with robots lying on trunk, hips, thighs and calves: the 12-rows-per-leg rare path against the
+    float32 oracle from identical float32 states, re-seated every step; nobody sinks into the floor."""
+    from oracle.qso import Oracle
+    n = 40
+    v = vec_env(n, friction_model=model, solver_residual_threshold=0.0, **RAW)
+    o = Oracle(v.cfg, "f32")
+    o.reset(); v.reset()
+    rng = np.random.default_rng(5)
+    s = o.get_state()
+    lying = np.arange(n) % 3 != 0
+    s[lying] = fallen_states(s[lying], rng)
+    o.set_state(s); v.set_state(s.astype(np.float32))
+    loaded = 0
+    for i in range(60):
+        tau = (4.0 * rng.normal(size=(n, 12))).astype(np.float32) if i > 15 else np.zeros((n, 12), np.float32)
+        st = o.get_state()
+        o.set_state(st); v.set_state(st.astype(np.float32))
+        o.step(tau); v.step(tau)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        np.testing.assert_allclose(sv[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(sv[:, 7:13], so[:, 7:13], atol=2e-2, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=2e-4, err_msg=f"q step {i}")
+        np.testing.assert_allclose(sv[:, 25:], so[:, 25:], atol=1e-1, err_msg=f"qd step {i}")
+        np.testing.assert_array_equal(v.get_info("n_invalid").cpu().numpy()[:, 0] > 0, o.get_info(5)[:, 0] > 0)
+        loaded += sum(1 for k in range(n) for c in o.contacts(k) if c[1] == 0 and c[2] not in (5, 9, 13, 17) and c[5] > 1.0)
+    assert loaded > 1000, loaded
+    assert sv[:, 2].min() > 0.03
+    assert v.counter("limit_path_substeps") > 0
+    v.close()
+
+
+def test_fallen_robot_comes_to_rest_on_the_floor(torch_cuda):
+    """The known answer on the device: dropped on its side without torques, the robot ends up at rest on trunk, hip and leg links
+    (NO_TASK never terminates); with body_contacts=False (round 1's behaviour) it keeps falling through the floor."""
+    from scipy.spatial.transform import Rotation as Rot
+    out = {}
+    for bc in (True, False):
+        v = vec_env(16, body_contacts=bc, **RAW)
+        v.reset()
+        s = v.get_state().cpu().numpy()
+        s[:, :3] = [0, 0, 0.16]; s[:, 3:7] = Rot.from_euler("x", 1.45).as_quat(); s[:, 7:] = 0; s[:, 13:25] = np.tile([0.0, 1.2, -2.4], 4)
+        v.set_state(s)
+        for _ in range(150):
+            v.step(np.zeros((16, 12), np.float32))
+        out[bc] = v.get_state().cpu().numpy()
+        v.close()
+    assert np.abs(out[True][:, 7:13]).max() < 2e-2 and np.abs(out[True][:, 25:]).max() < 0.2
+    assert 0.03 < out[True][:, 2].min() and out[True][:, 2].max() < 0.2
+    assert out[False][:, 2].max() < -0.05
+
+
+def crossed(s):
+    s = s.copy()
+    s[:, :3] = [0, 0, 0.6]; s[:, 3:7] = [0, 0, 0, 1]; s[:, 7:] = 0
+    q = np.tile([0.0, 0.8, -1.6], 4).astype(np.float32)
+    q[0], q[3] = 0.55, -0.55
+    s[:, 13:25] = q
+    return s
+
+
+def test_crossed_calves_terminate_the_episode(torch_cuda):
+    """quadruped.py:237-241 -> task_base.py:137-147: a self-contact that involves a calf ends the episode (terminated, not truncated)."""
+    v = vec_env(32)
+    v.reset()
+    s = v.get_state().cpu().numpy()
+    bad = np.arange(32) % 4 == 1
+    s[bad] = crossed(s[bad])
+    v.set_state(s)
+    _, _, done, infos = v.step(np.zeros((32, 6), np.float32))
+    assert np.array_equal(done, bad), done
+    assert all(not infos[i]["TimeLimit.truncated"] for i in np.nonzero(bad)[0])
+    assert np.array_equal(v.get_info("n_invalid").cpu().numpy()[:, 0] > 0, bad)
+    v.close()
+    w = vec_env(32, self_collision=False)
+    w.reset()
+    w.set_state(s)
+    _, _, done, _ = w.step(np.zeros((32, 6), np.float32))
+    assert not done.any()
+    w.close()
+
+
+def test_self_contact_counts_match_the_oracle(torch_cuda):
+    from oracle.qso import Oracle
+    from scipy.spatial.transform import Rotation as Rot
+    n = 64
+    v = vec_env(n, action_repeat=1, **RAW)             # one substep per step: the count is that of the given configuration
+    o = Oracle(v.cfg)
+    o.reset(); v.reset()
+    rng = np.random.default_rng(2)
+    hits = 0
+    for i in range(40):
+        s = o.get_state()
+        s[:, :3] = [0, 0, 1.0]; s[:, 3:7] = Rot.random(n, random_state=i).as_quat(); s[:, 7:] = 0
+        s[:, 13:25] = rng.uniform(np.tile([-1.04, -0.66, -2.72], 4), np.tile([1.04, 2.96, -0.84], 4), size=(n, 12))
+        half = np.arange(n) % 2 == 0
+        s[half, 13:25] = crossed(s[half])[:, 13:25] + 0.15 * rng.normal(size=(int(half.sum()), 12))
+        v.set_state(s.astype(np.float32))
+        o.set_state(v.get_state().cpu().numpy().astype(np.float64))       # the same float32 numbers on both sides
+        o.step(np.zeros((n, 12), np.float32))
+        v.step(np.zeros((n, 12), np.float32))
+        no, nv = o.get_info(5)[:, 0], v.get_info("n_invalid").cpu().numpy()[:, 0]
+        hits += int((no > 0).sum())
+        assert ((nv > 0) != (no > 0)).sum() <= 1, f"config {i}: {no} {nv}"     # float32 / float64 may differ on a grazing contact
+    assert hits > 300
+    v.close()
+
+
+def test_sensor_noise_statistics(torch_cuda):
+    """The device noise path (Philox + Box-Muller on v_log / v_sin / v_cos; sensor.py:25-32, 46-52): two handles that differ only in
+    `noise` run the same actions, so their observations differ by the noise alone.  Per element: mean 0, sigma of go1_config within
+    3 %, flags and sigma-0 sensors noise-free, normal distribution, no correlation between elements or steps."""
+    from scipy import stats
+    n, steps = 8192, 200
+    kw = dict(observation_space_mode="PPO_BASIC_CONTACT", env_randomizer_mode="GROUND_RANDOMIZER", seed=7)
+    a, b = vec_env(n, noise=True, **kw), vec_env(n, noise=False, **kw)
+    oa, ob = a.reset_tensor().clone(), b.reset_tensor().clone()
+    std = np.array(a.meta["layout"]["std"])
+    assert (std > 0).sum() >= 27 and (std == 0).sum() >= 5
+    torch = torch_cuda
+    gen = torch.Generator(device=a.device).manual_seed(0)
+    diffs = [(oa - ob).cpu().numpy()]
+    for t in range(steps):
+        act = torch.rand((n, a.action_dim), generator=gen, device=a.device) * 2 - 1
+        xa = a.step_tensor(act)[0].clone()
+        xb = b.step_tensor(act)[0].clone()
+        diffs.append((xa - xb).cpu().numpy())
+    assert torch.equal(a.get_state(), b.get_state())          # the noise does not touch the simulation
+    d = np.stack(diffs)                                       # [steps + 1, n, obs]
+    for k in range(d.shape[2]):
+        x = d[:, :, k].ravel()
+        if std[k] == 0:
+            assert np.all(x == 0), f"element {k} must be noise-free"
+            continue
+        assert abs(x.std() / std[k] - 1) < 0.03, (k, x.std(), std[k])
+        assert abs(x.mean()) < 5 * std[k] / np.sqrt(x.size), (k, x.mean())
+        sub = x[:: max(1, x.size // 200000)] / std[k]
+        # the observation is rounded to float32 after the noise was added: for |obs| ~ 1 and sigma ~ 2e-4 the quantum is 3e-4 sigma
+        assert stats.kstest(sub, "norm").pvalue > 1e-4, (k, stats.kstest(sub, "norm"))
+    nz = np.nonzero(std > 0)[0]
+    z = d[:, :, nz] / std[nz]
+    c_el = np.corrcoef(z.reshape(-1, len(nz)).T)
+    assert np.abs(c_el - np.eye(len(nz))).max() < 0.01                                   # between elements
+    assert abs(np.mean(z[1:] * z[:-1])) < 0.005                                          # between consecutive steps
+    assert abs(np.mean(z[:, 1:] * z[:, :-1])) < 0.005                                    # between neighbouring environments
+    a.close(); b.close()
+
+
+def test_sharded_step_on_one_nccl_rank(torch_cuda):
+    """The production branch of ShardedVecEnv.step (qs_step_fused writing into the gathered buffer, in place; RCCL as the backend)
+    equals step_tensor bit for bit, into the internal buffer and into a caller's rollout row."""
+    import torch.distributed as dist
+    from qs_amd.sharded import ShardedVecEnv
+    torch = torch_cuda
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = 512
+        kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, reset_pool=256, seed=3, noise=True)
+        a, b = vec_env(n, **kw), vec_env(n, **kw)
+        sh = ShardedVecEnv(a, learner_rank=0)
+        o1 = sh.reset().clone()
+        o2 = b.reset_tensor().clone()
+        assert torch.equal(o1, o2)
+        roll = torch.zeros((4, n, a.obs_dim + 2), device=a.device)
+        gen = torch.Generator(device=a.device).manual_seed(1)
+        saw_done = False
+        for t in range(150):
+            act = torch.rand((n, a.action_dim), generator=gen, device=a.device) * 2 - 1
+            if t % 50 > 35:
+                act[:] = torch.tensor([0.0, -1.0, 1.0, 0.0, -1.0, 1.0], device=a.device)
+            out = roll[t % 4] if t % 2 else None
+            obs, rew, done, trunc = sh.step(act, out=out)
+            eo, er, ed, et = b.step_tensor(act)
+            assert torch.equal(obs, eo) and torch.equal(rew, er) and torch.equal(done, ed.bool()) and torch.equal(trunc, et.bool()), t
+            if out is not None:
+                assert obs.data_ptr() == out.data_ptr()          # a view of the caller's row: nothing was copied
+            saw_done |= bool(done.any())
+        assert saw_done
+        a.close(); b.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [48, 23])
+def test_exact_auto_reset_in_a_partial_wave(torch_cuda, n):
+    """reset_pool = 0: a finished environment settles inside the step while its wave's other environments are done stepping.  Those
+    must come out exactly as in a run without any reset, and the reset ones as a reset of their own."""
+    kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", seed=5, settle_steps=400)
+    a, b = vec_env(n, auto_reset=True, reset_pool=0, **kw), vec_env(n, auto_reset=False, **kw)
+    a.reset(); b.reset()
+    s = b.get_state().cpu().numpy()
+    fall = np.zeros(n, bool); fall[[1, 17, 18, n - 1]] = True
+    s[fall, 2] = 0.05; s[fall, 3:7] = [0.7071, 0, 0, 0.7071]            # on their side, below the fallen height: terminate at once
+    a.set_state(s); b.set_state(s)
+    act = np.random.default_rng(0).uniform(-1, 1, size=(n, 6)).astype(np.float32)
+    oa, ra, da, ia = a.step(act)
+    ob, rb, db, _ = b.step(act)
+    assert np.array_equal(da, db) and np.array_equal(da, fall)
+    assert np.array_equal(ra, rb)
+    keep = ~fall
+    assert np.array_equal(oa[keep], ob[keep])
+    assert np.array_equal(a.get_state().cpu().numpy()[keep], b.get_state().cpu().numpy()[keep])
+    for i in np.nonzero(fall)[0]:
+        assert np.array_equal(ia[i]["terminal_observation"], ob[i])
+    # the reset ones: standing again, and a second run of the same thing gives the same bits
+    sa = a.get_state().cpu().numpy()
+    assert np.all(sa[fall, 2] > 0.2) and np.all(a.get_info("foot_contact").cpu().numpy()[fall] == 1)
+    c = vec_env(n, auto_reset=True, reset_pool=0, **kw)
+    c.reset(); c.set_state(s)
+    oc = c.step(act)[0]
+    assert np.array_equal(oc, oa) and np.array_equal(c.get_state().cpu().numpy(), sa)
+    # and the steps after it agree as well (the environments that were not reset carry nothing over from the settle)
+    act2 = np.random.default_rng(1).uniform(-1, 1, size=(n, 6)).astype(np.float32)
+    o2a = a.step(act2)[0]; o2b = b.step(act2)[0]
+    assert np.array_equal(o2a[keep], o2b[keep])
+    a.close(); b.close(); c.close()
+
+
+def test_pooled_resets_rarely_reuse_a_stale_entry(torch_cuda):
+    """The pooled auto-reset draws entry Philox(env, episode) mod P.  Over 2000 steps at N = 8192 with the streaming refill on: how many
+    resets got an entry that another reset had already used and that was not re-settled in between (seen as an identical parameter
+    draw), and are the consumed draws distributed as the reference's randomizers prescribe (env_randomizer.py:67-83, 110-117, 287-289)."""
+    from scipy import stats
+    torch = torch_cuda
+    n, steps, P = 8192, 2000, 16384
+    v = vec_env(n, env_randomizer_mode="TEST_RANDOMIZER", auto_reset=True, reset_pool=P, seed=11)
+    v.reset_tensor()
+    v.pool_streaming(True)
+    gen = torch.Generator(device=v.device).manual_seed(2)
+    draws = []
+    for t in range(steps):
+        act = torch.rand((n, v.action_dim), generator=gen, device=v.device) * 2 - 1
+        _, _, done, _ = v.step_tensor(act)
+        if t % 4 == 0:                                    # sample every fourth step (reading params costs a launch)
+            idx = torch.nonzero(done).flatten()
+            if len(idx):
+                draws.append(v.get_info("params")[idx].cpu().numpy())
+    st = v.stats()
+    v.pool_streaming(False)
+    d = np.concatenate(draws)
+    assert len(d) > 3000, len(d)
+    mu, k, b, m_leg, m_pay = d[:, 0], d[:, 1:4], d[:, 4:7], d[:, 17:20], d[:, 20]
+    _, counts = np.unique(d.view(np.dtype((np.void, d.dtype.itemsize * d.shape[1]))), return_counts=True)
+    reused = int((counts - 1).sum())
+    print(f"pooled resets sampled: {len(d)}, of which {reused} ({100.0 * reused / len(d):.1f} %) drew an entry already used and not yet re-settled; "
+          f"settle work ratio {st['settle_substeps'] / max(1, st['resets'] * 2500):.2f}")
+    assert reused / len(d) < 0.25
+    for name, x, lo, hi in [("mu", mu, 0.5, 1.0), ("k_hip", k[:, 0], 18.0, 22.0), ("k_calf", k[:, 2], 27.0, 33.0), ("b", b[:, 1], 0.27, 0.33),
+                            ("m_thigh", m_leg[:, 1], 0.828, 1.012), ("m_payload", m_pay, 0.0, 1.0)]:
+        u = np.unique(x)                                  # one value per distinct pool entry: the draws themselves
+        assert u.min() >= lo - 1e-6 and u.max() <= hi + 1e-6, name
+        p = stats.kstest((u - lo) / (hi - lo), "uniform").pvalue
+        assert p > 1e-3, (name, p)
+    v.close()

@@ -16,6 +16,9 @@ def make(n=1, springs=True, dt=0.001, **kw):
     kw.setdefault("task_env", "JUMPING_IN_PLACE")
     kw.setdefault("observation_space_mode", "PPO_BASIC")
     kw.setdefault("env_randomizer_mode", "NONE")
+    # the known answers are those of the fully converged solve: all `solver_iters` sweeps, no early exit (PyBullet's default
+    # solverResidualThreshold = 1e-7, this build's default too, stops a few 1e-4 m/s short of it)
+    kw.setdefault("solver_residual_threshold", 0.0)
     cfg, meta = build_config(n_envs=n, enable_springs=springs, noise=False, time_step=dt, **kw)
     return Oracle(cfg), cfg
 
@@ -112,10 +115,12 @@ def test_k6_static_stance(springs):
     assert 0.25 < s[2] < 0.34
 
 
-def test_k7_coulomb_cone():
-    """Sliding feet: the horizontal impulse of every substep equals mu * (sum of normal impulses) exactly."""
+@pytest.mark.parametrize("model", ["pyramid", "cone"])
+def test_k7_coulomb_cone(model):
+    """Sliding feet: the horizontal impulse of every substep equals mu * (sum of normal impulses) exactly (with the implicit cone it
+    is the NORM of the impulse that does: its direction follows the contact inertia, see k7b)."""
     mu = 0.5
-    o, cfg = make()
+    o, cfg = make(friction_model=model)
     cfg.randomizer_flags = 8
     o = Oracle(cfg)
     o.set_params(0, np.array([mu]))
@@ -125,12 +130,15 @@ def test_k7_coulomb_cone():
     o.set_state(s)
     tau_hold = o.get_info(2)[0] + o.get_info(3)[0]
     for _ in range(5):
-        p0 = o.energy(0)["p"][0]
+        p0 = o.energy(0)["p"][:2].copy()
         o.phys_step(0, tau_hold)
-        dp = o.energy(0)["p"][0] - p0
+        dpv = o.energy(0)["p"][:2] - p0
+        dp = dpv[0] if model == "pyramid" else -np.linalg.norm(dpv)
         fn = o.get_info(0)[0].sum()
-        assert fn > 50
-        assert dp == pytest.approx(-mu * fn * cfg.dt, rel=2e-3)
+        assert fn > 50 and dpv[0] < 0
+        # cone: each foot's impulse has norm mu x its normal impulse, but the four directions differ by a few degrees (they follow
+        # each contact's inertia), so the norm of their sum falls short of the sum of their norms by ~0.2 %
+        assert dp == pytest.approx(-mu * fn * cfg.dt, rel=2e-3 if model == "pyramid" else 4e-3)
     # and a foot at rest on the ground is not dragged: |f_t| stays inside the cone (robot keeps standing still)
     o.reset()
     for _ in range(100):

@@ -34,7 +34,8 @@ def test_trace(golden, name):
     state_ref = g[f"{name}_state"]
     # the trajectories run free (no re-synchronisation): the float32 rounding of the config limits is amplified by the
     # contact dynamics; the Cartesian mode adds the IK's square roots on top
-    tol = 5e-3 if kw["motor_control_mode"] == "CARTESIAN_PD" else 5e-4
+    # (with PyBullet's solverResidualThreshold the number of sweeps of a substep can differ by one between the two replays)
+    tol = 5e-3 if kw["motor_control_mode"] == "CARTESIAN_PD" else 1e-3
     resync = kw["motor_control_mode"] == "TORQUE"   # an open-loop torque script has no feedback to hold a free-running replay together
     for t in range(len(acts)):
         if resync and t > 0 and t not in reset_at:

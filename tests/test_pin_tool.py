@@ -1,6 +1,6 @@
 """tools/pin_against_pybullet.py (the recipe that pins the oracle's substep against real PyBullet) cannot meet PyBullet in this image.
 Here its whole control flow runs against a stand-in client that answers the PyBullet calls the tool makes from the oracle itself
-(contact_erp = 0.2): the matching hypothesis must come out with zero deviation, a different one must not, and the fixture it
+(the build's defaults: implicit cone, contact_erp = 0.08): the matching hypothesis must come out with zero deviation, a different one must not, and the fixture it
 writes must hold the compared rows."""
 import os
 import sys
@@ -77,9 +77,9 @@ def test_pin_recipe_runs_against_a_stand_in_client(tmp_path, monkeypatch, capsys
     text = capsys.readouterr().out
     blocks = text.split("one-substep deviation oracle")
     assert len(blocks) == 5                                   # 2 friction models x 2 contact ERPs
-    assert "friction_model = pyramid, contact_erp = 0.2" in blocks[1] and "overall          pos 0.000e+00" in blocks[1] and "force_rel 0.000e+00" in blocks[1].splitlines()[-1]
-    assert "friction_model = pyramid, contact_erp = 0.08" in blocks[2] and "force_rel 0.000e+00" not in blocks[2].split("overall")[1]
-    assert "friction_model = cone, contact_erp = 0.2" in blocks[3] and "overall          pos 0.000e+00" not in blocks[3]      # the hop slides a little: the models differ
+    assert "friction_model = cone, contact_erp = 0.08" in blocks[1] and "overall          pos 0.000e+00" in blocks[1] and "force_rel 0.000e+00" in blocks[1].splitlines()[-1]
+    assert "friction_model = cone, contact_erp = 0.2" in blocks[2] and "force_rel 0.000e+00" not in blocks[2].split("overall")[1]
+    assert "friction_model = pyramid, contact_erp = 0.08" in blocks[3] and "overall          pos 0.000e+00" not in blocks[3]      # the hop slides a little: the models differ
     z = np.load(out)
     assert z["state"].shape == (1750, 37) and z["tau"].shape == (1750, 12) and z["foot_force"].shape == (1750, 4)
     assert z["state"][:, 2].max() > 0.38 and (z["foot_force"].sum(axis=1) == 0).sum() > 100      # the script hops: there is a flight phase

@@ -191,7 +191,8 @@ def test_collision_geometry_matches_the_urdf(model, seed):
     primitives counted as invalid contacts when they clearly penetrate and not when they clearly do not."""
     rng = np.random.default_rng(seed)
     from scipy.spatial.transform import Rotation
-    cfg, _ = build_config(n_envs=1, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=False, env_randomizer_mode="NONE")
+    # self_collision off: this test is about the primitives against the plane (a random hip angle of 1 rad does cross two calves)
+    cfg, _ = build_config(n_envs=1, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=False, env_randomizer_mode="NONE", self_collision=False)
     o = Oracle(cfg)
     feet = ["FR_foot", "FL_foot", "RR_foot", "RL_foot"]
     for trial in range(6):
@@ -235,7 +236,9 @@ def test_contact_step_balances_impulse_and_momentum(model, seed, friction, engin
     rng = np.random.default_rng(seed)
     mu, dt, r_foot = 0.7, 1e-3, 0.02
     cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
-                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False, friction_model=friction)
+                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False, friction_model=friction,
+                          solver_residual_threshold=0.0)     # the converged solve: all sweeps
+    slop = cfg.contact_slop
     o = Oracle(cfg)
     o.reset()
     hold = o.get_info(2)[0].copy()                         # the joint torques that carry the settled stance
@@ -293,4 +296,5 @@ def test_contact_step_balances_impulse_and_momentum(model, seed, friction, engin
         assert np.any(np.hypot(imp[touching, 0], imp[touching, 1]) >= mu * imp[touching, 2] * (1 - slack) - slack * dt)   # and some foot is on its rim
     assert np.all(np.abs(imp[~touching]) < 1e-9 + slack * dt)
     vz = (J @ nu).reshape(4, 3)[:, 2]
-    assert np.all(vz[touching] >= -np.maximum(gap[touching], 0) / dt - 2e-3), "a touching foot still moves into the ground"
+    # a contact row lets a foot that is still `gap` (+ Bullet's linear slop) above the plane close exactly that distance in this step
+    assert np.all(vz[touching] >= -np.maximum(gap[touching] + slop, 0) / dt - 2e-3), "a touching foot still moves into the ground"

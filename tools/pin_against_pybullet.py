@@ -91,11 +91,16 @@ def main():
     ap.add_argument("--substeps", type=int, default=2600)
     ap.add_argument("--springs", type=int, default=1)
     ap.add_argument("--mu", type=float, default=1.0, help="ground lateralFriction (env_randomizer.py:287-289 draws 0.5 .. 1)")
-    ap.add_argument("--grid", nargs="+", default=["friction_model=pyramid,cone", "contact_erp=0.2,0.08"],
-                    help="solver settings of the oracle to try, key=v1,v2,... each (keywords of qs_amd.config.build_config: friction_model, "
-                         "contact_erp, joint_erp, warmstart, solver_residual_threshold); every combination gets its own table.  Defaults: the "
-                         "friction pyramid with Bullet's skip rule vs the implicit cone PyBullet's documentation calls its default "
-                         "(enableConeFriction), and Bullet's contact ERP 0.2 vs the erp2 = 0.08 PyBullet may set")
+    ap.add_argument("--grid", nargs="+", default=["friction_model=cone,pyramid", "contact_erp=0.08,0.2"],
+                    help="hypotheses about the engine to try, key=v1,v2,... each (keywords of qs_amd.config.build_config: friction_model, "
+                         "contact_erp, contact_slop, joint_erp, warmstart, solver_residual_threshold, mass_inertia_rule, body_contacts, self_collision); "
+                         "every combination gets its own table, the build's defaults first.  Defaults: the implicit cone (btMultiBodyDynamicsWorld sets "
+                         "SOLVER_USE_2_FRICTION_DIRECTIONS, implicit cone friction is on unless disabled) vs the pyramid with Bullet's skip rule, and "
+                         "PyBullet's erp2 = 0.08 vs Bullet's 0.2.  mass_inertia_rule=collision_shape,scale only shows with --remass")
+    ap.add_argument("--remass", action="store_true",
+                    help="call changeDynamics(mass = URDF mass) on trunk and leg links first, as the reference's mass randomizer does at every reset "
+                         "(quadruped.py:761, 776): PyBullet then replaces their inertia by its collision-shape rule; the oracle is built with the "
+                         "mass randomizer's rule (mass_inertia_rule of the grid) and nominal masses")
     ap.add_argument("--write", default="", help="save the compared rows as an .npz fixture")
     args = ap.parse_args()
     try:
@@ -112,13 +117,18 @@ def main():
     axes = []
     for item in args.grid:
         key, _, vals = item.partition("=")
-        axes.append([(key, v if key == "friction_model" else float(v)) for v in vals.split(",")])
+        conv = (lambda v: v) if key in ("friction_model", "mass_inertia_rule") else (lambda v: bool(int(v))) if key in ("body_contacts", "self_collision") else float
+        axes.append([(key, conv(v)) for v in vals.split(",")])
     oracles, labels = [], []
     for combo in itertools.product(*axes):
         cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
-                              enable_springs=bool(args.springs), env_randomizer_mode="NONE", enable_action_filter=False, **dict(combo))
+                              enable_springs=bool(args.springs), env_randomizer_mode="MASS_RANDOMIZER" if args.remass else "NONE",
+                              enable_action_filter=False, **dict(combo))
+        cfg.randomizer_flags = 8                     # keep the parameters set below: nominal masses, no payload
         oracles.append(Oracle(cfg))
-        oracles[-1].set_params(0, np.array([[args.mu]]))
+        par = oracles[-1].get_info(6)
+        par[0, 0], par[0, 16:24] = args.mu, [5.204, 0.591, 0.92, 0.131, 0.0, 0.0, 0.0, 0.0]
+        oracles[-1].set_params(5, par)
         labels.append(", ".join(f"{k} = {v}" for k, v in combo))
 
     p = bullet_client.BulletClient(connection_mode=pybullet.DIRECT)
@@ -136,6 +146,10 @@ def main():
     p.changeDynamics(plane, -1, lateralFriction=args.mu)
     for j in MOTOR_IDS:
         p.changeDynamics(robot, j, maxJointVelocity=30.1)
+    if args.remass:
+        p.changeDynamics(robot, 0, mass=5.204)
+        for j, m in zip(MOTOR_IDS, [0.591, 0.92, 0.131] * 4):
+            p.changeDynamics(robot, j, mass=m)
     for j in range(nj):
         p.setJointMotorControl2(robot, j, p.VELOCITY_CONTROL, targetVelocity=0, force=0)
     for j, a in zip(MOTOR_IDS, INIT_Q):
@@ -146,6 +160,7 @@ def main():
     worst = [dict.fromkeys(keys, 0.0) for _ in oracles]
     phase_of = lambda i: "stand" if i < 1000 else "crouch" if i < 1400 else "push" if i < 1430 else "flight+landing"
     by_phase = [dict() for _ in oracles]
+    noted_other = False
     for i in range(args.substeps):
         s = bullet_state(p, robot)
         q, qd = s[13:25], s[25:37]
@@ -160,11 +175,11 @@ def main():
             o.phys_step(0, tau_m + tau_s)
         p.stepSimulation()
         other = [c[3] for c in p.getContactPoints(bodyA=robot) if c[3] not in FOOT_IDS]
-        if other:
-            # the oracle and the kernel DETECT these contacts (they end the episode of every task, task_base.py:137-147) but apply no
-            # contact force to them: the comparison is meaningless from here on
-            print(f"substep {i}: PyBullet reports contact on non-foot link(s) {sorted(set(other))}; stopping the comparison here")
-            break
+        if other and not noted_other:
+            # the oracle (body_contacts) lets these links push back too, with at most two support points per leg; only the feet's forces
+            # are compared below
+            print(f"substep {i}: PyBullet reports contact on non-foot link(s) {sorted(set(other))}")
+            noted_other = True
         sb, fb = bullet_state(p, robot), foot_forces(p, robot, plane)
         for k_o, o in enumerate(oracles):
             so, fo = o.get_state()[0], o.get_info(0)[0]
