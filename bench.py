@@ -239,7 +239,13 @@ def main():
     kernel_ms = []
     barrier()
     stats0 = env.stats()
-    limit0 = env.counter("limit_path_substeps")
+    def narrow():
+        try:
+            return env.counter("self_narrow_substeps")
+        except RuntimeError:       # a library of round 1 (QS_LIB_PATH, A/B runs) has no such counter
+            return 0
+
+    limit0, narrow0 = env.counter("limit_path_substeps"), narrow()
     refills0 = env.pool_streaming(True) if streaming else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -247,7 +253,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stats1 = env.stats()
-    limit1 = env.counter("limit_path_substeps")
+    limit1, narrow1 = env.counter("limit_path_substeps"), narrow()
     refills1 = env.pool_streaming(True) if streaming else 0
     local_elapsed = None
     if sharded:   # the same number of steps without the exchange, to price it (reported as config.exchange_us; not the headline)
@@ -328,6 +334,7 @@ def main():
                        # inside the region; short runs see less because an entry takes settle_steps / action_repeat launches to settle)
                        "settle_work_ratio": (settle_sub / (resets * env.cfg.settle_steps)) if resets else None,
                        "joint_limit_path_wave_substeps": int(limit1 - limit0),
+                       "self_collision_narrow_phase_wave_substeps": int(narrow1 - narrow0),
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step (both skipped on one rank), results land in rank 0's rollout buffer" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -187,8 +187,11 @@ enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset
        QS_COUNTER_RESETS = 1,               /* environment resets */
        QS_COUNTER_POOL_CONSUMED = 2,        /* auto-resets served from the reset pool */
        QS_COUNTER_POOL_REFILLED = 3,        /* pool entries re-settled by the streaming refill */
-       QS_COUNTER_LIMIT_PATH_SUBSTEPS = 4   /* wave-substeps in which some joint of the wave's 16 environments sat at a stop: those run
-                                               the slow 6-rows-per-leg solver (per process, not per handle) */ };
+       QS_COUNTER_LIMIT_PATH_SUBSTEPS = 4,  /* wave-substeps in which some joint of the wave's 16 environments sat at a stop or (body_contacts)
+                                               a non-foot link touched the plane: those run the slow many-rows-per-leg solver (per
+                                               process, not per handle) */
+       QS_COUNTER_SELF_NARROW_SUBSTEPS = 5  /* wave-substeps whose self-collision broad phase found a calf close enough to another leg or
+                                               the trunk to run the link-link tests (per process) */ };
 int qs_counter(qs_handle* h, int which, uint64_t* value);
 /* HIP events bracketing the step kernel of the most recent qs_step (on the handle's stream): elapsed milliseconds, for
  * bench.py's roofline leg.  Recording is off by default (qs_enable_timing). */

@@ -217,7 +217,11 @@ template <> struct Rng<LaneEmu> {
 // ------------------------------------------------------------------ rigid-body substep
 // CONE: friction model of the contact rows, a compile-time choice so that neither variant costs the other registers or a branch:
 // false = pyramid with Bullet's skip rule, true = implicit cone (qs_config::friction_cone; the kernels are built for both).
-template <class T, bool CONE = false> struct Sim {
+// HOT: the build of the substep that holds the common path ONLY.  Where a wave would need one of the rare paths (a joint at its stop,
+// a non-foot link on the plane, the link-link tests of the self-collision rule) substep() gives up and returns true instead: the step
+// kernel then repeats the whole env step of that wave with the full build (HOT = false), whose rare code thus sits outside the hot
+// loop and costs it neither registers nor schedule (measured: inlined into the loop the rare code took 20 % off the headline).
+template <class T, bool CONE = false, bool HOT = false> struct Sim {
     using V = typename T::V;
     using M = typename T::M;
     using V3v = V3<V>;
@@ -378,6 +382,9 @@ template <class T, bool CONE = false> struct Sim {
         QS_PHASE_G(9)
         const V big = V(1e10f), zero = V(0.0f);
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
+        // (the implicit cone's projection is not idempotent in floating point: once an environment is frozen its friction bound is lifted,
+        // so that the sweeps the rest of the wave still needs leave it exactly alone and no result depends on the wave's other environments)
+        V mu_c = mu;
         for (int it = 0; it < cfg.solver_iters; it++) {
             V dvmax = zero;   // largest |row velocity change| of this sweep (replicated over the quad)
             // Row (K, RR): every lane clamps the candidate of ITS row RR, lane K's result is the real one; one DPP-fused
@@ -405,7 +412,7 @@ template <class T, bool CONE = false> struct Sim {
 #define QS_PAIR_UPDATE(K)                                                                                              \
     {                                                                                                                  \
         constexpr int ia_ = NR * (K) + 1, ib_ = NR * (K) + 2;                                                          \
-        V lim = mu * lam_all[NR * (K)];                                                                                \
+        V lim = mu_c * lam_all[NR * (K)];                                                                              \
         V r2 = res[1] * res[1] + res[2] * res[2];                                                                      \
         V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));   /* min(1, mu lambda_n / |c|) */                      \
         V da = T::template bcast<K>(res[1] * sc) - lam_all[ia_], db = T::template bcast<K>(res[2] * sc) - lam_all[ib_]; \
@@ -424,6 +431,7 @@ template <class T, bool CONE = false> struct Sim {
 #undef QS_ROW_UPDATE
             if (TRACK) {
                 M conv = qle(dvmax, thr);
+                if (CONE) mu_c = qsel(conv, V(1e30f), mu_c);
                 // frozen environment: make clamp(cand) == lam for its rows from now on
 #pragma unroll
                 for (int c = 0; c < NR; c++) {
@@ -526,6 +534,7 @@ template <class T, bool CONE = false> struct Sim {
 #undef QS_RWARM
         const bool track = cfg.solver_residual_threshold > 0.0f;
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
+        V mu_c = mu;   // friction bound of the cone rows; lifted once the environment is frozen (see solve_and_integrate)
         // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the normal impulse
         // of its contact point (row N0 of the same leg)
 #define QS_RROW(K, R, KIND, N0)                                                                                        \
@@ -541,7 +550,7 @@ template <class T, bool CONE = false> struct Sim {
         // implicit cone friction: both friction rows of a contact point of leg K together (see solve_and_integrate)
 #define QS_RPAIR(K, N0)                                                                                                \
     {                                                                                                                  \
-        V ca = lam[(N0) + 1] + res[(N0) + 1], cb = lam[(N0) + 2] + res[(N0) + 2], lim = mu * lam[N0];                  \
+        V ca = lam[(N0) + 1] + res[(N0) + 1], cb = lam[(N0) + 2] + res[(N0) + 2], lim = mu_c * lam[N0];                \
         V r2 = ca * ca + cb * cb;                                                                                      \
         V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));                                                       \
         ca = ca * sc; cb = cb * sc;                                                                                    \
@@ -571,6 +580,7 @@ template <class T, bool CONE = false> struct Sim {
             QS_RFRICTION(0) QS_RFRICTION(1) QS_RFRICTION(2) QS_RFRICTION(3)
             if (track) {
                 M conv = qle(dvmax, thr);
+                if (CONE) mu_c = qsel(conv, V(1e30f), mu_c);
 #pragma unroll
                 for (int c = 0; c < NRW; c++) res[c] = qsel(conv, zero, res[c]);
                 if (!T::any(qnot(conv))) break;
@@ -678,7 +688,11 @@ template <class T, bool CONE = false> struct Sim {
         return n;
     }
 
-    static QS_FN void substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o) {
+    // returns true iff HOT and the wave needs a rare path (nothing it wrote is valid then).
+    // `detect`: classify the contacts of the non-foot links, the payload block and the link-link pairs (o.n_invalid).  The reference reads
+    // GetContactInfo after the LAST stepSimulation of an env step (task_base.py:137-147 via gym_env.py:241-245), so the callers ask for it
+    // there only -- unless cfg.body_contacts, where those links' heights decide in every substep whether they push back.
+    static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true) {
         using namespace go1;
         Model P;
         {   // opaque copies keep the compiler from hoisting the 24 leg constants out of the substep loop (where they would
@@ -844,13 +858,16 @@ template <class T, bool CONE = false> struct Sim {
         o.foot_contact = active;
         // height of the lowest vertex of each primitive (this lane: the trunk corner on its own side, its hip, the two ends of its
         // thigh box, the two ends of its calf box)
-        const V az = dot(Rz, Y), gx2 = dot(Rz, X2), gx3 = dot(Rz, X3), gp2 = dot(Rz, p2), gp3 = dot(Rz, p3);
-        const V h_trunk = zc + Rz.x * (fx * TRUNK_HALF[0]) + Rz.y * (sy * TRUNK_HALF[1]) - qabs(Rz.z) * TRUNK_HALF[2];
-        const V h_hip = zc + dot(Rz, p1) - HIP_CYL_HALF_LEN * qabs(az) - HIP_CYL_R * qsqrt(qmax(one - az * az, zero));
-        const V th_off = qabs(gx2) * THIGH_HALF[0] + qabs(az) * THIGH_HALF[1], cf_off = (qabs(gx3) + qabs(az)) * CALF_HALF[0];
-        const V h_th_hi = zc + gp2 - th_off, h_th_lo = zc + gp3 - th_off, h_cf_hi = zc + gp3 - cf_off, h_cf_lo = zc + grf - cf_off;
+        V az = zero, gx2 = zero, gx3 = zero, h_trunk = zero, h_hip = zero, h_th_hi = zero, h_th_lo = zero, h_cf_hi = zero;
         M any_extra = qlt(one, zero);
-        {
+        if (detect) {
+            az = dot(Rz, Y); gx2 = dot(Rz, X2); gx3 = dot(Rz, X3);
+            const V gp2 = dot(Rz, p2), gp3 = dot(Rz, p3);
+            h_trunk = zc + Rz.x * (fx * TRUNK_HALF[0]) + Rz.y * (sy * TRUNK_HALF[1]) - qabs(Rz.z) * TRUNK_HALF[2];
+            h_hip = zc + dot(Rz, p1) - HIP_CYL_HALF_LEN * qabs(az) - HIP_CYL_R * qsqrt(qmax(one - az * az, zero));
+            const V th_off = qabs(gx2) * THIGH_HALF[0] + qabs(az) * THIGH_HALF[1], cf_off = (qabs(gx3) + qabs(az)) * CALF_HALF[0];
+            h_th_hi = zc + gp2 - th_off; h_th_lo = zc + gp3 - th_off; h_cf_hi = zc + gp3 - cf_off;
+            const V h_cf_lo = zc + grf - cf_off;
             M m_trunk = qlt(h_trunk, V(THR_TRUNK)), m_hip = qlt(h_hip, V(THR_HIP));
             M m_thigh = qlt(qmin(h_th_hi, h_th_lo), V(THR_THIGH)), m_calf = qlt(qmin(h_cf_hi, h_cf_lo), V(THR_CALF));
             V trunk = qflag(qgt(T::quad_sum(qflag(m_trunk)), zero));
@@ -861,7 +878,7 @@ template <class T, bool CONE = false> struct Sim {
             o.n_invalid = T::quad_sum(n) + trunk + pay;
             if (cfg.body_contacts) any_extra = qor(qor(m_trunk, m_hip), qor(m_thigh, qlt(h_cf_hi, V(THR_CALF))));
         }
-        if (cfg.self_collision) {
+        if (detect && cfg.self_collision) {
             // Link-link contacts count only when a calf is involved (quadruped.py:237-241).  Broad phase, every substep: extents of
             // the own calf and of the own whole leg towards the robot's centre planes, in mirrored coordinates (sy y: towards the own
             // side, fx x: towards the own end); thigh within 0.021 of its axis, calf and foot within 0.02, hip housing within 0.046.
@@ -875,6 +892,8 @@ template <class T, bool CONE = false> struct Sim {
             M c3 = qand(qlt(mc + T::template xorl<3>(ml), V(MARGIN)), qlt(nc + T::template xorl<3>(nl), V(MARGIN)));   // diagonal
             M ctr = qand(qand(qlt(mc, V(TRUNK_HALF[1] + MARGIN)), qgt(qmax(p3.z, rf.z) + 0.02f, V(-TRUNK_HALF[2] - MARGIN))), qlt(nc, V(TRUNK_HALF[0] + MARGIN)));
             if (T::any(qor(qor(cy1, cx2), qor(c3, ctr)))) {
+                if (HOT) return true;
+                T::count_self_narrow();
                 LegGeom lg;
                 lg.p1 = p1; lg.ct = p2 + Z2 * V(LINK_BOX_Z); lg.X2 = X2; lg.Y = Y; lg.Z2 = Z2; lg.cc = p3 + Z3 * V(LINK_BOX_Z); lg.X3 = X3; lg.Z3 = Z3; lg.rf = rf;
                 o.n_invalid = o.n_invalid + T::quad_sum(self_contacts(lg, qflag(cy1), qflag(cx2), qflag(c3), qflag(ctr)));
@@ -897,6 +916,7 @@ template <class T, bool CONE = false> struct Sim {
         // Nothing to solve when no foot of the wave's 16 environments is within contact range and no joint sits at a stop:
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
+        if (HOT && T::any(qor(any_lim, any_extra))) return true;
         if (T::any(qor(qor(act_m, any_lim), any_extra))) {
         QS_PHASE(8)
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
@@ -963,7 +983,7 @@ template <class T, bool CONE = false> struct Sim {
     _Pragma("unroll") for (int i = 0; i < 6; i++) (A).Ld[i] = Ld[i];                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int i = 0; i < 6; i++) (A).BK[j][i] = BK[j][i]; \
     _Pragma("unroll") for (int i = 0; i < 9; i++) (A).R[i] = R[i];
-        if (T::any(any_extra)) {
+        if (!HOT && T::any(any_extra)) {
             // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
             // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
             T::count_rare_path();
@@ -1011,7 +1031,7 @@ template <class T, bool CONE = false> struct Sim {
             QS_LIMIT_ROWS(a.rows + 9)
             QS_RARE_COMMON(a)
             solve_with_limits<3>(cfg, Pr.mu, s, o, a);
-        } else if (T::any(any_lim)) {
+        } else if (!HOT && T::any(any_lim)) {
             T::count_rare_path();
             QS_LIMIT_ROWS(rows + 3)
             RareArgs<1> a;
@@ -1049,6 +1069,7 @@ template <class T, bool CONE = false> struct Sim {
         for (int j = 0; j < 3; j++) s.q[j] = s.q[j] + dt * s.qd[j];
         QS_PHASE(12)
         QS_PHASE_END
+        return false;
     }
 };
 

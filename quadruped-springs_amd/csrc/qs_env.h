@@ -8,10 +8,10 @@ namespace qs {
 QS_FN float i2f(int v) { union { int i; float f; } u; u.i = v; return u.f; }
 QS_FN int f2i(float v) { union { int i; float f; } u; u.f = v; return u.i; }
 
-template <class T, bool CONE = false> struct Env {
+template <class T, bool CONE = false, bool HOT = false> struct Env {
     using V = typename T::V;
     using M = typename T::M;
-    using S = Sim<T, CONE>;
+    using S = Sim<T, CONE, HOT>;
     using V3v = V3<V>;
     static constexpr float PI = 3.14159265358979323846f;
 
@@ -457,7 +457,7 @@ template <class T, bool CONE = false> struct Env {
         default: return {false, false, false, false, 0, false};
         }
     }
-    struct StepOut { V reward, done, trunc; };
+    struct StepOut { V reward, done, trunc; bool redo; };   // redo (HOT builds, wave-uniform): the wave needs the full build, nothing here is valid
 
     // One env.step(action) (gym_env.py:227-256).  `rec` = this environment's record, `act` = its action row,
     // `obs` = QS_MAX_OBS floats of staging for its observation.
@@ -594,13 +594,13 @@ template <class T, bool CONE = false> struct Env {
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             QS_PHASE_SUB_BEGIN
             S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
-            S::substep(cfg, P, s, tau, o);
+            if (S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts)) { StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = true; return z; }
             QS_PHASE_SUB(k)
             if (any_trace) {
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
             }
         }
-        if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); return z; }
+        if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = false; return z; }
         QS_PHASE(32)
         if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;
@@ -641,6 +641,7 @@ template <class T, bool CONE = false> struct Env {
         reward = reward + qsel(qgt(done, V(0.5f)), task_reward_end(cfg, t, term, now), V(0.0f));  // :250-251
         QS_PHASE(35)
         StepOut r; r.reward = reward; r.done = done; r.trunc = qsel(qgt(term, V(0.5f)), V(0.0f), done);  // :246
+        r.redo = false;
         if (cfg.wrapper_mode != QS_WRAP_NONE) {
             float* w = rec + R_WRAP;
             M running = qlt(done, V(0.5f));
@@ -768,7 +769,10 @@ template <class T, bool CONE = false> struct Env {
             V cmd[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
-            for (int n = 0; n < cfg.settle_steps; n++) { V tau[3]; S::actuate(cfg, P, s, cmd, o, tau, true); S::substep(cfg, P, s, tau, o); }
+            for (int n = 0; n < cfg.settle_steps; n++) {
+                V tau[3]; S::actuate(cfg, P, s, cmd, o, tau, true);
+                S::substep(cfg, P, s, tau, o, n == cfg.settle_steps - 1 || cfg.body_contacts);
+            }
             store_state(rec, s, o);
         } else {  // the record already holds a settled state (copied from the pre-settled pool)
             load_state(rec, s);

@@ -79,7 +79,8 @@ template <bool CONE> static __device__ __forceinline__ void step_body(const qs_c
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, PoolView pool,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
-    using E = Env<LaneDev, CONE>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
+    using E = Env<LaneDev, CONE>;          // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
+    using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
@@ -116,7 +117,21 @@ template <bool CONE> static __device__ __forceinline__ void step_body(const qs_c
     if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
-    typename E::StepOut r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, any_trace && env == tap.env ? tap.rows : nullptr, any_trace, demo.rows, demo.length);
+    float* const trow = any_trace && env == tap.env ? tap.rows : nullptr;
+    typename E::StepOut r;
+    {
+        typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+        r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
+    }
+    if (r.redo) {
+        // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
+        // env step of the whole wave with the full build
+        __syncthreads();
+        tile_load(s_rec, base, first, limit);
+        __syncthreads();
+        if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
+        r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+    }
     QS_PHASE(14)
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
@@ -620,6 +635,7 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
     case QS_COUNTER_POOL_CONSUMED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_CONSUMED], sizeof(v), hipMemcpyDeviceToHost)); break;
     case QS_COUNTER_POOL_REFILLED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_REFILLED], sizeof(v), hipMemcpyDeviceToHost)); break;
     case QS_COUNTER_LIMIT_PATH_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_rare_path_substeps), sizeof(v))); break;
+    case QS_COUNTER_SELF_NARROW_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_self_narrow_substeps), sizeof(v))); break;
     default: QS_FAIL(-1, "unknown counter %d", which);
     }
     *value = v;

@@ -90,6 +90,8 @@ QS_FN float qflag(bool m) { return m ? 1.0f : 0.0f; }
 #if defined(__HIPCC__)
 // telemetry: wave-substeps that took the joint-limit solver path (all handles of the process; read through qs_counter)
 __device__ unsigned long long qs_rare_path_substeps;
+// ... and wave-substeps whose self-collision broad phase asked for the link-link tests
+__device__ unsigned long long qs_self_narrow_substeps;
 struct LaneDev {
     using V = float;
     using M = bool;
@@ -142,6 +144,7 @@ struct LaneDev {
     // keeps the scheduler from moving instructions across this point (bounds live ranges in the unrolled joint-limit sweeps)
     static QS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
     static QS_DEV void count_rare_path() { if (threadIdx.x == 0) atomicAdd(&qs_rare_path_substeps, 1ull); }
+    static QS_DEV void count_self_narrow() { if (threadIdx.x == 0) atomicAdd(&qs_self_narrow_substeps, 1ull); }
     // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
     static QS_DEV void sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -205,6 +208,7 @@ struct LaneEmu {
     static int opaque_zero() { return 0; }
     static void sched_fence() {}
     static void count_rare_path() {}
+    static void count_self_narrow() {}
     struct Acc4 { V4 k[4]; };
     static Acc4 acc4_zero() { Acc4 z; for (int i = 0; i < 4; i++) z.k[i] = V4(0.0f); return z; }
     static void outer_fma(V4 a, V4 b, Acc4& acc) { for (int K = 0; K < 4; K++) for (int l = 0; l < 4; l++) acc.k[K].v[l] = fmaf(a.v[K], b.v[l], acc.k[K].v[l]); }

@@ -279,7 +279,7 @@ def build_config(
     joint_erp=0.2,
     warmstart=0.1,
     friction_model="cone",
-    body_contacts=True,
+    body_contacts="auto",
     self_collision=True,
     mass_inertia_rule="collision_shape",
     **_ignored,
@@ -380,6 +380,12 @@ def build_config(
     # what tools/pin_against_pybullet.py finds on a machine that has PyBullet
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = float(contact_erp), float(joint_erp), float(warmstart), rc.VELOCITY_LIMITS[0]
     cfg.contact_slop = float(contact_slop)
+    # "auto": the non-foot links push back where the episode goes on after they touched the ground, i.e. under NO_TASK (the reference's
+    # CPG driver, hopf_network.py:183-190).  Every other task ends the episode at the end of the env step in which such a contact
+    # appears (task_base.py:137-147), so the response would only shape the last <= action_repeat substeps of an episode that is over,
+    # at the price of the slow many-row solver path for the whole wave.  True forces it on everywhere.
+    if body_contacts == "auto":
+        body_contacts = task_env == "NO_TASK"
     cfg.body_contacts, cfg.self_collision = int(bool(body_contacts)), int(bool(self_collision))
     # changeDynamics(mass=...) is only ever called by the mass randomizer (env_randomizer.py:56-83 -> quadruped.py:761, 776), at every
     # reset and for every randomised link, also when the drawn mass equals the URDF's: without it the URDF tensors stay

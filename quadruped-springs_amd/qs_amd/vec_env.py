@@ -146,7 +146,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         _lib.check(self.lib.qs_stats(self.h, C.byref(a), C.byref(b)))
         return dict(settle_substeps=a.value, resets=b.value)
 
-    COUNTERS = dict(settle_substeps=0, resets=1, pool_consumed=2, pool_refilled=3, limit_path_substeps=4)
+    COUNTERS = dict(settle_substeps=0, resets=1, pool_consumed=2, pool_refilled=3, limit_path_substeps=4, self_narrow_substeps=5)
 
     def counter(self, which):
         v = C.c_uint64(0)
