@@ -85,6 +85,8 @@ def parse_args(argv=None):
                     help="PyBullet's implicit cone (its default, and this build's) or the friction pyramid with Bullet's skip rule")
     ap.add_argument("--solver-residual-threshold", type=float, default=1e-7,
                     help="PyBullet solverResidualThreshold (its default 1e-7 is this build's default); 0 = always int(300/action_repeat) sweeps")
+    ap.add_argument("--env-kw", nargs="*", default=[], metavar="KEY=VALUE",
+                    help="extra QuadrupedVecEnv keywords for experiments (python literals), e.g. self_collision=False body_contacts=True")
     return ap.parse_args(argv)
 
 
@@ -181,6 +183,9 @@ def main():
     n_default, kw = workload(args.workload)
     kw["solver_residual_threshold"] = args.solver_residual_threshold
     kw["friction_model"] = args.friction_model
+    import ast
+    extra_kw = {k: ast.literal_eval(v) for k, v in (item.split("=", 1) for item in args.env_kw)}
+    kw.update(extra_kw)
     n = args.envs_per_gpu or n_default
     if args.total_envs:
         assert args.total_envs % (16 * world) == 0, "--total-envs must split into whole waves (16 environments) per rank"
@@ -322,7 +327,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
-                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
+                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True,
                        "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
                                   ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
 
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
 // The body is compiled twice (k_step / k_step_dense below) under different register budgets.
-template <bool CONE> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+// EXACT: the build that can settle a finished environment inside the step (reset_pool = 0); the pooled builds leave that code out
+template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                  const float* __restrict__ actions, float* __restrict__ obs_out,
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
@@ -155,7 +156,7 @@ template <bool CONE> static __device__ __forceinline__ void step_body(const qs_c
                 for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
                 if ((threadIdx.x & 3) == 0) atomicAdd(&stats[1], 1ull);
             }
-            if (pool.size > 0) {
+            if (!EXACT || pool.size > 0) {
                 if (do_reset) {
                     uint32_t rr[4];
                     qs::philox4x32(cfg.seed, gid, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
@@ -214,11 +215,11 @@ template <bool CONE> static __device__ __forceinline__ void step_body(const qs_c
 #define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap, demo
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
-template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE>(QS_STEP_PASS); }
+template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, EXACT>(QS_STEP_PASS); }
 // Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
 // issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
 // (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
-template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE>(QS_STEP_PASS); }
+template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, EXACT>(QS_STEP_PASS); }
 
 // Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
 // settling into the pool (they replace the entries at the rotating cursor) ...
@@ -575,8 +576,11 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && 2 * grid > 3 * h->n_simd);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
                                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo)
-    if (h->cfg.friction_cone) { if (dense) QS_LAUNCH_STEP(k_step_dense<true>); else QS_LAUNCH_STEP(k_step<true>); }
-    else { if (dense) QS_LAUNCH_STEP(k_step_dense<false>); else QS_LAUNCH_STEP(k_step<false>); }
+    const bool exact = h->cfg.auto_reset && h->pool_size == 0;   // finished environments settle inside the step
+#define QS_PICK(C, X) { if (dense) QS_LAUNCH_STEP((k_step_dense<C, X>)); else QS_LAUNCH_STEP((k_step<C, X>)); }
+    if (h->cfg.friction_cone) { if (exact) QS_PICK(true, true) else QS_PICK(true, false) }
+    else { if (exact) QS_PICK(false, true) else QS_PICK(false, false) }
+#undef QS_PICK
 #undef QS_LAUNCH_STEP
     if (h->timing) hipEventRecord(h->ev1, h->stream);
     QS_HIP(hipGetLastError());
