@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Copy what a GPU call of tools/r02_gpu_profiles.sh left under gpurun_out/ into profiles/ (tracked), named per round and tag.
+usage: python tools/collect_profiles.py gpurun_out/r02p gpurun_out/prof_r02a r02_a"""
+import os
+import shutil
+import sys
+
+run, prof, tag = sys.argv[1:4]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+rnd = tag.split("_")[0]
+for f in sorted(os.listdir(run)):
+    if f.endswith(".json") and os.path.getsize(os.path.join(run, f)) > 10:
+        shutil.copy(os.path.join(run, f), os.path.join(dst, f"{tag}_{f[:-5]}_bench.json"))
+for src, name in (("summary.md", "kernel_trace_pmc.md"), ("pmc.json", "pmc.json"), ("kernel_stats.csv", "kernel_stats.csv"), ("bench.json", "profiled_command_bench.json")):
+    if os.path.exists(os.path.join(prof, src)):
+        shutil.copy(os.path.join(prof, src), os.path.join(dst, f"{tag}_{name}"))
+print(sorted(x for x in os.listdir(dst) if x.startswith(tag)))

@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output directories (kernel stats + one directory per --pmc pass) for one kernel.
-usage: python tools/pmc_summary.py gpurun_out/prof3 k_step"""
+"""Summarise rocprofv3 CSV output directories (kernel stats + one directory per --pmc pass) for one kernel, over ALL of its launches.
+usage: python tools/pmc_summary.py gpurun_out/prof_x k_step [bench.json pmc.json]
+With the last two arguments the per-launch averages are also written as the pmc.json that bench.py reads (roofline.traffic)."""
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
 root, kernel = sys.argv[1], sys.argv[2]
+bench_json, out_json = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else (None, None)
 
 
 def base(name):
-    """'void k_step<false>(qs_config const*, ...)' -> 'k_step<false>'"""
+    """'void k_step<false, true>(qs_config const*, ...)' -> 'k_step<false, true>'"""
     n = name.split("(")[0].strip()
     return n[5:] if n.startswith("void ") else n
 
@@ -28,15 +31,30 @@ for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=Tru
             print(f"| {n[:50]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {r['Percentage']} |")
 print()
 print("| counter | per-launch avg | min | max | launches |\n|---|---|---|---|---|")
-meta = None
+meta, avg, names = None, {}, collections.Counter()
 for f in sorted(glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True)):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if wanted(r["Kernel_Name"]):
             d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            names[base(r["Kernel_Name"])] += 1
             meta = r
     for c, v in d.items():
+        avg[c] = (sum(v) / len(v), len(v))
         print(f"| {c} | {sum(v) / len(v):.6g} | {min(v):.6g} | {max(v):.6g} | {len(v)} |")
 if meta:
     print(f"\n{kernel}: grid {meta['Grid_Size']}, workgroup {meta['Workgroup_Size']}, LDS {meta['LDS_Block_Size']} B, scratch {meta['Scratch_Size']} B/lane, "
           f"VGPR {meta['VGPR_Count']}, AGPR {meta['Accum_VGPR_Count']}, SGPR {meta['SGPR_Count']}")
+if out_json and avg:
+    b = json.load(open(bench_json))
+    c = b["config"]
+    j = {"kernel": names.most_common(1)[0][0], "workload": c["workload"], "envs_per_gpu": c["envs_per_gpu"],
+         "reset_pool": int(c["reset"].split()[2]) if c["reset"].startswith("pool of") else 0, "settle_lanes": "settle lanes" in c["reset"],
+         "friction_model": c["friction_model"], "solver_residual_threshold": c["solver_residual_threshold"],
+         "fetch_size_kb": avg["FETCH_SIZE"][0], "write_size_kb": avg["WRITE_SIZE"][0], "fetch_correction": 2.0,
+         "sq_insts_valu": avg.get("SQ_INSTS_VALU", (None, 0))[0], "sq_waves": avg.get("SQ_WAVES", (None, 0))[0],
+         "launches": avg["FETCH_SIZE"][1], "bench_value": b["value"], "bench_kernel_ms": b["roofline"]["kernel_ms"],
+         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, per-launch averages over ALL launches of the step kernel in "
+                 "the profiled command (same table as the *_kernel_trace_pmc.md next to this file); FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                 "(16-B-per-lane streaming reads are tallied at half their bytes on gfx950)"}
+    json.dump(j, open(out_json, "w"), indent=1)

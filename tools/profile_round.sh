@@ -1,14 +1,16 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r01_*: kernel trace + stats, then one PMC pass per counter group (never combined with
-# sys/hip/hsa traces).  Run on the GPU box:  bash tools/profile_round.sh <tag> [bench.py flags]
+# rocprofv3 passes behind profiles/rNN_<tag>_*: one unprofiled bench line, kernel trace + stats, then one PMC pass per counter group
+# (never combined with sys / hip / hsa traces).  Every table and the pmc.json are computed from ALL launches of the step kernel; the
+# raw per-launch CSVs are deleted afterwards (nothing is re-summarised from a trimmed sample).
+#   bash tools/profile_round.sh <tag> [bench.py flags]     on the GPU box; results in gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-d}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 200 --warmup 20 --no-cpu-baseline $*"
-python3 $REPO/bench.py $ARGS > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+ARGS="--steps 1000 --warmup 50 --no-cpu-baseline $*"
+python3 $REPO/bench.py $ARGS 2> "$OUT/bench.err" | tail -1 > "$OUT/bench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS" "GRBM_GUI_ACTIVE"; do
@@ -16,8 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BU
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python3 $REPO/bench.py $ARGS > "$OUT/pmc$i.log" 2>&1
 done
 cd "$REPO"
-python3 tools/pmc_summary.py "$OUT" k_step > "$OUT/summary.md" 2>&1
-# keep what travels back small: drop the per-launch traces, keep stats + counter files trimmed to the step kernel
-find "$OUT" -name "*_kernel_trace.csv" -delete
-for f in $(find "$OUT" -name "*_counter_collection.csv"); do head -1 "$f" > "$f.k"; grep k_step "$f" | tail -400 >> "$f.k"; mv "$f.k" "$f"; done
-du -sh "$OUT"; cat "$OUT/summary.md"; cat "$OUT/bench_unprofiled.json" | cut -c1-400
+python3 tools/pmc_summary.py "$OUT" k_step "$OUT/bench.json" "$OUT/pmc.json" > "$OUT/summary.md" 2>&1
+cp $(find "$OUT/trace" -name "*_kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
+rm -rf "$OUT/trace" "$OUT"/pmc[0-9] "$OUT"/*.log
+du -sh "$OUT"; cat "$OUT/summary.md"; cut -c1-300 "$OUT/bench.json"
