@@ -891,7 +891,7 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
             M cx2 = qlt(nc + T::template xorl<2>(nl), V(MARGIN));                                   // same side, other end
             M c3 = qand(qlt(mc + T::template xorl<3>(ml), V(MARGIN)), qlt(nc + T::template xorl<3>(nl), V(MARGIN)));   // diagonal
             M ctr = qand(qand(qlt(mc, V(TRUNK_HALF[1] + MARGIN)), qgt(qmax(p3.z, rf.z) + 0.02f, V(-TRUNK_HALF[2] - MARGIN))), qlt(nc, V(TRUNK_HALF[0] + MARGIN)));
-            if (T::any(qor(qor(cy1, cx2), qor(c3, ctr)))) {
+            if (__builtin_expect(T::any(qor(qor(cy1, cx2), qor(c3, ctr))), 0)) {
                 if (HOT) return true;
                 T::count_self_narrow();
                 LegGeom lg;
@@ -916,7 +916,7 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
         // Nothing to solve when no foot of the wave's 16 environments is within contact range and no joint sits at a stop:
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
-        if (HOT && T::any(qor(any_lim, any_extra))) return true;
+        if (HOT && __builtin_expect(T::any(qor(any_lim, any_extra)), 0)) return true;
         if (T::any(qor(qor(act_m, any_lim), any_extra))) {
         QS_PHASE(8)
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)

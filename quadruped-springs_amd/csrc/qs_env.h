@@ -594,9 +594,9 @@ template <class T, bool CONE = false, bool HOT = false> struct Env {
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             QS_PHASE_SUB_BEGIN
             S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
-            if (S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts)) { StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = true; return z; }
+            if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts), 0)) { StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = true; return z; }
             QS_PHASE_SUB(k)
-            if (any_trace) {
+            if (__builtin_expect(any_trace, 0)) {
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
             }
         }

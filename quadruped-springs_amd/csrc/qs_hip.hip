@@ -102,12 +102,24 @@ template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_bod
     const bool valid = env < limit;
     const int d = cfg.action_dim, od = cfg.obs_dim;
     QS_PHASE(26)
+    // the quad of an environment fetches its action row (lane l takes entries l, l + 4, l + 8) -- issued before the tile loads, whose
+    // latency then covers it
+    float a_pre[3] = {0.0f, 0.0f, 0.0f};
+    if (!settling) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int k = (int)(threadIdx.x & 3u) + 4 * j;
+            if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
+        }
+    }
     tile_load(s_rec, base, first, limit);
     QS_PHASE(27)
-    if (!settling) {   // the quad of an environment fetches its action row: lane l takes entries l, l + 4, l + 8
+    if (!settling) {
 #pragma unroll
-        for (int k = (int)(threadIdx.x & 3u); k < 12; k += 4)
-            if (k < d) s_act[slot * 12 + k] = valid ? actions[(size_t)env * d + k] : 0.0f;
+        for (int j = 0; j < 3; j++) {
+            const int k = (int)(threadIdx.x & 3u) + 4 * j;
+            if (k < d) s_act[slot * 12 + k] = a_pre[j];
+        }
     }
     QS_PHASE(28)
     __syncthreads();
@@ -124,7 +136,7 @@ template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_bod
         typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
         r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
     }
-    if (r.redo) {
+    if (__builtin_expect(r.redo, 0)) {
         // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
         // env step of the whole wave with the full build
         __syncthreads();
@@ -150,7 +162,7 @@ template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_bod
     }
     if (cfg.auto_reset) {
         const bool do_reset = dn && valid;
-        if (__any(do_reset)) {
+        if (__builtin_expect(__any(do_reset), 0)) {
             LaneDev::sync();
             if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
                 for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
