@@ -185,6 +185,9 @@ def main():
     kw["friction_model"] = args.friction_model
     import ast
     extra_kw = {k: ast.literal_eval(v) for k, v in (item.split("=", 1) for item in args.env_kw)}
+    # a learner that consumes observations, rewards and done flags (SB3 PPO) never reads the records' info block (torques, foot forces,
+    # the task's pose cache): the steps do not write it (info_fields = False; getters for it would fail loudly).  --env-kw info_fields=True
+    kw.setdefault("info_fields", False)
     kw.update(extra_kw)
     n = args.envs_per_gpu or n_default
     if args.total_envs:
@@ -327,7 +330,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
-                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
+                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True,
                        "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
                                   ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))

@@ -114,7 +114,11 @@ typedef struct qs_config {
                                 * rare path, at most two support points per leg); 0: they only count as invalid contacts (quadruped.py:243-249) */
     int32_t self_collision;    /* 1: link-link contacts that involve a calf are detected and counted as invalid contacts
                                 * (URDF_USE_SELF_COLLISION quadruped.py:533-539, rule :237-241); 0: no link-link test */
-    float reserved_f[5];
+    int32_t info_fields;       /* 1: every step also writes the info block of the records (foot forces and flags, motor and spring torque, the
+                                * task's pose cache: what QS_INFO_FOOT_FORCE / _FOOT_CONTACT / _TORQUE / _SPRING_TORQUE and the cache slots of
+                                * QS_INFO_TASK return); 0: a learner that reads observations, rewards and done flags only skips those stores,
+                                * and the getters fail */
+    float reserved_f[4];
     /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
     float cpg_lo[5], cpg_hi[5];/* action -> (omega_swing, omega_stance, mu, des_step_len, robot_height) */

@@ -172,7 +172,7 @@ template <class T, bool CONE = false, bool HOT = false> struct Env {
         const float* p = rec + R_TASK;
         t.switched = T::ld(p, T_SWITCHED); t.all_air = T::ld(p, T_ALL_AIR); t.is_jumping = T::ld(p, T_IS_JUMPING); t.t_takeoff = T::ld(p, T_TAKEOFF);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { t.pose_to[k] = T::ld(p, T_POSE_TO + k); t.pos[k] = T::ld(rec, R_POSE_CACHE + k); t.vel[k] = T::ld(rec, R_POSE_CACHE + 3 + k); t.rpy[k] = T::ld(rec, R_POSE_CACHE + 6 + k); }
+        for (int k = 0; k < 3; k++) { t.pose_to[k] = T::ld(p, T_POSE_TO + k); t.pos[k] = V(0.0f); t.vel[k] = V(0.0f); t.rpy[k] = V(0.0f); }   // the pose cache is a result (info block): task_on_step fills it before any use
         t.yaw_to = T::ld(p, T_YAW_TO); t.init_h = T::ld(p, T_INIT_H); t.max_flight = T::ld(p, T_MAX_FLIGHT); t.max_fwd = T::ld(p, T_MAX_FWD);
         t.max_pitch = T::ld(p, T_MAX_PITCH); t.rel_max_h = T::ld(p, T_REL_MAX_H); t.max_dx = T::ld(p, T_MAX_DX); t.max_h = T::ld(p, T_MAX_H);
         t.cum_fwd = T::ld(p, T_CUM_FWD); t.cum_ft = T::ld(p, T_CUM_FT); t.old_fwd = T::ld(p, T_OLD_FWD); t.actual_fwd = T::ld(p, T_ACTUAL_FWD);

@@ -20,21 +20,29 @@ using E = Env<LaneDev>;
 #define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC)
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
-__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs) {
-    // (the 16 rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
-    // 15.6 KB at once -- 8 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
+__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, bool full = false) {
+    // Only the hot block [0, QS_HOT) of each record is fetched (the info block behind it is written, never read back, by a step).
+    // (the rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
+    // records at once -- ~9 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
     // was measured slower)
     const float4* src = reinterpret_cast<const float4*>(g + (size_t)first_env * QS_REC);
     float4* dst = reinterpret_cast<float4*>(lds);
-    int nvalid = min(QS_ENVS_PER_WAVE, n_envs - first_env) * (QS_REC / 4);
-    for (int i = threadIdx.x; i < QS_TILE_FLOATS / 4; i += QS_WAVE)
-        dst[i] = i < nvalid ? src[i] : src[i % (QS_REC / 4)];  // tail quads replay the tile's first record (never stored)
+    const int per = (full ? QS_REC : QS_HOT) / 4;
+    const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
+    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * per; i += QS_WAVE) {
+        const int e = i / per, o = i - e * per;
+        dst[e * (QS_REC / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  // tail quads replay the tile's first record (never stored)
+    }
 }
-__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs) {
+__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, bool full = true) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
-    int nvalid = min(QS_ENVS_PER_WAVE, n_envs - first_env) * (QS_REC / 4);
-    for (int i = threadIdx.x; i < nvalid; i += QS_WAVE) dst[i] = src[i];
+    const int per = (full ? QS_REC : QS_HOT) / 4;
+    const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
+    for (int i = threadIdx.x; i < nenv * per; i += QS_WAVE) {
+        const int e = i / per, o = i - e * per;
+        dst[e * (QS_REC / 4) + o] = src[e * (QS_REC / 4) + o];
+    }
 }
 
 struct PoolView { const float* pool; int size; };
@@ -52,7 +60,9 @@ enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3
 __device__ __forceinline__ void copy_settled(float* rec, const float* src) {
     const int lane = threadIdx.x & 3;
     for (int i = lane; i < R_LAST_ACTION; i += 4) rec[i] = src[i];                       // rigid-body state + warm start
-    for (int i = R_PARAMS + lane; i < R_POSE_CACHE; i += 4) rec[i] = src[i];             // params, contact results, torques
+    for (int i = R_PARAMS + lane; i < R_PARAMS + QS_PARAM_DIM; i += 4) rec[i] = src[i];  // params
+    for (int i = R_FOOT_FORCE + lane; i < R_TAU_SPRING + 12; i += 4) rec[i] = src[i];    // contact results, torques
+    if (lane == 0) rec[R_N_INVALID] = src[R_N_INVALID];
 }
 
 // ------------------------------------------------------------------ kernels
@@ -182,7 +192,7 @@ template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_bod
                 // ignores EXEC, so it must not run under a divergent branch: what the step produced is published first, then EVERY quad
                 // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
                 __syncthreads();
-                tile_store(s_rec, recs, first, cfg.n_envs);
+                tile_store(s_rec, recs, first, cfg.n_envs, cfg.info_fields != 0);
                 {
                     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
                     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
@@ -210,7 +220,7 @@ template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_bod
         }
     }
     __syncthreads();
-    tile_store(s_rec, recs, first, cfg.n_envs);
+    tile_store(s_rec, recs, first, cfg.n_envs, cfg.info_fields != 0);
     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
         float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
@@ -348,15 +358,15 @@ __global__ void k_scatter(float* __restrict__ recs, int n, int off, int dim, con
     recs[(size_t)(i / dim) * QS_REC + off + i % dim] = in[i];
     if (zero_warm && i % dim < 4) recs[(size_t)(i / dim) * QS_REC + R_WARM + i % dim] = 0.0f;
 }
-__global__ void k_task_info(const float* __restrict__ recs, int n, float* __restrict__ out, int demo) {
+__global__ void k_task_info(const float* __restrict__ recs, int n, float* __restrict__ out, int demo, int info) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const float* r = recs + (size_t)e * QS_REC;
     float* o = out + (size_t)e * QS_TASK_DIM;
     for (int k = 0; k < T_N; k++) o[k] = r[R_TASK + k];
-    for (int k = 0; k < 9; k++) o[T_N + k] = r[R_POSE_CACHE + k];
+    for (int k = 0; k < 9; k++) o[T_N + k] = info ? r[R_POSE_CACHE + k] : 0.0f;   // the pose cache and the force sum come from the info block
     o[41] = r[R_N_INVALID];
-    o[42] = r[R_FOOT_FORCE] + r[R_FOOT_FORCE + 1] + r[R_FOOT_FORCE + 2] + r[R_FOOT_FORCE + 3];
+    o[42] = info ? r[R_FOOT_FORCE] + r[R_FOOT_FORCE + 1] + r[R_FOOT_FORCE + 2] + r[R_FOOT_FORCE + 3] : 0.0f;
     o[43] = (float)qs::f2i(r[R_SIM_STEP]);
     o[44] = demo ? r[R_DEMO] : 0.0f; o[45] = demo ? r[R_DEMO + 1] : 0.0f;   // demo counter, and at the start of the episode
     for (int k = 46; k < QS_TASK_DIM; k++) o[k] = 0.0f;
@@ -698,6 +708,7 @@ __global__ __launch_bounds__(QS_WAVE) void k_reward_end(const qs_config* __restr
     const float* rec = recs + (size_t)(env < cfg.n_envs ? env : 0) * QS_REC;
     typename E::S::State s; E::Task t;
     E::load_state(rec, s); E::load_task(rec, t);
+    t.pos[0] = s.pos.x; t.pos[1] = s.pos.y; t.pos[2] = s.pos.z;   // the task's pose cache after a step IS the state (task_base.py:72-75)
     float term = E::task_terminated(cfg, t, s, rec[R_N_INVALID], false);
     float r = E::task_reward_end(cfg, t, term, (float)((double)qs::f2i(rec[R_SIM_STEP]) * cfg.dt));
     if (env < cfg.n_envs && (threadIdx.x & 3) == 0) out[env] = r;
@@ -735,6 +746,8 @@ int qs_info_dim(const qs_handle* h, int which) {
 int qs_get_info(qs_handle* h, int which, float* out) {
     if (!h || !out) QS_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);
+    if (!h->cfg.info_fields && (which == QS_INFO_FOOT_FORCE || which == QS_INFO_FOOT_CONTACT || which == QS_INFO_TORQUE || which == QS_INFO_SPRING_TORQUE))
+        QS_FAIL(-1, "info id %d lives in the records' info block, which this handle does not write (cfg.info_fields = 0)", which);
     switch (which) {
     case QS_INFO_FOOT_FORCE: return gather(h, R_FOOT_FORCE, 4, out, 0);
     case QS_INFO_FOOT_CONTACT: return gather(h, R_FOOT_CONTACT, 4, out, 0);
@@ -751,7 +764,7 @@ int qs_get_info(qs_handle* h, int which, float* out) {
         QS_HIP(hipGetLastError());
         return 0;
     case QS_INFO_TASK:
-        hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out, (int)E::demo_task(h->cfg.task));
+        hipLaunchKernelGGL(k_task_info, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, out, (int)E::demo_task(h->cfg.task), h->cfg.info_fields);
         QS_HIP(hipGetLastError());
         return 0;
     case QS_INFO_TERMINAL_OBS:

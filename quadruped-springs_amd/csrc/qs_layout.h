@@ -6,6 +6,7 @@
 #pragma once
 
 enum {
+    // ---- hot block [0, QS_HOT): what a step reads AND writes; the tile load fetches only this
     // rigid-body state, same order as qs_get_state rows (quadruped.py:107-207)
     R_POS = 0, R_QUAT = 3, R_VLIN = 7, R_VANG = 10, R_Q = 13, R_QD = 25,
     R_WARM = 37,          // 4: normal impulse of each foot at the previous substep (contact warm start)
@@ -17,19 +18,21 @@ enum {
     R_TASK = 105,         // 32 slots, see T_* below
     R_NEW_TAU = 137,      // 12: task._new_torque
     R_PARAMS = 149,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
-    R_FOOT_FORCE = 173,   // 4
-    R_FOOT_CONTACT = 177, // 4
-    R_N_INVALID = 181,
-    R_TAU_PD = 182,       // 12: observed motor torque of the last substep (quadruped.py:299)
-    R_TAU_SPRING = 194,   // 12
-    R_POSE_CACHE = 206,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
-    R_FLAGS = 215,
-    R_CPG = 216,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
-    R_DEMO = 216,         // 2: demo counter and its value at the start of the episode (task_base.py:177-183); shares the CPG slots,
+    R_CPG = 173,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
+    R_DEMO = 173,         // 2: demo counter and its value at the start of the episode (task_base.py:177-183); shares the CPG slots,
                           //    the DEMO tasks do not take the CPG action layer (qs_create refuses the combination)
-    R_WRAP = 224,         // 18: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
-                          //     h_actual, held or ramp-start action [12]
-    QS_REC = 244,         // multiple of 4 (16-byte vector moves)
+    R_WRAP = 181,         // 20: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
+                          //     h_actual, held or ramp-start action [12], scripted, disarmed
+    R_N_INVALID = 201,    // invalid contacts of the last substep (a result; kept in the hot block: get_reward_end_episode reads it)
+    // ---- info block: results of the last substep that no step reads back (the reference keeps them as Python attributes; getters,
+    // the pooled reset and the trace consumers use them).  Written by every step unless cfg.info_fields == 0.
+    R_POSE_CACHE = 202,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75); the first two floats lie in the hot block
+    R_FOOT_FORCE = 211,   // 4
+    R_FOOT_CONTACT = 215, // 4
+    R_TAU_PD = 219,       // 12: observed motor torque of the last substep (quadruped.py:299)
+    R_TAU_SPRING = 231,   // 12
+    QS_HOT = 204,         // multiple of 4 (16-byte vector moves)
+    QS_REC = 244,         // multiple of 4
 };
 enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };
 enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO = 4, T_YAW_TO = 7, T_INIT_H = 8, T_MAX_FLIGHT = 9,

@@ -129,7 +129,7 @@ int qse_field(const char* name) {
 #define F(n) if (!strcmp(name, #n)) return n;
     F(R_POS) F(R_QUAT) F(R_VLIN) F(R_VANG) F(R_Q) F(R_QD) F(R_WARM) F(R_LAST_ACTION) F(R_XHIST) F(R_YHIST) F(R_SIM_STEP) F(R_ENV_STEP)
     F(R_EPISODE) F(R_TOTAL_STEPS) F(R_TASK) F(R_NEW_TAU) F(R_PARAMS) F(R_FOOT_FORCE) F(R_FOOT_CONTACT) F(R_N_INVALID) F(R_TAU_PD)
-    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_FLAGS) F(R_CPG) F(R_DEMO) F(R_WRAP)
+    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_CPG) F(R_DEMO) F(R_WRAP)
 #undef F
     return -1;
 }

@@ -299,3 +299,34 @@ def test_pooled_resets_rarely_reuse_a_stale_entry(torch_cuda):
         p = stats.kstest((u - lo) / (hi - lo), "uniform").pvalue
         assert p > 1e-3, (name, p)
     v.close()
+
+
+def test_info_block_is_optional_and_changes_nothing_else(torch_cuda):
+    """info_fields=False: the steps skip the stores of the records' info block (torques, foot forces and flags, pose cache).  Observations,
+    rewards, done flags and the state must be bit for bit those of the default handle, through falls and pooled auto-resets; the getters
+    of the info block fail loudly, the others keep working."""
+    torch = torch_cuda
+    n = 200
+    kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, reset_pool=160, seed=4, noise=True)
+    a, b = vec_env(n, info_fields=True, **kw), vec_env(n, info_fields=False, **kw)
+    assert torch.equal(a.reset_tensor(), b.reset_tensor())
+    gen = torch.Generator(device=a.device).manual_seed(3)
+    resets = 0
+    for t in range(200):
+        act = torch.rand((n, a.action_dim), generator=gen, device=a.device) * 2 - 1
+        if t % 50 > 35:
+            act[:] = torch.tensor([0.0, -1.0, 1.0, 0.0, -1.0, 1.0], device=a.device)
+        ra, rb = a.step_tensor(act), b.step_tensor(act)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+        resets += int(ra[2].sum())
+    assert resets > 50
+    assert torch.equal(a.get_state(), b.get_state())
+    ta, tb = a.get_info("task"), b.get_info("task")
+    assert torch.equal(ta[:, :32], tb[:, :32]) and torch.equal(ta[:, 41], tb[:, 41]) and torch.equal(ta[:, 43:], tb[:, 43:])
+    assert torch.equal(a.get_info("reward_end"), b.get_info("reward_end"))
+    assert float(a.get_info("foot_force").sum()) > 0
+    for which in ("foot_force", "foot_contact", "torque", "spring_torque"):
+        with pytest.raises(RuntimeError, match="info block"):
+            b.get_info(which)
+    a.close(); b.close()
