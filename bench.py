@@ -168,6 +168,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus
+    if rank != 0:
+        # only rank 0 reports: whatever the other ranks (or the RCCL they load) write to stdout goes to stderr, so that the JSON line
+        # stays the last thing on the job's stdout whichever rank exits last
+        sys.stdout.flush()
+        os.dup2(2, 1)
     sharded = args.workload == "config4_sharded"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the simulation step has no CPU path")
