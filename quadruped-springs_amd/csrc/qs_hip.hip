@@ -51,6 +51,7 @@ struct PoolView { const float* pool; int size; };
 // The staging copy is split into QS_COHORTS slices whose settles start QS_COHORTS-th of an epoch apart, so that finished
 // records reach the pool (and the demand is re-read) every epoch / QS_COHORTS launches instead of once per epoch.
 #define QS_COHORTS 5
+#define QS_MAX_SLICE 2048
 struct SettleLanes { float* staging; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], settle_n[QS_COHORTS], generation[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
 struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
@@ -575,7 +576,10 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
         // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder);
         // cohort c runs the same schedule c * epoch / QS_COHORTS launches later
         const int rep = h->cfg.action_repeat, epoch = (h->cfg.settle_steps + rep - 1) / rep;
-        const int slice = (h->pool_size / QS_COHORTS) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE;
+        // a cohort settles at most QS_MAX_SLICE records at a time, whatever the size of the pool: the launch then carries at most
+        // QS_COHORTS * QS_MAX_SLICE / 16 extra workgroups (640), enough for 40 resets per step, and a large pool (few stale draws) costs no
+        // idle workgroups (a 65536-entry pool with slices of a fifth of it: 4096 of them, -20 % env-steps/s)
+        const int slice = min((h->pool_size / QS_COHORTS) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE, QS_MAX_SLICE);
         lanes.staging = h->d_pool_back; lanes.slice = slice; lanes.waves_per_cohort = slice / QS_ENVS_PER_WAVE;
         for (int c = 0; c < QS_COHORTS; c++) {
             const long long t = h->tick - (long long)c * epoch / QS_COHORTS;

@@ -269,7 +269,7 @@ def test_pooled_resets_rarely_reuse_a_stale_entry(torch_cuda):
     draw), and are the consumed draws distributed as the reference's randomizers prescribe (env_randomizer.py:67-83, 110-117, 287-289)."""
     from scipy import stats
     torch = torch_cuda
-    n, steps, P = 8192, 2000, 16384
+    n, steps, P = 8192, 2000, 65536
     v = vec_env(n, env_randomizer_mode="TEST_RANDOMIZER", auto_reset=True, reset_pool=P, seed=11)
     v.reset_tensor()
     v.pool_streaming(True)
@@ -291,7 +291,7 @@ def test_pooled_resets_rarely_reuse_a_stale_entry(torch_cuda):
     reused = int((counts - 1).sum())
     print(f"pooled resets sampled: {len(d)}, of which {reused} ({100.0 * reused / len(d):.1f} %) drew an entry already used and not yet re-settled; "
           f"settle work ratio {st['settle_substeps'] / max(1, st['resets'] * 2500):.2f}")
-    assert reused / len(d) < 0.25
+    assert reused / len(d) < 0.10
     for name, x, lo, hi in [("mu", mu, 0.5, 1.0), ("k_hip", k[:, 0], 18.0, 22.0), ("k_calf", k[:, 2], 27.0, 33.0), ("b", b[:, 1], 0.27, 0.33),
                             ("m_thigh", m_leg[:, 1], 0.828, 1.012), ("m_payload", m_pay, 0.0, 1.0)]:
         u = np.unique(x)                                  # one value per distinct pool entry: the draws themselves
