@@ -118,7 +118,10 @@ typedef struct qs_config {
                                 * task's pose cache: what QS_INFO_FOOT_FORCE / _FOOT_CONTACT / _TORQUE / _SPRING_TORQUE and the cache slots of
                                 * QS_INFO_TASK return); 0: a learner that reads observations, rewards and done flags only skips those stores,
                                 * and the getters fail */
-    float reserved_f[4];
+    int32_t payload_soft;      /* 0: the payload block of the mass randomizer is welded to the trunk (the product's model); 1: a second body held by a
+                                * six-row fixed constraint in the same PGS, as the reference builds it (quadruped.py:796-819).  ORACLE ONLY -- it is
+                                * there to measure what the weld leaves out (tests/test_body_contacts.py); qs_create refuses it */
+    float reserved_f[3];
     /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
     float cpg_lo[5], cpg_hi[5];/* action -> (omega_swing, omega_stance, mu, des_step_len, robot_height) */

@@ -141,6 +141,12 @@ class Oracle:
         args = [np.ascontiguousarray(x, self.real) for x in (ca, Ra, ha, cb, Rb, hb)]
         return bool(self.lib.qso_geom_boxes_overlap(*[self._p(x) for x in args]))
 
+    def block(self):
+        """payload block as its own body (payload="soft"): dict of pos, quat, v, w, lam [N, .] and gap [N]."""
+        out = np.zeros((self.n, 20), self.real)
+        self._check(self.lib.qso_get_block(self.h, self._p(out)))
+        return dict(pos=out[:, :3], quat=out[:, 3:7], v=out[:, 7:10], w=out[:, 10:13], lam=out[:, 13:19], gap=out[:, 19])
+
     def set_gravity(self, g):
         self.lib.qso_phys_set_gravity(self.h, self._creal(g))
 

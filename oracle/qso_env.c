@@ -582,7 +582,7 @@ static void randomize(const qso_config* cfg, qso_env* e, int env_id) {
         /* :43-47,61-65: total_mass sums EVERY URDF link, so the imu (0.001) and floating-base (1e-5) masses end up in the trunk too */
         e->m_trunk = QSO_M_TRUNK + (real)0.00101 + legs0 - legs - e->m_pay;
     }
-    qso_model_build(&e->model, cfg->unit_inertia, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
+    qso_model_build(&e->model, cfg->unit_inertia, e->m_trunk, e->m_leg, cfg->payload_soft ? 0 : e->m_pay, e->r_pay);
 }
 
 static void reset_env_to(qso_handle* h, int i, const real* st37);
@@ -603,10 +603,12 @@ static void reset_env_to(qso_handle* h, int i, const real* st37) {
     memset(e->warm, 0, sizeof(e->warm)); memset(e->foot_force, 0, sizeof(e->foot_force));
     memset(e->foot_contact, 0, sizeof(e->foot_contact)); e->n_invalid = 0;
     memset(e->tau_pd, 0, sizeof(e->tau_pd)); memset(e->tau_spring, 0, sizeof(e->tau_spring));
+    qso_block_place(e);   /* _add_base_mass_offset (quadruped.py:778-819): the block appears next to the freshly spawned robot */
     /* interface_base.py:182-200: settle, sim counter frozen */
     if (st37) {
         memcpy(e->s.pos, st37, 3 * sizeof(real)); memcpy(e->s.quat, st37 + 3, 4 * sizeof(real)); memcpy(e->s.vlin, st37 + 7, 3 * sizeof(real));
         memcpy(e->s.vang, st37 + 10, 3 * sizeof(real)); memcpy(e->s.q, st37 + 13, 12 * sizeof(real)); memcpy(e->s.qd, st37 + 25, 12 * sizeof(real));
+        qso_block_place(e);   /* (the reference leaves the block at the spawn pose and lets the constraint drag it; here it moves with the robot) */
     } else {
         real cmd[12]; for (int k = 0; k < 12; k++) cmd[k] = cfg->settle_cmd[k];
         for (int n = 0; n < cfg->settle_steps; n++) apply_and_step_mode(cfg, e, cmd, h->gravity, 1);
@@ -826,6 +828,7 @@ int qso_set_state(qso_handle* h, const real* st) {
         memcpy(s->pos, o, 3 * sizeof(real)); memcpy(s->quat, o + 3, 4 * sizeof(real)); memcpy(s->vlin, o + 7, 3 * sizeof(real));
         memcpy(s->vang, o + 10, 3 * sizeof(real)); memcpy(s->q, o + 13, 12 * sizeof(real)); memcpy(s->qd, o + 25, 12 * sizeof(real));
         memset(h->env[i].warm, 0, sizeof(h->env[i].warm));
+        qso_block_place(&h->env[i]);
     }
     return 0;
 }
@@ -882,7 +885,8 @@ int qso_set_params(qso_handle* h, int which, const real* v) {
             e->mu = o[0];
             for (int k = 0; k < 3; k++) { e->k[k] = o[1 + k]; e->b[k] = o[4 + k]; e->rest[k] = o[7 + k]; e->kp[k] = o[10 + k]; e->kd[k] = o[13 + k]; e->m_leg[k] = o[17 + k]; e->r_pay[k] = o[21 + k]; }
             e->m_trunk = o[16]; e->m_pay = o[20];
-            qso_model_build(&e->model, h->cfg.unit_inertia, e->m_trunk, e->m_leg, e->m_pay, e->r_pay);
+            qso_model_build(&e->model, h->cfg.unit_inertia, e->m_trunk, e->m_leg, h->cfg.payload_soft ? 0 : e->m_pay, e->r_pay);
+            qso_block_place(e);
             break; }
         default: FAIL("unknown param id %d", which);
         }

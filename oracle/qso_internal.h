@@ -10,6 +10,7 @@
 #define NB 13   /* rigid bodies after merging fixed joints: 0 = base+trunk+imu(+payload), 1+3L+j = leg L link j */
 #define NJ 12
 #define NV 18
+#define NVX 24  /* + the six velocities of the payload block when it is a body of its own */
 #define QSO_MAX_CONTACTS 64   /* generalized velocity: [w_b(3) v_b(3)] in base coordinates, then qd(12) */
 
 /* Go1 rigid-body model, restated from go1/go1_description/urdf/go1.urdf (see qso_model.c). */
@@ -58,6 +59,9 @@ typedef struct {
     struct { int body_a, body_b, link_a, link_b; real dist, force; } contacts[QSO_MAX_CONTACTS];
     int n_contacts;
     real warm[4];
+    /* payload block as its own body (cfg->payload_soft): position of its centre, orientation, velocities (world); constraint impulses of
+       the last substep and the distance between the two pivots */
+    struct { real pos[3], quat[4], v[3], w[3], lam[6], gap; } blk;
     real tau_pd[NJ], tau_spring[NJ];
     /* env-level */
     real last_action[12], last_filtered[12], xhist[24], yhist[24];
@@ -80,6 +84,7 @@ struct qso_handle {
 
 /* qso_model.c */
 void qso_model_build(qso_model* M, const float (*unit)[6], real m_trunk, const real* m_leg3, real m_pay, const real* r_pay);
+void qso_block_place(qso_env* e);   /* puts the payload block where the fixed constraint wants it, at the base's velocity */
 extern const real QSO_TRUNK_I[6], QSO_HIP_I[6], QSO_THIGH_I[6], QSO_CALF_I[6];   /* URDF tensors (FR-leg magnitudes) */
 extern const real QSO_M_TRUNK, QSO_M_LEG[3];
 extern const real QSO_JOINT_LO[3], QSO_JOINT_HI[3];

@@ -317,7 +317,11 @@ static int collect_invalid(const qso_config* cfg, qso_env* e, const phys_cache* 
     }
     if (e->m_pay > 0) { /* the block is a second body bolted to the base (quadruped.py:778-819); its box is aligned with the base frame */
         static const real ph[3] = {PAYLOAD_HALF, PAYLOAD_HALF, PAYLOAD_HALF};
-        if ((d = box_min_z(C->Rw[0], C->ow[0], e->r_pay, ph)) < THR_PAYLOAD) { n++; push_contact(e, 2, 0, -1, -1, d); }
+        if (cfg->payload_soft) {
+            real Rb[3][3]; qso_quat_to_mat(e->blk.quat, Rb);
+            d = box_min_z(Rb, e->blk.pos, zc, ph);
+        } else d = box_min_z(C->Rw[0], C->ow[0], e->r_pay, ph);
+        if (d < THR_PAYLOAD) { n++; push_contact(e, 2, 0, -1, -1, d); }
     }
     if (cfg->self_collision) {
         obox trunk, thigh[4], calf[4];
@@ -340,9 +344,23 @@ static int collect_invalid(const qso_config* cfg, qso_env* e, const phys_cache* 
     return n;
 }
 
+/* ------------------------------------------------------------------ payload block as a body of its own (cfg->payload_soft; ORACLE ONLY)
+ * quadruped.py:778-819: createMultiBody(mass, box of half extent 0.05) at base + delta, createConstraint(robot base, block, JOINT_FIXED,
+ * parentFramePosition 0, childFramePosition -delta): a btMultiBodyFixedConstraint -- three rows that hold the block's point -delta on the
+ * base origin, three that hold the two frames parallel -- in the same PGS as the contacts, ERP m_erp = 0.2, impulse bound 500 N x dt. */
+void qso_block_place(qso_env* e) {
+    real R0[3][3]; qso_quat_to_mat(e->s.quat, R0);
+    real d[3]; m3v(R0, e->r_pay, d);
+    for (int k = 0; k < 3; k++) { e->blk.pos[k] = e->s.pos[k] + d[k]; e->blk.w[k] = e->s.vang[k]; }
+    memcpy(e->blk.quat, e->s.quat, sizeof(e->blk.quat));
+    real wxd[3]; v3cross(e->s.vang, d, wxd);
+    for (int k = 0; k < 3; k++) e->blk.v[k] = e->s.vlin[k] + wxd[k];
+    memset(e->blk.lam, 0, sizeof(e->blk.lam)); e->blk.gap = 0;
+}
+
 /* ------------------------------------------------------------------ one stepSimulation() */
 typedef struct {
-    real J[NV], W[NV];   /* Jacobian row and H^-1 J^T */
+    real J[NVX], W[NVX]; /* Jacobian row and H^-1 J^T; entries 18..23: the payload block as its own body (w, v in world coordinates) */
     real dinv, rhs, lo, hi, lam;
     int fric_of;         /* index of the normal row bounding this friction row, -1 otherwise */
     real mu;
@@ -442,6 +460,49 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             r->lo = 0; r->hi = 1e10; r->fric_of = -1;
         }
     }
+    int fixed0 = -1;   /* first of the six rows of the payload constraint in lim[] */
+    real vblk[6] = {0, 0, 0, 0, 0, 0};
+    if (cfg->payload_soft && e->m_pay > 0) {
+        /* the block's own step: gravity (isotropic inertia: no gyroscopic term) */
+        e->blk.v[2] -= dt * g;
+        for (int k = 0; k < 3; k++) { vblk[k] = e->blk.w[k]; vblk[3 + k] = e->blk.v[k]; }
+        real Rb[3][3]; qso_quat_to_mat(e->blk.quat, Rb);
+        real nd[3] = {-e->r_pay[0], -e->r_pay[1], -e->r_pay[2]}, rB[3];
+        m3v(Rb, nd, rB);                                             /* block centre -> its pivot, world */
+        real perr[3]; for (int k = 0; k < 3; k++) perr[k] = s->pos[k] - (e->blk.pos[k] + rB[k]);    /* pivot A (base origin) - pivot B */
+        e->blk.gap = sqrt(v3dot(perr, perr));
+        /* orientation error: rotation vector of q_A q_B^-1 (world), small-angle */
+        const real* qa = s->quat; const real* qb = e->blk.quat;
+        real qe[4] = {qa[3] * -qb[0] + qa[0] * qb[3] + qa[1] * -qb[2] - qa[2] * -qb[1],
+                      qa[3] * -qb[1] - qa[0] * -qb[2] + qa[1] * qb[3] + qa[2] * -qb[0],
+                      qa[3] * -qb[2] + qa[0] * -qb[1] - qa[1] * -qb[0] + qa[2] * qb[3],
+                      qa[3] * qb[3] - qa[0] * -qb[0] - qa[1] * -qb[1] - qa[2] * -qb[2]};
+        real sg = qe[3] < 0 ? -2 : 2, aerr[3] = {sg * qe[0], sg * qe[1], sg * qe[2]};
+        real mI = 1 / (e->m_pay * (real)(0.1 * 0.1 / 6.0)), mM = 1 / e->m_pay, bound = (real)500.0 * dt;
+        fixed0 = nlim;
+        for (int k = 0; k < 6; k++) {
+            row* r = &lim[nlim++];
+            memset(r, 0, sizeof(*r));
+            real ax[3] = {k % 3 == 0, k % 3 == 1, k % 3 == 2}, ab[3];
+            m3tv(C.R0, ax, ab);
+            if (k < 3) {   /* linear row along world axis k at the pivots: robot side = base origin (no lever), block side lever rB */
+                for (int i = 0; i < 3; i++) r->J[3 + i] = ab[i];
+                real t[3]; v3cross(rB, ax, t);
+                for (int i = 0; i < 3; i++) { r->J[18 + i] = -t[i]; r->J[21 + i] = -ax[i]; }
+            } else {       /* angular row */
+                for (int i = 0; i < 3; i++) { r->J[i] = ab[i]; r->J[18 + i] = -ax[i]; }
+            }
+            minv_apply(M, &C, r->J, r->W);
+            for (int i = 0; i < 3; i++) { r->W[18 + i] = r->J[18 + i] * mI; r->W[21 + i] = r->J[21 + i] * mM; }
+            real d = 0; for (int i = 0; i < NVX; i++) d += r->J[i] * r->W[i];
+            r->dinv = 1 / d;
+            real rel = 0; for (int i = 0; i < NV; i++) rel += r->J[i] * v[i];
+            for (int i = 0; i < 6; i++) rel += r->J[18 + i] * vblk[i];
+            real err = k < 3 ? perr[k] : aerr[k - 3];         /* d(err)/dt = J v for both kinds of rows */
+            r->rhs = (-err * cfg->joint_erp / dt - rel) * r->dinv;
+            r->lo = -bound; r->hi = bound; r->fric_of = -1;
+        }
+    }
     /* contacts, leg by leg: the foot, then (cfg->body_contacts) up to two more support points of the leg -- the lowest of
        {the trunk corner on the leg's side, hip housing, the two ends of the thigh box, knee end of the calf box} within contact range */
     for (int L = 0; L < 4; L++) {
@@ -499,9 +560,9 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
     }
     e->n_invalid = collect_invalid(cfg, e, &C, s);
     /* ---- projected Gauss-Seidel in velocity space (btMultiBodyConstraintSolver::solveSingleIteration order) ---- */
-    real dv[NV]; memset(dv, 0, sizeof(dv));
+    real dv[NVX]; memset(dv, 0, sizeof(dv));
     for (int i = 0; i < nn; i++)
-        if (nor[i].lam != 0) for (int k = 0; k < NV; k++) dv[k] += nor[i].W[k] * nor[i].lam;
+        if (nor[i].lam != 0) for (int k = 0; k < NVX; k++) dv[k] += nor[i].W[k] * nor[i].lam;
     for (int it = 0; it < cfg->solver_iters; it++) {
         real maxres2 = 0; /* btMultiBodyConstraintSolver: leastSquaredResidual = max over rows of (deltaImpulse / jacDiagABInv)^2 */
         for (int jj = 0; jj < nlim + nn + nf; jj++) {
@@ -517,13 +578,13 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
                 jj++;
                 real lim = a->mu * nor[a->fric_of].lam;
                 real ja = 0, jb = 0;
-                for (int k = 0; k < NV; k++) { ja += a->J[k] * dv[k]; jb += b->J[k] * dv[k]; }
+                for (int k = 0; k < NVX; k++) { ja += a->J[k] * dv[k]; jb += b->J[k] * dv[k]; }
                 real sa = a->lam + (a->rhs - ja * a->dinv), sb = b->lam + (b->rhs - jb * b->dinv);
                 real r2 = sa * sa + sb * sb;
                 if (r2 > lim * lim) { real sc = lim / sqrt(r2); sa *= sc; sb *= sc; }
                 real da = sa - a->lam, db = sb - b->lam;
                 a->lam = sa; b->lam = sb;
-                for (int k = 0; k < NV; k++) dv[k] += a->W[k] * da + b->W[k] * db;
+                for (int k = 0; k < NVX; k++) dv[k] += a->W[k] * da + b->W[k] * db;
                 real ra = da / a->dinv, rb = db / b->dinv;
                 if (ra * ra > maxres2) maxres2 = ra * ra;
                 if (rb * rb > maxres2) maxres2 = rb * rb;
@@ -534,13 +595,13 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
                 if (!(tot > 0)) continue;
                 r->lo = -r->mu * tot; r->hi = r->mu * tot;
             }
-            real jdv = 0; for (int k = 0; k < NV; k++) jdv += r->J[k] * dv[k];
+            real jdv = 0; for (int k = 0; k < NVX; k++) jdv += r->J[k] * dv[k];
             real dl = r->rhs - jdv * r->dinv;
             real sum = r->lam + dl;
             if (sum < r->lo) { dl = r->lo - r->lam; sum = r->lo; }
             else if (sum > r->hi) { dl = r->hi - r->lam; sum = r->hi; }
             r->lam = sum;
-            for (int k = 0; k < NV; k++) dv[k] += r->W[k] * dl;
+            for (int k = 0; k < NVX; k++) dv[k] += r->W[k] * dl;
             real resid = dl / r->dinv;
             if (resid * resid > maxres2) maxres2 = resid * resid;
         }
@@ -557,6 +618,19 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             for (int c = 0; c < e->n_contacts; c++)
                 if (e->contacts[c].body_a == 1 && e->contacts[c].body_b == 0 && e->contacts[c].link_a == -1 - nor_contact[i]) { e->contacts[c].force += nor[i].lam / dt; break; }
         }
+    }
+    if (fixed0 >= 0) {
+        for (int k = 0; k < 6; k++) e->blk.lam[k] = lim[fixed0 + k].lam;
+        for (int k = 0; k < 3; k++) { e->blk.w[k] += dv[18 + k]; e->blk.v[k] += dv[21 + k]; }
+        for (int k = 0; k < 3; k++) e->blk.pos[k] += dt * e->blk.v[k];
+        real w[3] = {e->blk.w[0], e->blk.w[1], e->blk.w[2]};
+        real th = sqrt(v3dot(w, w)) * dt, sc = th < 1e-6 ? (real)0.5 * dt : sin((real)0.5 * th) / (th / dt);
+        real dq[4] = {w[0] * sc, w[1] * sc, w[2] * sc, cos((real)0.5 * th)};
+        const real* q = e->blk.quat;
+        real nq[4] = {dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1], dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0],
+                      dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3], dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2]};
+        real n = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+        for (int k = 0; k < 4; k++) e->blk.quat[k] = nq[k] / n;
     }
     /* apply constraint impulses, clamp, integrate positions */
     {
@@ -655,6 +729,14 @@ int qso_phys_step(qso_handle* h, int env, const real* tau) {
     return 0;
 }
 int qso_phys_set_gravity(qso_handle* h, real g) { h->gravity = g; return 0; }
+int qso_get_block(qso_handle* h, real* out /*[N,20]: pos3 quat4 v3 w3 lam6 gap*/) {
+    for (int i = 0; i < h->cfg.n_envs; i++) {
+        const qso_env* e = &h->env[i]; real* o = out + 20 * i;
+        memcpy(o, e->blk.pos, 3 * sizeof(real)); memcpy(o + 3, e->blk.quat, 4 * sizeof(real)); memcpy(o + 7, e->blk.v, 3 * sizeof(real));
+        memcpy(o + 10, e->blk.w, 3 * sizeof(real)); memcpy(o + 13, e->blk.lam, 6 * sizeof(real)); o[19] = e->blk.gap;
+    }
+    return 0;
+}
 int qso_get_contacts(qso_handle* h, int env, int32_t* ids /*[max][4]*/, real* dist_force /*[max][2]*/, int max) {
     const qso_env* e = &h->env[env];
     int n = e->n_contacts < max ? e->n_contacts : max;

@@ -429,6 +429,7 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (cfg->task >= QS_TASK_JUMPING_IN_PLACE_DEMO && cfg->task <= QS_TASK_CONT_JUMPING_FORWARD_DEMO && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
         QS_FAIL(-1, "the DEMO tasks compare the policy's action with a recorded one: they need an RL action space (not CPG, not raw commands)");
     if (cfg->task < 0 || cfg->task > QS_TASK_CONT_JUMPING_FORWARD_DEMO) QS_FAIL(-1, "unknown task id %d", cfg->task);
+    if (cfg->payload_soft) QS_FAIL(-1, "payload=\"soft\" (the payload block as a second body on a fixed constraint) exists in the oracle only; the kernels weld the block to the trunk");
     if (cfg->friction_cone != 0 && cfg->friction_cone != 1) QS_FAIL(-1, "friction_cone must be 0 (pyramid) or 1 (implicit cone), got %d", cfg->friction_cone);
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");

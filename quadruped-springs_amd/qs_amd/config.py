@@ -123,7 +123,7 @@ class QsConfig(C.Structure):
         ("spring_k", C.c_float * 3), ("spring_b", C.c_float * 3), ("spring_rest", C.c_float * 3),
         ("fallen_height", C.c_float), ("leg_len", C.c_float * 3),
         ("contact_erp", C.c_float), ("joint_erp", C.c_float), ("warmstart", C.c_float), ("vel_cap", C.c_float),
-        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("contact_slop", C.c_float), ("body_contacts", C.c_int32), ("self_collision", C.c_int32), ("info_fields", C.c_int32), ("reserved_f", C.c_float * 4),
+        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("contact_slop", C.c_float), ("body_contacts", C.c_int32), ("self_collision", C.c_int32), ("info_fields", C.c_int32), ("payload_soft", C.c_int32), ("reserved_f", C.c_float * 3),
         ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
         ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
         ("solver_residual_threshold", C.c_float), ("friction_cone", C.c_int32),
@@ -283,6 +283,7 @@ def build_config(
     self_collision=True,
     mass_inertia_rule="collision_shape",
     info_fields=True,
+    payload="weld",
     **_ignored,
 ):
     """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
@@ -382,6 +383,7 @@ def build_config(
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = float(contact_erp), float(joint_erp), float(warmstart), rc.VELOCITY_LIMITS[0]
     cfg.contact_slop = float(contact_slop)
     cfg.info_fields = int(bool(info_fields))
+    cfg.payload_soft = {"weld": 0, "soft": 1}[payload]   # "soft" exists in the oracle only (qs_create refuses it): DESIGN.md 7
     # "auto": the non-foot links push back where the episode goes on after they touched the ground, i.e. under NO_TASK (the reference's
     # CPG driver, hopf_network.py:183-190).  Every other task ends the episode at the end of the env step in which such a contact
     # appears (task_base.py:137-147), so the response would only shape the last <= action_repeat substeps of an episode that is over,

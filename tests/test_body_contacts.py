@@ -281,3 +281,52 @@ def test_contacts_are_classified_as_the_reference_does():
         np.testing.assert_array_equal(e.get("R_FOOT_CONTACT", 4)[0], ref[6:10])
         np.testing.assert_allclose(e.get("R_FOOT_FORCE", 4)[0], o.get_info(0)[0], rtol=3e-2, atol=0.5)
     assert {(1, 0, "foot"), (1, 0, "calf"), (1, 0, "thigh"), (1, 0, "other"), (2, 0, "other"), (1, 1, "calf")} <= kinds, kinds
+
+
+# ------------------------------------------------------------------------------------------------ what the payload weld leaves out
+def test_payload_weld_against_the_soft_fixed_constraint():
+    """The product welds the mass randomizer's payload block to the trunk; the reference holds it as a second body on a six-row fixed
+    constraint of the same PGS (quadruped.py:796-819).  The oracle can do both (payload="soft" is oracle-only): over jump episodes with
+    random actions the constraint keeps the pivots within a tenth of a millimetre with 7 % of its impulse budget, and one env step from
+    the same state moves the base by micrometres differently -- the weld is the soft constraint up to that."""
+    kw = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
+              env_randomizer_mode="TEST_RANDOMIZER", noise=False, seed=5, isRLGymInterface=True, motor_control_mode="PD")
+    n = 8
+    cw, _ = build_config(n_envs=n, payload="weld", **kw)
+    cs, _ = build_config(n_envs=n, payload="soft", **kw)
+    ow, osf = Oracle(cw), Oracle(cs)
+    a0, a1 = ow.reset(), osf.reset()
+    assert ow.get_info(6)[:, 20].min() > 0.05                      # every environment drew a payload
+    np.testing.assert_allclose(a1, a0, atol=2e-4)                   # the settled poses agree
+    assert osf.block()["gap"].max() < 1e-4
+    rng = np.random.default_rng(0)
+    worst_pose = worst_vel = gap = lam = 0.0
+    for t in range(150):
+        a = rng.uniform(-1, 1, size=(n, 6)).astype(np.float32)
+        if t % 50 > 35:
+            a[:] = [0, -1, 1, 0, -1, 1]
+        sw = ow.get_state()
+        if t % 10 == 0:                                             # free-running in between: the block keeps its own history
+            osf.set_state(sw)
+        else:
+            ow.set_state(osf.get_state())
+        s_in = ow.get_state()
+        dw, ds = ow.step(a), osf.step(a)
+        s0, s1 = ow.get_state(), osf.get_state()
+        worst_pose = max(worst_pose, np.abs(s0[:, :7] - s1[:, :7]).max())
+        worst_vel = max(worst_vel, np.abs(s0[:, 7:13] - s1[:, 7:13]).max())
+        b = osf.block()
+        gap, lam = max(gap, b["gap"].max()), max(lam, np.abs(b["lam"]).max())
+        done = dw[2] | ds[2]
+        if done.any():
+            ow.reset(done.astype(np.uint8)); osf.reset(done.astype(np.uint8))
+            osf.set_state(ow.get_state())
+    assert gap < 5e-4 and lam < 0.1, (gap, lam)                     # impulse bound of the constraint: 500 N x dt = 0.5 N s
+    assert worst_pose < 5e-5 and worst_vel < 2e-2, (worst_pose, worst_vel)
+
+
+def test_product_configuration_refuses_the_soft_payload():
+    cfg, _ = build_config(n_envs=1, payload="soft", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="MASS_RANDOMIZER")
+    assert cfg.payload_soft == 1     # the switch reaches the C ABI, where qs_create rejects it (GPU: test_create_rejects_bad_config)
+    with pytest.raises(KeyError):
+        build_config(n_envs=1, payload="glued")
