@@ -61,6 +61,8 @@ def test_pin_recipe_runs_against_a_stand_in_client(tmp_path, monkeypatch, capsys
         def getContactPoints(self, bodyA=None, bodyB=None):
             return [(0, 1, 0, P.FOOT_IDS[k], -1, 0, 0, 0, 0, self.f[k]) for k in range(4) if self.f[k] > 0]
 
+        GEOM_BOX, JOINT_FIXED = 3, 4
+
         def __getattr__(self, name):     # resetSimulation, setGravity, changeDynamics, ...: nothing to do
             return lambda *a, **k: None
 

@@ -101,6 +101,10 @@ def main():
                     help="call changeDynamics(mass = URDF mass) on trunk and leg links first, as the reference's mass randomizer does at every reset "
                          "(quadruped.py:761, 776): PyBullet then replaces their inertia by its collision-shape rule; the oracle is built with the "
                          "mass randomizer's rule (mass_inertia_rule of the grid) and nominal masses")
+    ap.add_argument("--payload", nargs=3, type=float, default=None, metavar=("MASS", "X", "Z"),
+                    help="attach the mass randomizer's payload block as the reference does (quadruped.py:778-819: createMultiBody with a box of half "
+                         "extent 0.05 at base + (X, 0, Z), createConstraint(JOINT_FIXED), collisions with the robot's links off); the oracle gets the same "
+                         "block, welded or on its own fixed constraint: --grid payload=weld,soft")
     ap.add_argument("--write", default="", help="save the compared rows as an .npz fixture")
     args = ap.parse_args()
     try:
@@ -117,7 +121,7 @@ def main():
     axes = []
     for item in args.grid:
         key, _, vals = item.partition("=")
-        conv = (lambda v: v) if key in ("friction_model", "mass_inertia_rule") else (lambda v: bool(int(v))) if key in ("body_contacts", "self_collision") else float
+        conv = (lambda v: v) if key in ("friction_model", "mass_inertia_rule", "payload") else (lambda v: bool(int(v))) if key in ("body_contacts", "self_collision") else float
         axes.append([(key, conv(v)) for v in vals.split(",")])
     oracles, labels = [], []
     for combo in itertools.product(*axes):
@@ -128,6 +132,8 @@ def main():
         oracles.append(Oracle(cfg))
         par = oracles[-1].get_info(6)
         par[0, 0], par[0, 16:24] = args.mu, [5.204, 0.591, 0.92, 0.131, 0.0, 0.0, 0.0, 0.0]
+        if args.payload:
+            par[0, 20], par[0, 21], par[0, 23] = args.payload
         oracles[-1].set_params(5, par)
         labels.append(", ".join(f"{k} = {v}" for k, v in combo))
 
@@ -146,6 +152,13 @@ def main():
     p.changeDynamics(plane, -1, lateralFriction=args.mu)
     for j in MOTOR_IDS:
         p.changeDynamics(robot, j, maxJointVelocity=30.1)
+    if args.payload:
+        mass, px, pz = args.payload
+        shape = p.createCollisionShape(p.GEOM_BOX, halfExtents=[0.05] * 3, collisionFramePosition=[0, 0, 0])
+        block = p.createMultiBody(baseMass=mass, baseCollisionShapeIndex=shape, basePosition=[px, 0, 0.32 + pz], baseOrientation=[0, 0, 0, 1])
+        p.createConstraint(robot, -1, block, -1, p.JOINT_FIXED, [0, 0, 0], [0, 0, 0], [-px, 0, -pz])
+        for j in range(-1, nj):
+            p.setCollisionFilterPair(robot, block, j, -1, 0)
     if args.remass:
         p.changeDynamics(robot, 0, mass=5.204)
         for j, m in zip(MOTOR_IDS, [0.591, 0.92, 0.131] * 4):
