@@ -582,13 +582,19 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
         // idle workgroups (a 65536-entry pool with slices of a fifth of it: 4096 of them, -20 % env-steps/s)
         const int slice = min((h->pool_size / QS_COHORTS) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE, QS_MAX_SLICE);
         lanes.staging = h->d_pool_back; lanes.slice = slice; lanes.waves_per_cohort = slice / QS_ENVS_PER_WAVE;
+        // With one wave per SIMD a launch of more waves than SIMDs runs in two rounds.  While the environments leave at least
+        // QS_COHORTS x 64 SIMDs free (room to settle 20 resets' worth per step) the settle lanes are trimmed to the free SIMDs and the
+        // one-wave-per-SIMD kernel stays; beyond that the two-waves-per-SIMD build takes the whole launch (below).
+        const int free_simd = h->n_simd - lanes.n_env_waves;
+        if (h->step_variant != 2 && free_simd / QS_COHORTS >= 64 && lanes.waves_per_cohort > free_simd / QS_COHORTS) lanes.waves_per_cohort = free_simd / QS_COHORTS;
+        const int cohort_cap = lanes.waves_per_cohort * QS_ENVS_PER_WAVE;
         for (int c = 0; c < QS_COHORTS; c++) {
             const long long t = h->tick - (long long)c * epoch / QS_COHORTS;
             if (t < 0) continue;                       // not started yet: settle_n stays 0
             const int phase = (int)(t % epoch);
             if (phase == 0) {
                 hipLaunchKernelGGL(k_pool_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_pool_back, h->d_pool, h->pool_size, c, slice);
-                hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, c, slice, 0);
+                hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, c, cohort_cap, 0);
                 h->pool_generation++;
                 h->cohort_generation[c] = h->pool_generation;
             }
@@ -599,8 +605,9 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
         h->tick++;
     }
     if (h->timing) hipEventRecord(h->ev0, h->stream);
-    // more waves than 1.5 x the SIMDs of the device: the two-waves-per-SIMD build of the same body wins (see k_step_dense)
-    const bool dense = h->step_variant == 2 || (h->step_variant == 0 && 2 * grid > 3 * h->n_simd);
+    // more waves than SIMDs: the two-waves-per-SIMD build of the same body (see k_step_dense) instead of a second round of one-wave-per-
+    // SIMD workgroups (N = 12288 with its settle lanes: 0.109 ms in two rounds)
+    const bool dense = h->step_variant == 2 || (h->step_variant == 0 && grid > h->n_simd);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
                                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo)
     const bool exact = h->cfg.auto_reset && h->pool_size == 0;   // finished environments settle inside the step
