@@ -223,7 +223,7 @@ def main():
 
         def sharded_step(_unused):
             k = state["t"] % n_roll
-            shard.step(roll_act[k] if rank == 0 else None, out=roll_res[k if rank == 0 else 0])
+            shard.step(roll_act[k] if rank == 0 else None, out=roll_res[k if rank == 0 else 0], unpack=False)   # the rollout buffer keeps the fused rows
             state["t"] += 1
 
         step_fn = sharded_step

@@ -63,11 +63,13 @@ class ShardedVecEnv:
         self._all_gather(g)
         return self._unpack(g)[0]
 
-    def step(self, actions=None, out=None):
+    def step(self, actions=None, out=None, unpack=True):
         """`actions`: the global [N, d] batch on the learner rank (ignored elsewhere).  `out` (optional): a contiguous float32
         [N, o + 2] tensor that receives the gathered rows (e.g. one row block of the learner's rollout buffer) instead of the
         internal buffer.  Returns the global (obs [N,o], rew [N], done [N], truncated [N]) on every rank: views of / computed
-        from that buffer, valid until it is written again."""
+        from that buffer, valid until it is written again.  `unpack=False` returns the gathered [N, o + 2] buffer itself and launches
+        nothing for the flags (two comparison kernels otherwise): a learner that stores the fused rows decodes them when it reads them
+        (`decode_flags`)."""
         g = self._check_out(out)
         learner = self.rank == self.learner_rank
         direct = learner and actions.is_contiguous() and actions.dtype == torch.float32 and actions.device == self._actions.device
@@ -86,4 +88,4 @@ class ShardedVecEnv:
             rows[:, self.obs_dim] = rew
             rows[:, self.obs_dim + 1] = done.to(torch.float32) + 2 * trunc.to(torch.float32)
         self._all_gather(g)
-        return self._unpack(g)
+        return self._unpack(g) if unpack else g

@@ -34,6 +34,18 @@ class OracleEnv:
         return torch.from_numpy(obs), torch.from_numpy(rew), torch.from_numpy(done), torch.from_numpy(trunc)
 
 
+class FusedOracleEnv(OracleEnv):
+    """... and with QuadrupedVecEnv.step_fused: the rows [obs | reward | done + 2 truncated] written into the caller's slice, which is
+    the branch of ShardedVecEnv.step the GPU build takes (in-place all-gather of the learner's buffer)."""
+
+    def step_fused(self, a, out):
+        obs, rew, done, trunc = self.o.step(a.numpy())
+        out[:, : self.obs_dim] = torch.from_numpy(obs)
+        out[:, self.obs_dim] = torch.from_numpy(rew)
+        out[:, self.obs_dim + 1] = torch.from_numpy(done.astype(np.float32) + 2 * trunc.astype(np.float32))
+        return out
+
+
 def actions():
     rng = np.random.default_rng(3)
     a = rng.uniform(-1, 1, size=(STEPS, N_GLOBAL, 6)).astype(np.float32)
@@ -41,17 +53,25 @@ def actions():
     return a
 
 
-def worker(rank, world, port, out):
+def worker(rank, world, port, out, fused=False):
     for p in (REPO, os.path.join(REPO, "quadruped-springs_amd")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from qs_amd.sharded import ShardedVecEnv
     n = N_GLOBAL // world
-    env = ShardedVecEnv(OracleEnv(n, ShardedVecEnv.env_id_offset(n)), learner_rank=0)
+    from qs_amd.sharded import decode_flags
+    env = ShardedVecEnv((FusedOracleEnv if fused else OracleEnv)(n, ShardedVecEnv.env_id_offset(n)), learner_rank=0)
     res = [env.reset().clone()]
-    for a in actions():
-        o, r, d, t = env.step(torch.from_numpy(a) if rank == 0 else None)
+    roll = torch.zeros((3, N_GLOBAL, env.obs_dim + 2))
+    for k, a in enumerate(actions()):
+        if fused and k % 2:      # the learner's own rollout row as the gather buffer, flags decoded by the reader
+            g = env.step(torch.from_numpy(a) if rank == 0 else None, out=roll[k % 3], unpack=False)
+            assert g.data_ptr() == roll[k % 3].data_ptr()
+            o, r = g[:, : env.obs_dim], g[:, env.obs_dim]
+            d, t = decode_flags(g[:, env.obs_dim + 1])
+        else:
+            o, r, d, t = env.step(torch.from_numpy(a) if rank == 0 else None)
         res.append(torch.cat([o, r[:, None], d[:, None].float(), t[:, None].float()], dim=1).clone())
     if rank == 1:  # every rank holds the full gathered result
         torch.save(torch.stack([x if x.shape[1] == res[1].shape[1] else torch.nn.functional.pad(x, (0, 3)) for x in res]), out)
@@ -60,10 +80,11 @@ def worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one(tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_ranks_equal_one(tmp_path, fused):
     out = str(tmp_path / "r1.pt")
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + os.getpid() % 2000 + (7 if fused else 0)
+    mp.spawn(worker, args=(2, port, out, fused), nprocs=2, join=True)
     got = torch.load(out).numpy()
     single = OracleEnv(N_GLOBAL, 0)
     ref = [np.pad(single.reset_tensor().numpy(), ((0, 0), (0, 3)))]
