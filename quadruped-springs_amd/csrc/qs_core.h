@@ -221,7 +221,10 @@ template <> struct Rng<LaneEmu> {
 // a non-foot link on the plane, the link-link tests of the self-collision rule) substep() gives up and returns true instead: the step
 // kernel then repeats the whole env step of that wave with the full build (HOT = false), whose rare code thus sits outside the hot
 // loop and costs it neither registers nor schedule (measured: inlined into the loop the rare code took 20 % off the headline).
-template <class T, bool CONE = false, bool HOT = false> struct Sim {
+// CALLS (full build of the one-wave-per-SIMD kernel only): the many-rows solvers are real functions, so that their register needs stay out of
+// the allocation of the full build's own common path (a device function cannot be given a register budget, so the two-waves-per-SIMD
+// kernel inlines them).
+template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> struct Sim {
     using V = typename T::V;
     using M = typename T::M;
     using V3v = V3<V>;
@@ -478,97 +481,89 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
 
     // The rare path: rows beyond the three foot-contact rows of a leg -- one row per violated joint limit (falls) and, with NCP = 3,
     // normal + friction rows of up to two more support points of the leg (trunk corner, hip housing, thigh ends, knee end of the calf:
-    // a fallen robot rests on them).  It is written with its (4 NRW) x NRW Delassus block and row data in private (scratch) memory
-    // instead of hundreds of extra registers: the common path then needs no spills at all, and the scratch traffic exists only in waves
-    // that actually take this branch.  Same arithmetic as solve_and_integrate<3>.  Row layout of a leg: contact point c = 0 .. NCP-1
-    // (0 = the foot) at rows 3c (normal), 3c + 1, 3c + 2 (friction), joint limits at rows 3 NCP + j.
+    // a fallen robot rests on them).  Row layout of a leg: contact point c = 0 .. NCP-1 (0 = the foot) at rows 3c (normal), 3c + 1,
+    // 3c + 2 (friction), joint limits at rows 3 NCP + j.
+    //
+    // Same projected Gauss-Seidel as solve_and_integrate, in VELOCITY space: with y = sum_i w_i lambda_i (the base part of J^T lambda in the
+    // whitened coordinates of the Cholesky factor, replicated over the quad) and x = sum_{own rows} u_r lambda_r (the own leg's part) the
+    // velocity of row i along its own direction is w_i . y + jq_i . x, because A_ij = w_i . w_j + [same leg] jq_i . u_j.  A row update is
+    // then: that dot product (9 FMAs on the lane's own row data), clamp, one DPP broadcast of the owner's delta, y += w_owner delta (six
+    // v_fmac_dpp), x += u delta on the owner.  No (4 NRW) x NRW Delassus block is built or fetched: round 2's first version kept that block
+    // in scratch and spent ~0.4 ms per substep waiting for its rows (a fallen-robot wave: 4 ms per env step).  The row data (15 values
+    // x NRW) are loaded from the argument block once; in the one-wave-per-SIMD kernel this is a real function with its own registers.
+    // Rows that are empty in the whole wave are skipped (an empty row's update is exactly a no-op).
     template <int NCP> struct RareArgs { Row rows[3 * NCP + 3]; V Sm[21], Ld[6], BK[3][6], R[9]; };
     template <int NCP> static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs<NCP>& a) {
         constexpr int NRW = 3 * NCP + 3, LIM = 3 * NCP;
         const float dt = (float)cfg.dt;
         const V zero = V(0.0f), big = V(1e10f);
-        // Everything that is indexed below goes through a runtime zero, so the Delassus block and the row data live in
-        // private memory and are fetched row by row with constant offsets; the loops are unrolled, the impulses and residuals of
-        // the own rows stay in registers and every broadcast is a DPP quad_perm.
-        const int z0 = T::opaque_zero();
-        const Row* rows = a.rows + z0;
-        V Ap[4 * NRW * NRW], wcs[NRW * 6];
-        V* ApB = Ap + z0; V* wc = wcs + z0;
-#pragma clang loop unroll(disable)
-        for (int c = 0; c < NRW; c++) {
-            V di = rows[c].dinv;
+        Row rw[NRW];
 #pragma unroll
-            for (int i = 0; i < 6; i++) wc[6 * c + i] = rows[c].w[i] * di;
-        }
-        const V own0 = qflag(T::is_leg(0)), own1 = qflag(T::is_leg(1)), own2 = qflag(T::is_leg(2)), own3 = qflag(T::is_leg(3));
-        // the NRW^2 (row kind, column kind) blocks: rolled, six MFMAs each (built once per substep; only the sweeps below are unrolled)
-#pragma clang loop unroll(disable)
+        for (int r = 0; r < NRW; r++) rw[r] = a.rows[r];
+        // which rows exist at all in this wave: bit NRW K + R <=> row R of leg K is active in some environment (a friction row with its normal row)
+        unsigned long long on = 0ull;
+#pragma unroll
         for (int r = 0; r < NRW; r++) {
-            V wr[6], jr[3];
+            const M act = qgt(rw[r < LIM ? r - r % 3 : r].act, V(0.5f));
 #pragma unroll
-            for (int i = 0; i < 6; i++) wr[i] = rows[r].w[i];
-#pragma unroll
-            for (int j = 0; j < 3; j++) jr[j] = rows[r].jq[j];
-#pragma clang loop unroll(disable)
-            for (int c = 0; c < NRW; c++) {
-                typename T::Acc4 acc = T::acc4_zero();
-#pragma unroll
-                for (int i = 0; i < 6; i++) T::outer_fma(wr[i], wc[6 * c + i], acc);
-                V locs = (jr[0] * rows[c].u[0] + jr[1] * rows[c].u[1] + jr[2] * rows[c].u[2]) * rows[c].dinv;
-                ApB[(NRW * 0 + r) * NRW + c] = T::template acc4_get<0>(acc) + own0 * locs;
-                ApB[(NRW * 1 + r) * NRW + c] = T::template acc4_get<1>(acc) + own1 * locs;
-                ApB[(NRW * 2 + r) * NRW + c] = T::template acc4_get<2>(acc) + own2 * locs;
-                ApB[(NRW * 3 + r) * NRW + c] = T::template acc4_get<3>(acc) + own3 * locs;
-            }
+            for (int k = 0; k < 4; k++)
+                if (T::any(qand(T::is_leg(k), act))) on |= 1ull << (NRW * k + r);
         }
-        V lam[NRW], res[NRW];
+        V lam[NRW], y[6], x[3];
 #pragma unroll
-        for (int r = 0; r < NRW; r++) { lam[r] = zero; res[r] = rows[r].rhs; }
-        lam[0] = s.warm * cfg.warmstart * rows[0].act;
-#define QS_RWARM(K)                                                                                                    \
-    {                                                                                                                  \
-        V lk = T::template bcast<K>(lam[0]);                                                                           \
-        _Pragma("unroll") for (int c = 0; c < NRW; c++) res[c] = res[c] - ApB[(NRW * (K)) * NRW + c] * lk;             \
-    }
-        QS_RWARM(0) QS_RWARM(1) QS_RWARM(2) QS_RWARM(3)
-#undef QS_RWARM
+        for (int r = 0; r < NRW; r++) lam[r] = zero;
+        // warm start: normal rows of the feet only, factor cfg.warmstart
+        lam[0] = s.warm * cfg.warmstart * rw[0].act;
+#pragma unroll
+        for (int i = 0; i < 6; i++) y[i] = T::quad_sum(rw[0].w[i] * lam[0]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) x[j] = rw[0].u[j] * lam[0];
         const bool track = cfg.solver_residual_threshold > 0.0f;
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
-        V mu_c = mu;   // friction bound of the cone rows; lifted once the environment is frozen (see solve_and_integrate)
-        // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the normal impulse
-        // of its contact point (row N0 of the same leg)
-#define QS_RROW(K, R, KIND, N0)                                                                                        \
+        V mu_c = mu;        // friction bound of the cone rows; lifted once the environment is frozen (see solve_and_integrate)
+        V live = V(1.0f);   // 0 once the environment is frozen: its deltas are dropped
+        // the lane's own row R: unclamped candidate from the current velocities
+#define QS_RCAND(R) (lam[R] + (rw[R].rhs - rw[R].dinv * (rw[R].w[0] * y[0] + rw[R].w[1] * y[1] + rw[R].w[2] * y[2] + rw[R].w[3] * y[3] + rw[R].w[4] * y[4] + \
+                                                         rw[R].w[5] * y[5] + rw[R].jq[0] * x[0] + rw[R].jq[1] * x[1] + rw[R].jq[2] * x[2])))
+        // apply the delta of row (K, R): dl = the lane's own (clamped candidate - impulse); the owner's counts
+#define QS_RAPPLY(K, R, DL)                                                                                            \
     {                                                                                                                  \
-        V cand = lam[R] + res[R];                                                                                      \
+        V d_ = T::template bcast<K>(DL);                                                                               \
+        V dk_ = qsel(T::is_leg(K), d_, zero);                                                                          \
+        lam[R] = lam[R] + dk_;                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) y[i] = T::template fma_bcast<K>(rw[R].w[i], d_, y[i]);          \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) x[j] = x[j] + rw[R].u[j] * dk_;                                  \
+        if (track) dvmax = qmax(dvmax, T::template bcast<K>(qabs((DL) * rw[R].diag)));                                 \
+    }
+        // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the normal impulse
+        // of its contact point (row N0 of the same leg), left alone while that impulse is not positive (Bullet's rule)
+#define QS_RROW(K, R, KIND, N0)                                                                                        \
+    if ((on >> (NRW * (K) + (R))) & 1ull) {                                                                            \
+        V cand = QS_RCAND(R);                                                                                          \
         if (KIND == 0) cand = qmin(qmax(cand, zero), big);                                                             \
         else { V tot = lam[N0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[R]); }  \
-        V dk = T::template bcast<K>(cand - lam[R]);                                                                    \
-        lam[R] = qsel(T::is_leg(K), cand, lam[R]);                                                                     \
-        _Pragma("unroll") for (int c = 0; c < NRW; c++) res[c] = res[c] - ApB[(NRW * (K) + (R)) * NRW + c] * dk;       \
-        if (track) dvmax = qmax(dvmax, qabs(dk * T::template bcast<K>(rows[R].diag)));                                 \
+        V dl = (cand - lam[R]) * live;                                                                                 \
+        QS_RAPPLY(K, R, dl)                                                                                            \
     }
-        // implicit cone friction: both friction rows of a contact point of leg K together (see solve_and_integrate)
+        // implicit cone friction: both friction rows of a contact point of leg K from the same velocities, projected onto the disc
 #define QS_RPAIR(K, N0)                                                                                                \
-    {                                                                                                                  \
-        V ca = lam[(N0) + 1] + res[(N0) + 1], cb = lam[(N0) + 2] + res[(N0) + 2], lim = mu_c * lam[N0];                \
+    if ((on >> (NRW * (K) + (N0))) & 1ull) {                                                                           \
+        V ca = QS_RCAND((N0) + 1), cb = QS_RCAND((N0) + 2), lim = mu_c * lam[N0];                                      \
         V r2 = ca * ca + cb * cb;                                                                                      \
         V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));                                                       \
-        ca = ca * sc; cb = cb * sc;                                                                                    \
-        V da = T::template bcast<K>(ca - lam[(N0) + 1]), db = T::template bcast<K>(cb - lam[(N0) + 2]);                \
-        lam[(N0) + 1] = qsel(T::is_leg(K), ca, lam[(N0) + 1]); lam[(N0) + 2] = qsel(T::is_leg(K), cb, lam[(N0) + 2]);  \
-        _Pragma("unroll") for (int c = 0; c < NRW; c++)                                                                \
-            res[c] = res[c] - (ApB[(NRW * (K) + (N0) + 1) * NRW + c] * da + ApB[(NRW * (K) + (N0) + 2) * NRW + c] * db); \
-        if (track) dvmax = qmax(dvmax, qmax(qabs(da * T::template bcast<K>(rows[(N0) + 1].diag)), qabs(db * T::template bcast<K>(rows[(N0) + 2].diag)))); \
+        V da = (ca * sc - lam[(N0) + 1]) * live, db = (cb * sc - lam[(N0) + 2]) * live;                                \
+        QS_RAPPLY(K, (N0) + 1, da)                                                                                     \
+        QS_RAPPLY(K, (N0) + 2, db)                                                                                     \
     }
-#define QS_RLEG_FWD(K) QS_RROW(K, LIM + 0, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 2, 0, 0) T::sched_fence();
-#define QS_RLEG_BWD(K) QS_RROW(K, LIM + 2, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 0, 0, 0) T::sched_fence();
-#define QS_RNORMALS(K) { QS_RROW(K, 0, 0, 0) if constexpr (NCP == 3) { QS_RROW(K, 3, 0, 3) QS_RROW(K, 6, 0, 6) } T::sched_fence(); }
+#define QS_RLEG_FWD(K) QS_RROW(K, LIM + 0, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 2, 0, 0)
+#define QS_RLEG_BWD(K) QS_RROW(K, LIM + 2, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 0, 0, 0)
+#define QS_RNORMALS(K) { QS_RROW(K, 0, 0, 0) if constexpr (NCP == 3) { QS_RROW(K, 3, 0, 3) QS_RROW(K, 6, 0, 6) } }
 #define QS_RFRICTION(K)                                                                                               \
     {                                                                                                                  \
-        if (CONE) { QS_RPAIR(K, 0) T::sched_fence(); if constexpr (NCP == 3) { QS_RPAIR(K, 3) T::sched_fence(); QS_RPAIR(K, 6) T::sched_fence(); } } \
+        if (CONE) { QS_RPAIR(K, 0) if constexpr (NCP == 3) { QS_RPAIR(K, 3) QS_RPAIR(K, 6) } }                         \
         else {                                                                                                         \
-            QS_RROW(K, 1, 1, 0) QS_RROW(K, 2, 1, 0) T::sched_fence();                                                  \
-            if constexpr (NCP == 3) { QS_RROW(K, 4, 1, 3) QS_RROW(K, 5, 1, 3) T::sched_fence(); QS_RROW(K, 7, 1, 6) QS_RROW(K, 8, 1, 6) T::sched_fence(); } \
+            QS_RROW(K, 1, 1, 0) QS_RROW(K, 2, 1, 0)                                                                    \
+            if constexpr (NCP == 3) { QS_RROW(K, 4, 1, 3) QS_RROW(K, 5, 1, 3) QS_RROW(K, 7, 1, 6) QS_RROW(K, 8, 1, 6) } \
         }                                                                                                              \
     }
         for (int it = 0; it < cfg.solver_iters; it++) {
@@ -580,10 +575,8 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
             QS_RFRICTION(0) QS_RFRICTION(1) QS_RFRICTION(2) QS_RFRICTION(3)
             if (track) {
                 M conv = qle(dvmax, thr);
-                if (CONE) mu_c = qsel(conv, V(1e30f), mu_c);
-#pragma unroll
-                for (int c = 0; c < NRW; c++) res[c] = qsel(conv, zero, res[c]);
-                if (!T::any(qnot(conv))) break;
+                live = qsel(conv, zero, live);
+                if (!T::any(qgt(live, V(0.5f)))) break;
             }
         }
 #undef QS_RFRICTION
@@ -592,23 +585,19 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
 #undef QS_RLEG_BWD
 #undef QS_RPAIR
 #undef QS_RROW
+#undef QS_RAPPLY
+#undef QS_RCAND
         o.foot_force = lam[0] * qrcp(dt);
         s.warm = lam[0];
+        // delta v = H^-1 J^T lambda :  dv_b = L^-T y ;  dqd = x - (B K)^T dv_b
         V z[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            V t = zero;
-#pragma unroll
-            for (int r = 0; r < NRW; r++) t = t + rows[r].w[i] * lam[r];
-            z[i] = T::quad_sum(t);
-        }
+        for (int i = 0; i < 6; i++) z[i] = y[i];
         ltsolve6<V>(a.Sm, a.Ld, z);
         const V cap = V(cfg.vel_cap);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            V t = zero;
-#pragma unroll
-            for (int r = 0; r < NRW; r++) t = t + rows[r].u[j] * lam[r];
+            V t = x[j];
 #pragma unroll
             for (int i = 0; i < 6; i++) t = t - a.BK[j][i] * z[i];
             s.qd[j] = clampv<V>(s.qd[j] + t, -cap, cap);
@@ -620,6 +609,9 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
         s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), -cap, cap);
         s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), -cap, cap);
         s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
+    }
+    template <int NCP> static QS_NOINLINE void solve_with_limits_call(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs<NCP>& a) {
+        solve_with_limits<NCP>(cfg, mu, s, o, a);
     }
 
     // ---- link-link tests of the self-collision rule (rare path)
@@ -1030,7 +1022,8 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
             }
             QS_LIMIT_ROWS(a.rows + 9)
             QS_RARE_COMMON(a)
-            solve_with_limits<3>(cfg, Pr.mu, s, o, a);
+            if (CALLS) solve_with_limits_call<3>(cfg, Pr.mu, s, o, a);
+            else solve_with_limits<3>(cfg, Pr.mu, s, o, a);
         } else if (!HOT && T::any(any_lim)) {
             T::count_rare_path();
             QS_LIMIT_ROWS(rows + 3)
@@ -1038,7 +1031,8 @@ template <class T, bool CONE = false, bool HOT = false> struct Sim {
 #pragma unroll
             for (int r = 0; r < 6; r++) a.rows[r] = rows[r];
             QS_RARE_COMMON(a)
-            solve_with_limits<1>(cfg, Pr.mu, s, o, a);
+            if (CALLS) solve_with_limits_call<1>(cfg, Pr.mu, s, o, a);
+            else solve_with_limits<1>(cfg, Pr.mu, s, o, a);
         } else {
             if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
             else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);

@@ -85,13 +85,13 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
 // The body is compiled twice (k_step / k_step_dense below) under different register budgets.
 // EXACT: the build that can settle a finished environment inside the step (reset_pool = 0); the pooled builds leave that code out
-template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                  const float* __restrict__ actions, float* __restrict__ obs_out,
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, PoolView pool,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
-    using E = Env<LaneDev, CONE>;          // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
+    using E = Env<LaneDev, CONE, false, WAVES == 1>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
     using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
@@ -238,11 +238,11 @@ template <bool CONE, bool EXACT> static __device__ __forceinline__ void step_bod
 #define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap, demo
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
-template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, EXACT>(QS_STEP_PASS); }
+template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, EXACT, 1>(QS_STEP_PASS); }
 // Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
 // issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
 // (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
-template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, EXACT>(QS_STEP_PASS); }
+template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, EXACT, 2>(QS_STEP_PASS); }
 
 // Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
 // settling into the pool (they replace the entries at the rotating cursor) ...
