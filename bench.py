@@ -87,8 +87,9 @@ def parse_args(argv=None):
                     help="PyBullet's implicit cone (its default, and this build's) or the friction pyramid with Bullet's skip rule")
     ap.add_argument("--solver-residual-threshold", type=float, default=1e-7,
                     help="PyBullet solverResidualThreshold (its default 1e-7 is this build's default); 0 = always int(300/action_repeat) sweeps")
-    ap.add_argument("--env-kw", nargs="*", default=[], metavar="KEY=VALUE",
-                    help="extra QuadrupedVecEnv keywords for experiments (python literals), e.g. self_collision=False body_contacts=True")
+    ap.add_argument("--env-kw", nargs="*", action="extend", default=[], metavar="KEY=VALUE",
+                    help="extra QuadrupedVecEnv keywords for experiments (python literals, anything else is taken as a string), "
+                         "e.g. self_collision=False payload=soft env_randomizer_mode=MASS_RANDOMIZER")
     return ap.parse_args(argv)
 
 
@@ -191,7 +192,12 @@ def main():
     kw["solver_residual_threshold"] = args.solver_residual_threshold
     kw["friction_model"] = args.friction_model
     import ast
-    extra_kw = {k: ast.literal_eval(v) for k, v in (item.split("=", 1) for item in args.env_kw)}
+    def literal(v):
+        try:
+            return ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            return v
+    extra_kw = {k: literal(v) for k, v in (item.split("=", 1) for item in args.env_kw)}
     # a learner that consumes observations, rewards and done flags (SB3 PPO) never reads the records' info block (torques, foot forces,
     # the task's pose cache): the steps do not write it (info_fields = False; getters for it would fail loudly).  --env-kw info_fields=True
     kw.setdefault("info_fields", False)

@@ -118,9 +118,10 @@ typedef struct qs_config {
                                 * task's pose cache: what QS_INFO_FOOT_FORCE / _FOOT_CONTACT / _TORQUE / _SPRING_TORQUE and the cache slots of
                                 * QS_INFO_TASK return); 0: a learner that reads observations, rewards and done flags only skips those stores,
                                 * and the getters fail */
-    int32_t payload_soft;      /* 0: the payload block of the mass randomizer is welded to the trunk (the product's model); 1: a second body held by a
-                                * six-row fixed constraint in the same PGS, as the reference builds it (quadruped.py:796-819).  ORACLE ONLY -- it is
-                                * there to measure what the weld leaves out (tests/test_body_contacts.py); qs_create refuses it */
+    int32_t payload_soft;      /* 0: the payload block of the mass randomizer is welded to the trunk (the default: same motion to micrometres,
+                                * tests/test_body_contacts.py, and the common-path kernel); 1: a second body held by a six-row fixed constraint
+                                * in the same PGS, as the reference builds it (quadruped.py:796-819) -- every substep then takes the many-rows
+                                * solver (about 6x the step time); its state: QS_INFO_PAYLOAD_BLOCK */
     float reserved_f[3];
     /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
@@ -176,6 +177,8 @@ enum {
     QS_INFO_FILTERED_ACTION = 11,  /* [N,12]: output of the action filter at the last step (get_last_filtered_action, gym_env.py:385-387) */
     QS_INFO_REWARD_END = 12,  /* [N,1]: get_reward_end_episode() (gym_env.py:363-365): the end-of-episode bonus / malus the task would add
                                * if the episode ended in the current state */
+    QS_INFO_PAYLOAD_BLOCK = 13,  /* [N,20], cfg.payload_soft only: the block's centre 3, quaternion 4, linear 3 and angular 3 velocity (world), the
+                                  * six impulses of its fixed constraint at the last substep, the distance between the two pivots */
     QS_INFO_WRAPPER = 10,  /* [N,4]: phase after the step (0 policy, 1 take-off hold, 2 landing, 3 rest), scripted (the step just
                             * made ignored the caller's action), timer, end time */
 };

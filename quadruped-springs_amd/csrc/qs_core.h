@@ -261,7 +261,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         V3v zero = mk3<V>(V(0.0f), V(0.0f), V(0.0f));
         I0 = I0 + part_inertia<V>(m_trunk, mk3<V>(V(TRUNK_CX), V(0.0f), V(TRUNK_CZ)), It, zero, ex, ey, ez);
         I0 = I0 + point_inertia<V>(V(IMU_M), V(IMU_I), mk3<V>(V(IMU_X), V(IMU_Y), V(IMU_Z)));
-        I0 = I0 + point_inertia<V>(m_pay, m_pay * PAYLOAD_I, r_pay);
+        if (!cfg.payload_soft) I0 = I0 + point_inertia<V>(m_pay, m_pay * PAYLOAD_I, r_pay);   // welded to the trunk; "soft": a body of its own
         P.I0 = I0;
         P.mtot = I0.m + 4.0f * (P.m_leg[0] + P.m_leg[1] + P.m_leg[2] + FOOT_M);
         P.m_pay = m_pay; P.r_pay = r_pay;
@@ -492,8 +492,19 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
     // in scratch and spent ~0.4 ms per substep waiting for its rows (a fallen-robot wave: 4 ms per env step).  The row data (15 values
     // x NRW) are loaded from the argument block once; in the one-wave-per-SIMD kernel this is a real function with its own registers.
     // Rows that are empty in the whole wave are skipped (an empty row's update is exactly a no-op).
-    template <int NCP> struct RareArgs { Row rows[3 * NCP + 3]; V Sm[21], Ld[6], BK[3][6], R[9]; };
-    template <int NCP> static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs<NCP>& a) {
+    //
+    // cfg.payload_soft (quadruped.py:778-819): the payload block is a rigid body of its own, held on the base by a fixed constraint -- six
+    // more rows (three hold the block's pivot on the base origin, three hold the frames parallel; impulse bound 500 N x dt, ERP
+    // cfg.joint_erp), swept with the joint-limit rows as Bullet sorts them (after them forwards, before them backwards).  They have no
+    // joint part and touch every lane's y alike, so every lane of the quad computes them redundantly: no broadcast.  The block's side
+    // of a row is analytic (isotropic inertia mI^-1, mass mM^-1, lever rB): J = (-(rB x e_k), -e_k) resp. (-e_k, 0).
+    struct PayRows {
+        V w[6][6], rhs[6], dinv[6], diag[6];   // base side (whitened), right-hand side x dinv, 1 / A_kk, A_kk
+        V3v rB; V mI, mM, act;                  // block centre -> pivot (world), 1 / inertia, 1 / mass, 1 while the block exists
+        V lam[6]; V3v dw, dv;                   // results: impulses, the block's velocity change (world)
+    };
+    template <int NCP> struct RareArgs { Row rows[3 * NCP + 3]; V Sm[21], Ld[6], BK[3][6], R[9]; PayRows pay; bool has_pay; };
+    template <int NCP> static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, RareArgs<NCP>& a) {
         constexpr int NRW = 3 * NCP + 3, LIM = 3 * NCP;
         const float dt = (float)cfg.dt;
         const V zero = V(0.0f), big = V(1e10f);
@@ -520,8 +531,45 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         for (int j = 0; j < 3; j++) x[j] = rw[0].u[j] * lam[0];
         const bool track = cfg.solver_residual_threshold > 0.0f;
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
-        V mu_c = mu;        // friction bound of the cone rows; lifted once the environment is frozen (see solve_and_integrate)
-        V live = V(1.0f);   // 0 once the environment is frozen: its deltas are dropped
+        V live = V(1.0f);   // 0 once the environment is frozen (its residual passed under the threshold): its deltas are dropped
+        // payload rows (replicated)
+        const bool pay = a.has_pay;
+        V pw[6][6], prhs[6], pdinv[6], pdiag[6], plam[6], mI = zero, mM = zero, pact = zero;
+        V3v pja[6], dwb = mk3<V>(zero, zero, zero), dvb = mk3<V>(zero, zero, zero);
+        const V bound = V(500.0f * dt);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            plam[k] = zero; prhs[k] = zero; pdinv[k] = zero; pdiag[k] = zero; pja[k] = mk3<V>(zero, zero, zero);
+#pragma unroll
+            for (int i = 0; i < 6; i++) pw[k][i] = zero;
+        }
+        if (pay) {
+            const PayRows& q = a.pay;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                prhs[k] = q.rhs[k]; pdinv[k] = q.dinv[k]; pdiag[k] = q.diag[k];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pw[k][i] = q.w[k][i];
+            }
+            mI = q.mI; mM = q.mM; pact = q.act;
+            pja[0] = mk3<V>(zero, -q.rB.z, q.rB.y); pja[1] = mk3<V>(q.rB.z, zero, -q.rB.x); pja[2] = mk3<V>(-q.rB.y, q.rB.x, zero);   // -(rB x e_k)
+            pja[3] = mk3<V>(V(-1.0f), zero, zero); pja[4] = mk3<V>(zero, V(-1.0f), zero); pja[5] = mk3<V>(zero, zero, V(-1.0f));
+        }
+        // payload row P (0..2 linear along world axis P, 3..5 angular)
+#define QS_PROW(P)                                                                                                     \
+    {                                                                                                                  \
+        V rel = dot(pja[P], dwb) - ((P) == 0 ? dvb.x : (P) == 1 ? dvb.y : (P) == 2 ? dvb.z : zero);                    \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) rel = rel + pw[P][i] * y[i];                                     \
+        V cand = qmin(qmax(plam[P] + (prhs[P] - pdinv[P] * rel), -bound), bound);                                      \
+        V dl = (cand - plam[P]) * (live * pact);                                                                       \
+        plam[P] = plam[P] + dl;                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) y[i] = y[i] + pw[P][i] * dl;                                     \
+        dwb = dwb + pja[P] * (mI * dl);                                                                                \
+        if ((P) == 0) dvb.x = dvb.x - mM * dl;                                                                         \
+        if ((P) == 1) dvb.y = dvb.y - mM * dl;                                                                         \
+        if ((P) == 2) dvb.z = dvb.z - mM * dl;                                                                         \
+        if (track) dvmax = qmax(dvmax, qabs(dl * pdiag[P]));                                                           \
+    }
         // the lane's own row R: unclamped candidate from the current velocities
 #define QS_RCAND(R) (lam[R] + (rw[R].rhs - rw[R].dinv * (rw[R].w[0] * y[0] + rw[R].w[1] * y[1] + rw[R].w[2] * y[2] + rw[R].w[3] * y[3] + rw[R].w[4] * y[4] + \
                                                          rw[R].w[5] * y[5] + rw[R].jq[0] * x[0] + rw[R].jq[1] * x[1] + rw[R].jq[2] * x[2])))
@@ -548,7 +596,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         // implicit cone friction: both friction rows of a contact point of leg K from the same velocities, projected onto the disc
 #define QS_RPAIR(K, N0)                                                                                                \
     if ((on >> (NRW * (K) + (N0))) & 1ull) {                                                                           \
-        V ca = QS_RCAND((N0) + 1), cb = QS_RCAND((N0) + 2), lim = mu_c * lam[N0];                                      \
+        V ca = QS_RCAND((N0) + 1), cb = QS_RCAND((N0) + 2), lim = mu * lam[N0];                                      \
         V r2 = ca * ca + cb * cb;                                                                                      \
         V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));                                                       \
         V da = (ca * sc - lam[(N0) + 1]) * live, db = (cb * sc - lam[(N0) + 2]) * live;                                \
@@ -569,8 +617,13 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         for (int it = 0; it < cfg.solver_iters; it++) {
             V dvmax = zero;
             // per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), the normal rows (leg by leg, foot first), the friction rows
-            if (it & 1) { QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3) }
-            else { QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0) }
+            if (it & 1) {
+                QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3)
+                if (pay) { QS_PROW(0) QS_PROW(1) QS_PROW(2) QS_PROW(3) QS_PROW(4) QS_PROW(5) }
+            } else {
+                if (pay) { QS_PROW(5) QS_PROW(4) QS_PROW(3) QS_PROW(2) QS_PROW(1) QS_PROW(0) }
+                QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0)
+            }
             QS_RNORMALS(0) QS_RNORMALS(1) QS_RNORMALS(2) QS_RNORMALS(3)
             QS_RFRICTION(0) QS_RFRICTION(1) QS_RFRICTION(2) QS_RFRICTION(3)
             if (track) {
@@ -579,6 +632,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                 if (!T::any(qgt(live, V(0.5f)))) break;
             }
         }
+#undef QS_PROW
 #undef QS_RFRICTION
 #undef QS_RNORMALS
 #undef QS_RLEG_FWD
@@ -589,6 +643,11 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
 #undef QS_RCAND
         o.foot_force = lam[0] * qrcp(dt);
         s.warm = lam[0];
+        if (pay) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.pay.lam[k] = plam[k];
+            a.pay.dw = dwb; a.pay.dv = dvb;
+        }
         // delta v = H^-1 J^T lambda :  dv_b = L^-T y ;  dqd = x - (B K)^T dv_b
         V z[6];
 #pragma unroll
@@ -610,7 +669,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), -cap, cap);
         s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
     }
-    template <int NCP> static QS_NOINLINE void solve_with_limits_call(const qs_config& cfg, V mu, State& s, Out& o, const RareArgs<NCP>& a) {
+    template <int NCP> static QS_NOINLINE void solve_with_limits_call(const qs_config& cfg, V mu, State& s, Out& o, RareArgs<NCP>& a) {
         solve_with_limits<NCP>(cfg, mu, s, o, a);
     }
 
@@ -681,11 +740,109 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
     }
 
     // returns true iff HOT and the wave needs a rare path (nothing it wrote is valid then).
+    // ---- cfg.payload_soft: the payload block as a body of its own (quadruped.py:778-819: createMultiBody(box of half extent 0.05) +
+    // createConstraint(base, block, JOINT_FIXED, child pivot -delta) = a btMultiBodyFixedConstraint in the same PGS as the contacts)
+    // puts the block where the constraint wants it, at the base's velocity (a reset's spawn, qs_set_state, qs_set_params)
+    static QS_FN void block_place(float* blk, const State& s, const Par& Pr) {
+        V x = s.qx, y = s.qy, z = s.qz, w = s.qw;
+        V sc = V(2.0f) * qrcp(x * x + y * y + z * z + w * w);
+        V xs = x * sc, ys = y * sc, zs = z * sc;
+        V wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+        const V3v r = Pr.r_pay;
+        V3v d = mk3<V>((V(1.0f) - (yy + zz)) * r.x + (xy - wz) * r.y + (xz + wy) * r.z, (xy + wz) * r.x + (V(1.0f) - (xx + zz)) * r.y + (yz - wx) * r.z,
+                       (xz - wy) * r.x + (yz + wx) * r.y + (V(1.0f) - (xx + yy)) * r.z);
+        V3v v = s.vlin + cross(s.vang, d);
+        T::st(blk, B_POS, s.pos.x + d.x); T::st(blk, B_POS + 1, s.pos.y + d.y); T::st(blk, B_POS + 2, s.pos.z + d.z);
+        T::st(blk, B_QUAT, s.qx); T::st(blk, B_QUAT + 1, s.qy); T::st(blk, B_QUAT + 2, s.qz); T::st(blk, B_QUAT + 3, s.qw);
+        T::st(blk, B_V, v.x); T::st(blk, B_V + 1, v.y); T::st(blk, B_V + 2, v.z);
+        T::st(blk, B_W, s.vang.x); T::st(blk, B_W + 1, s.vang.y); T::st(blk, B_W + 2, s.vang.z);
+        for (int k = 0; k < 7; k++) T::st(blk, B_LAM + k, V(0.0f));
+    }
+    // the six rows of the fixed constraint from the predicted velocities; applies gravity to the block (its only other force: the
+    // inertia is isotropic, so there is no gyroscopic term) and leaves the result in the record
+    static QS_FN void payload_rows(const qs_config& cfg, const Par& Pr, const State& s, const Spv& vs, V3v Rx, V3v Ry, V3v Rz, const V* Sm, const V* Ld,
+                                   float* blk, PayRows& q) {
+        const float dt = (float)cfg.dt;
+        const V zero = V(0.0f), one = V(1.0f);
+        V3v bp = mk3<V>(T::ld(blk, B_POS), T::ld(blk, B_POS + 1), T::ld(blk, B_POS + 2));
+        V bx = T::ld(blk, B_QUAT), by = T::ld(blk, B_QUAT + 1), bz = T::ld(blk, B_QUAT + 2), bw = T::ld(blk, B_QUAT + 3);
+        V3v bv = mk3<V>(T::ld(blk, B_V), T::ld(blk, B_V + 1), T::ld(blk, B_V + 2) - dt * cfg.gravity);
+        V3v bo = mk3<V>(T::ld(blk, B_W), T::ld(blk, B_W + 1), T::ld(blk, B_W + 2));
+        T::st(blk, B_V + 2, bv.z);
+        V3v rB;
+        {
+            V sc = V(2.0f) * qrcp(bx * bx + by * by + bz * bz + bw * bw);
+            V xs = bx * sc, ys = by * sc, zs = bz * sc;
+            V wx = bw * xs, wy = bw * ys, wz = bw * zs, xx = bx * xs, xy = bx * ys, xz = bx * zs, yy = by * ys, yz = by * zs, zz = bz * zs;
+            V3v n = mk3<V>(-Pr.r_pay.x, -Pr.r_pay.y, -Pr.r_pay.z);
+            rB = mk3<V>((one - (yy + zz)) * n.x + (xy - wz) * n.y + (xz + wy) * n.z, (xy + wz) * n.x + (one - (xx + zz)) * n.y + (yz - wx) * n.z,
+                        (xz - wy) * n.x + (yz + wx) * n.y + (one - (xx + yy)) * n.z);
+        }
+        V perr[3] = {s.pos.x - (bp.x + rB.x), s.pos.y - (bp.y + rB.y), s.pos.z - (bp.z + rB.z)};   // pivot on the base (its origin) - pivot on the block
+        T::st(blk, B_GAP, qsqrt(perr[0] * perr[0] + perr[1] * perr[1] + perr[2] * perr[2]));
+        // orientation error: rotation vector of q_base q_block^-1 (world), small angle
+        V ex = s.qw * (-bx) + s.qx * bw + s.qy * (-bz) - s.qz * (-by);
+        V ey = s.qw * (-by) - s.qx * (-bz) + s.qy * bw + s.qz * (-bx);
+        V ez = s.qw * (-bz) + s.qx * (-by) - s.qy * (-bx) + s.qz * bw;
+        V ew = s.qw * bw - s.qx * (-bx) - s.qy * (-by) - s.qz * (-bz);
+        V sg = qsel(qlt(ew, zero), V(-2.0f), V(2.0f));
+        V aerr[3] = {sg * ex, sg * ey, sg * ez};
+        M has = qgt(Pr.m_pay, zero);
+        V mp = qsel(has, Pr.m_pay, one);
+        q.act = qflag(has);
+        q.mM = qrcp(mp); q.mI = qrcp(mp * go1::PAYLOAD_I);
+        q.rB = rB;
+        V3v ja[3] = {mk3<V>(zero, -rB.z, rB.y), mk3<V>(rB.z, zero, -rB.x), mk3<V>(-rB.y, rB.x, zero)};   // -(rB x e_k)
+        V3v ab[3] = {Rx, Ry, Rz};                                                                         // R^T e_k
+        V bvk[3] = {bv.x, bv.y, bv.z}, bok[3] = {bo.x, bo.y, bo.z};
+        const V erp = V(cfg.joint_erp * (1.0f / dt));
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int c = k % 3;
+            if (k < 3) { q.w[k][0] = zero; q.w[k][1] = zero; q.w[k][2] = zero; q.w[k][3] = ab[c].x * q.act; q.w[k][4] = ab[c].y * q.act; q.w[k][5] = ab[c].z * q.act; }
+            else { q.w[k][0] = ab[c].x * q.act; q.w[k][1] = ab[c].y * q.act; q.w[k][2] = ab[c].z * q.act; q.w[k][3] = zero; q.w[k][4] = zero; q.w[k][5] = zero; }
+            lsolve6<V>(Sm, Ld, q.w[k]);
+            V diag = k < 3 ? q.mI * dot(ja[c], ja[c]) + q.mM : q.mI;
+#pragma unroll
+            for (int i = 0; i < 6; i++) diag = diag + q.w[k][i] * q.w[k][i];
+            q.diag[k] = diag; q.dinv[k] = qrcp(diag);
+            V rel = k < 3 ? dot(ab[c], vs.l) + dot(ja[c], bo) - bvk[c] : dot(ab[c], vs.a) - bok[c];
+            V err = k < 3 ? perr[c] : aerr[c];
+            q.rhs[k] = ((-err) * erp - rel) * q.dinv[k] * q.act;
+        }
+    }
+    // after the solve: the block's velocities, then its pose (semi-implicit Euler, exponential map like the base)
+    static QS_FN void payload_integrate(const qs_config& cfg, float* blk, const PayRows& q) {
+        const float dt = (float)cfg.dt;
+        const V one = V(1.0f);
+        V3v bv = mk3<V>(T::ld(blk, B_V) + q.dv.x, T::ld(blk, B_V + 1) + q.dv.y, T::ld(blk, B_V + 2) + q.dv.z);
+        V3v bo = mk3<V>(T::ld(blk, B_W) + q.dw.x, T::ld(blk, B_W + 1) + q.dw.y, T::ld(blk, B_W + 2) + q.dw.z);
+        V bx = T::ld(blk, B_QUAT), by = T::ld(blk, B_QUAT + 1), bz = T::ld(blk, B_QUAT + 2), bw = T::ld(blk, B_QUAT + 3);
+        T::st(blk, B_V, bv.x); T::st(blk, B_V + 1, bv.y); T::st(blk, B_V + 2, bv.z);
+        T::st(blk, B_W, bo.x); T::st(blk, B_W + 1, bo.y); T::st(blk, B_W + 2, bo.z);
+        T::st(blk, B_POS, T::ld(blk, B_POS) + dt * bv.x); T::st(blk, B_POS + 1, T::ld(blk, B_POS + 1) + dt * bv.y); T::st(blk, B_POS + 2, T::ld(blk, B_POS + 2) + dt * bv.z);
+        V th2 = dot(bo, bo) * (dt * dt);
+        V sc = V(0.5f * dt) * (one - th2 * (1.0f / 24.0f) * (one - th2 * (1.0f / 80.0f)));
+        V dw = one - th2 * 0.125f * (one - th2 * (1.0f / 48.0f));
+        V dx = bo.x * sc, dy = bo.y * sc, dz = bo.z * sc;
+        V nx = dw * bx + dx * bw + dy * bz - dz * by;
+        V ny = dw * by - dx * bz + dy * bw + dz * bx;
+        V nz = dw * bz + dx * by - dy * bx + dz * bw;
+        V nw = dw * bw - dx * bx - dy * by - dz * bz;
+        V inv = qrsqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+        T::st(blk, B_QUAT, nx * inv); T::st(blk, B_QUAT + 1, ny * inv); T::st(blk, B_QUAT + 2, nz * inv); T::st(blk, B_QUAT + 3, nw * inv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) T::st(blk, B_LAM + k, q.lam[k]);
+    }
+
     // `detect`: classify the contacts of the non-foot links, the payload block and the link-link pairs (o.n_invalid).  The reference reads
     // GetContactInfo after the LAST stepSimulation of an env step (task_base.py:137-147 via gym_env.py:241-245), so the callers ask for it
     // there only -- unless cfg.body_contacts, where those links' heights decide in every substep whether they push back.
-    static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true) {
+    // `blk`: the payload block's state in the record (R_BLOCK) under cfg.payload_soft, nullptr otherwise
+    static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true, float* blk = nullptr) {
         using namespace go1;
+        if (HOT && cfg.payload_soft) return true;   // the block's constraint rows live on the many-rows path
+        const bool soft = !HOT && cfg.payload_soft && blk != nullptr;
         Model P;
         {   // opaque copies keep the compiler from hoisting the 24 leg constants out of the substep loop (where they would
             // occupy registers for the whole env step); rebuilding them is ~40 multiplications per substep
@@ -866,6 +1023,11 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             V n = qflag(m_hip) + qflag(m_thigh) + qflag(m_calf);
             // payload block (a second body in the reference, quadruped.py:778-819: a plane / block contact is an invalid one, :248-249)
             V h_pay = zc + dot(Rz, Pr.r_pay) - (qabs(Rz.x) + qabs(Rz.y) + qabs(Rz.z)) * PAYLOAD_HALF;
+            if (soft) {   // the block's own pose: third row of its rotation matrix
+                V bx = T::ld(blk, B_QUAT), by = T::ld(blk, B_QUAT + 1), bz = T::ld(blk, B_QUAT + 2), bw = T::ld(blk, B_QUAT + 3);
+                V sc = V(2.0f) * qrcp(bx * bx + by * by + bz * bz + bw * bw);
+                h_pay = T::ld(blk, B_POS + 2) - (qabs((bx * bz - bw * by) * sc) + qabs((by * bz + bw * bx) * sc) + qabs(one - (bx * bx + by * by) * sc)) * PAYLOAD_HALF;
+            }
             V pay = qflag(qand(qgt(Pr.m_pay, zero), qlt(h_pay, V(THR_PAYLOAD))));
             o.n_invalid = T::quad_sum(n) + trunk + pay;
             if (cfg.body_contacts) any_extra = qor(qor(m_trunk, m_hip), qor(m_thigh, qlt(h_cf_hi, V(THR_CALF))));
@@ -909,7 +1071,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
         if (HOT && __builtin_expect(T::any(qor(any_lim, any_extra)), 0)) return true;
-        if (T::any(qor(qor(act_m, any_lim), any_extra))) {
+        if (soft || T::any(qor(qor(act_m, any_lim), any_extra))) {
         QS_PHASE(8)
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
         Row rows[6];
@@ -971,6 +1133,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;                                  \
     }
 #define QS_RARE_COMMON(A)                                                                                              \
+    (A).has_pay = soft;                                                                                                \
+    if (soft) payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, (A).pay);                                          \
     _Pragma("unroll") for (int i = 0; i < 21; i++) (A).Sm[i] = Sm[i];                                                  \
     _Pragma("unroll") for (int i = 0; i < 6; i++) (A).Ld[i] = Ld[i];                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int i = 0; i < 6; i++) (A).BK[j][i] = BK[j][i]; \
@@ -1024,7 +1188,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             QS_RARE_COMMON(a)
             if (CALLS) solve_with_limits_call<3>(cfg, Pr.mu, s, o, a);
             else solve_with_limits<3>(cfg, Pr.mu, s, o, a);
-        } else if (!HOT && T::any(any_lim)) {
+            if (soft) payload_integrate(cfg, blk, a.pay);
+        } else if (!HOT && (soft || T::any(any_lim))) {
             T::count_rare_path();
             QS_LIMIT_ROWS(rows + 3)
             RareArgs<1> a;
@@ -1033,6 +1198,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             QS_RARE_COMMON(a)
             if (CALLS) solve_with_limits_call<1>(cfg, Pr.mu, s, o, a);
             else solve_with_limits<1>(cfg, Pr.mu, s, o, a);
+            if (soft) payload_integrate(cfg, blk, a.pay);
         } else {
             if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
             else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);

@@ -594,7 +594,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
             QS_PHASE_SUB_BEGIN
             S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
-            if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts), 0)) { StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = true; return z; }
+            if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts, cfg.payload_soft ? rec + R_BLOCK : nullptr), 0)) { StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = true; return z; }
             QS_PHASE_SUB(k)
             if (__builtin_expect(any_trace, 0)) {
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
@@ -749,6 +749,14 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         o.foot_force = zero; o.foot_contact = zero; o.n_invalid = zero;
         for (int j = 0; j < 3; j++) { o.tau_pd[j] = zero; o.tau_spring[j] = zero; }
         store_state(rec, s, o);
+        if (cfg.payload_soft) { typename S::Par P; load_par(cfg, rec, P); S::block_place(rec + R_BLOCK, s, P); }
+    }
+    // cfg.payload_soft: the block goes where the fixed constraint wants it for the state and parameters in the record (qs_set_state,
+    // qs_set_params, reference-state initialisation; the reference leaves it at the spawn pose and lets the constraint drag it)
+    static QS_FN void place_block(const qs_config& cfg, float* rec) {
+        typename S::State s; typename S::Par P;
+        load_state(rec, s); load_par(cfg, rec, P);
+        S::block_place(rec + R_BLOCK, s, P);
     }
     static QS_FN void reset(const qs_config& cfg, float* rec, float* obs, uint32_t env_id, bool settle) {
         int episode = f2i(rec[R_EPISODE]) + 1;
@@ -766,12 +774,13 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             o.foot_force = zero; o.foot_contact = zero; o.n_invalid = zero;
             for (int j = 0; j < 3; j++) { o.tau_pd[j] = zero; o.tau_spring[j] = zero; }
             load_par(cfg, rec, P);
+            if (cfg.payload_soft) S::block_place(rec + R_BLOCK, s, P);   // _add_base_mass_offset: the block appears next to the freshly spawned robot
             V cmd[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
             for (int n = 0; n < cfg.settle_steps; n++) {
                 V tau[3]; S::actuate(cfg, P, s, cmd, o, tau, true);
-                S::substep(cfg, P, s, tau, o, n == cfg.settle_steps - 1 || cfg.body_contacts);
+                S::substep(cfg, P, s, tau, o, n == cfg.settle_steps - 1 || cfg.body_contacts, cfg.payload_soft ? rec + R_BLOCK : nullptr);
             }
             store_state(rec, s, o);
         } else {  // the record already holds a settled state (copied from the pre-settled pool)

@@ -20,24 +20,28 @@ using E = Env<LaneDev>;
 #define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC)
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
-__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, bool full = false) {
+// extent of a record that a step moves: the hot block; + the info block (stores under cfg.info_fields); + the payload block's
+// own state at the end of the record (cfg.payload_soft, loads and stores)
+enum { TILE_HOT = QS_HOT, TILE_INFO = R_BLOCK, TILE_ALL = QS_REC };
+__device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) { return cfg.payload_soft ? TILE_ALL : (store && cfg.info_fields ? TILE_INFO : TILE_HOT); }
+__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent = TILE_HOT) {
     // Only the hot block [0, QS_HOT) of each record is fetched (the info block behind it is written, never read back, by a step).
     // (the rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
     // records at once -- ~9 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
     // was measured slower)
     const float4* src = reinterpret_cast<const float4*>(g + (size_t)first_env * QS_REC);
     float4* dst = reinterpret_cast<float4*>(lds);
-    const int per = (full ? QS_REC : QS_HOT) / 4;
+    const int per = extent / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
     for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * per; i += QS_WAVE) {
         const int e = i / per, o = i - e * per;
         dst[e * (QS_REC / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  // tail quads replay the tile's first record (never stored)
     }
 }
-__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, bool full = true) {
+__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int extent = TILE_ALL) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
-    const int per = (full ? QS_REC : QS_HOT) / 4;
+    const int per = extent / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
     for (int i = threadIdx.x; i < nenv * per; i += QS_WAVE) {
         const int e = i / per, o = i - e * per;
@@ -58,8 +62,9 @@ struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonst
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_REFILLED = 4, CTL_CURSOR = 5, CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
 
 // settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
-__device__ __forceinline__ void copy_settled(float* rec, const float* src) {
+__device__ __forceinline__ void copy_settled(float* rec, const float* src, bool block) {
     const int lane = threadIdx.x & 3;
+    if (block) for (int i = R_BLOCK + lane; i < R_BLOCK + QS_BLOCK_DIM; i += 4) rec[i] = src[i];   // the payload block settled with the robot
     for (int i = lane; i < R_LAST_ACTION; i += 4) rec[i] = src[i];                       // rigid-body state + warm start
     for (int i = R_PARAMS + lane; i < R_PARAMS + QS_PARAM_DIM; i += 4) rec[i] = src[i];  // params
     for (int i = R_FOOT_FORCE + lane; i < R_TAU_SPRING + 12; i += 4) rec[i] = src[i];    // contact results, torques
@@ -123,7 +128,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
     }
-    tile_load(s_rec, base, first, limit);
+    tile_load(s_rec, base, first, limit, tile_extent(cfg, false));
     QS_PHASE(27)
     if (!settling) {
 #pragma unroll
@@ -143,24 +148,27 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     QS_PHASE(13)
     float* const trow = any_trace && env == tap.env ? tap.rows : nullptr;
     typename E::StepOut r;
-    {
+    r.redo = true;
+    if (!cfg.payload_soft) {   // (the payload block's constraint rows are not in the common-path build)
         typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
         r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
+        if (__builtin_expect(r.redo, 0)) {
+            // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
+            // env step of the whole wave with the full build
+            __syncthreads();
+            tile_load(s_rec, base, first, limit);
+            __syncthreads();
+            if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
+        }
     }
     if (__builtin_expect(r.redo, 0)) {
-        // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
-        // env step of the whole wave with the full build
-        __syncthreads();
-        tile_load(s_rec, base, first, limit);
-        __syncthreads();
-        if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
         r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
     }
     QS_PHASE(14)
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
         __syncthreads();
-        tile_store(s_rec, base, first, limit);
+        tile_store(s_rec, base, first, limit, TILE_ALL);
         return;
     }
     const bool dn = r.done > 0.5f;
@@ -183,7 +191,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                 if (do_reset) {
                     uint32_t rr[4];
                     qs::philox4x32(cfg.seed, gid, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
-                    copy_settled(rec, pool.pool + (size_t)(rr[0] % (uint32_t)pool.size) * QS_REC);
+                    copy_settled(rec, pool.pool + (size_t)(rr[0] % (uint32_t)pool.size) * QS_REC, cfg.payload_soft != 0);
                     if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_CONSUMED], 1ull);   // pool entries consumed: what the streaming refill owes
                 }
                 LaneDev::sync();
@@ -193,7 +201,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                 // ignores EXEC, so it must not run under a divergent branch: what the step produced is published first, then EVERY quad
                 // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
                 __syncthreads();
-                tile_store(s_rec, recs, first, cfg.n_envs, cfg.info_fields != 0);
+                tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true));
                 {
                     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
                     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
@@ -221,7 +229,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
         }
     }
     __syncthreads();
-    tile_store(s_rec, recs, first, cfg.n_envs, cfg.info_fields != 0);
+    tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true));
     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
         float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
@@ -289,7 +297,7 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
     const bool valid = env < cfg.n_envs;
     const bool sel = valid && (mask == nullptr || mask[env] != 0);
     if (!__any(sel)) return;
-    tile_load(s_rec, recs, first, cfg.n_envs);
+    tile_load(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, false));
     const int od = cfg.obs_dim;
     __syncthreads();
     float* rec = s_rec + slot * QS_REC;
@@ -308,6 +316,7 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
             }
         }
         LaneDev::sync();
+        if (cfg.payload_soft) { E::place_block(cfg, rec); LaneDev::sync(); }
         E::reset(cfg, rec, ob, gid, false);
         LaneDev::sync();
         if (sel)   // no settle ran, so _last_action and with it the filter history stay zero (gym_env.py:284, 267-269)
@@ -429,7 +438,6 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
     if (cfg->task >= QS_TASK_JUMPING_IN_PLACE_DEMO && cfg->task <= QS_TASK_CONT_JUMPING_FORWARD_DEMO && (cfg->action_space_mode == QS_ACT_CPG || !cfg->rl_interface))
         QS_FAIL(-1, "the DEMO tasks compare the policy's action with a recorded one: they need an RL action space (not CPG, not raw commands)");
     if (cfg->task < 0 || cfg->task > QS_TASK_CONT_JUMPING_FORWARD_DEMO) QS_FAIL(-1, "unknown task id %d", cfg->task);
-    if (cfg->payload_soft) QS_FAIL(-1, "payload=\"soft\" (the payload block as a second body on a fixed constraint) exists in the oracle only; the kernels weld the block to the trunk");
     if (cfg->friction_cone != 0 && cfg->friction_cone != 1) QS_FAIL(-1, "friction_cone must be 0 (pyramid) or 1 (implicit cone), got %d", cfg->friction_cone);
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
@@ -700,6 +708,19 @@ int qs_refresh_pool(qs_handle* h) {  // redraw the pre-settled reset states (new
     return 0;
 }
 
+// cfg.payload_soft: after qs_set_state / qs_set_params the payload block goes where its fixed constraint wants it
+__global__ __launch_bounds__(QS_WAVE) void k_block_place(const qs_config* __restrict__ cfgp, float* __restrict__ recs) {
+    const qs_config& cfg = *cfgp;
+    const int env = blockIdx.x * QS_ENVS_PER_WAVE + (threadIdx.x >> 2);
+    if (env >= cfg.n_envs) return;
+    E::place_block(cfg, recs + (size_t)env * QS_REC);
+}
+static int place_blocks(qs_handle* h) {
+    if (!h->cfg.payload_soft) return 0;
+    hipLaunchKernelGGL(k_block_place, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec);
+    QS_HIP(hipGetLastError());
+    return 0;
+}
 static int gather(qs_handle* h, int off, int dim, float* out, int as_int) {
     int total = h->cfg.n_envs * dim;
     hipLaunchKernelGGL(k_gather, dim3((total + 255) / 256), dim3(256), 0, h->stream, h->d_rec, h->cfg.n_envs, off, dim, out, as_int);
@@ -738,7 +759,12 @@ static int gather_wrapper(qs_handle* h, float* out) {
 }
 
 int qs_get_state(qs_handle* h, float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); QS_ON_DEVICE(h); return gather(h, R_POS, QS_STATE_DIM, st, 0); }
-int qs_set_state(qs_handle* h, const float* st) { if (!h || !st) QS_FAIL(-1, "null argument"); QS_ON_DEVICE(h); return scatter(h, R_POS, QS_STATE_DIM, st, 1); }
+int qs_set_state(qs_handle* h, const float* st) {
+    if (!h || !st) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
+    if (int rc = scatter(h, R_POS, QS_STATE_DIM, st, 1)) return rc;
+    return place_blocks(h);
+}
 
 int qs_info_dim(const qs_handle* h, int which) {
     switch (which) {
@@ -751,6 +777,7 @@ int qs_info_dim(const qs_handle* h, int which) {
     case QS_INFO_WRAPPER: return 4;
     case QS_INFO_FILTERED_ACTION: return 12;
     case QS_INFO_REWARD_END: return 1;
+    case QS_INFO_PAYLOAD_BLOCK: return QS_BLOCK_DIM;
     default: return -1;
     }
 }
@@ -771,6 +798,9 @@ int qs_get_info(qs_handle* h, int which, float* out) {
     case QS_INFO_LAST_ACTION: return gather(h, R_LAST_ACTION, 12, out, 0);
     case QS_INFO_WRAPPER: return gather_wrapper(h, out);
     case QS_INFO_FILTERED_ACTION: return gather(h, R_YHIST, 12, out, 0);
+    case QS_INFO_PAYLOAD_BLOCK:
+        if (!h->cfg.payload_soft) QS_FAIL(-1, "the payload block is a body of its own only under cfg.payload_soft");
+        return gather(h, R_BLOCK, QS_BLOCK_DIM, out, 0);
     case QS_INFO_REWARD_END:
         hipLaunchKernelGGL(k_reward_end, dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, out);
         QS_HIP(hipGetLastError());
@@ -795,7 +825,7 @@ int qs_set_params(qs_handle* h, int which, const float* v) {
     case QS_PARAM_SPRING_B: return scatter(h, R_PARAMS + P_B, 3, v, 0);
     case QS_PARAM_KP: return scatter(h, R_PARAMS + P_KP, 3, v, 0);
     case QS_PARAM_KD: return scatter(h, R_PARAMS + P_KD, 3, v, 0);
-    case QS_PARAM_ALL: return scatter(h, R_PARAMS, QS_PARAM_DIM, v, 0);
+    case QS_PARAM_ALL: if (int rc = scatter(h, R_PARAMS, QS_PARAM_DIM, v, 0)) return rc; return place_blocks(h);
     default: QS_FAIL(-1, "unknown param id %d", which);
     }
 }

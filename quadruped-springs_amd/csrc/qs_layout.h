@@ -31,9 +31,14 @@ enum {
     R_FOOT_CONTACT = 215, // 4
     R_TAU_PD = 219,       // 12: observed motor torque of the last substep (quadruped.py:299)
     R_TAU_SPRING = 231,   // 12
+    // ---- payload block as a body of its own (cfg.payload_soft; quadruped.py:778-819): position of its centre 3, quaternion 4, linear 3 and
+    // angular 3 velocity (world), the six impulses of the fixed constraint at the last substep, the pivot gap (the qs_get_block row).
+    // Moved by the tile load / store only under cfg.payload_soft.
+    R_BLOCK = 244,        // 20
     QS_HOT = 204,         // multiple of 4 (16-byte vector moves)
-    QS_REC = 244,         // multiple of 4
+    QS_REC = 264,         // multiple of 4
 };
+enum { B_POS = 0, B_QUAT = 3, B_V = 7, B_W = 10, B_LAM = 13, B_GAP = 19, QS_BLOCK_DIM = 20 };
 enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };
 enum { T_SWITCHED = 0, T_ALL_AIR = 1, T_IS_JUMPING = 2, T_TAKEOFF = 3, T_POSE_TO = 4, T_YAW_TO = 7, T_INIT_H = 8, T_MAX_FLIGHT = 9,
        T_MAX_FWD = 10, T_MAX_PITCH = 11, T_REL_MAX_H = 12, T_MAX_DX = 13, T_MAX_H = 14, T_CUM_FWD = 15, T_CUM_FT = 16,

@@ -383,7 +383,7 @@ def build_config(
     cfg.contact_erp, cfg.joint_erp, cfg.warmstart, cfg.vel_cap = float(contact_erp), float(joint_erp), float(warmstart), rc.VELOCITY_LIMITS[0]
     cfg.contact_slop = float(contact_slop)
     cfg.info_fields = int(bool(info_fields))
-    cfg.payload_soft = {"weld": 0, "soft": 1}[payload]   # "soft" exists in the oracle only (qs_create refuses it): DESIGN.md 7
+    cfg.payload_soft = {"weld": 0, "soft": 1}[payload]   # "soft": the block as a second body on a fixed constraint (many-rows solver in every substep)
     # "auto": the non-foot links push back where the episode goes on after they touched the ground, i.e. under NO_TASK (the reference's
     # CPG driver, hopf_network.py:183-190).  Every other task ends the episode at the end of the env step in which such a contact
     # appears (task_base.py:137-147), so the response would only shape the last <= action_repeat substeps of an episode that is over,

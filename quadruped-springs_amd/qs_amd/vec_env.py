@@ -14,7 +14,7 @@ from .sharded import decode_flags
 from .spaces import Box, SB3VecEnv
 
 INFO = dict(foot_force=0, foot_contact=1, torque=2, spring_torque=3, task=4, n_invalid=5, params=6, counters=7,
-            last_action=8, terminal_obs=9, wrapper=10, filtered_action=11, reward_end=12)
+            last_action=8, terminal_obs=9, wrapper=10, filtered_action=11, reward_end=12, payload_block=13)
 PHASE = ("policy", "take_off", "landing", "rest")
 PARAM = dict(mu=0, spring_k=1, spring_b=2, kp=3, kd=4, all=5)
 

@@ -84,6 +84,10 @@ class Emu:
         f = self.field(name)
         return self.records()[:, f:f + dim].copy()
 
+    def block(self):
+        """the payload block as its own body (payload="soft"): rows as in Oracle.block()"""
+        return self.get("R_BLOCK", 20)
+
     def set_mu(self, mu):
         self.records()[:, self.field("R_PARAMS")] = mu
 

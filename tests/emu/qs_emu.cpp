@@ -30,7 +30,7 @@ template <class EV> static void phys_step_impl(Emu* e, int i, const float* tau12
     EV::load_state(rec, s); EV::load_par(e->cfg, rec, P);
     V4 tau[3];
     for (int j = 0; j < 3; j++) { tau[j] = LaneEmu::ld_leg(tau12, j, 3); o.tau_pd[j] = V4(0.0f); o.tau_spring[j] = V4(0.0f); }
-    EV::S::substep(e->cfg, P, s, tau, o);
+    EV::S::substep(e->cfg, P, s, tau, o, true, e->cfg.payload_soft ? rec + R_BLOCK : nullptr);
     EV::store_state(rec, s, o);
 }
 
@@ -67,6 +67,7 @@ int qse_reset_to(void* h, const uint8_t* mask, const float* states) {
         for (int k = 0; k < 4; k++) { rec[R_WARM + k] = 0.0f; rec[R_FOOT_FORCE + k] = 0.0f; rec[R_FOOT_CONTACT + k] = 0.0f; }
         rec[R_N_INVALID] = 0.0f;
         for (int k = 0; k < 24; k++) rec[R_TAU_PD + k] = 0.0f;
+        if (e->cfg.payload_soft) E::place_block(e->cfg, rec);
         E::reset(e->cfg, rec, &e->obs[(size_t)i * QS_MAX_OBS], gid, false);
         for (int k = 0; k < 12 + 24 + 24; k++) rec[R_LAST_ACTION + k] = 0.0f;
     }
@@ -120,7 +121,14 @@ int qse_set_state(void* h, const float* st) {
         float* r = &e->rec[(size_t)i * QS_REC];
         memcpy(r, st + (size_t)i * 37, 37 * sizeof(float));
         for (int k = 0; k < 4; k++) r[R_WARM + k] = 0.0f;
+        if (e->cfg.payload_soft) E::place_block(e->cfg, r);
     }
+    return 0;
+}
+// the payload block as its own body (cfg.payload_soft): [N, 20], the oracle's qso_get_block row
+int qse_get_block(void* h, float* out) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++) memcpy(out + (size_t)i * QS_BLOCK_DIM, &e->rec[(size_t)i * QS_REC + R_BLOCK], QS_BLOCK_DIM * sizeof(float));
     return 0;
 }
 float* qse_records(void* h) { return ((Emu*)h)->rec.data(); }
@@ -129,7 +137,7 @@ int qse_field(const char* name) {
 #define F(n) if (!strcmp(name, #n)) return n;
     F(R_POS) F(R_QUAT) F(R_VLIN) F(R_VANG) F(R_Q) F(R_QD) F(R_WARM) F(R_LAST_ACTION) F(R_XHIST) F(R_YHIST) F(R_SIM_STEP) F(R_ENV_STEP)
     F(R_EPISODE) F(R_TOTAL_STEPS) F(R_TASK) F(R_NEW_TAU) F(R_PARAMS) F(R_FOOT_FORCE) F(R_FOOT_CONTACT) F(R_N_INVALID) F(R_TAU_PD)
-    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_CPG) F(R_DEMO) F(R_WRAP)
+    F(R_TAU_SPRING) F(R_POSE_CACHE) F(R_CPG) F(R_DEMO) F(R_WRAP) F(R_BLOCK)
 #undef F
     return -1;
 }

@@ -286,7 +286,7 @@ def test_contacts_are_classified_as_the_reference_does():
 # ------------------------------------------------------------------------------------------------ what the payload weld leaves out
 def test_payload_weld_against_the_soft_fixed_constraint():
     """The product welds the mass randomizer's payload block to the trunk; the reference holds it as a second body on a six-row fixed
-    constraint of the same PGS (quadruped.py:796-819).  The oracle can do both (payload="soft" is oracle-only): over jump episodes with
+    constraint of the same PGS (quadruped.py:796-819).  Both exist (payload="weld" | "soft"; the weld is the default): over jump episodes with
     random actions the constraint keeps the pivots within a tenth of a millimetre with 7 % of its impulse budget, and one env step from
     the same state moves the base by micrometres differently -- the weld is the soft constraint up to that."""
     kw = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
@@ -325,8 +325,70 @@ def test_payload_weld_against_the_soft_fixed_constraint():
     assert worst_pose < 5e-5 and worst_vel < 2e-2, (worst_pose, worst_vel)
 
 
-def test_product_configuration_refuses_the_soft_payload():
-    cfg, _ = build_config(n_envs=1, payload="soft", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="MASS_RANDOMIZER")
-    assert cfg.payload_soft == 1     # the switch reaches the C ABI, where qs_create rejects it (GPU: test_create_rejects_bad_config)
+@pytest.mark.parametrize("model", ["cone", "pyramid"])
+def test_emu_matches_oracle_with_the_soft_payload(model):
+    """payload="soft" in the kernel arithmetic (six replicated rows of the fixed constraint in the many-rows solver, the block's state in
+    the record): free-running against the float32 oracle from the same reset, jump episodes under random actions with the mass randomizer's
+    payload draws -- robot state, block state, constraint impulses and pivot gap."""
+    n = 4
+    kw = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
+              env_randomizer_mode="TEST_RANDOMIZER", noise=False, seed=5, isRLGymInterface=True, motor_control_mode="PD", settle_steps=400)
+    cfg, _ = build_config(n_envs=n, payload="soft", friction_model=model, solver_residual_threshold=0.0, **kw)
+    o, e = Oracle(cfg, "f32"), Emu(cfg)
+    oo, oe = o.reset(), e.reset()
+    np.testing.assert_allclose(oe, oo, atol=1e-3)
+    assert o.get_info(6)[:, 20].min() > 0.05                       # every environment drew a payload
+    b0, b1 = o.block(), e.block()
+    np.testing.assert_allclose(b1[:, :3], b0["pos"], atol=1e-5)
+    assert b1[:, 19].max() < 1e-4                                   # the settle left the pivots together
+    rng = np.random.default_rng(0)
+    lam = 0.0
+    for t in range(60):
+        a = rng.uniform(-1, 1, size=(n, 6)).astype(np.float32)
+        if t % 30 > 20:
+            a[:] = [0, -1, 1, 0, -1, 1]
+        st = o.get_state()
+        if t % 10 == 9:                                             # re-seat now and then: both place the block anew
+            o.set_state(st); e.set_state(st)
+        ro, re_ = o.step(a), e.step(a)
+        so, se = o.get_state(), e.get_state()
+        np.testing.assert_allclose(se[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {t}")
+        np.testing.assert_allclose(se[:, 7:13], so[:, 7:13], atol=5e-3, err_msg=f"base velocity step {t}")
+        b0, b1 = o.block(), e.block()
+        np.testing.assert_allclose(b1[:, :3], b0["pos"], atol=5e-5, err_msg=f"block position step {t}")
+        np.testing.assert_allclose(b1[:, 3:7], b0["quat"], atol=5e-5)
+        np.testing.assert_allclose(b1[:, 7:10], b0["v"], atol=5e-3)
+        np.testing.assert_allclose(b1[:, 13:19], b0["lam"], atol=2e-4, err_msg=f"constraint impulses step {t}")
+        np.testing.assert_allclose(b1[:, 19], b0["gap"], atol=2e-5)
+        lam = max(lam, np.abs(b0["lam"]).max())
+        np.testing.assert_array_equal(re_[2], ro[2])
+        done = ro[2]
+        if done.any():
+            o.reset(done.astype(np.uint8)); e.reset(done.astype(np.uint8))
+            e.set_state(o.get_state().astype(np.float32)); o.set_state(o.get_state().astype(np.float32))
+    assert 1e-3 < lam < 0.1, lam                                    # the constraint carried the block (bound 0.5 N s)
+
+
+def test_soft_payload_block_hits_the_ground_with_its_own_pose():
+    """The invalid-contact rule for the payload block (quadruped.py:248-249) reads the block's own pose under payload="soft": a block
+    hanging 0.1 under a crouched trunk is the only thing on the floor between z = 0.14 and 0.15."""
+    cfg, _ = build_config(n_envs=1, payload="soft", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="MASS_RANDOMIZER",
+                          settle_steps=50)
+    cfg.randomizer_flags |= 8          # keep the parameters given below
+    o, e = Oracle(cfg), Emu(cfg)
+    o.reset(); e.reset()
+    p = o.get_info(6).copy()
+    p[0, 20:24] = [0.6, 0.0, 0.0, -0.1]
+    o.set_params(5, p)
+    e.records()[0, e.field("R_PARAMS"):e.field("R_PARAMS") + 24] = p[0]
+    s = o.get_state()
+    s[:, 7:] = 0; s[:, 13:25] = np.tile([0.0, 1.3, -2.6], 4)
+    for z, only_block in ((0.145, True), (0.155, False)):
+        s[:, 2] = z
+        o.set_state(s); e.set_state(s.astype(np.float32))
+        np.testing.assert_allclose(e.block()[0, :3], o.block()["pos"][0], atol=1e-6)
+        o.phys_step(0, np.zeros(12)); e.phys_step(0, np.zeros(12))
+        assert [c[:3] for c in o.contacts(0)] == ([(2, 0, -1)] if only_block else [])
+        assert (e.get("R_N_INVALID", 1)[0, 0] > 0) == only_block
     with pytest.raises(KeyError):
         build_config(n_envs=1, payload="glued")
