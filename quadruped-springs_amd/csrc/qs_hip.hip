@@ -20,11 +20,19 @@ using E = Env<LaneDev>;
 #define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC)
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
-// extent of a record that a step moves: the hot block; + the info block (stores under cfg.info_fields); + the payload block's
-// own state at the end of the record (cfg.payload_soft, loads and stores)
-enum { TILE_HOT = QS_HOT, TILE_INFO = R_BLOCK, TILE_ALL = QS_REC };
-__device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) { return cfg.payload_soft ? TILE_ALL : (store && cfg.info_fields ? TILE_INFO : TILE_HOT); }
-__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent = TILE_HOT) {
+// Leading extent of a record that a step moves (qs_layout.h).  Loads: the read-write block and the parameters; the wrapper / CPG / DEMO
+// slots behind them only for handles that use those layers (or that store the info block, which lies behind them); everything under
+// cfg.payload_soft (the block's own state ends the record).  Stores: the read-write block only -- through the parameters when a pooled
+// reset rewrote them, through the optional layers' slots when in use, through the info block under cfg.info_fields.
+enum { TILE_INFO = R_BLOCK, TILE_ALL = QS_REC };
+__device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store, bool params = false) {
+    if (cfg.payload_soft) return TILE_ALL;
+    if (cfg.info_fields) return store ? TILE_INFO : QS_HOT_ALL;
+    if (cfg.action_space_mode == QS_ACT_CPG || E::demo_task(cfg.task)) return QS_HOT_ALL;
+    if (cfg.wrapper_mode != QS_WRAP_NONE) return QS_HOT_WRAP;
+    return store && !params ? QS_HOT_RW : QS_HOT;
+}
+__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent) {
     // Only the hot block [0, QS_HOT) of each record is fetched (the info block behind it is written, never read back, by a step).
     // (the rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
     // records at once -- ~9 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
@@ -128,7 +136,8 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
     }
-    tile_load(s_rec, base, first, limit, tile_extent(cfg, false));
+    const int load_extent = settling ? max(tile_extent(cfg, false), (int)QS_HOT_ALL) : tile_extent(cfg, false);   // (a settle stores through the info block)
+    tile_load(s_rec, base, first, limit, load_extent);
     QS_PHASE(27)
     if (!settling) {
 #pragma unroll
@@ -156,7 +165,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
             // env step of the whole wave with the full build
             __syncthreads();
-            tile_load(s_rec, base, first, limit);
+            tile_load(s_rec, base, first, limit, load_extent);
             __syncthreads();
             if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
         }
@@ -168,7 +177,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
         __syncthreads();
-        tile_store(s_rec, base, first, limit, TILE_ALL);
+        tile_store(s_rec, base, first, limit, cfg.payload_soft ? TILE_ALL : TILE_INFO);   // (copy_settled takes the info block's results)
         return;
     }
     const bool dn = r.done > 0.5f;
@@ -179,9 +188,11 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
         }
     }
+    bool any_reset = false;   // wave-uniform: a pooled reset rewrote the parameters of some record of the tile
     if (cfg.auto_reset) {
         const bool do_reset = dn && valid;
         if (__builtin_expect(__any(do_reset), 0)) {
+            any_reset = true;
             LaneDev::sync();
             if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
                 for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
@@ -229,7 +240,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
         }
     }
     __syncthreads();
-    tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true));
+    tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true, any_reset));
     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
         float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];

@@ -5,5 +5,5 @@ run default
 run pyramid0 --friction-model pyramid --solver-residual-threshold 0
 run masses_weld --env-kw env_randomizer_mode=MASS_RANDOMIZER
 run masses_soft --env-kw env_randomizer_mode=MASS_RANDOMIZER --env-kw payload=soft --steps 100 --warmup 20
-python -m pytest tests/test_gpu_round2.py -q -p no:cacheprovider -k soft > $OUT/pytest_soft.log 2>&1; tail -30 $OUT/pytest_soft.log
+python -m pytest tests/test_gpu_round2.py -q -p no:cacheprovider -k soft 2>&1 | tail -5
 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $OUT/pytest.log 2>&1; tail -15 $OUT/pytest.log
