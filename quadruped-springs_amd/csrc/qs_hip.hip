@@ -24,7 +24,7 @@ using E = Env<LaneDev>;
 // slots behind them only for handles that use those layers (or that store the info block, which lies behind them); everything under
 // cfg.payload_soft (the block's own state ends the record).  Stores: the read-write block only -- through the parameters when a pooled
 // reset rewrote them, through the optional layers' slots when in use, through the info block under cfg.info_fields.
-enum { TILE_INFO = R_BLOCK, TILE_ALL = QS_REC };
+enum { TILE_INFO = QS_INFO_END, TILE_ALL = QS_REC };
 __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store, bool params = false) {
     if (cfg.payload_soft) return TILE_ALL;
     if (cfg.info_fields) return store ? TILE_INFO : QS_HOT_ALL;
@@ -32,7 +32,8 @@ __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store, boo
     if (cfg.wrapper_mode != QS_WRAP_NONE) return QS_HOT_WRAP;
     return store && !params ? QS_HOT_RW : QS_HOT;
 }
-__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent) {
+// `stride`: floats between two records in LDS (QS_REC, or QS_INFO_END in the step kernels of handles without the payload block's state)
+__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent, int stride = QS_REC) {
     // Only the hot block [0, QS_HOT) of each record is fetched (the info block behind it is written, never read back, by a step).
     // (the rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
     // records at once -- ~9 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
@@ -43,17 +44,17 @@ __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ 
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
     for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * per; i += QS_WAVE) {
         const int e = i / per, o = i - e * per;
-        dst[e * (QS_REC / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  // tail quads replay the tile's first record (never stored)
+        dst[e * (stride / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  // tail quads replay the tile's first record (never stored)
     }
 }
-__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int extent = TILE_ALL) {
+__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int extent = TILE_ALL, int stride = QS_REC) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
     const int per = extent / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
     for (int i = threadIdx.x; i < nenv * per; i += QS_WAVE) {
         const int e = i / per, o = i - e * per;
-        dst[e * (QS_REC / 4) + o] = src[e * (QS_REC / 4) + o];
+        dst[e * (QS_REC / 4) + o] = src[e * (stride / 4) + o];
     }
 }
 
@@ -106,10 +107,13 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
     using E = Env<LaneDev, CONE, false, WAVES == 1>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
     using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
-    __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
-    __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
-    __shared__ __attribute__((aligned(16))) float s_act[QS_ENVS_PER_WAVE * 12];
+    // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const qs_config& cfg = *cfgp;
+    const int ls = cfg.payload_soft ? (int)QS_REC : (int)QS_INFO_END;
+    float* const s_rec = s_dyn;
+    float* const s_obs = s_dyn + QS_ENVS_PER_WAVE * ls;
+    float* const s_act = s_obs + QS_ENVS_PER_WAVE * QS_MAX_OBS;
     QS_PHASE_BEGIN
     const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles pool records
     const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
@@ -137,7 +141,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
         }
     }
     const int load_extent = settling ? max(tile_extent(cfg, false), (int)QS_HOT_ALL) : tile_extent(cfg, false);   // (a settle stores through the info block)
-    tile_load(s_rec, base, first, limit, load_extent);
+    tile_load(s_rec, base, first, limit, load_extent, ls);
     QS_PHASE(27)
     if (!settling) {
 #pragma unroll
@@ -149,7 +153,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     QS_PHASE(28)
     __syncthreads();
     QS_PHASE(29)
-    float* rec = s_rec + slot * QS_REC;
+    float* rec = s_rec + slot * ls;
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
     if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
@@ -165,7 +169,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
             // env step of the whole wave with the full build
             __syncthreads();
-            tile_load(s_rec, base, first, limit, load_extent);
+            tile_load(s_rec, base, first, limit, load_extent, ls);
             __syncthreads();
             if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
         }
@@ -177,7 +181,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
         __syncthreads();
-        tile_store(s_rec, base, first, limit, cfg.payload_soft ? TILE_ALL : TILE_INFO);   // (copy_settled takes the info block's results)
+        tile_store(s_rec, base, first, limit, cfg.payload_soft ? TILE_ALL : TILE_INFO, ls);   // (copy_settled takes the info block's results)
         return;
     }
     const bool dn = r.done > 0.5f;
@@ -212,7 +216,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                 // ignores EXEC, so it must not run under a divergent branch: what the step produced is published first, then EVERY quad
                 // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
                 __syncthreads();
-                tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true));
+                tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true), ls);
                 {
                     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
                     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
@@ -228,7 +232,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                 LaneDev::sync();
                 if (do_reset) {
                     float* g = recs + (size_t)env * QS_REC;
-                    for (int i = threadIdx.x & 3; i < QS_REC; i += 4) g[i] = rec[i];
+                    for (int i = threadIdx.x & 3; i < ls; i += 4) g[i] = rec[i];
                     for (int i = threadIdx.x & 3; i < od; i += 4) {
                         if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
                         else obs_out[(size_t)env * (od + 2) + i] = ob[i];
@@ -240,7 +244,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
         }
     }
     __syncthreads();
-    tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true, any_reset));
+    tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true, any_reset), ls);
     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
         float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
@@ -627,7 +631,8 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     // more waves than SIMDs: the two-waves-per-SIMD build of the same body (see k_step_dense) instead of a second round of one-wave-per-
     // SIMD workgroups (N = 12288 with its settle lanes: 0.109 ms in two rounds)
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && grid > h->n_simd);
-#define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
+    const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
+#define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), lds, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
                                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo)
     const bool exact = h->cfg.auto_reset && h->pool_size == 0;   // finished environments settle inside the step
 #define QS_PICK(C, X) { if (dense) QS_LAUNCH_STEP((k_step_dense<C, X>)); else QS_LAUNCH_STEP((k_step<C, X>)); }

@@ -19,30 +19,34 @@ enum {
     R_TASK = 105,         // 32 slots, see T_* below
     R_NEW_TAU = 137,      // 12: task._new_torque
     R_N_INVALID = 149,    // invalid contacts of the last substep (a result; kept here: get_reward_end_episode reads it)
-    QS_HOT_RW = 152,      // what a step stores when nothing else is asked for (multiple of 4: 16-byte vector moves)
     // ---- read by every step, written by resets and setters only
-    R_PARAMS = 152,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
-    QS_HOT = 176,         // what a step loads when nothing else is asked for
+    R_PARAMS = 150,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
     // ---- state of optional layers: moved only by handles that use them
-    R_WRAP = 176,         // 20: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
+    R_WRAP = 174,         // 20: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
                           //     h_actual, held or ramp-start action [12], scripted, disarmed
-    QS_HOT_WRAP = 196,
-    R_CPG = 196,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
-    R_DEMO = 196,         // 2: demo counter and its value at the start of the episode (task_base.py:177-183); shares the CPG slots,
+    R_CPG = 194,          // 8: Hopf oscillator amplitudes r[4] and phases theta[4] (hopf_network.py:50)
+    R_DEMO = 194,         // 2: demo counter and its value at the start of the episode (task_base.py:177-183); shares the CPG slots,
                           //    the DEMO tasks do not take the CPG action layer (qs_create refuses the combination)
-    QS_HOT_ALL = 204,
     // ---- info block: results of the last substep that no step reads back (the reference keeps them as Python attributes; getters,
     // the pooled reset and the trace consumers use them).  Written by every step unless cfg.info_fields == 0.
-    R_POSE_CACHE = 204,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
-    R_FOOT_FORCE = 213,   // 4
-    R_FOOT_CONTACT = 217, // 4
-    R_TAU_PD = 221,       // 12: observed motor torque of the last substep (quadruped.py:299)
-    R_TAU_SPRING = 233,   // 12
+    R_POSE_CACHE = 202,   // 9: task._pos_abs, _vel_abs, _orient_rpy (task_base.py:72-75)
+    R_FOOT_FORCE = 211,   // 4
+    R_FOOT_CONTACT = 215, // 4
+    R_TAU_PD = 219,       // 12: observed motor torque of the last substep (quadruped.py:299)
+    R_TAU_SPRING = 231,   // 12
     // ---- payload block as a body of its own (cfg.payload_soft; quadruped.py:778-819): position of its centre 3, quaternion 4, linear 3 and
     // angular 3 velocity (world), the six impulses of the fixed constraint at the last substep, the pivot gap (the QS_INFO_PAYLOAD_BLOCK
     // row).  Moved by the tile load / store only under cfg.payload_soft.
-    R_BLOCK = 248,        // 20
-    QS_REC = 268,         // multiple of 4
+    R_BLOCK = 244,        // 20
+    QS_REC = 264,
+    // ---- leading extents that the tile load / store move (multiples of 4 floats = 16-byte vector moves; an extent may end inside the next
+    // field: what is stored was loaded)
+    QS_HOT_RW = 152,      // covers [0, 150): what a step stores when nothing else is asked for
+    QS_HOT = 176,         // + the parameters: what a step loads when nothing else is asked for
+    QS_HOT_WRAP = 196,    // + the wrapper machine
+    QS_HOT_ALL = 204,     // + CPG / DEMO slots
+    QS_INFO_END = 244,    // + the info block; also the LDS stride of a record unless cfg.payload_soft (then QS_REC): 16 records + observation
+                          //   and action rows = 20480 B per workgroup, eight workgroups per CU for the two-waves-per-SIMD kernel
 };
 enum { B_POS = 0, B_QUAT = 3, B_V = 7, B_W = 10, B_LAM = 13, B_GAP = 19, QS_BLOCK_DIM = 20 };
 enum { P_MU = 0, P_K = 1, P_B = 4, P_REST = 7, P_KP = 10, P_KD = 13, P_M_TRUNK = 16, P_M_LEG = 17, P_M_PAY = 20, P_R_PAY = 21 };

@@ -12,5 +12,10 @@ run cone_resid0 --solver-residual-threshold 0 --no-cpu-baseline
 run pyramid_resid1e-7 --friction-model pyramid --no-cpu-baseline
 run n65536 --envs-per-gpu 65536 --no-pool-streaming --no-cpu-baseline
 run n16384 --envs-per-gpu 16384 --no-pool-streaming --no-cpu-baseline
-bash tools/profile_round.sh r02a > $OUT/profile.log 2>&1
+run masses_weld --env-kw env_randomizer_mode=MASS_RANDOMIZER --no-cpu-baseline
+run masses_soft --env-kw env_randomizer_mode=MASS_RANDOMIZER payload=soft --steps 100 --warmup 20 --no-cpu-baseline
+python tools/time_rare_path.py > $OUT/rare_path.txt 2>&1; grep "ms per step" $OUT/rare_path.txt
+[ -f quadruped-springs_amd/qs_amd/exp/prof.so ] && QS_LIB_PATH=$PWD/quadruped-springs_amd/qs_amd/exp/prof.so python tools/phase_profile.py > $OUT/phase_cycles.txt 2>&1
+tail -20 $OUT/phase_cycles.txt
+bash tools/profile_round.sh ${2:-r02b} > $OUT/profile.log 2>&1
 tail -30 $OUT/profile.log
