@@ -20,17 +20,17 @@ using E = Env<LaneDev>;
 #define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC)
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
-// Leading extent of a record that a step moves (qs_layout.h).  Loads: the read-write block and the parameters; the wrapper / CPG / DEMO
+// Range of a record that a step moves (qs_layout.h).  Loads [0, end): the parameters, the read-write block; the wrapper / CPG / DEMO
 // slots behind them only for handles that use those layers (or that store the info block, which lies behind them); everything under
-// cfg.payload_soft (the block's own state ends the record).  Stores: the read-write block only -- through the parameters when a pooled
-// reset rewrote them, through the optional layers' slots when in use, through the info block under cfg.info_fields.
+// cfg.payload_soft (the block's own state ends the record).  Stores [QS_RW_BEGIN, end) -- from 0 when a pooled reset rewrote the
+// parameters --: through the read-write block, the optional layers' slots when in use, the info block under cfg.info_fields.
 enum { TILE_INFO = QS_INFO_END, TILE_ALL = QS_REC };
-__device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store, bool params = false) {
+__device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) {
     if (cfg.payload_soft) return TILE_ALL;
     if (cfg.info_fields) return store ? TILE_INFO : QS_HOT_ALL;
     if (cfg.action_space_mode == QS_ACT_CPG || E::demo_task(cfg.task)) return QS_HOT_ALL;
     if (cfg.wrapper_mode != QS_WRAP_NONE) return QS_HOT_WRAP;
-    return store && !params ? QS_HOT_RW : QS_HOT;
+    return QS_HOT;
 }
 // `stride`: floats between two records in LDS (QS_REC, or QS_INFO_END in the step kernels of handles without the payload block's state)
 __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent, int stride = QS_REC) {
@@ -47,13 +47,13 @@ __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ 
         dst[e * (stride / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  // tail quads replay the tile's first record (never stored)
     }
 }
-__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int extent = TILE_ALL, int stride = QS_REC) {
+__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int begin, int end, int stride = QS_REC) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
-    const int per = extent / 4;
+    const int per = (end - begin) / 4, b4 = begin / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
     for (int i = threadIdx.x; i < nenv * per; i += QS_WAVE) {
-        const int e = i / per, o = i - e * per;
+        const int e = i / per, o = i - e * per + b4;
         dst[e * (QS_REC / 4) + o] = src[e * (stride / 4) + o];
     }
 }
@@ -65,7 +65,7 @@ struct PoolView { const float* pool; int size; };
 // records reach the pool (and the demand is re-read) every epoch / QS_COHORTS launches instead of once per epoch.
 #define QS_COHORTS 5
 #define QS_MAX_SLICE 2048
-struct SettleLanes { float* staging; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], settle_n[QS_COHORTS], generation[QS_COHORTS]; };
+struct SettleLanes { float* staging; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS], generation[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
 struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_REFILLED = 4, CTL_CURSOR = 5, CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
@@ -74,7 +74,7 @@ enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3
 __device__ __forceinline__ void copy_settled(float* rec, const float* src, bool block) {
     const int lane = threadIdx.x & 3;
     if (block) for (int i = R_BLOCK + lane; i < R_BLOCK + QS_BLOCK_DIM; i += 4) rec[i] = src[i];   // the payload block settled with the robot
-    for (int i = lane; i < R_LAST_ACTION; i += 4) rec[i] = src[i];                       // rigid-body state + warm start
+    for (int i = R_POS + lane; i < R_WARM + 4; i += 4) rec[i] = src[i];                  // rigid-body state + warm start
     for (int i = R_PARAMS + lane; i < R_PARAMS + QS_PARAM_DIM; i += 4) rec[i] = src[i];  // params
     for (int i = R_FOOT_FORCE + lane; i < R_TAU_SPRING + 12; i += 4) rec[i] = src[i];    // contact results, torques
     if (lane == 0) rec[R_N_INVALID] = src[R_N_INVALID];
@@ -140,7 +140,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
     }
-    const int load_extent = settling ? max(tile_extent(cfg, false), (int)QS_HOT_ALL) : tile_extent(cfg, false);   // (a settle stores through the info block)
+    const int load_extent = settling && !cfg.payload_soft ? (int)QS_SETTLE_END : tile_extent(cfg, false);
     tile_load(s_rec, base, first, limit, load_extent, ls);
     QS_PHASE(27)
     if (!settling) {
@@ -181,7 +181,10 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
         __syncthreads();
-        tile_store(s_rec, base, first, limit, cfg.payload_soft ? TILE_ALL : TILE_INFO, ls);   // (copy_settled takes the info block's results)
+        // a slice of a settle changes the rigid-body state and the warm start; its first slice also drew the parameters, its last one
+        // leaves the info block's results (and n_invalid) that copy_settled hands to a reset
+        tile_store(s_rec, base, first, limit, lanes.spawn[cohort] ? 0 : (int)QS_RW_BEGIN,
+                   cfg.payload_soft ? (int)TILE_ALL : (lanes.last[cohort] ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
         return;
     }
     const bool dn = r.done > 0.5f;
@@ -216,7 +219,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                 // ignores EXEC, so it must not run under a divergent branch: what the step produced is published first, then EVERY quad
                 // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
                 __syncthreads();
-                tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true), ls);
+                tile_store(s_rec, recs, first, cfg.n_envs, QS_RW_BEGIN, tile_extent(cfg, true), ls);
                 {
                     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
                     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
@@ -244,7 +247,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
         }
     }
     __syncthreads();
-    tile_store(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, true, any_reset), ls);
+    tile_store(s_rec, recs, first, cfg.n_envs, any_reset ? 0 : (int)QS_RW_BEGIN, tile_extent(cfg, true), ls);
     const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
     for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
         float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
@@ -621,7 +624,7 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
                 h->pool_generation++;
                 h->cohort_generation[c] = h->pool_generation;
             }
-            lanes.spawn[c] = phase == 0; lanes.generation[c] = h->cohort_generation[c];
+            lanes.spawn[c] = phase == 0; lanes.last[c] = phase == epoch - 1; lanes.generation[c] = h->cohort_generation[c];
             lanes.settle_n[c] = phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
         }
         grid += QS_COHORTS * lanes.waves_per_cohort;

@@ -1,26 +1,26 @@
 // qs_layout.h -- persistent per-environment record (env-major: records[N][QS_REC] float32 in HBM).
 //
 // A wavefront owns 16 consecutive environments = 16 records, of which it moves the leading part a step needs (704 B in, 608 B out per
-// record by default; more only for handles that use the optional layers below) HBM <-> LDS with coalesced 16-byte-per-lane loads / stores
+// record by default, 272 B in and 176 B out for a slice of a reset's settle; more only for handles that use the optional layers below) HBM <-> LDS with coalesced 16-byte-per-lane loads / stores
 // at kernel entry / exit; the lanes then pick their fields out of LDS.
 // Fields mirror the state the reference carries between env.step() calls.
 #pragma once
 
 enum {
-    // ---- read-write block [0, QS_HOT_RW): what every step reads AND writes
-    // rigid-body state, same order as qs_get_state rows (quadruped.py:107-207)
-    R_POS = 0, R_QUAT = 3, R_VLIN = 7, R_VANG = 10, R_Q = 13, R_QD = 25,
-    R_WARM = 37,          // 4: normal impulse of each foot at the previous substep (contact warm start)
-    R_LAST_ACTION = 41,   // 12: gym_env.py:230,284
-    R_XHIST = 53,         // 2 x 12: action_filter.py:98-108 (row 0 newest)
-    R_YHIST = 77,         // 2 x 12
-    R_SIM_STEP = 101, R_ENV_STEP = 102, R_EPISODE = 103, R_TOTAL_STEPS = 104,  // integers stored as float bit patterns
-    // task scalars (task_base.py:44-59, 228-233; robot_tasks.py:418-425, 524-530), order of QS_INFO_TASK
-    R_TASK = 105,         // 32 slots, see T_* below
-    R_NEW_TAU = 137,      // 12: task._new_torque
-    R_N_INVALID = 149,    // invalid contacts of the last substep (a result; kept here: get_reward_end_episode reads it)
     // ---- read by every step, written by resets and setters only
-    R_PARAMS = 150,       // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
+    R_PARAMS = 0,         // 24: mu, k3, b3, rest3, kp3, kd3, m_trunk, m_leg3, m_pay, r_pay3
+    // ---- read-write block [24, 174): what every step reads AND writes
+    // rigid-body state, same order as qs_get_state rows (quadruped.py:107-207); with the parameters in front of it, all a settle needs
+    R_POS = 24, R_QUAT = 27, R_VLIN = 31, R_VANG = 34, R_Q = 37, R_QD = 49,
+    R_WARM = 61,          // 4: normal impulse of each foot at the previous substep (contact warm start)
+    R_LAST_ACTION = 65,   // 12: gym_env.py:230,284
+    R_XHIST = 77,         // 2 x 12: action_filter.py:98-108 (row 0 newest)
+    R_YHIST = 101,        // 2 x 12
+    R_SIM_STEP = 125, R_ENV_STEP = 126, R_EPISODE = 127, R_TOTAL_STEPS = 128,  // integers stored as float bit patterns
+    // task scalars (task_base.py:44-59, 228-233; robot_tasks.py:418-425, 524-530), order of QS_INFO_TASK
+    R_TASK = 129,         // 32 slots, see T_* below
+    R_NEW_TAU = 161,      // 12: task._new_torque
+    R_N_INVALID = 173,    // invalid contacts of the last substep (a result; kept here: get_reward_end_episode reads it)
     // ---- state of optional layers: moved only by handles that use them
     R_WRAP = 174,         // 20: scripted-phase machine of the landing / go-to-rest wrappers: phase, timer, end, t_start, h_old,
                           //     h_actual, held or ramp-start action [12], scripted, disarmed
@@ -39,10 +39,11 @@ enum {
     // row).  Moved by the tile load / store only under cfg.payload_soft.
     R_BLOCK = 244,        // 20
     QS_REC = 264,
-    // ---- leading extents that the tile load / store move (multiples of 4 floats = 16-byte vector moves; an extent may end inside the next
-    // field: what is stored was loaded)
-    QS_HOT_RW = 152,      // covers [0, 150): what a step stores when nothing else is asked for
-    QS_HOT = 176,         // + the parameters: what a step loads when nothing else is asked for
+    // ---- ranges [begin, end) that the tile load / store move (multiples of 4 floats = 16-byte vector moves; a range may end inside the
+    // next field: what is stored was loaded).  Loads start at 0, stores at QS_RW_BEGIN unless the parameters were rewritten.
+    QS_RW_BEGIN = 24,
+    QS_SETTLE_END = 68,   // parameters + rigid-body state + warm start: all that a slice of a reset's settle loads, and stores from QS_RW_BEGIN
+    QS_HOT = 176,         // what a step loads (704 B) and, from QS_RW_BEGIN, stores (608 B) when nothing else is asked for
     QS_HOT_WRAP = 196,    // + the wrapper machine
     QS_HOT_ALL = 204,     // + CPG / DEMO slots
     QS_INFO_END = 244,    // + the info block; also the LDS stride of a record unless cfg.payload_soft (then QS_REC): 16 records + observation

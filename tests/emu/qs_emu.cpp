@@ -112,14 +112,14 @@ int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* don
 }
 int qse_get_state(void* h, float* st) {
     Emu* e = (Emu*)h;
-    for (int i = 0; i < e->cfg.n_envs; i++) memcpy(st + (size_t)i * 37, &e->rec[(size_t)i * QS_REC], 37 * sizeof(float));
+    for (int i = 0; i < e->cfg.n_envs; i++) memcpy(st + (size_t)i * 37, &e->rec[(size_t)i * QS_REC + R_POS], 37 * sizeof(float));
     return 0;
 }
 int qse_set_state(void* h, const float* st) {
     Emu* e = (Emu*)h;
     for (int i = 0; i < e->cfg.n_envs; i++) {
         float* r = &e->rec[(size_t)i * QS_REC];
-        memcpy(r, st + (size_t)i * 37, 37 * sizeof(float));
+        memcpy(r + R_POS, st + (size_t)i * 37, 37 * sizeof(float));
         for (int k = 0; k < 4; k++) r[R_WARM + k] = 0.0f;
         if (e->cfg.payload_soft) E::place_block(e->cfg, r);
     }

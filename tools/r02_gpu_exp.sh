@@ -3,7 +3,5 @@ OUT=gpurun_out/${1:-r02h}; mkdir -p $OUT
 run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 > $OUT/$name.json; python -c "import json; d=json.load(open('$OUT/$name.json')); print('$name:', round(d['value']/1e6,2),'M', round(d['ms_per_step'],4),'ms kernel', round(d['roofline']['kernel_ms'],4))"; }
 run default
 run pyramid0 --friction-model pyramid --solver-residual-threshold 0
-run masses_weld --env-kw env_randomizer_mode=MASS_RANDOMIZER
-run masses_soft --env-kw env_randomizer_mode=MASS_RANDOMIZER --env-kw payload=soft --steps 100 --warmup 20
-python -m pytest tests/test_gpu_round2.py -q -p no:cacheprovider -k soft 2>&1 | tail -5
-python -m pytest tests -m gpu -q -p no:cacheprovider -x > $OUT/pytest.log 2>&1; tail -15 $OUT/pytest.log
+run n65536 --envs-per-gpu 65536 --no-pool-streaming
+python -m pytest tests -m gpu -q -p no:cacheprovider -x > $OUT/pytest.log 2>&1; tail -12 $OUT/pytest.log | head -6
