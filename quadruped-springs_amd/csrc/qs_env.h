@@ -82,13 +82,11 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                 V t = qsel(front, act[j], act[3 + j]);
                 a[j] = j == cfg.symm_idx ? t * (-T::sy()) : t;  // left legs mirror index symm_idx
             }
-        } else {
-            int k = 0;
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                if (j == cfg.symm_idx) a[j] = V(0.0f);
-                else { a[j] = qsel(front, act[k], act[2 + k]); k++; }
-            }
+        } else {   // the dropped joint takes 0, the two others the pairs (front, rear) in order; constant indices: act[] stays in registers
+            const int sx = cfg.symm_idx;
+            a[0] = sx == 0 ? V(0.0f) : qsel(front, act[0], act[2]);
+            a[1] = sx == 1 ? V(0.0f) : (sx < 1 ? qsel(front, act[0], act[2]) : qsel(front, act[1], act[3]));
+            a[2] = sx == 2 ? V(0.0f) : qsel(front, act[1], act[3]);
         }
         V s[3];
 #pragma unroll
@@ -487,14 +485,20 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
         // raw action: d == 12 -> every lane holds the 3 entries of its own leg in act[12..14];
         //             d  < 12 -> the d values are replicated over the quad in act[0..d)
+        // (every loop over these arrays runs to a constant bound under `#pragma unroll` with the runtime d as a guard: a runtime trip count
+        // would put the arrays into scratch memory -- ~120 dword stores per environment and step, measured as WRITE_SIZE)
         V act[15], act_in[15];
+#pragma unroll
         for (int k = 0; k < 15; k++) act[k] = V(0.0f);
         if (d == 12) {
 #pragma unroll
             for (int j = 0; j < 3; j++) act[12 + j] = T::ld_leg(act_row, j, 3);
         } else {
-            for (int k = 0; k < d; k++) act[k] = T::ld(act_row, k);
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (k < d) act[k] = T::ld(act_row, k);
         }
+#pragma unroll
         for (int k = 0; k < 15; k++) act_in[k] = act[k];
         // scripted phases of the landing / go-to-rest wrappers (one inner env.step per call)
         V w_phase = V(0.0f), w_timer = V(0.0f), w_end = V(0.0f), w_tstart = V(0.0f);
@@ -516,6 +520,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                     w_timer = qsel(hold, w_timer + env_dt, w_timer);
                 }
                 M land = qgt(w_phase, V(1.5f));
+#pragma unroll
                 for (int k = 0; k < 15; k++) {
                     if ((d == 12) != (k >= 12)) continue;
                     V held = d == 12 ? T::ld_leg(w, W_ACTION + (k - 12), 3) : T::ld(w, W_ACTION + k);
@@ -528,6 +533,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                 M rest = qgt(w_phase, V(2.5f));
                 V t1 = w_tstart + cfg.rest_time;
                 V frac = clampv<V>((now0 - w_tstart) * qrcp(V(cfg.rest_time)), V(0.0f), V(1.0f));
+#pragma unroll
                 for (int k = 0; k < 15; k++) {
                     if ((d == 12) != (k >= 12)) continue;
                     V u0 = d == 12 ? T::ld_leg(w, W_ACTION + (k - 12), 3) : T::ld(w, W_ACTION + k);
@@ -542,6 +548,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             T::st(rec, R_WRAP + W_SCRIPTED, qflag(qgt(w_phase, V(0.5f))));
         }
         V act_last[15];   // what env.step was given (after the scripted phases): _last_action, gym_env.py:230
+#pragma unroll
         for (int k = 0; k < 15; k++) act_last[k] = act[k];
         if (d == 12) {  // DEFAULT space / raw commands: every lane filters the 3 entries of its own leg
 #pragma unroll
@@ -557,7 +564,9 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                 act[12 + j] = a;
             }
         } else {        // SYMMETRIC (6) / SYMMETRIC_NO_HIP (4) / CPG (5): the few values are replicated over the quad
-            for (int k = 0; k < d; k++) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                if (k >= d) continue;
                 V a = act[k];
                 T::st(rec, R_LAST_ACTION + k, a);
                 if (cfg.enable_filter) {
@@ -626,7 +635,9 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                 for (int j = 0; j < 3; j++) { V e = T::ld_leg(a, j, 3) - act_last[12 + j]; n2 = n2 + e * e; }
                 n2 = T::quad_sum(n2);
             } else {
-                for (int k = 0; k < d; k++) { V e = T::ld(a, k) - act_last[k]; n2 = n2 + e * e; }
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    if (k < d) { V e = T::ld(a, k) - act_last[k]; n2 = n2 + e * e; }
             }
             reward = qexp(qsqrt(n2) * (-0.35f)) / (V((float)demo_len) - start);
             cnt = cnt + 1.0f;
@@ -653,6 +664,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
                 go = qand(qand(running, pol), qand(qgt(wt.trigger_jumping ? t.is_jumping : t.switched, V(0.5f)), qlt(disarmed, V(0.5f))));   // landing_wrapper.py:54-66
                 w_timer = qsel(go, now, w_timer);
                 w_end = qsel(go, now + s.vlin.z * (1.0f / 9.81f), w_end);
+#pragma unroll
                 for (int k = 0; k < 15; k++) {
                     if ((d == 12) != (k >= 12)) continue;
                     if (d == 12) T::st_leg(w, W_ACTION + (k - 12), 3, qsel(go, act_in[k], T::ld_leg(w, W_ACTION + (k - 12), 3)));

@@ -19,3 +19,6 @@ python tools/time_rare_path.py > $OUT/rare_path.txt 2>&1; grep "ms per step" $OU
 tail -20 $OUT/phase_cycles.txt
 bash tools/profile_round.sh ${2:-r02b} > $OUT/profile.log 2>&1
 tail -30 $OUT/profile.log
+# the same passes with the streaming refill off: what the environments' own steps move (no settle lanes in the launch)
+bash tools/profile_round.sh ${2:-r02b}_static --no-pool-streaming > $OUT/profile_static.log 2>&1
+tail -16 $OUT/profile_static.log | head -14
