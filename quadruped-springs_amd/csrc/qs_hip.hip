@@ -40,22 +40,30 @@ __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ 
     // was measured slower)
     const float4* src = reinterpret_cast<const float4*>(g + (size_t)first_env * QS_REC);
     float4* dst = reinterpret_cast<float4*>(lds);
-    const int per = extent / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
-    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * per; i += QS_WAVE) {
-        const int e = i / per, o = i - e * per;
-        dst[e * (stride / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  // tail quads replay the tile's first record (never stored)
+    // (the usual extent as a constant: the index split is a multiply-shift instead of a division by a runtime value)
+#define QS_TILE_LOAD_LOOP(PER)                                                                                         \
+    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * (PER); i += QS_WAVE) {                                            \
+        const int e = i / (PER), o = i - e * (PER);                                                                    \
+        dst[e * (stride / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  /* tail quads replay the tile's first record (never stored) */ \
     }
+    if (extent == QS_HOT) { QS_TILE_LOAD_LOOP(QS_HOT / 4) }
+    else { const int per = extent / 4; QS_TILE_LOAD_LOOP(per) }
+#undef QS_TILE_LOAD_LOOP
 }
 __device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int begin, int end, int stride = QS_REC) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
-    const int per = (end - begin) / 4, b4 = begin / 4;
+    const int b4 = begin / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
-    for (int i = threadIdx.x; i < nenv * per; i += QS_WAVE) {
-        const int e = i / per, o = i - e * per + b4;
-        dst[e * (QS_REC / 4) + o] = src[e * (stride / 4) + o];
+#define QS_TILE_STORE_LOOP(PER)                                                                                        \
+    for (int i = threadIdx.x; i < nenv * (PER); i += QS_WAVE) {                                                        \
+        const int e = i / (PER), o = i - e * (PER) + b4;                                                               \
+        dst[e * (QS_REC / 4) + o] = src[e * (stride / 4) + o];                                                         \
     }
+    if (begin == QS_RW_BEGIN && end == QS_HOT) { QS_TILE_STORE_LOOP((QS_HOT - QS_RW_BEGIN) / 4) }
+    else { const int per = (end - begin) / 4; QS_TILE_STORE_LOOP(per) }
+#undef QS_TILE_STORE_LOOP
 }
 
 struct PoolView { const float* pool; int size; };
