@@ -14,4 +14,15 @@ for f in sorted(os.listdir(run)):
 for src, name in (("summary.md", "kernel_trace_pmc.md"), ("pmc.json", "pmc.json"), ("kernel_stats.csv", "kernel_stats.csv"), ("bench.json", "profiled_command_bench.json")):
     if os.path.exists(os.path.join(prof, src)):
         shutil.copy(os.path.join(prof, src), os.path.join(dst, f"{tag}_{name}"))
+# the same PMC passes with the streaming refill off (tools/r02_gpu_profiles.sh), phase cycles and rare-path timings of the same call
+static = prof.rstrip("/") + "_static"
+for src, name in (("summary.md", "static_pool_kernel_trace_pmc.md"), ("pmc.json", "static_pool_pmc.json")):
+    if os.path.exists(os.path.join(static, src)):
+        shutil.copy(os.path.join(static, src), os.path.join(dst, f"{tag}_{name}"))
+for src, name, title in (("phase_cycles.txt", "phase_cycles.md", "Cycles per phase of one physics substep (tools/phase_profile.py, -DQS_PROFILE_PHASES build of the same source)"),
+                         ("rare_path.txt", "rare_path.md", "Step time when waves take the many-rows solver (tools/time_rare_path.py: NO_TASK, raw torques, N = 8192)")):
+    if os.path.exists(os.path.join(run, src)):
+        body = [l for l in open(os.path.join(run, src)).read().splitlines() if "amdgpu.ids" not in l]
+        with open(os.path.join(dst, f"{tag}_{name}"), "w") as f:
+            f.write(f"# {title}\n\n```\n" + "\n".join(body) + "\n```\n")
 print(sorted(x for x in os.listdir(dst) if x.startswith(tag)))
