@@ -66,6 +66,20 @@ __device__ __forceinline__ void tile_store(const float* lds, float* __restrict__
 #undef QS_TILE_STORE_LOOP
 }
 
+// the observation rows of the tile (LDS, QS_MAX_OBS apart) to the caller's rows ([N, od], or [N, od + 2] in the fused layout) and the
+// handle's own copy.  i / od by multiply-shift: exact for i < 16 * 64, od <= 64 with inv = ceil(2^16 / od) (one division per wave
+// instead of two per element)
+__device__ __forceinline__ void obs_store(const float* s_obs, int nrow, int od, int first, float* __restrict__ obs_out, bool fused, float* __restrict__ obs_keep) {
+    const unsigned inv = (65536u + (unsigned)od - 1u) / (unsigned)od;
+    const int row = fused ? od + 2 : od;
+    for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
+        const int e = (int)(((unsigned)i * inv) >> 16), o = i - e * od;
+        const float v = s_obs[e * QS_MAX_OBS + o];
+        obs_out[(size_t)(first + e) * row + o] = v;
+        obs_keep[(size_t)first * od + i] = v;
+    }
+}
+
 struct PoolView { const float* pool; int size; };
 // Streaming refill of the reset pool ("settle lanes"): workgroups beyond the environments' ones advance records of the
 // staging copy through a reset's settle, one slice of substeps per launch; ctl = the counters in qs_handle::d_stats.
@@ -228,15 +242,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
                 // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
                 __syncthreads();
                 tile_store(s_rec, recs, first, cfg.n_envs, QS_RW_BEGIN, tile_extent(cfg, true), ls);
-                {
-                    const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
-                    for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
-                        float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
-                        if (rew_out) obs_out[(size_t)first * od + i] = v;
-                        else obs_out[(size_t)(first + i / od) * (od + 2) + (i % od)] = v;
-                        obs_keep[(size_t)first * od + i] = v;
-                    }
-                }
+                obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
                 __syncthreads();
                 E::reset(cfg, rec, ob, gid, true);
                 if (do_reset && (threadIdx.x & 3) == 0) atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps);
@@ -256,13 +262,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     }
     __syncthreads();
     tile_store(s_rec, recs, first, cfg.n_envs, any_reset ? 0 : (int)QS_RW_BEGIN, tile_extent(cfg, true), ls);
-    const int nrow = min(QS_ENVS_PER_WAVE, cfg.n_envs - first);
-    for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
-        float v = s_obs[(i / od) * QS_MAX_OBS + (i % od)];
-        if (rew_out) obs_out[(size_t)first * od + i] = v;
-        else obs_out[(size_t)(first + i / od) * (od + 2) + (i % od)] = v;
-        obs_keep[(size_t)first * od + i] = v;
-    }
+    obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
     QS_PHASE(15)
 }
 
