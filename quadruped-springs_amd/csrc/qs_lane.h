@@ -139,10 +139,6 @@ struct LaneDev {
     static QS_DEV void st(float* rec, int i, float v) { if ((threadIdx.x & 3u) == 0) rec[i] = v; }
     static QS_DEV float first(float x) { return x; }
     static QS_DEV void opaque(float& x) { asm volatile("" : "+v"(x)); }
-    // a zero the compiler cannot see through: arrays indexed as a[opaque_zero() + constant] stay in private memory
-    static QS_DEV int opaque_zero() { int z = 0; asm volatile("" : "+s"(z)); return z; }
-    // keeps the scheduler from moving instructions across this point (bounds live ranges in the unrolled joint-limit sweeps)
-    static QS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
     static QS_DEV void count_rare_path() { if (threadIdx.x == 0) atomicAdd(&qs_rare_path_substeps, 1ull); }
     static QS_DEV void count_self_narrow() { if (threadIdx.x == 0) atomicAdd(&qs_self_narrow_substeps, 1ull); }
     // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
@@ -205,8 +201,6 @@ struct LaneEmu {
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
     static void fma2(V4 a0, V4 a1, V4 b, V4& c0, V4& c1) { for (int l = 0; l < 4; l++) { c0.v[l] = fmaf(a0.v[l], b.v[l], c0.v[l]); c1.v[l] = fmaf(a1.v[l], b.v[l], c1.v[l]); } }
-    static int opaque_zero() { return 0; }
-    static void sched_fence() {}
     static void count_rare_path() {}
     static void count_self_narrow() {}
     struct Acc4 { V4 k[4]; };
