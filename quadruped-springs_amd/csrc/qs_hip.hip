@@ -17,14 +17,14 @@
 using qs::Env;
 using E = Env<LaneDev>;
 
-#define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC)
+#define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC_END)
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
 // Range of a record that a step moves (qs_layout.h).  Loads [0, end): the parameters, the read-write block; the wrapper / CPG / DEMO
 // slots behind them only for handles that use those layers (or that store the info block, which lies behind them); everything under
 // cfg.payload_soft (the block's own state ends the record).  Stores [QS_RW_BEGIN, end) -- from 0 when a pooled reset rewrote the
 // parameters --: through the read-write block, the optional layers' slots when in use, the info block under cfg.info_fields.
-enum { TILE_INFO = QS_INFO_END, TILE_ALL = QS_REC };
+enum { TILE_INFO = QS_INFO_END, TILE_ALL = QS_REC_END };
 __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) {
     if (cfg.payload_soft) return TILE_ALL;
     if (cfg.info_fields) return store ? TILE_INFO : QS_HOT_ALL;
@@ -32,8 +32,8 @@ __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) {
     if (cfg.wrapper_mode != QS_WRAP_NONE) return QS_HOT_WRAP;
     return QS_HOT;
 }
-// `stride`: floats between two records in LDS (QS_REC, or QS_INFO_END in the step kernels of handles without the payload block's state)
-__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent, int stride = QS_REC) {
+// `stride`: floats between two records in LDS (QS_REC_END, or QS_INFO_END in the step kernels of handles without the payload block's state)
+__device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent, int stride = QS_REC_END) {
     // Only the hot block [0, QS_HOT) of each record is fetched (the info block behind it is written, never read back, by a step).
     // (the rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
     // records at once -- ~9 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
@@ -51,7 +51,7 @@ __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ 
     else { const int per = extent / 4; QS_TILE_LOAD_LOOP(per) }
 #undef QS_TILE_LOAD_LOOP
 }
-__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int begin, int end, int stride = QS_REC) {
+__device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int begin, int end, int stride = QS_REC_END) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
     const int b4 = begin / 4;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
     int env = blockIdx.x * QS_ENVS_PER_WAVE + (threadIdx.x >> 2);
     if (env >= cfg.n_envs) return;
     float* r = recs + (size_t)env * QS_REC;
-    for (int i = threadIdx.x & 3; i < QS_REC; i += 4) r[i] = 0.0f;
+    for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) r[i] = 0.0f;
     LaneDev::sync();
     if ((threadIdx.x & 3) == 0) {
         r[R_EPISODE] = qs::i2f(-1);
@@ -132,7 +132,7 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const qs_config& cfg = *cfgp;
-    const int ls = cfg.payload_soft ? (int)QS_REC : (int)QS_INFO_END;
+    const int ls = cfg.payload_soft ? (int)QS_REC_END : (int)QS_INFO_END;
     float* const s_rec = s_dyn;
     float* const s_obs = s_dyn + QS_ENVS_PER_WAVE * ls;
     float* const s_act = s_obs + QS_ENVS_PER_WAVE * QS_MAX_OBS;
@@ -326,7 +326,7 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
     tile_load(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, false));
     const int od = cfg.obs_dim;
     __syncthreads();
-    float* rec = s_rec + slot * QS_REC;
+    float* rec = s_rec + slot * QS_REC_END;
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = (uint32_t)((valid ? env : 0) + cfg.env_id_offset);
     if (states) {   // reference-state initialisation (gym_env.py:278-297 with robot_desired_state set): randomizers, then the given
@@ -357,7 +357,7 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
     __syncthreads();
     if (sel) {
         float* g = recs + (size_t)env * QS_REC;
-        for (int i = threadIdx.x & 3; i < QS_REC; i += 4) g[i] = rec[i];
+        for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];
         for (int i = threadIdx.x & 3; i < od; i += 4) obs_keep[(size_t)env * od + i] = ob[i];
     }
 }
@@ -369,8 +369,8 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(c
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     const qs_config& cfg = *cfgp;
     const int slot = threadIdx.x >> 2, p = first + blockIdx.x * QS_ENVS_PER_WAVE + slot;   // entries [first, size) of the pool
-    float* rec = s_rec + slot * QS_REC;
-    for (int i = threadIdx.x & 3; i < QS_REC; i += 4) rec[i] = 0.0f;
+    float* rec = s_rec + slot * QS_REC_END;
+    for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) rec[i] = 0.0f;
     LaneDev::sync();
     if ((threadIdx.x & 3) == 0) rec[R_EPISODE] = qs::i2f(generation - 1);
     LaneDev::sync();
@@ -378,7 +378,7 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(c
     LaneDev::sync();
     if (p < size) {
         float* g = pool + (size_t)p * QS_REC;
-        for (int i = threadIdx.x & 3; i < QS_REC; i += 4) g[i] = rec[i];
+        for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];
     }
 }
 
@@ -642,7 +642,7 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     // more waves than SIMDs: the two-waves-per-SIMD build of the same body (see k_step_dense) instead of a second round of one-wave-per-
     // SIMD workgroups (N = 12288 with its settle lanes: 0.109 ms in two rounds)
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && grid > h->n_simd);
-    const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
+    const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC_END : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), lds, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
                                                  h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo)
     const bool exact = h->cfg.auto_reset && h->pool_size == 0;   // finished environments settle inside the step

@@ -1,4 +1,4 @@
-// qs_layout.h -- persistent per-environment record (env-major: records[N][QS_REC] float32 in HBM).
+// qs_layout.h -- persistent per-environment record (env-major: records[N][QS_REC] float32 in HBM, QS_REC_END of them used).
 //
 // A wavefront owns 16 consecutive environments = 16 records, of which it moves the leading part a step needs (704 B in, 608 B out per
 // record by default, 272 B in and 176 B out for a slice of a reset's settle; more only for handles that use the optional layers below) HBM <-> LDS with coalesced 16-byte-per-lane loads / stores
@@ -38,7 +38,9 @@ enum {
     // angular 3 velocity (world), the six impulses of the fixed constraint at the last substep, the pivot gap (the QS_INFO_PAYLOAD_BLOCK
     // row).  Moved by the tile load / store only under cfg.payload_soft.
     R_BLOCK = 244,        // 20
-    QS_REC = 264,
+    QS_REC_END = 264,     // end of the used floats (the LDS stride of a record under cfg.payload_soft)
+    QS_REC = 288,         // HBM stride: 1152 B = 9 x 128 B, so that the 704-B range a step fetches starts on a 128-byte line (6 lines instead of
+                          // 6 or 7: the fetch counters read 8 % less)
     // ---- ranges [begin, end) that the tile load / store move (multiples of 4 floats = 16-byte vector moves; a range may end inside the
     // next field: what is stored was loaded).  Loads start at 0, stores at QS_RW_BEGIN unless the parameters were rewritten.
     QS_RW_BEGIN = 24,

@@ -5,7 +5,11 @@ run default
 run default2
 run pyramid0 --friction-model pyramid --solver-residual-threshold 0
 run config2 --workload config2_4096
-run config4 --workload config4_sharded
 run config5 --workload config5_8192
 run n65536 --envs-per-gpu 65536 --no-pool-streaming
+run n16384 --envs-per-gpu 16384 --no-pool-streaming
 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $OUT/pytest.log 2>&1; tail -12 $OUT/pytest.log | head -6
+bash tools/profile_round.sh x_static --no-pool-streaming > $OUT/profile_static.log 2>&1
+tail -16 $OUT/profile_static.log | head -5
+bash tools/profile_round.sh x_stream > $OUT/profile_stream.log 2>&1
+tail -16 $OUT/profile_stream.log | head -5
