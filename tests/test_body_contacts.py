@@ -228,6 +228,34 @@ def test_emu_matches_oracle_on_fallen_robots(model):
     assert so[:, 2].min() > 0.03                                # and nobody fell through the floor
 
 
+def test_emu_matches_oracle_on_fallen_robots_with_the_soft_payload():
+    """All kinds of rows in one solve: 12 contact / limit rows per leg and the six rows of the payload block's fixed constraint."""
+    n = 6
+    cfg = make(n, solver_residual_threshold=0.0, payload="soft", env_randomizer_mode="MASS_RANDOMIZER", seed=3, settle_steps=300)
+    o, e = Oracle(cfg, "f32"), Emu(cfg)
+    o.reset(); e.reset()
+    s = fallen_state(o)
+    for i, (r, p) in enumerate([(1.45, 0.0), (0.0, 0.0), (0.0, 0.5), (-1.45, 0.2), (3.0, 0.0), (0.7, -0.4)]):
+        s[i, 3:7] = Rot.from_euler("xyz", [r, p, 0]).as_quat()
+    s[:, 2] = 0.2
+    o.set_state(s); e.set_state(s)
+    rng = np.random.default_rng(5)
+    lam = 0.0
+    for i in range(40):
+        tau = (4.0 * rng.normal(size=(n, 12))).astype(np.float32) if i > 10 else np.zeros((n, 12), np.float32)
+        st = o.get_state()
+        o.set_state(st); e.set_state(st)
+        o.step(tau); e.step(tau)
+        so, se = o.get_state(), e.get_state()
+        np.testing.assert_allclose(se[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(se[:, 13:25], so[:, 13:25], atol=2e-4, err_msg=f"q step {i}")
+        b0, b1 = o.block(), e.block()
+        np.testing.assert_allclose(b1[:, :3], b0["pos"], atol=5e-5, err_msg=f"block position step {i}")
+        np.testing.assert_allclose(b1[:, 13:19], b0["lam"], atol=1e-3, err_msg=f"constraint impulses step {i}")
+        lam = max(lam, np.abs(b0["lam"]).max())
+    assert so[:, 2].min() > 0.03 and lam > 1e-3
+
+
 def test_emu_counts_the_same_self_contacts():
     cfg = make(4)
     o, e = Oracle(cfg), Emu(cfg)

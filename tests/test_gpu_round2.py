@@ -75,6 +75,38 @@ def test_fallen_robots_parity(torch_cuda, model):
     v.close()
 
 
+def test_fallen_robots_with_the_soft_payload(torch_cuda):
+    """Every kind of row at once: robots lying on trunk / hips / thighs / calves (12 rows per leg), joints at their stops, and the payload
+    block on its six-row fixed constraint (payload="soft", mass randomizer) -- against the float32 oracle, re-seated every step."""
+    from oracle.qso import Oracle
+    n = 24
+    v = vec_env(n, payload="soft", env_randomizer_mode="MASS_RANDOMIZER", solver_residual_threshold=0.0, seed=3, settle_steps=300, **RAW)
+    o = Oracle(v.cfg, "f32")
+    o.reset(); v.reset()
+    assert 0 < o.get_info(6)[:, 20].min() < 0.05          # the draws include a block of a few grams: the stiffest case for float32
+    rng = np.random.default_rng(6)
+    s = o.get_state()
+    lying = np.arange(n) % 3 != 0
+    s[lying] = fallen_states(s[lying], rng)
+    o.set_state(s); v.set_state(s.astype(np.float32))
+    lam = 0.0
+    for i in range(40):
+        tau = (4.0 * rng.normal(size=(n, 12))).astype(np.float32) if i > 10 else np.zeros((n, 12), np.float32)
+        st = o.get_state()
+        o.set_state(st); v.set_state(st.astype(np.float32))
+        o.step(tau); v.step(tau)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        np.testing.assert_allclose(sv[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(sv[:, 7:13], so[:, 7:13], atol=2e-2, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=2e-4, err_msg=f"q step {i}")
+        b0, b1 = o.block(), v.get_info("payload_block").cpu().numpy()
+        np.testing.assert_allclose(b1[:, :3], b0["pos"], atol=5e-5, err_msg=f"block position step {i}")
+        np.testing.assert_allclose(b1[:, 13:19], b0["lam"], atol=1e-3, err_msg=f"constraint impulses step {i}")
+        lam = max(lam, np.abs(b0["lam"]).max())
+    assert sv[:, 2].min() > 0.03 and 1e-3 < lam <= 0.5 + 1e-6, lam
+    v.close()
+
+
 def test_fallen_robot_comes_to_rest_on_the_floor(torch_cuda):
     """The known answer on the device: dropped on its side without torques, the robot ends up at rest on trunk, hip and leg links
     (NO_TASK never terminates); with body_contacts=False (round 1's behaviour) it keeps falling through the floor."""
