@@ -19,6 +19,9 @@ CASES = [
     dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="TEST_RANDOMIZER", friction_model="cone", wrapper="LANDING"),
     dict(task_env="NO_TASK", observation_space_mode="ENCODER", env_randomizer_mode="GROUND_RANDOMIZER", friction_model="cone", isRLGymInterface=False,
          motor_control_mode="TORQUE", enable_action_filter=False),     # raw torques in [-1.2, 1.2] Nm: the robots sag onto their joint stops
+    dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="TEST_RANDOMIZER", payload="soft"),   # block on its fixed constraint
+    dict(task_env="NO_TASK", observation_space_mode="ENCODER", env_randomizer_mode="MASS_RANDOMIZER", payload="soft", isRLGymInterface=False,
+         motor_control_mode="TORQUE", enable_action_filter=False),     # fallen robots carrying the block: every kind of solver row
     dict(task_env="JUMPING_FORWARD_DEMO", observation_space_mode="PPO_BASIC", env_randomizer_mode="SPRING_RANDOMIZER", action_space_mode="DEFAULT",
          demo=np.random.default_rng(0).uniform(-1, 1, size=(137, 50)).astype(np.float32)),     # an arbitrary "demonstration": only its action columns matter here
 ]
@@ -44,9 +47,8 @@ for variant in ("1", "2"):
                 assert torch.isfinite(st).all() and torch.isfinite(obs).all() and torch.isfinite(rew).all(), (kw, i)
                 qn = st[:, 3:7].norm(dim=1)
                 assert (qn - 1).abs().max() < 1e-3, (kw, i, float((qn - 1).abs().max()))
-                # NO_TASK never ends an episode and non-foot links carry no contact force (deviations): a fallen robot
-                # pivots on its feet and its trunk dips below the floor there
-                zmin = -1.0 if kw["task_env"] == "NO_TASK" else -0.05
+                # NO_TASK never ends an episode; its non-foot links push back (body_contacts = "auto"), so a fallen robot stays on the floor
+                zmin = -0.05
                 assert st[:, 2].min() > zmin and st[:, 2].max() < 3.0, (kw, i, float(st[:, 2].min()), float(st[:, 2].max()))
                 assert st[:, 7:13].abs().max() <= 30.2 and st[:, 25:].abs().max() <= 30.2, (kw, i)
         ninv = env.get_info("n_invalid").max().item()
