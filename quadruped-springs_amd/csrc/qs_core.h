@@ -420,7 +420,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));   /* min(1, mu lambda_n / |c|) */                      \
         V da = T::template bcast<K>(res[1] * sc) - lam_all[ia_], db = T::template bcast<K>(res[2] * sc) - lam_all[ib_]; \
         lam_all[ia_] = lam_all[ia_] + da; lam_all[ib_] = lam_all[ib_] + db;                                             \
-        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + (Ap[ia_][c] * da + Ap[ib_][c] * db);          \
+        /* two chained FMAs per candidate (not res + (a da + b db): one instruction and one level of the dependency chain less) */ \
+        _Pragma("unroll") for (int c = 0; c < NR; c++) { res[c] = res[c] + Ap[ia_][c] * da; res[c] = res[c] + Ap[ib_][c] * db; } \
         if (TRACK) dvmax = qmax(dvmax, qmax(qabs(da * diag_all[TRACK ? ia_ : 0]), qabs(db * diag_all[TRACK ? ib_ : 0]))); \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
