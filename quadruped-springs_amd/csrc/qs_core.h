@@ -422,7 +422,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         lam_all[ia_] = lam_all[ia_] + da; lam_all[ib_] = lam_all[ib_] + db;                                             \
         /* two chained FMAs per candidate (not res + (a da + b db): one instruction and one level of the dependency chain less) */ \
         _Pragma("unroll") for (int c = 0; c < NR; c++) { res[c] = res[c] + Ap[ia_][c] * da; res[c] = res[c] + Ap[ib_][c] * db; } \
-        if (TRACK) dvmax = qmax(dvmax, qmax(qabs(da * diag_all[TRACK ? ia_ : 0]), qabs(db * diag_all[TRACK ? ib_ : 0]))); \
+        if (TRACK) dvmax = T::absmax_mul2(dvmax, da, diag_all[TRACK ? ia_ : 0], db, diag_all[TRACK ? ib_ : 0]);           \
     }
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
             if (NR == 3 && CONE) {

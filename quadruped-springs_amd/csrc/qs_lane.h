@@ -120,6 +120,12 @@ struct LaneDev {
         c = __builtin_elementwise_fma(a, bb, c);
         c0 = c.x; c1 = c.y;
     }
+    // max(m, |x0 d0|, |x1 d1|): one v_pk_mul_f32 and one v_max3_f32 with |.| source modifiers (the residual tracking of the solver sweeps)
+    static QS_DEV float absmax_mul2(float m, float x0, float d0, float x1, float d1) {
+        F2 x = {x0, x1}, d = {d0, d1};
+        F2 p = x * d;
+        return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(p.x), __builtin_fabsf(p.y)));
+    }
     // acc[K] += (a of lane K of the quad) * (b of this lane), K = 0..3: one v_mfma_f32_4x4x1_16b_f32 does it for the sixteen
     // quads of the wave (16 independent 4x4 outer products, block = quad; measured layout: tools/mfma_layout.hip).  The
     // instruction ignores EXEC, so it may only be used where the whole wave runs the same path.
@@ -200,6 +206,11 @@ struct LaneEmu {
     static V4 fx() { return V4(1, 1, -1, -1); }
     static V4 sy() { return V4(-1, 1, -1, 1); }
     static M4 is_leg(int k) { M4 m; for (int i = 0; i < 4; i++) m.v[i] = (i == k); return m; }
+    static V4 absmax_mul2(V4 m, V4 x0, V4 d0, V4 x1, V4 d1) {
+        V4 r;
+        for (int l = 0; l < 4; l++) r.v[l] = fmaxf(m.v[l], fmaxf(fabsf(x0.v[l] * d0.v[l]), fabsf(x1.v[l] * d1.v[l])));
+        return r;
+    }
     static void fma2(V4 a0, V4 a1, V4 b, V4& c0, V4& c1) { for (int l = 0; l < 4; l++) { c0.v[l] = fmaf(a0.v[l], b.v[l], c0.v[l]); c1.v[l] = fmaf(a1.v[l], b.v[l], c1.v[l]); } }
     static void count_rare_path() {}
     static void count_self_narrow() {}

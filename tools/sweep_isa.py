@@ -40,5 +40,5 @@ for name, label in (("_Z6k_stepILb0ELb0EE", "pyramid"), ("_Z6k_stepILb1ELb0EE", 
         print(f"  sweep loop {k}: {n} instructions, {dpp} DPP row broadcasts, {scr} scratch")
     if want == label and loops:
         print("\n```")
-        print("\n".join("    " + x for x in loops[0][4]))
+        print("\n".join("    " + x for x in loops[int(os.environ.get("QS_SWEEP_LOOP", "0"))][4]))
         print("```")
