@@ -1087,19 +1087,25 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
 #define QS_CONTACT_ROW_AT(ROW, DIR, NORMAL, RC, G1, G2, G3, DIST, ACT)                                                 \
     {                                                                                                                  \
         Row& r_ = ROW;                                                                                                 \
-        V3v d_ = DIR;                                                                                                  \
+        /* the row direction of an inactive contact is the zero vector: jq, u, w and the relative velocity vanish with it (no   \
+           masking multiplications further down); its 1 / diag is a finite 1e30 */                                     \
+        V3v d_ = (DIR) * (ACT);                                                                                        \
         V3v ja = cross(RC, d_);                                                                                        \
         r_.jq[0] = dot(d_, G1); r_.jq[1] = dot(d_, G2); r_.jq[2] = dot(d_, G3);                                        \
         r_.u[0] = K11 * r_.jq[0] + K12 * r_.jq[1] + K13 * r_.jq[2];                                                    \
         r_.u[1] = K12 * r_.jq[0] + K22 * r_.jq[1] + K23 * r_.jq[2];                                                    \
         r_.u[2] = K13 * r_.jq[0] + K23 * r_.jq[1] + K33 * r_.jq[2];                                                    \
         V jb[6] = {ja.x, ja.y, ja.z, d_.x, d_.y, d_.z};                                                                \
-        _Pragma("unroll") for (int i = 0; i < 6; i++)                                                                  \
-            r_.w[i] = (jb[i] - (Bm[0][i] * r_.u[0] + Bm[1][i] * r_.u[1] + Bm[2][i] * r_.u[2])) * (ACT);                \
+        /* jb - B u as three chained FMAs per component */                                                            \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) {                                                                \
+            V t_ = jb[i] - Bm[0][i] * r_.u[0];                                                                         \
+            t_ = t_ - Bm[1][i] * r_.u[1];                                                                              \
+            r_.w[i] = t_ - Bm[2][i] * r_.u[2];                                                                         \
+        }                                                                                                              \
         lsolve6<V>(Sm, Ld, r_.w);                                                                                      \
         V diag = r_.jq[0] * r_.u[0] + r_.jq[1] * r_.u[1] + r_.jq[2] * r_.u[2];                                         \
         _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
-        r_.dinv = qrcp(diag); r_.diag = diag;                                                                          \
+        r_.dinv = qrcp(qmax(diag, V(1e-30f))); r_.diag = diag;                                                         \
         V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
         if (NORMAL) {                                                                                                  \
             V pen_ = (DIST) + cfg.contact_slop;                                                                        \
@@ -1107,10 +1113,9 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             V vel_err = (-rel) - qsel(qgt(pen_, zero), pen_ * inv_dt, zero);                                           \
             r_.rhs = (pos_err + vel_err) * r_.dinv * (ACT);                                                            \
         } else {                                                                                                       \
-            r_.rhs = (-rel) * r_.dinv * (ACT);                                                                         \
+            r_.rhs = (-rel) * r_.dinv;                                                                                 \
         }                                                                                                              \
         r_.act = (ACT);                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 3; j++) { r_.jq[j] = r_.jq[j] * (ACT); r_.u[j] = r_.u[j] * (ACT); }      \
     }
 #define QS_CONTACT_ROW(IDX, DIR, NORMAL) QS_CONTACT_ROW_AT(rows[IDX], DIR, NORMAL, rc, g1, g2, g3, dist, active)
         QS_CONTACT_ROW(0, Rz, true)
