@@ -94,9 +94,21 @@ template <class V> QS_FN V3<V> mul(S3<V> I, V3<V> w) {
 }
 template <class V> struct Sp { V3<V> a, l; };  // spatial vector: (angular; linear) for motion, (moment; force) for force
 template <class V> QS_FN Sp<V> operator+(Sp<V> p, Sp<V> q) { Sp<V> r; r.a = p.a + q.a; r.l = p.l + q.l; return r; }
-template <class V> QS_FN V dot(Sp<V> p, Sp<V> q) { return dot(p.a, q.a) + dot(p.l, q.l); }
-template <class V> QS_FN Sp<V> crm(Sp<V> v, Sp<V> u) { Sp<V> r; r.a = cross(v.a, u.a); r.l = cross(v.a, u.l) + cross(v.l, u.a); return r; }
-template <class V> QS_FN Sp<V> crf(Sp<V> v, Sp<V> f) { Sp<V> r; r.a = cross(v.a, f.a) + cross(v.l, f.l); r.l = cross(v.a, f.l); return r; }
+// (Sums of products are written as ONE left-associated chain: without reassociation the compiler turns exactly that into a multiply and
+// a chain of FMAs; `cross(..) + cross(..)` or `dot(..) + dot(..)` cost an extra add per component and a longer dependency chain.)
+template <class V> QS_FN V dot(Sp<V> p, Sp<V> q) { return p.a.x * q.a.x + p.a.y * q.a.y + p.a.z * q.a.z + p.l.x * q.l.x + p.l.y * q.l.y + p.l.z * q.l.z; }
+template <class V> QS_FN Sp<V> crm(Sp<V> v, Sp<V> u) {
+    Sp<V> r; r.a = cross(v.a, u.a);
+    r.l = mk3<V>(v.a.y * u.l.z - v.a.z * u.l.y + v.l.y * u.a.z - v.l.z * u.a.y, v.a.z * u.l.x - v.a.x * u.l.z + v.l.z * u.a.x - v.l.x * u.a.z,
+                 v.a.x * u.l.y - v.a.y * u.l.x + v.l.x * u.a.y - v.l.y * u.a.x);
+    return r;
+}
+template <class V> QS_FN Sp<V> crf(Sp<V> v, Sp<V> f) {
+    Sp<V> r; r.l = cross(v.a, f.l);
+    r.a = mk3<V>(v.a.y * f.a.z - v.a.z * f.a.y + v.l.y * f.l.z - v.l.z * f.l.y, v.a.z * f.a.x - v.a.x * f.a.z + v.l.z * f.l.x - v.l.x * f.l.z,
+                 v.a.x * f.a.y - v.a.y * f.a.x + v.l.x * f.l.y - v.l.y * f.l.x);
+    return r;
+}
 // spatial inertia about the base origin, base coordinates
 template <class V> struct SI { V m; V3<V> h; S3<V> I; };
 template <class V> QS_FN SI<V> operator+(SI<V> p, SI<V> q) {
@@ -104,7 +116,14 @@ template <class V> QS_FN SI<V> operator+(SI<V> p, SI<V> q) {
     r.I.xx = p.I.xx + q.I.xx; r.I.xy = p.I.xy + q.I.xy; r.I.xz = p.I.xz + q.I.xz; r.I.yy = p.I.yy + q.I.yy; r.I.yz = p.I.yz + q.I.yz; r.I.zz = p.I.zz + q.I.zz;
     return r;
 }
-template <class V> QS_FN Sp<V> apply(SI<V> I, Sp<V> v) { Sp<V> f; f.a = mul(I.I, v.a) + cross(I.h, v.l); f.l = v.l * I.m - cross(I.h, v.a); return f; }
+template <class V> QS_FN Sp<V> apply(SI<V> I, Sp<V> v) {   // (I w + h x v ; m v - h x w)
+    Sp<V> f;
+    f.a = mk3<V>(I.I.xx * v.a.x + I.I.xy * v.a.y + I.I.xz * v.a.z + I.h.y * v.l.z - I.h.z * v.l.y,
+                 I.I.xy * v.a.x + I.I.yy * v.a.y + I.I.yz * v.a.z + I.h.z * v.l.x - I.h.x * v.l.z,
+                 I.I.xz * v.a.x + I.I.yz * v.a.y + I.I.zz * v.a.z + I.h.x * v.l.y - I.h.y * v.l.x);
+    f.l = mk3<V>(v.l.x * I.m - I.h.y * v.a.z + I.h.z * v.a.y, v.l.y * I.m - I.h.z * v.a.x + I.h.x * v.a.z, v.l.z * I.m - I.h.x * v.a.y + I.h.y * v.a.x);
+    return f;
+}
 // rigid part with mass m, COM cl and inertia Il (6 unique, about the COM) given in a link frame whose origin is p and whose
 // axes are X, Y, Z (all in base coordinates)
 template <class V> QS_FN SI<V> part_inertia(V m, V3<V> cl, S3<V> Il, V3<V> p, V3<V> X, V3<V> Y, V3<V> Z) {
