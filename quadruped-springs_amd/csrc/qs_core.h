@@ -399,7 +399,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             lam_all[NR * 2] = T::template bcast<2>(l_own); lam_all[NR * 3] = T::template bcast<3>(l_own);
 #pragma unroll
             for (int c = 0; c < NR; c++)
-                res[c] = res[c] + (Ap[NR * 0][c] * lam_all[NR * 0] + Ap[NR * 1][c] * lam_all[NR * 1] + Ap[NR * 2][c] * lam_all[NR * 2] + Ap[NR * 3][c] * lam_all[NR * 3]);
+                res[c] = res[c] + Ap[NR * 0][c] * lam_all[NR * 0] + Ap[NR * 1][c] * lam_all[NR * 1] + Ap[NR * 2][c] * lam_all[NR * 2] + Ap[NR * 3][c] * lam_all[NR * 3];
         }
         QS_PHASE_G(9)
         const V big = V(1e10f), zero = V(0.0f);
@@ -491,12 +491,12 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             s.qd[j] = clampv<V>(s.qd[j] + t, V(-cfg.vel_cap), V(cfg.vel_cap));
         }
         const V cap = V(cfg.vel_cap);
-        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), -cap, cap);
-        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), -cap, cap);
-        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), -cap, cap);
-        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), -cap, cap);
-        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), -cap, cap);
-        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
+        s.vang.x = clampv<V>(s.vang.x + R[0] * z[0] + R[1] * z[1] + R[2] * z[2], -cap, cap);
+        s.vang.y = clampv<V>(s.vang.y + R[3] * z[0] + R[4] * z[1] + R[5] * z[2], -cap, cap);
+        s.vang.z = clampv<V>(s.vang.z + R[6] * z[0] + R[7] * z[1] + R[8] * z[2], -cap, cap);
+        s.vlin.x = clampv<V>(s.vlin.x + R[0] * z[3] + R[1] * z[4] + R[2] * z[5], -cap, cap);
+        s.vlin.y = clampv<V>(s.vlin.y + R[3] * z[3] + R[4] * z[4] + R[5] * z[5], -cap, cap);
+        s.vlin.z = clampv<V>(s.vlin.z + R[6] * z[3] + R[7] * z[4] + R[8] * z[5], -cap, cap);
     }
 
     // The rare path: rows beyond the three foot-contact rows of a leg -- one row per violated joint limit (falls) and, with NCP = 3,
@@ -682,12 +682,12 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             s.qd[j] = clampv<V>(s.qd[j] + t, -cap, cap);
         }
         const V* R = a.R;
-        s.vang.x = clampv<V>(s.vang.x + (R[0] * z[0] + R[1] * z[1] + R[2] * z[2]), -cap, cap);
-        s.vang.y = clampv<V>(s.vang.y + (R[3] * z[0] + R[4] * z[1] + R[5] * z[2]), -cap, cap);
-        s.vang.z = clampv<V>(s.vang.z + (R[6] * z[0] + R[7] * z[1] + R[8] * z[2]), -cap, cap);
-        s.vlin.x = clampv<V>(s.vlin.x + (R[0] * z[3] + R[1] * z[4] + R[2] * z[5]), -cap, cap);
-        s.vlin.y = clampv<V>(s.vlin.y + (R[3] * z[3] + R[4] * z[4] + R[5] * z[5]), -cap, cap);
-        s.vlin.z = clampv<V>(s.vlin.z + (R[6] * z[3] + R[7] * z[4] + R[8] * z[5]), -cap, cap);
+        s.vang.x = clampv<V>(s.vang.x + R[0] * z[0] + R[1] * z[1] + R[2] * z[2], -cap, cap);
+        s.vang.y = clampv<V>(s.vang.y + R[3] * z[0] + R[4] * z[1] + R[5] * z[2], -cap, cap);
+        s.vang.z = clampv<V>(s.vang.z + R[6] * z[0] + R[7] * z[1] + R[8] * z[2], -cap, cap);
+        s.vlin.x = clampv<V>(s.vlin.x + R[0] * z[3] + R[1] * z[4] + R[2] * z[5], -cap, cap);
+        s.vlin.y = clampv<V>(s.vlin.y + R[3] * z[3] + R[4] * z[4] + R[5] * z[5], -cap, cap);
+        s.vlin.z = clampv<V>(s.vlin.z + R[6] * z[3] + R[7] * z[4] + R[8] * z[5], -cap, cap);
     }
     template <int NCP> static QS_NOINLINE void solve_with_limits_call(const qs_config& cfg, V mu, State& s, Out& o, RareArgs<NCP>& a) {
         solve_with_limits<NCP>(cfg, mu, s, o, a);
@@ -1125,7 +1125,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         V diag = r_.jq[0] * r_.u[0] + r_.jq[1] * r_.u[1] + r_.jq[2] * r_.u[2];                                         \
         _Pragma("unroll") for (int i = 0; i < 6; i++) diag = diag + r_.w[i] * r_.w[i];                                 \
         r_.dinv = qrcp(qmax(diag, V(1e-30f))); r_.diag = diag;                                                         \
-        V rel = dot(ja, vs.a) + dot(d_, vs.l) + r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];          \
+        V rel = ja.x * vs.a.x + ja.y * vs.a.y + ja.z * vs.a.z + d_.x * vs.l.x + d_.y * vs.l.y + d_.z * vs.l.z +       \
+                r_.jq[0] * s.qd[0] + r_.jq[1] * s.qd[1] + r_.jq[2] * s.qd[2];                                          \
         if (NORMAL) {                                                                                                  \
             V pen_ = (DIST) + cfg.contact_slop;                                                                        \
             V pos_err = qsel(qgt(pen_, zero), zero, (-pen_) * (cfg.contact_erp * inv_dt));                             \
