@@ -109,6 +109,21 @@ template <class V> QS_FN Sp<V> crf(Sp<V> v, Sp<V> f) {
                  v.a.x * f.a.y - v.a.y * f.a.x + v.l.x * f.l.y - v.l.y * f.l.x);
     return r;
 }
+// acc + crm(v, u), acc + crf(v, f): the accumulator starts each component's chain (no separate vector add)
+template <class V> QS_FN Sp<V> crm_add(Sp<V> c, Sp<V> v, Sp<V> u) {
+    Sp<V> r;
+    r.a = mk3<V>(c.a.x + v.a.y * u.a.z - v.a.z * u.a.y, c.a.y + v.a.z * u.a.x - v.a.x * u.a.z, c.a.z + v.a.x * u.a.y - v.a.y * u.a.x);
+    r.l = mk3<V>(c.l.x + v.a.y * u.l.z - v.a.z * u.l.y + v.l.y * u.a.z - v.l.z * u.a.y, c.l.y + v.a.z * u.l.x - v.a.x * u.l.z + v.l.z * u.a.x - v.l.x * u.a.z,
+                 c.l.z + v.a.x * u.l.y - v.a.y * u.l.x + v.l.x * u.a.y - v.l.y * u.a.x);
+    return r;
+}
+template <class V> QS_FN Sp<V> crf_add(Sp<V> c, Sp<V> v, Sp<V> f) {
+    Sp<V> r;
+    r.l = mk3<V>(c.l.x + v.a.y * f.l.z - v.a.z * f.l.y, c.l.y + v.a.z * f.l.x - v.a.x * f.l.z, c.l.z + v.a.x * f.l.y - v.a.y * f.l.x);
+    r.a = mk3<V>(c.a.x + v.a.y * f.a.z - v.a.z * f.a.y + v.l.y * f.l.z - v.l.z * f.l.y, c.a.y + v.a.z * f.a.x - v.a.x * f.a.z + v.l.z * f.l.x - v.l.x * f.l.z,
+                 c.a.z + v.a.x * f.a.y - v.a.y * f.a.x + v.l.x * f.l.y - v.l.y * f.l.x);
+    return r;
+}
 // spatial inertia about the base origin, base coordinates
 template <class V> struct SI { V m; V3<V> h; S3<V> I; };
 template <class V> QS_FN SI<V> operator+(SI<V> p, SI<V> q) {
@@ -924,13 +939,13 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         vj2.a = S2.a * s.qd[1]; vj2.l = S2.l * s.qd[1];
         vj3.a = S3j.a * s.qd[2]; vj3.l = S3j.l * s.qd[2];
         Spv v1 = v0 + vj1, v2 = v1 + vj2, v3 = v2 + vj3;
-        Spv a1 = a0 + crm(v0, vj1), a2 = a1 + crm(v1, vj2), a3 = a2 + crm(v2, vj3);
-        Spv f1 = apply(I1, a1) + crf(v1, apply(I1, v1));
-        Spv f2 = apply(I2, a2) + crf(v2, apply(I2, v2));
-        Spv f3 = apply(I3, a3) + crf(v3, apply(I3, v3));
+        Spv a1 = crm_add(a0, v0, vj1), a2 = crm_add(a1, v1, vj2), a3 = crm_add(a2, v2, vj3);
+        Spv f1 = crf_add(apply(I1, a1), v1, apply(I1, v1));
+        Spv f2 = crf_add(apply(I2, a2), v2, apply(I2, v2));
+        Spv f3 = crf_add(apply(I3, a3), v3, apply(I3, v3));
         Spv fs2 = f2 + f3, fs1 = f1 + fs2;
         V C1 = dot(S1, fs1), C2 = dot(S2, fs2), C3 = dot(S3j, f3);
-        Spv f0 = apply(Pr.I0, a0) + crf(v0, apply(Pr.I0, v0));
+        Spv f0 = crf_add(apply(Pr.I0, a0), v0, apply(Pr.I0, v0));
         V Cb[6] = {T::quad_sum(fs1.a.x) + f0.a.x, T::quad_sum(fs1.a.y) + f0.a.y, T::quad_sum(fs1.a.z) + f0.a.z,
                    T::quad_sum(fs1.l.x) + f0.l.x, T::quad_sum(fs1.l.y) + f0.l.y, T::quad_sum(fs1.l.z) + f0.l.z};
         QS_PHASE(4)
