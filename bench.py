@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--preroll", type=int, default=1500,
+                    help="untimed steps before the warmup steps that bring episode ages, reset rate and the streaming refill of the reset pool "
+                         "to their steady state (part of the preparation, like the pool fill; 0 to skip)")
     ap.add_argument("--workload", default="jump_in_place_8192")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--total-envs", type=int, default=0, help="strong scaling: this many environments split over the ranks (SURVEY 8e: 65536)")
@@ -255,6 +258,11 @@ def main():
         for i in range(1000 // groups):
             local_step(acts[i % n_act])
         torch.cuda.current_stream().synchronize()
+    # ... and let the reset rate and with it the streaming refill reach their steady state (episodes of random actions last ~700 steps, a
+    # settle takes 250 launches, a cohort publishes every 50): without this a short timed region (the driver's 20 steps) sees a refill
+    # that is still sized for the young episodes of the preparation (config.settle_work_ratio 0.14 instead of ~0.95)
+    for i in range(args.preroll):
+        local_step(acts[i % n_act])
     for i in range(args.warmup):
         step_fn(acts[i % n_act])
     kernel_ms = []
@@ -344,7 +352,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
                        "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
-                       "auto_reset": True,
+                       "auto_reset": True, "preroll_steps": args.preroll,
                        "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
                                   ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))
                                  if args.reset_pool else "2500-substep settle inside the step"),
