@@ -369,7 +369,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_file, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
                          "algorithmic_bytes_per_env_step": algo_bytes,
-                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / live k_step duration (HIP events on the kernel's stream; the events add ~1.5 % to a 0.1 ms launch); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same live duration, GB/s; the step is ~50 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
+                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / live k_step duration (HIP events on the kernel's stream; the events add ~1.5 % to a 0.1 ms launch); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same live duration, GB/s; the step is ~30 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
         }
         if sharded:
             out["config"]["local_ms_per_step"] = 1e3 * local_elapsed / args.steps
