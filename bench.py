@@ -77,9 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="jump_in_place_8192")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--total-envs", type=int, default=0, help="strong scaling: this many environments split over the ranks (SURVEY 8e: 65536)")
-    ap.add_argument("--reset-pool", type=int, default=65536,
-                    help="pre-settled reset states per GPU (0 = settle inside the step); 64 MB of records.  The fewer entries, the more often a reset "
-                         "draws one that another reset has used and the refill has not replaced yet (16384 entries: 16 %% of the resets of a 2000-step run)")
+    ap.add_argument("--reset-pool", type=int, default=262144,
+                    help="pre-settled reset states per GPU (0 = settle inside the step); 302 MB of records.  The fewer entries, the more often a reset "
+                         "draws one that another reset has used and the refill has not replaced yet (tools/pool_reuse.py, 2000 steps at N = 8192: "
+                         "16384 entries 16 %% of the resets, 65536: 5.5 %%, 262144: 1.4 %%, 1048576: 0.3 %%)")
     ap.add_argument("--no-pool-streaming", action="store_true",
                     help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
