@@ -4,8 +4,8 @@
 // per leg).  N = 8192 environments -> 512 single-wave workgroups spread over the 256 CUs; the kernel is a long chain of
 // dependent fp32 VALU work per lane, so the design goal is the shortest per-lane instruction stream, registers instead of
 // memory (everything between the tile load and the tile store lives in VGPRs), and DPP for the 4-lane reductions.
-// HBM traffic: each wave moves its 16 contiguous records (16 x 832 B) HBM -> LDS -> HBM with 16-byte-per-lane coalesced
-// accesses, plus the action / observation / reward rows.
+// HBM traffic: each wave moves the leading range of its 16 records that a step needs (704 B in, 608 B out per record by default,
+// qs_layout.h) HBM -> LDS -> HBM with 16-byte-per-lane coalesced accesses, plus the action / observation / reward rows.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
