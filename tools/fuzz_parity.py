@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Random configurations of QuadrupedVecEnv against the float32 oracle: task x sensor bundle x action space x motor mode x randomizer x
+wrapper x solver settings x record options, each for a reset and a few re-seated steps (what tests/test_gpu_parity.py does for its fixed
+list of cases).  Prints every configuration that deviates.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "quadruped-springs_amd"))
+import numpy as np
+from qs_amd import config as C
+from qs_amd.vec_env import QuadrupedVecEnv
+from oracle.qso import Oracle
+
+def run(cases, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    tasks = [t for t in C.TASKS if not t.endswith("_DEMO")]
+    wrappers = [None, None, None, "LANDING", "GO_TO_REST", "LANDING2", "LANDING_BACKFLIP", "LANDING_BACKFLIP2", "LANDING_CONTINUOUS"]
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    bad, ran = [], 0
+    for case in range(cases):
+        kw = dict(task_env=pick(tasks), observation_space_mode=pick(list(C.SENSOR_BUNDLES)), action_space_mode=pick(list(C.ACTION_SPACE_MODES)),
+                  motor_control_mode=pick(["PD", "PD", "CARTESIAN_PD", "TORQUE"]), env_randomizer_mode=pick(list(C.RANDOMIZERS)), wrapper=pick(wrappers),
+                  friction_model=pick(["cone", "pyramid"]), solver_residual_threshold=pick([0.0, 1e-7]), enable_springs=bool(rng.integers(2)),
+                  enable_action_filter=bool(rng.integers(2)), info_fields=bool(rng.integers(2)), payload=pick(["weld", "weld", "soft"]),
+                  mass_inertia_rule=pick(["collision_shape", "scale"]), seed=int(rng.integers(1000)), settle_steps=int(pick([200, 600])), noise=False)
+        if kw["motor_control_mode"] == "TORQUE":
+            kw["isRLGymInterface"] = False
+            kw["action_space_mode"] = "DEFAULT"
+        if rng.integers(4) == 0:
+            kw.update(time_step=0.002, action_repeat=5)
+        n = int(pick([5, 16, 20]))
+        try:
+            v = QuadrupedVecEnv(num_envs=n, auto_reset=False, **kw)
+        except (ValueError, KeyError, RuntimeError):      # combinations the reference (or qs_create) refuses
+            continue
+        ran += 1
+        o = Oracle(v.cfg, "f32")
+        try:
+            oo, ov = o.reset(), v.reset()
+            np.testing.assert_allclose(ov, oo, atol=2e-3, err_msg="reset observation")
+            for i in range(6):
+                a = rng.uniform(-1, 1, size=(n, v.action_dim)).astype(np.float32)
+                s = o.get_state()
+                o.set_state(s); v.set_state(s.astype(np.float32))
+                oo, ro, do, to = o.step(a)
+                vo, rv, dv, infos = v.step(a)
+                so, sv = o.get_state(), v.get_state().cpu().numpy()
+                np.testing.assert_allclose(sv[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {i}")
+                np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=2e-4, err_msg=f"q step {i}")
+                np.testing.assert_allclose(sv[:, 7:13], so[:, 7:13], atol=2e-2, err_msg=f"base velocity step {i}")
+                np.testing.assert_array_equal(dv, do, err_msg=f"done step {i}")
+                np.testing.assert_allclose(rv, ro, atol=1e-3, rtol=5e-3, err_msg=f"reward step {i}")
+                np.testing.assert_allclose(vo, oo, atol=1e-1, err_msg=f"obs step {i}")
+                if do.any():
+                    m = do.astype(np.uint8)
+                    o.reset(m); v.reset_tensor(mask=m)
+        except AssertionError as e:
+            bad.append((case, kw, str(e).strip().splitlines()[0:6]))
+            if verbose:
+                print(f"case {case}: {kw}\n   {bad[-1][2]}")
+        v.close()
+    return ran, bad
+
+
+if __name__ == "__main__":
+    ran, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f"{ran} configurations ran, {len(bad)} deviated")
