@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random configurations of QuadrupedVecEnv against the float32 oracle: task x sensor bundle x action space x motor mode x randomizer x
 wrapper x solver settings x record options, each for a reset and a few re-seated steps (what tests/test_gpu_parity.py does for its fixed
-list of cases).  Prints every configuration that deviates.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+list of cases).  Prints every configuration that deviates.  usage: python tools/fuzz_parity.py [cases] [seed] [fallen]
+With "fallen": NO_TASK with the links' contact response on, two thirds of the robots thrown onto trunk / hips / thighs / calves in random
+attitudes with random joint angles under raw random torques -- the many-rows solver path (12 rows per leg, joint stops, payload rows)."""
 import os
 import sys
 
@@ -11,7 +13,7 @@ from qs_amd import config as C
 from qs_amd.vec_env import QuadrupedVecEnv
 from oracle.qso import Oracle
 
-def run(cases, seed, verbose=True):
+def run(cases, seed, verbose=True, fallen=False):
     rng = np.random.default_rng(seed)
     tasks = [t for t in C.TASKS if not t.endswith("_DEMO")]
     wrappers = [None, None, None, "LANDING", "GO_TO_REST", "LANDING2", "LANDING_BACKFLIP", "LANDING_BACKFLIP2", "LANDING_CONTINUOUS"]
@@ -28,6 +30,9 @@ def run(cases, seed, verbose=True):
             kw["action_space_mode"] = "DEFAULT"
         if rng.integers(4) == 0:
             kw.update(time_step=0.002, action_repeat=5)
+        if fallen:
+            kw.update(task_env="NO_TASK", wrapper=None, motor_control_mode="TORQUE", isRLGymInterface=False, action_space_mode="DEFAULT", body_contacts=True,
+                      enable_action_filter=False)
         n = int(pick([5, 16, 20]))
         try:
             v = QuadrupedVecEnv(num_envs=n, auto_reset=False, **kw)
@@ -38,8 +43,19 @@ def run(cases, seed, verbose=True):
         try:
             oo, ov = o.reset(), v.reset()
             np.testing.assert_allclose(ov, oo, atol=2e-3, err_msg="reset observation")
+            if fallen:
+                from scipy.spatial.transform import Rotation as Rot
+                s = o.get_state()
+                lying = np.arange(n) % 3 != 0
+                k = int(lying.sum())
+                s[lying, 2] = rng.uniform(0.08, 0.25, k)
+                s[lying, 3:7] = Rot.from_euler("xyz", np.stack([rng.uniform(-3.1, 3.1, k), rng.uniform(-1.2, 1.2, k), rng.uniform(-3.1, 3.1, k)], 1)).as_quat()
+                s[lying, 7:13] = rng.normal(size=(k, 6)) * 0.5
+                s[lying, 13:25] = rng.uniform(np.tile([-1.0, -0.6, -2.7], 4), np.tile([1.0, 2.9, -0.9], 4), size=(k, 12))
+                o.set_state(s); v.set_state(s.astype(np.float32))
+                o.step(np.zeros((n, 12), np.float32)); v.step(np.zeros((n, 12), np.float32))     # let deep penetrations resolve first
             for i in range(6):
-                a = rng.uniform(-1, 1, size=(n, v.action_dim)).astype(np.float32)
+                a = rng.uniform(-1, 1, size=(n, v.action_dim)).astype(np.float32) * (4.0 if fallen else 1.0)
                 s = o.get_state()
                 o.set_state(s); v.set_state(s.astype(np.float32))
                 oo, ro, do, to = o.step(a)
@@ -63,5 +79,5 @@ def run(cases, seed, verbose=True):
 
 
 if __name__ == "__main__":
-    ran, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    ran, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0, fallen="fallen" in sys.argv[3:])
     print(f"{ran} configurations ran, {len(bad)} deviated")
