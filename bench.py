@@ -43,27 +43,49 @@ def workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(cfg_kwargs, budget_s=12.0):
-    """The oracle (CPU restatement, float64, scalar C, OpenMP over environments) timed on this box's host cores on a bounded sample."""
+def cpu_baseline(cfg_kwargs, budget_s=14.0):
+    """The oracle (CPU restatement, float64, scalar C) timed on this box's host cores on a bounded sample of the same workload: 64
+    environments per host thread, every thread stepping its own share without a barrier between steps (qso_rollout: independent workers
+    are the CPU's best case -- a reset's in-place 2500-substep settle then delays only its own thread), once on ONE thread and once on
+    all of them.  Also tries the reference's own PyBullet path."""
     import numpy as np
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     os.environ["OMP_NUM_THREADS"] = str(cores)          # read by libgomp when the oracle library is loaded
     os.environ["OMP_WAIT_POLICY"] = "passive"
     from oracle.qso import Oracle
     from qs_amd.config import build_config
-    n = 8 * cores
-    cfg, _ = build_config(n_envs=n, auto_reset=True, seed=1234, **cfg_kwargs)
-    o = Oracle(cfg)
-    o.reset()
-    rng = np.random.default_rng(0)
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        for _ in range(20):
-            o.step(rng.uniform(-1, 1, size=(n, cfg.action_dim)).astype(np.float32))
-        steps += 20
-    dt = time.perf_counter() - t0
-    return dict(value=n * steps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{n} envs x {steps} env-steps of the same workload on {cores} host threads (OpenMP over environments), auto-reset incl. 2500-substep settles ({dt:.1f} s)")
+    per_thread, rng = 64, np.random.default_rng(0)
+
+    def leg(threads, budget):
+        n = per_thread * threads
+        cfg, _ = build_config(n_envs=n, auto_reset=True, seed=1234, **cfg_kwargs)
+        o = Oracle(cfg)
+        o.set_threads(threads)
+        o.reset()
+        ring = rng.uniform(-1, 1, size=(64, n, cfg.action_dim)).astype(np.float32)
+        t0 = time.perf_counter(); o.rollout(ring, 4); probe = (time.perf_counter() - t0) / 4      # seconds per step of all n environments
+        steps = max(8, int(budget / max(probe, 1e-6)))
+        t0 = time.perf_counter(); resets = o.rollout(ring, steps); dt = time.perf_counter() - t0
+        o.close()
+        return dict(threads=threads, envs=n, env_steps=n * steps, seconds=dt, rate=n * steps / dt, resets=resets,
+                    settle_share=resets * cfg.settle_steps / (resets * cfg.settle_steps + n * steps * cfg.action_repeat))
+
+    one = leg(1, 0.3 * budget_s)
+    allt = leg(cores, 0.7 * budget_s) if cores > 1 else one
+    try:
+        import pybullet  # noqa: F401
+        ref = "pybullet importable, but the reference's QuadrupedGymEnv also needs gym and the reference tree, which the GPU box does not hold: not run"
+    except Exception as e:  # noqa: BLE001
+        ref = f"unavailable ({type(e).__name__}: pybullet==3.2.5 of the reference's setup.py:10 is not installed on this box)"
+    return dict(value=allt["rate"], unit="env-steps/s", cores=cores, kind="port",
+                single_thread=one["rate"], per_thread=allt["rate"] / cores,
+                parallel_efficiency=allt["rate"] / (cores * one["rate"]),
+                resets_in_sample=allt["resets"], settle_share_of_substeps=allt["settle_share"], single_thread_settle_share=one["settle_share"],
+                reference_pybullet=ref,
+                sample=(f"{allt['envs']} envs ({per_thread} per thread) x {allt['env_steps'] // allt['envs']} env-steps of the same workload on {cores} host "
+                        f"threads, each stepping its own environments with no barrier between steps, auto-reset incl. its in-place 2500-substep settles "
+                        f"({allt['resets']} resets = {100 * allt['settle_share']:.0f} % of the substeps; {allt['seconds']:.1f} s); single thread: "
+                        f"{one['envs']} envs x {one['env_steps'] // one['envs']} env-steps, {one['resets']} resets ({one['seconds']:.1f} s)"))
 
 
 def parse_args(argv=None):
@@ -72,17 +94,19 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--preroll", type=int, default=1500,
-                    help="untimed steps before the warmup steps that bring episode ages, reset rate and the streaming refill of the reset pool "
-                         "to their steady state (part of the preparation, like the pool fill; 0 to skip)")
+                    help="untimed steps before the warmup steps that bring episode ages, reset rate and the settle lanes "
+                         "to their steady state (part of the preparation; 0 to skip)")
     ap.add_argument("--workload", default="jump_in_place_8192")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--total-envs", type=int, default=0, help="strong scaling: this many environments split over the ranks (SURVEY 8e: 65536)")
-    ap.add_argument("--reset-pool", type=int, default=262144,
-                    help="pre-settled reset states per GPU (0 = settle inside the step); 302 MB of records.  The fewer entries, the more often a reset "
-                         "draws one that another reset has used and the refill has not replaced yet (tools/pool_reuse.py, 2000 steps at N = 8192: "
-                         "16384 entries 16 %% of the resets, 65536: 5.5 %%, 262144: 1.4 %%, 1048576: 0.3 %%)")
-    ap.add_argument("--no-pool-streaming", action="store_true",
-                    help="do not re-settle the reset pool in the background while stepping (the pool is then filled once, before the timed region)")
+    ap.add_argument("--reset-lookahead", type=int, default=16,
+                    help="K: reset states kept ready per environment (its own next K episodes, settled ahead of time by extra workgroups of the step "
+                         "kernel; results are bitwise those of 0 = every reset settles inside the step).  The benchmark's U(-1,1) actions come from a "
+                         "ring of 64 batches, so some environments fall every ~65 steps, episode after episode: five settles of such an environment are "
+                         "in flight at any time, and K must cover them (K = 16: 151 MB at N = 8192)")
+    ap.add_argument("--no-settle-lanes", action="store_true",
+                    help="experiments: leave the look-ahead states un-replenished (resets settle in place once an environment has used its K states)")
+    ap.add_argument("--no-info-line", action="store_true", help="skip the second timed loop with info_fields=True (value_info_fields_true)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     ap.add_argument("--dry-launch", action="store_true",
@@ -104,6 +128,34 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime in the launcher (its children must be the first to do so): the
+    KFD topology lists every node, CPUs with simd_count 0; HIP_/ROCR_/CUDA_VISIBLE_DEVICES restrict the list.  Falls back to
+    torch.cuda.device_count() in a short-lived child process."""
+    n = None
+    try:
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        n = None
+    if not n:
+        import subprocess
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+        try:
+            n = int(out.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh children, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
     set), BEFORE anything in this process touches a GPU; rank 0's child prints the JSON line.  Returns the exit code."""
@@ -115,8 +167,7 @@ def launch_ranks(args, argv):
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks
         envs.append(e)
-    import torch
-    visible = torch.cuda.device_count()   # counting devices does not initialise the GPU runtime in this process
+    visible = visible_gpus()
     if visible < args.gpus and not args.dry_launch:
         print(f"bench.py: --gpus {args.gpus} but {visible} GPU(s) visible on this box; refusing to report a {args.gpus}-GPU line from fewer devices",
               file=sys.stderr)
@@ -203,113 +254,118 @@ def main():
             return v
     extra_kw = {k: literal(v) for k, v in (item.split("=", 1) for item in args.env_kw)}
     # a learner that consumes observations, rewards and done flags (SB3 PPO) never reads the records' info block (torques, foot forces,
-    # the task's pose cache): the steps do not write it (info_fields = False; getters for it would fail loudly).  --env-kw info_fields=True
+    # the task's pose cache): the steps do not write it (info_fields = False; getters for it would fail loudly).  The rate of the default
+    # handle (info_fields = True) is measured by a second timed loop and reported as value_info_fields_true.
     kw.setdefault("info_fields", False)
     kw.update(extra_kw)
     n = args.envs_per_gpu or n_default
     if args.total_envs:
         assert args.total_envs % (16 * world) == 0, "--total-envs must split into whole waves (16 environments) per rank"
         n = args.total_envs // world
-    env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_pool=args.reset_pool, env_id_offset=n * rank,
-                          seed=1234, **kw)   # Philox streams keyed by the global environment id: one job of n x world environments
-    env.reset_tensor()
-    d = env.action_dim
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    d_gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     n_act = 64  # a ring of pre-generated U(-1,1) action batches, resident in HBM
-    acts = torch.rand((n_act, n, d), generator=gen, device=dev) * 2 - 1
-    local_step = step_fn = env.step_tensor
-    if sharded:
-        # the centralised-learner exchange of SURVEY.md 8e on top of the same local step.  Rank 0 owns an SB3-PPO-shaped rollout
-        # buffer (n_steps = 128): its action rows ARE the broadcast source and its result rows [N, o + 2] (observation | reward |
-        # done + 2 truncated) ARE the all-gather destination, so a step adds no copy kernel: broadcast (world > 1 only), the step
-        # kernel writing this rank's rows in place, one in-place all-gather (world > 1 only).
-        from qs_amd.sharded import ShardedVecEnv
-        shard = ShardedVecEnv(env, learner_rank=0)
-        n_glob, o_dim = n * world, env.obs_dim
-        n_roll = 128
-        roll_act = torch.rand((n_roll, n_glob, d), generator=gen, device=dev) * 2 - 1   # stands in for the policy's outputs
-        roll_res = torch.zeros((n_roll if rank == 0 else 1, n_glob, o_dim + 2), device=dev)
-        state = dict(t=0)
-
-        def sharded_step(_unused):
-            k = state["t"] % n_roll
-            shard.step(roll_act[k] if rank == 0 else None, out=roll_res[k if rank == 0 else 0], unpack=False)   # the rollout buffer keeps the fused rows
-            state["t"] += 1
-
-        step_fn = sharded_step
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Auto-reset draws pre-settled states from a pool; with streaming on, as many entries as were consumed are re-settled by
-    # extra workgroups of the step kernel (2500 substeps per state, new randomizer draws, action_repeat substeps per launch),
-    # so in the steady state the settle work of the resets consumed in the timed region is done in the timed region, next to the
-    # stepping (config.settle_work_ratio says how much of it this particular run did).
-    streaming = bool(args.reset_pool) and not args.no_pool_streaming
-    if streaming:
-        env.pool_streaming(True)
-    # Untimed preparation: put the environments at evenly spread episode phases, as in the steady state of a training run
-    # (they would otherwise all hit the 1000-step limit of gym_env.py:35 in the same step: one burst of N resets).
-    groups = 16
-    ids = torch.arange(n, device=dev)
-    for gidx in range(groups):
-        env.reset_tensor((ids % groups == gidx).to(torch.uint8))
-        for i in range(1000 // groups):
-            local_step(acts[i % n_act])
-        torch.cuda.current_stream().synchronize()
-    # ... and let the reset rate and with it the streaming refill reach their steady state (episodes of random actions last ~700 steps, a
-    # settle takes 250 launches, a cohort publishes every 50): without this a short timed region (the driver's 20 steps) sees a refill
-    # that is still sized for the young episodes of the preparation (config.settle_work_ratio 0.14 instead of ~0.95)
-    for i in range(args.preroll):
-        local_step(acts[i % n_act])
-    for i in range(args.warmup):
-        step_fn(acts[i % n_act])
-    kernel_ms = []
-    barrier()
-    stats0 = env.stats()
-    def narrow():
-        try:
-            return env.counter("self_narrow_substeps")
-        except RuntimeError:       # a library of round 1 (QS_LIB_PATH, A/B runs) has no such counter
-            return 0
+    def run(env_kw, with_exchange):
+        """Preparation + the timed region for one handle; returns the measurements of this rank."""
+        env = QuadrupedVecEnv(num_envs=n, device=local_rank, auto_reset=True, reset_lookahead=args.reset_lookahead, env_id_offset=n * rank,
+                              seed=1234, **env_kw)   # Philox streams keyed by the global environment id: one job of n x world environments
+        if args.no_settle_lanes and args.reset_lookahead:
+            env.settle_lanes(False)
+        env.reset_tensor()
+        d = env.action_dim
+        acts = torch.rand((n_act, n, d), generator=d_gen, device=dev) * 2 - 1
+        local_step = step_fn = env.step_tensor
+        if with_exchange:
+            # the centralised-learner exchange of SURVEY.md 8e on top of the same local step.  Rank 0 owns an SB3-PPO-shaped rollout
+            # buffer (n_steps = 128): its action rows ARE the broadcast source and its result rows [N, o + 2] (observation | reward |
+            # done + 2 truncated) ARE the all-gather destination, so a step adds no copy kernel: broadcast (world > 1 only), the step
+            # kernel writing this rank's rows in place, one in-place all-gather (world > 1 only).
+            from qs_amd.sharded import ShardedVecEnv
+            shard = ShardedVecEnv(env, learner_rank=0)
+            n_glob, o_dim = n * world, env.obs_dim
+            n_roll = 128
+            roll_act = torch.rand((n_roll, n_glob, d), generator=d_gen, device=dev) * 2 - 1   # stands in for the policy's outputs
+            roll_res = torch.zeros((n_roll if rank == 0 else 1, n_glob, o_dim + 2), device=dev)
+            state = dict(t=0)
 
-    limit0, narrow0 = env.counter("limit_path_substeps"), narrow()
-    refills0 = env.pool_streaming(True) if streaming else 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step_fn(acts[i % n_act])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stats1 = env.stats()
-    limit1, narrow1 = env.counter("limit_path_substeps"), narrow()
-    refills1 = env.pool_streaming(True) if streaming else 0
-    local_elapsed = None
-    if sharded:   # the same number of steps without the exchange, to price it (reported as config.exchange_us; not the headline)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
+            def sharded_step(_unused):
+                k = state["t"] % n_roll
+                shard.step(roll_act[k] if rank == 0 else None, out=roll_res[k if rank == 0 else 0], unpack=False)   # the rollout buffer keeps the fused rows
+                state["t"] += 1
+
+            step_fn = sharded_step
+        # Auto-reset: every environment takes its own next reset state (randomizer draws of (seed, environment, episode), spawn, 2500
+        # settle substeps -- computed ahead of time by extra workgroups of the step kernel, action_repeat substeps per launch), so the
+        # settle work of the resets consumed in the timed region is done in the timed region, next to the stepping
+        # (config.settle_work_ratio says how much of it this particular run did).
+        # Untimed preparation: put the environments at evenly spread episode phases, as in the steady state of a training run
+        # (they would otherwise all hit the 1000-step limit of gym_env.py:35 in the same step: one burst of N resets).
+        groups = 16
+        ids = torch.arange(n, device=dev)
+        for gidx in range(groups):
+            env.reset_tensor((ids % groups == gidx).to(torch.uint8))
+            for i in range(1000 // groups):
+                local_step(acts[i % n_act])
+            torch.cuda.current_stream().synchronize()
+        # ... and let the reset rate and with it the settle lanes reach their steady state (episodes of random actions last ~600 steps, a
+        # settle takes 250 launches, a cohort of lanes starts every 50)
+        for i in range(args.preroll):
             local_step(acts[i % n_act])
+        for i in range(args.warmup):
+            step_fn(acts[i % n_act])
         barrier()
-        local_elapsed = time.perf_counter() - t1
-    env.enable_timing(True)
-    # per-launch duration of the step kernel from HIP events on the kernel's own stream (separate short loop so that
-    # the event synchronisation does not sit inside the timed region)
-    for i in range(min(args.steps, 50)):
-        local_step(acts[i % n_act])
-        kernel_ms.append(env.last_step_kernel_ms())
-    env.enable_timing(False)
-    if streaming:
-        env.pool_streaming(False)
-    t = torch.tensor([elapsed, local_elapsed or 0.0], dtype=torch.float64, device=dev)
+        c0 = {k: env.counter(k) for k in ("settle_substeps", "resets", "lookahead_served", "lookahead_settled", "reset_stalls", "limit_path_substeps",
+                                          "self_narrow_substeps")}
+        # the step kernel's launches of the timed region between two HIP events on the kernel's own stream (qs_enable_timing: one event in
+        # front of the first launch, one behind the last): per-launch duration for the roofline, measured over the timed region itself
+        env.enable_timing(True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_fn(acts[i % n_act])
+        kernel_ms = env.last_step_kernel_ms()      # records the closing event here, in stream order, and waits for it
+        barrier()
+        elapsed = time.perf_counter() - t0
+        env.enable_timing(False)
+        c1 = {k: env.counter(k) for k in c0}
+        backlog = env.counter("lookahead_backlog") if args.reset_lookahead else 0
+        local_elapsed = None
+        if with_exchange:   # the same number of steps without the exchange, to price it (reported as config.exchange_us; not the headline)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                local_step(acts[i % n_act])
+            barrier()
+            local_elapsed = time.perf_counter() - t1
+        res = dict(elapsed=elapsed, kernel_ms=kernel_ms, local_elapsed=local_elapsed, delta={k: c1[k] - c0[k] for k in c0}, backlog=backlog,
+                   action_dim=d, obs_dim=env.obs_dim, settle_steps=env.cfg.settle_steps, lookahead=env.cfg.reset_lookahead)
+        env.close()
+        return res
+
+    m = run(kw, sharded)
+    m_info = None
+    if not kw["info_fields"] and not args.no_info_line and not sharded:
+        m_info = run(dict(kw, info_fields=True), False)
+    elapsed_local = m["elapsed"]
+    t = torch.tensor([m["elapsed"], m["local_elapsed"] or 0.0, m_info["elapsed"] if m_info else 0.0], dtype=torch.float64, device=dev)
+    tmin = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+    rccl_ranks = 1
     if world > 1:
+        rccl_ranks = torch.distributed.get_world_size()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed, local_elapsed = float(t[0].item()), (float(t[1].item()) if sharded else None)
+        torch.distributed.all_reduce(tmin, op=torch.distributed.ReduceOp.MIN)
+    elif sharded:
+        rccl_ranks = torch.distributed.get_world_size()
+    elapsed, local_elapsed, info_elapsed = float(t[0].item()), (float(t[1].item()) if sharded else None), float(t[2].item())
     total_steps = n * world * args.steps
     if rank == 0:
-        kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
-        algo_bytes = 736 + 44 * d + 4 * env.obs_dim + (64 if kw["action_space_mode"] == "CPG" else 0)   # B(d, o); 1112 for d = 6, o = 28
+        d = m["action_dim"]
+        kavg = m["kernel_ms"] * 1e-3
+        algo_bytes = 736 + 44 * d + 4 * m["obs_dim"] + (64 if kw["action_space_mode"] == "CPG" else 0)   # SURVEY.md 8(d): B(d, o); 1112 for d = 6, o = 28
         achieved = n * algo_bytes / kavg / 1e9
         # HBM bytes per launch: rocprofv3 cannot run inside this process, so the figure is the PMC byte count of the committed
         # passes of this very configuration (roofline.traffic_source names the file); null when the run differs from every profiled one
@@ -318,8 +374,8 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True):
                 p = json.load(open(f))
-                if (p["workload"], p["envs_per_gpu"], p["reset_pool"], p["settle_lanes"], p.get("friction_model", "pyramid"),
-                        float(p.get("solver_residual_threshold", 0.0))) == (args.workload, n, args.reset_pool, streaming, args.friction_model,
+                if (p["workload"], p["envs_per_gpu"], p.get("reset_lookahead"), p.get("friction_model", "pyramid"),
+                        float(p.get("solver_residual_threshold", 0.0))) == (args.workload, n, args.reset_lookahead, args.friction_model,
                                                                             float(args.solver_residual_threshold)):
                     pmc, pmc_file = p, os.path.relpath(f, REPO)
                     break
@@ -331,13 +387,14 @@ def main():
                     peak = prop.multi_processor_count * 4 * getattr(prop, "clock_rate", 2.4e6) * 1e3 / 4 / 1e9
                     valu = {"achieved": pmc["sq_insts_valu"] / kavg / 1e9, "peak": peak, "unit": "G wave-instructions/s",
                             "frac": pmc["sq_insts_valu"] / kavg / 1e9 / peak,
-                            "note": "SQ_INSTS_VALU per launch (committed PMC passes) / live step-kernel duration, against SIMDs x clock / 4; " +
+                            "note": "SQ_INSTS_VALU per launch (committed PMC passes, steady-state launches only) / live step-kernel duration, against SIMDs x clock / 4; " +
                                     (f"at N = {n} only {(n // 16) / (prop.multi_processor_count * 4):.0%} of the SIMDs hold a stepping wave"
                                      if n // 16 < prop.multi_processor_count * 4 else f"at N = {n} every SIMD holds {(n // 16) / (prop.multi_processor_count * 4):.0f} stepping waves")}
         except (OSError, KeyError, ValueError):
             pmc = None
-        resets = int(stats1["resets"] - stats0["resets"])
-        settle_sub = int(stats1["settle_substeps"] - stats0["settle_substeps"])
+        dl = m["delta"]
+        resets, settle_sub = int(dl["resets"]), int(dl["settle_substeps"])
+        K = m["lookahead"]
         out = {
             "metric": metric_name(args.workload, kw, n, world, args.total_envs),
             "value": total_steps / elapsed,
@@ -354,35 +411,44 @@ def main():
             "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
                        "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True, "preroll_steps": args.preroll,
-                       "reset": ((f"pool of {args.reset_pool} pre-settled states per GPU, " +
-                                  ("consumed entries re-settled by extra workgroups of the step kernel (settle lanes)" if streaming else "filled once before the timed region"))
-                                 if args.reset_pool else "2500-substep settle inside the step"),
+                       "reset_lookahead": K,
+                       "reset": ((f"exact: every environment takes its own next reset state (randomizer draws of (seed, env, episode), spawn, {m['settle_steps']} settle "
+                                  f"substeps), settled up to {K} episodes ahead by extra workgroups of the step kernel (settle lanes); bitwise the in-step settle")
+                                 if K else f"{m['settle_steps']}-substep settle inside the step"),
                        "resets_in_timed_region": resets,
-                       "pool_states_settled_in_timed_region": int(refills1 - refills0),
+                       # resets whose state was not ready (K consecutive episodes shorter than one settle): they settle inside the step, 2500 substeps
+                       # for their whole wave -- ~170 steps' time each
+                       "stalls": int(dl["reset_stalls"]),
+                       "lookahead_states_settled_in_timed_region": int(dl["lookahead_settled"]),
+                       "lookahead_backlog_at_end": int(m["backlog"]),
                        "settle_substeps_in_timed_region": settle_sub,
                        # settle work executed inside the timed region / the settle work its resets are worth (1.0 = every reset paid for
-                       # inside the region; short runs see less because an entry takes settle_steps / action_repeat launches to settle)
-                       "settle_work_ratio": (settle_sub / (resets * env.cfg.settle_steps)) if resets else None,
-                       "joint_limit_path_wave_substeps": int(limit1 - limit0),
-                       "self_collision_narrow_phase_wave_substeps": int(narrow1 - narrow0),
+                       # inside the region; a short region catches the bursts of the reset rate)
+                       "settle_work_ratio": (settle_sub / (resets * m["settle_steps"])) if resets else None,
+                       "joint_limit_path_wave_substeps": int(dl["limit_path_substeps"]),
+                       "self_collision_narrow_phase_wave_substeps": int(dl["self_narrow_substeps"]),
+                       "rccl_ranks": rccl_ranks,
+                       "rank_ms_per_step_min_max": [1e3 * float(tmin[0].item()) / args.steps, 1e3 * elapsed / args.steps],
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step (both skipped on one rank), results land in rank 0's rollout buffer" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_file, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
                          "algorithmic_bytes_per_env_step": algo_bytes,
-                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / live k_step duration (HIP events on the kernel's stream; the events add ~1.5 % to a 0.1 ms launch); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same live duration, GB/s; the step is ~30 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
+                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / average k_step launch duration over the timed region (two HIP events on the kernel's stream around all its launches: includes the ~1 us between back-to-back launches, so it lies between rocprofv3's kernel average and ms_per_step); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~30 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
         }
+        if m_info is not None:
+            out["value_info_fields_true"] = total_steps / info_elapsed     # the default handle of QuadrupedVecEnv: every step also stores torques, foot forces, pose cache
+            out["config"]["stalls_info_fields_true"] = int(m_info["delta"]["reset_stalls"])
         if sharded:
             out["config"]["local_ms_per_step"] = 1e3 * local_elapsed / args.steps
             out["config"]["exchange_us"] = 1e6 * (elapsed - local_elapsed) / args.steps
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a property of the box, reported with the single-GPU line only
             import subprocess
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
-                                    "--solver-residual-threshold", str(args.solver_residual_threshold), "--friction-model", args.friction_model], capture_output=True, text=True, timeout=300)
+                                    "--solver-residual-threshold", str(args.solver_residual_threshold), "--friction-model", args.friction_model], capture_output=True, text=True, timeout=400)
             if child.returncode != 0:
                 raise SystemExit("cpu_baseline child failed:\n" + child.stderr[-2000:])
             out["cpu_baseline"] = json.loads(child.stdout.strip().splitlines()[-1])
-    env.close()
     if world > 1 or sharded:
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -91,7 +91,13 @@ typedef struct qs_config {
     int32_t randomizer_flags;
     int32_t noise_enabled;
     int32_t auto_reset;          /* SB3 VecEnv convention: finished environments are reset inside qs_step */
-    int32_t reset_pool;          /* 0: every reset runs the 2500-substep settle; P > 0: resets draw from P pre-settled states */
+    int32_t reset_lookahead;     /* K: reset states kept ready per environment.  A reset's settled state depends on (seed, global environment
+                                  * id, episode number) only, so the states of an environment's next K episodes are computed ahead of
+                                  * time -- at qs_create for episodes 0 .. K-1, then one per reset by extra workgroups of the step kernel
+                                  * (qs_settle_lanes) -- and a reset copies its own.  0: every reset runs the 2500-substep settle in place.
+                                  * Either way the results are bitwise the same; K only decides when the settle work is done.  A reset
+                                  * whose state is not ready (K consecutive episodes shorter than one settle) settles in place and is
+                                  * counted (QS_COUNTER_RESET_STALLS).  Ignored under QS_RAND_KEEP.  N x K x 1152 bytes. */
     int32_t env_id_offset;       /* global id of environment 0 (sharded runs): RNG streams are keyed by the global id */
     int32_t wrapper_mode;        /* 0 none, 1 LandingWrapper, 2 GoToRestWrapper as a per-environment mode machine */
     uint64_t seed;
@@ -193,31 +199,33 @@ int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets);
  * kernel itself instead of being packed from four arrays afterwards. */
 int qs_step_fused(qs_handle* h, const float* actions, float* fused);
 /* Telemetry counters (synchronises the stream). */
-enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset, exact auto-resets, settle lanes) */
+enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset, in-step settles, settle lanes) */
        QS_COUNTER_RESETS = 1,               /* environment resets */
-       QS_COUNTER_POOL_CONSUMED = 2,        /* auto-resets served from the reset pool */
-       QS_COUNTER_POOL_REFILLED = 3,        /* pool entries re-settled by the streaming refill */
+       QS_COUNTER_LOOKAHEAD_SERVED = 2,     /* resets that took a look-ahead state */
+       QS_COUNTER_LOOKAHEAD_SETTLED = 3,    /* look-ahead states the settle lanes have delivered */
        QS_COUNTER_LIMIT_PATH_SUBSTEPS = 4,  /* wave-substeps in which some joint of the wave's 16 environments sat at a stop or (body_contacts)
                                                a non-foot link touched the plane: those run the slow many-rows-per-leg solver (per
                                                process, not per handle) */
-       QS_COUNTER_SELF_NARROW_SUBSTEPS = 5  /* wave-substeps whose self-collision broad phase found a calf close enough to another leg or
-                                               the trunk to run the link-link tests (per process) */ };
+       QS_COUNTER_SELF_NARROW_SUBSTEPS = 5, /* wave-substeps whose self-collision broad phase found a calf close enough to another leg or
+                                               the trunk to run the link-link tests (per process) */
+       QS_COUNTER_RESET_STALLS = 6,         /* resets of a handle with reset_lookahead > 0 whose state was not ready: settled in place */
+       QS_COUNTER_LOOKAHEAD_BACKLOG = 7,    /* settles queued and not yet taken by a settle lane */
+       QS_COUNTER_LOOKAHEAD_DROPPED = 8     /* settles that found the queue full (re-queued by the environment's next reset) */ };
 int qs_counter(qs_handle* h, int which, uint64_t* value);
-/* HIP events bracketing the step kernel of the most recent qs_step (on the handle's stream): elapsed milliseconds, for
- * bench.py's roofline leg.  Recording is off by default (qs_enable_timing). */
+/* Average duration of the step-kernel launches of a BATCH of qs_step calls, from two HIP events on the handle's stream: one recorded in
+ * front of the first step launched after qs_enable_timing(h, 1), one recorded by qs_last_step_kernel_ms, which waits for it, returns
+ * elapsed milliseconds / launches since the first event and starts the next batch.  For bench.py's roofline leg: the figure covers the
+ * timed region itself and includes the gaps between back-to-back launches, so it can never be shorter than the kernel's own duration nor
+ * longer than the wall time per step (a pair of events around every single 0.07-ms launch read 5 % high). */
 int qs_enable_timing(qs_handle* h, int on);
 int qs_last_step_kernel_ms(qs_handle* h, float* ms);
-/* redraw the pool of pre-settled reset states (cfg.reset_pool > 0): new parameter draws, 2500 settle substeps each */
-int qs_refresh_pool(qs_handle* h);
-/* Demand-driven refill of the pool while the environments step ("settle lanes").  While on, every qs_step launch carries
- * extra workgroups that advance records of a staging copy through a reset's settle (gym_env.py:278-297, 325-327: randomizer
- * draws, spawn, 2500 substeps under the settling command), action_repeat substeps per launch through the same substep loop
- * as the environments.  An epoch = the settle_steps/action_repeat launches one settle takes; between epochs the finished
- * records replace pool entries at a rotating cursor, and the next epoch settles as many records as auto-resets have consumed
- * since (at most reset_pool).  Every pooled reset is thus backed by settle work executed next to the stepping, and the
- * schedule depends only on the sequence of qs_step calls (bitwise reproducible).  `refilled` (may be NULL; reading it
- * synchronises the stream) receives the number of entries re-settled so far; qs_stats counts their substeps. */
-int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled);
+/* The settle lanes of a handle with cfg.reset_lookahead > 0 (on from qs_create).  While on, every qs_step launch carries extra
+ * workgroups that advance the queued resets (gym_env.py:278-297, 325-327: randomizer draws, spawn, 2500 substeps under the settling
+ * command) by action_repeat substeps each, through the same substep loop as the environments; a finished one goes to its environment's
+ * look-ahead slot.  An epoch = the settle_steps / action_repeat launches one settle takes; the lanes work in five cohorts that start a
+ * fifth of an epoch apart.  Off: queued settles wait (the ones in progress start over when the lanes come back), resets use up the
+ * states that are ready and then settle in place -- results do not change, only when the work is done. */
+int qs_settle_lanes(qs_handle* h, int on);
 /* Per-substep trace tap for ONE environment (evaluation_wrapper.py:14,36-41 set_sub_step_callback; monitor_state.py:66-85):
  * while set, every qs_step writes action_repeat rows of QS_TRACE_DIM floats into `rows` (device memory, caller owned), one per
  * physics substep of environment `env`: sim time, base position 3, quaternion xyzw 4, linear velocity 3, angular velocity 3,

@@ -68,6 +68,13 @@ class Oracle:
         self._check(self.lib.qso_step(self.h, self._p(a), self._p(obs), self._p(rew), self._p(done), self._p(trunc)))
         return obs, rew, done.astype(bool), trunc.astype(bool)
 
+    def rollout(self, ring, steps):
+        """bench.py's cpu_baseline: `steps` env steps with the action ring [n_ring, n, d], threads not meeting between steps; -> episodes ended."""
+        ring = np.ascontiguousarray(ring, np.float32).reshape(-1, self.n, self.d)
+        resets = C.c_ulonglong(0)
+        self._check(self.lib.qso_rollout(self.h, self._p(ring), int(ring.shape[0]), int(steps), C.byref(resets)))
+        return int(resets.value)
+
     def get_state(self):
         s = np.zeros((self.n, 37), self.real)
         self._check(self.lib.qso_get_state(self.h, self._p(s)))

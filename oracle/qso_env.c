@@ -671,7 +671,7 @@ int qso_set_demo_counter(qso_handle* h, const uint8_t* mask, const int32_t* valu
 
 int qso_reset(qso_handle* h, const uint8_t* mask) {
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (int i = 0; i < h->cfg.n_envs; i++) if (!mask || mask[i]) reset_env(h, i);
     return 0;
@@ -698,19 +698,13 @@ static wrap_traits wrap_traits_of(int mode) {
     }
 }
 
-int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
+/* one QuadrupedGymEnv.step of environment i (gym_env.py:227-256); returns 1 when the episode ended */
+static int step_env(qso_handle* h, int i, const float* action_row, float* obs_row, float* rew, uint8_t* done, uint8_t* trunc) {
     const qso_config* cfg = &h->cfg; int d = cfg->action_dim;
-    if (task_family_demo(cfg->task) && !h->demo) FAIL("the DEMO tasks need a demonstration: qso_set_demo first");
-    /* environments are independent (gym_env.py:132-137): with -fopenmp they spread over OMP_NUM_THREADS host threads, which is
-       what bench.py's cpu_baseline uses; the default is one thread */
-#ifdef _OPENMP
-#pragma omp parallel for schedule(static)
-#endif
-    for (int i = 0; i < cfg->n_envs; i++) {
+    {
         qso_env* e = &h->env[i];
-        /* gym_env.py:227-256 */
         real act[12], act_in[12];
-        for (int k = 0; k < d; k++) act_in[k] = act[k] = actions[(size_t)i * d + k];
+        for (int k = 0; k < d; k++) act_in[k] = act[k] = action_row[k];
         /* scripted phases of the wrappers, one inner env.step per call (landing_wrapper*.py, go_to_rest_wrapper.py:43-80) */
         real kp_save[3], kd_save[3]; int swapped = 0;
         const real env_dt = (real)cfg->action_repeat * (real)cfg->dt;
@@ -796,10 +790,51 @@ int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_
         }
         read_sensors(cfg, e, e->obs);
         add_noise(cfg, e, i, e->obs);
-        rew[i] = (float)r; done[i] = (uint8_t)dn; trunc[i] = (uint8_t)(dn && !term);
+        *rew = (float)r; *done = (uint8_t)dn; *trunc = (uint8_t)(dn && !term);
         if (dn && cfg->auto_reset) { memcpy(e->term_obs, e->obs, sizeof(e->obs)); reset_env(h, i); }
-        memcpy(obs + (size_t)i * cfg->obs_dim, e->obs, cfg->obs_dim * sizeof(float));
+        if (obs_row) memcpy(obs_row, e->obs, cfg->obs_dim * sizeof(float));
+        return dn;
     }
+}
+
+int qso_step(qso_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
+    const qso_config* cfg = &h->cfg; const int d = cfg->action_dim;
+    if (task_family_demo(cfg->task) && !h->demo) FAIL("the DEMO tasks need a demonstration: qso_set_demo first");
+    /* environments are independent (gym_env.py:132-137): with -fopenmp they spread over OMP_NUM_THREADS host threads (default: one).
+       dynamic, 1: an environment that ends its episode settles 2500 substeps inside its step (250 steps' worth of work) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int i = 0; i < cfg->n_envs; i++)
+        step_env(h, i, actions + (size_t)i * d, obs + (size_t)i * cfg->obs_dim, rew + i, done + i, trunc + i);
+    return 0;
+}
+
+/* Throughput harness of bench.py's cpu_baseline leg.  Every host thread owns a contiguous share of the environments and steps them
+   `steps` times with the actions ring[t % n_ring][env][:] WITHOUT meeting the other threads between steps: the reference scaled over the
+   host's cores as independent workers is the CPU's best case -- a reset's in-place settle (2500 substeps, gym_env.py:323-329) then delays
+   its own thread only, not a whole lock-stepped batch.  resets (may be NULL) receives the number of episodes that ended. */
+int qso_rollout(qso_handle* h, const float* ring, int n_ring, int steps, unsigned long long* resets) {
+    const qso_config* cfg = &h->cfg; const int d = cfg->action_dim, n = cfg->n_envs;
+    if (task_family_demo(cfg->task) && !h->demo) FAIL("the DEMO tasks need a demonstration: qso_set_demo first");
+    if (n_ring <= 0 || steps < 0) FAIL("qso_rollout: bad ring / step count");
+    unsigned long long total = 0;
+#ifdef _OPENMP
+#pragma omp parallel reduction(+ : total)
+#endif
+    {
+        int nt = 1, me = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads(); me = omp_get_thread_num();
+#endif
+        const int lo = (int)((long long)n * me / nt), hi = (int)((long long)n * (me + 1) / nt);
+        float r; uint8_t dn, tr;
+        for (int t = 0; t < steps; t++) {
+            const float* a = ring + (size_t)(t % n_ring) * n * d;
+            for (int i = lo; i < hi; i++) total += (unsigned long long)step_env(h, i, a + (size_t)i * d, NULL, &r, &dn, &tr);
+        }
+    }
+    if (resets) *resets = total;
     return 0;
 }
 

@@ -22,7 +22,7 @@ using E = Env<LaneDev>;
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
 // Range of a record that a step moves (qs_layout.h).  Loads [0, end): the parameters, the read-write block; the wrapper / CPG / DEMO
 // slots behind them only for handles that use those layers (or that store the info block, which lies behind them); everything under
-// cfg.payload_soft (the block's own state ends the record).  Stores [QS_RW_BEGIN, end) -- from 0 when a pooled reset rewrote the
+// cfg.payload_soft (the block's own state ends the record).  Stores [QS_RW_BEGIN, end) -- from 0 when a look-ahead reset rewrote the
 // parameters --: through the read-write block, the optional layers' slots when in use, the info block under cfg.info_fields.
 enum { TILE_INFO = QS_INFO_END, TILE_ALL = QS_REC_END };
 __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) {
@@ -80,19 +80,33 @@ __device__ __forceinline__ void obs_store(const float* s_obs, int nrow, int od, 
     }
 }
 
-struct PoolView { const float* pool; int size; };
-// Streaming refill of the reset pool ("settle lanes"): workgroups beyond the environments' ones advance records of the
-// staging copy through a reset's settle, one slice of substeps per launch; ctl = the counters in qs_handle::d_stats.
-// The staging copy is split into QS_COHORTS slices whose settles start QS_COHORTS-th of an epoch apart, so that finished
-// records reach the pool (and the demand is re-read) every epoch / QS_COHORTS launches instead of once per epoch.
+// ------------------------------------------------------------------ look-ahead resets
+// reset() = randomizer draws + spawn + settle_steps (2500) substeps (gym_env.py:278-297, 323-329): 250 env-steps' worth of physics whose
+// result depends on (seed, global environment id, episode number) only, not on the trajectory.  So every environment's NEXT K reset states
+// are computed ahead of time: slot (env, X mod K) holds the settled state of episode X once its R_EPISODE field says X.  A reset to
+// episode X copies that slot and queues the settle of episode X + K; the queue is served by extra workgroups of k_step ("settle lanes"),
+// action_repeat substeps per launch through the step's own substep loop, so the settle work of a run's resets is executed inside the run,
+// next to the stepping, on SIMDs the environments leave idle.  A reset that finds its slot not ready (K consecutive episodes shorter than
+// one settle: counted as a stall) settles inside the step as with K = 0 -- every output is bitwise what reset_lookahead = 0 produces.
+struct LookAhead {
+    float* slots;           // [N][K] records
+    int* queued;            // [N]: last episode of each environment whose settle has been queued
+    int2* jobs;             // ring of (environment, episode) waiting for a settle lane; head / tail in the handle's counters
+    unsigned qmask;         // ring size - 1 (a power of two)
+    int K;
+};
+// Settle lanes: workgroups beyond the environments' ones advance records of a staging area through a reset's settle, one slice of substeps
+// per launch; ctl = the counters in qs_handle::d_stats.  The staging area is split into QS_COHORTS slices whose settles start QS_COHORTS-th
+// of an epoch (= the launches one settle takes) apart, so that queued jobs wait at most epoch / QS_COHORTS launches for a lane.
 #define QS_COHORTS 5
 #define QS_MAX_SLICE 2048
-struct SettleLanes { float* staging; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS], generation[QS_COHORTS]; };
+struct SettleLanes { float* staging; const int2* stage_jobs; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
 struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
-enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_CONSUMED = 2, CTL_BACKED = 3, CTL_REFILLED = 4, CTL_CURSOR = 5, CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
+enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_Q_TAIL = 4, CTL_Q_HEAD = 5, CTL_STALLS = 6, CTL_DROPPED = 7,
+       CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
 
-// settled-state fields a pooled reset copies into the record (everything the 2500-substep settle determines)
+// settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines)
 __device__ __forceinline__ void copy_settled(float* rec, const float* src, bool block) {
     const int lane = threadIdx.x & 3;
     if (block) for (int i = R_BLOCK + lane; i < R_BLOCK + QS_BLOCK_DIM; i += 4) rec[i] = src[i];   // the payload block settled with the robot
@@ -100,6 +114,37 @@ __device__ __forceinline__ void copy_settled(float* rec, const float* src, bool 
     for (int i = R_PARAMS + lane; i < R_PARAMS + QS_PARAM_DIM; i += 4) rec[i] = src[i];  // params
     for (int i = R_FOOT_FORCE + lane; i < R_TAU_SPRING + 12; i += 4) rec[i] = src[i];    // contact results, torques
     if (lane == 0) rec[R_N_INVALID] = src[R_N_INVALID];
+}
+// A reset of `env` to episode X (called by the four lanes of its quad): the slot that holds the settled state of that episode, or null when
+// it is not there (yet); lane 0 queues the settles that the window X + 1 .. X + K now lacks (normally the one of episode X + K).
+__device__ __forceinline__ const float* lookahead_take(const LookAhead& la, unsigned long long* __restrict__ ctl, int env, int X, bool count = true) {
+    if (la.K == 0) return nullptr;
+    const float* slot = la.slots + ((size_t)env * la.K + (size_t)(X % la.K)) * QS_REC;
+    const bool ready = qs::f2i(slot[R_EPISODE]) == X;
+    if ((threadIdx.x & 3) == 0) {
+        const int q = la.queued[env], to = X + la.K;
+        int Y = (q > X ? q : X) + 1;
+        for (; Y <= to; Y++) {
+            unsigned long long t = ctl[CTL_Q_TAIL];
+            bool room;
+            for (;;) {      // reserve a ring entry unless the ring is full (then the job is not queued now: the next reset tries again)
+                room = t - ctl[CTL_Q_HEAD] <= (unsigned long long)la.qmask;
+                if (!room) break;
+                const unsigned long long seen = atomicCAS(&ctl[CTL_Q_TAIL], t, t + 1);
+                if (seen == t) break;
+                t = seen;
+            }
+            if (!room) { atomicAdd(&ctl[CTL_DROPPED], 1ull); break; }
+            la.jobs[(unsigned)t & la.qmask] = make_int2(env, Y);
+        }
+        if (Y - 1 > q) la.queued[env] = Y - 1;
+        if (count) atomicAdd(&ctl[ready ? CTL_SERVED : CTL_STALLS], 1ull);
+    }
+    return ready ? slot : nullptr;
+}
+__device__ __forceinline__ void zero_tile_tail(float* lds, int from, int stride) {   // floats [from, stride) of the 16 records in LDS
+    const int per = stride - from;
+    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * per; i += QS_WAVE) { const int e = i / per; lds[e * stride + from + (i - e * per)] = 0.0f; }
 }
 
 // ------------------------------------------------------------------ kernels
@@ -120,12 +165,13 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
 
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
 // The body is compiled twice (k_step / k_step_dense below) under different register budgets.
-// EXACT: the build that can settle a finished environment inside the step (reset_pool = 0); the pooled builds leave that code out
-template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+// RESET: the build for handles with cfg.auto_reset (a finished environment takes its look-ahead slot, or settles inside the step when
+// that is not ready / reset_lookahead = 0); handles without auto-reset leave that code out
+template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                  const float* __restrict__ actions, float* __restrict__ obs_out,
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
-                                                 float* __restrict__ term_obs, PoolView pool,
+                                                 float* __restrict__ term_obs, LookAhead la,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
     using E = Env<LaneDev, CONE, false, WAVES == 1>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
     using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
@@ -137,11 +183,11 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     float* const s_obs = s_dyn + QS_ENVS_PER_WAVE * ls;
     float* const s_act = s_obs + QS_ENVS_PER_WAVE * QS_MAX_OBS;
     QS_PHASE_BEGIN
-    const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles pool records
+    const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles staging records
     const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
     const int first = settling ? cohort * lanes.slice + (((int)blockIdx.x - lanes.n_env_waves) % lanes.waves_per_cohort) * QS_ENVS_PER_WAVE
                                : (int)blockIdx.x * QS_ENVS_PER_WAVE;
-    // CTL_R[cohort] is only written between launches (k_pool_plan)
+    // CTL_R[cohort] is only written between launches (k_lookahead_plan)
     const int limit = settling ? cohort * lanes.slice + (int)stats[CTL_R + cohort] : cfg.n_envs;
     if (first >= limit) return;
     const int settle_n = settling ? lanes.settle_n[cohort] : 0;
@@ -155,15 +201,20 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     // the quad of an environment fetches its action row (lane l takes entries l, l + 4, l + 8) -- issued before the tile loads, whose
     // latency then covers it
     float a_pre[3] = {0.0f, 0.0f, 0.0f};
+    int2 job = make_int2(0, 0);                                          // settle lanes: whose reset this record is (environment, episode)
     if (!settling) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int k = (int)(threadIdx.x & 3u) + 4 * j;
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
-    }
-    const int load_extent = settling && !cfg.payload_soft ? (int)QS_SETTLE_END : tile_extent(cfg, false);
-    tile_load(s_rec, base, first, limit, load_extent, ls);
+    } else job = lanes.stage_jobs[valid ? env : first];
+    const bool spawn = settling && lanes.spawn[cohort], last = settling && lanes.last[cohort];
+    const int load_extent = settling ? (spawn ? 0 : (cfg.payload_soft ? (int)TILE_ALL : (int)QS_SETTLE_END)) : tile_extent(cfg, false);
+    // (a settle's first slice writes parameters and spawn state itself and reads nothing; its last slice leaves a whole record behind,
+    // of which only the settled fields mean anything: the rest is zero rather than whatever the LDS held)
+    if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
+    if (spawn || last) zero_tile_tail(s_rec, load_extent, ls);
     QS_PHASE(27)
     if (!settling) {
 #pragma unroll
@@ -177,8 +228,9 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
     QS_PHASE(29)
     float* rec = s_rec + slot * ls;
     float* ob = s_obs + slot * QS_MAX_OBS;
-    const uint32_t gid = settling ? 0x40000000u + (uint32_t)env : (uint32_t)(env + cfg.env_id_offset);
-    if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
+    if (cfg.info_fields && (threadIdx.x & 3) == 0) rec[QS_INFO_END - 1] = 0.0f;   // the pad float behind the info block, stored with it
+    const uint32_t gid = (uint32_t)((settling ? job.x : env) + cfg.env_id_offset);
+    if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
     float* const trow = any_trace && env == tap.env ? tap.rows : nullptr;
@@ -191,9 +243,10 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
             // env step of the whole wave with the full build
             __syncthreads();
-            tile_load(s_rec, base, first, limit, load_extent, ls);
+            if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
+            if (spawn || last) zero_tile_tail(s_rec, load_extent, ls);
             __syncthreads();
-            if (settling && lanes.spawn[cohort]) { E::settle_spawn(cfg, rec, gid, lanes.generation[cohort]); LaneDev::sync(); }
+            if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
         }
     }
     if (__builtin_expect(r.redo, 0)) {
@@ -205,8 +258,8 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
         __syncthreads();
         // a slice of a settle changes the rigid-body state and the warm start; its first slice also drew the parameters, its last one
         // leaves the info block's results (and n_invalid) that copy_settled hands to a reset
-        tile_store(s_rec, base, first, limit, lanes.spawn[cohort] ? 0 : (int)QS_RW_BEGIN,
-                   cfg.payload_soft ? (int)TILE_ALL : (lanes.last[cohort] ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
+        tile_store(s_rec, base, first, limit, spawn ? 0 : (int)QS_RW_BEGIN,
+                   cfg.payload_soft ? (int)TILE_ALL : (last ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
         return;
     }
     const bool dn = r.done > 0.5f;
@@ -217,39 +270,38 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
             row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
         }
     }
-    bool any_reset = false;   // wave-uniform: a pooled reset rewrote the parameters of some record of the tile
-    if (cfg.auto_reset) {
+    bool any_reset = false;   // wave-uniform: a look-ahead reset rewrote the parameters of some record of the tile
+    if (RESET) {
         const bool do_reset = dn && valid;
         if (__builtin_expect(__any(do_reset), 0)) {
             any_reset = true;
             LaneDev::sync();
+            const float* ahead = nullptr;
             if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
                 for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
-                if ((threadIdx.x & 3) == 0) atomicAdd(&stats[1], 1ull);
+                if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
+                ahead = lookahead_take(la, stats, env, qs::f2i(rec[R_EPISODE]) + 1);
+                if (ahead) copy_settled(rec, ahead, cfg.payload_soft != 0);
             }
-            if (!EXACT || pool.size > 0) {
-                if (do_reset) {
-                    uint32_t rr[4];
-                    qs::philox4x32(cfg.seed, gid, 2u, (uint32_t)(qs::f2i(rec[R_EPISODE]) + 1), 0u, rr);
-                    copy_settled(rec, pool.pool + (size_t)(rr[0] % (uint32_t)pool.size) * QS_REC, cfg.payload_soft != 0);
-                    if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_CONSUMED], 1ull);   // pool entries consumed: what the streaming refill owes
-                }
-                LaneDev::sync();
-                if (do_reset) E::reset(cfg, rec, ob, gid, false);
-            } else {
-                // exact mode: the whole wave walks through the 2500-substep settle.  The settle's solver uses v_mfma_f32_4x4x1, which
-                // ignores EXEC, so it must not run under a divergent branch: what the step produced is published first, then EVERY quad
-                // runs the reset on its LDS copy (as k_reset does) and only the finished environments keep the result.
+            LaneDev::sync();
+            if (ahead) E::reset(cfg, rec, ob, gid, false);
+            const bool stalled = do_reset && !ahead;
+            if (__builtin_expect(__any(stalled), 0)) {
+                // no settled state ahead (reset_lookahead = 0, or all K slots used up faster than the lanes settle): the whole wave walks
+                // through the 2500-substep settle.  The settle's solver uses v_mfma_f32_4x4x1, which ignores EXEC, so it must not run
+                // under a divergent branch: what the step produced is published first, then EVERY quad runs the reset on its LDS copy (as
+                // k_reset does) and only the stalled environments keep the result.
                 __syncthreads();
-                tile_store(s_rec, recs, first, cfg.n_envs, QS_RW_BEGIN, tile_extent(cfg, true), ls);
+                tile_store(s_rec, recs, first, cfg.n_envs, 0, tile_extent(cfg, true), ls);
                 obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
                 __syncthreads();
                 E::reset(cfg, rec, ob, gid, true);
-                if (do_reset && (threadIdx.x & 3) == 0) atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps);
+                if (stalled && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
                 LaneDev::sync();
-                if (do_reset) {
+                if (stalled) {
                     float* g = recs + (size_t)env * QS_REC;
-                    for (int i = threadIdx.x & 3; i < ls; i += 4) g[i] = rec[i];
+                    const int end = tile_extent(cfg, true);       // (what lies behind it was neither loaded nor is it this handle's to write)
+                    for (int i = threadIdx.x & 3; i < end; i += 4) g[i] = i == QS_INFO_END - 1 ? 0.0f : rec[i];   // (the pad float of the info block)
                     for (int i = threadIdx.x & 3; i < od; i += 4) {
                         if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
                         else obs_out[(size_t)env * (od + 2) + i] = ob[i];
@@ -268,52 +320,66 @@ template <bool CONE, bool EXACT, int WAVES> static __device__ __forceinline__ vo
 
 #define QS_STEP_ARGS const qs_config* __restrict__ cfgp, float* __restrict__ recs, const float* __restrict__ actions, float* __restrict__ obs_out,    \
                      float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep, \
-                     float* __restrict__ term_obs, PoolView pool, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo
-#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, pool, stats, lanes, tap, demo
+                     float* __restrict__ term_obs, LookAhead la, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo
+#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, la, stats, lanes, tap, demo
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
-template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, EXACT, 1>(QS_STEP_PASS); }
+template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, RESET, 1>(QS_STEP_PASS); }
 // Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
 // issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
 // (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
-template <bool CONE, bool EXACT> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, EXACT, 2>(QS_STEP_PASS); }
+template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, RESET, 2>(QS_STEP_PASS); }
 
-// Streaming refill, between two epochs (an epoch = the launches one settle takes): publish the staging records that finished
-// settling into the pool (they replace the entries at the rotating cursor) ...
-__global__ void k_pool_publish(const unsigned long long* __restrict__ ctl, const float* __restrict__ staging, float* __restrict__ pool, int pool_size,
-                               int cohort, int slice) {
-    const size_t total = (size_t)ctl[CTL_R + cohort] * QS_REC;
-    const size_t cursor = (size_t)ctl[CTL_CURSOR];
+// Settle lanes, between two settles of a cohort (an epoch = the launches one settle takes): the staging records that finished settling go
+// to the look-ahead slots of their environments (the settled fields of copy_settled; R_EPISODE marks the slot as holding that episode) ...
+__global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const float* __restrict__ staging, const int2* __restrict__ stage_jobs,
+                                    LookAhead la, int cohort, int slice) {
+    const int n = (int)ctl[CTL_R + cohort];
     const float* src = staging + (size_t)cohort * slice * QS_REC;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t e = i / QS_REC, f = i % QS_REC;
-        pool[((cursor + e) % (size_t)pool_size) * QS_REC + f] = src[i];
+    const int2* jobs = stage_jobs + (size_t)cohort * slice;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * QS_REC_END; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i / QS_REC_END), f = (int)(i % QS_REC_END);
+        const int2 job = jobs[e];
+        float* dst = la.slots + ((size_t)job.x * la.K + (size_t)(job.y % la.K)) * QS_REC;
+        dst[f] = f == R_EPISODE ? qs::i2f(job.y) : src[(size_t)e * QS_REC + f];
     }
 }
-// ... then decide how many records this cohort settles next: as many as auto-resets have consumed and no refill has matched yet.
-__global__ void k_pool_plan(unsigned long long* __restrict__ ctl, int pool_size, int cohort, int slice, int abort_all) {
-    if (blockIdx.x || threadIdx.x) return;
-    const unsigned long long P = (unsigned long long)pool_size;
-    if (abort_all) {   // streaming switched off: settles in progress are dropped, nothing was delivered for them
-        for (int c = 0; c < QS_COHORTS; c++) { ctl[CTL_BACKED] -= ctl[CTL_R + c]; ctl[CTL_R + c] = 0; }
-        return;
+// ... then the cohort takes the jobs that wait in the ring, at most `cap` (the lanes the launch geometry gives it).
+__global__ void k_lookahead_plan(unsigned long long* __restrict__ ctl, LookAhead la, int2* __restrict__ stage_jobs, int cohort, int slice, int cap) {
+    __shared__ unsigned long long s_head;
+    __shared__ int s_n;
+    if (threadIdx.x == 0) {
+        ctl[CTL_SETTLED] += ctl[CTL_R + cohort];
+        const unsigned long long head = ctl[CTL_Q_HEAD], tail = ctl[CTL_Q_TAIL];
+        unsigned long long n = tail - head;
+        if (n > (unsigned long long)cap) n = (unsigned long long)cap;
+        s_head = head; s_n = (int)n;
     }
-    ctl[CTL_CURSOR] = (ctl[CTL_CURSOR] + ctl[CTL_R + cohort]) % P;
-    ctl[CTL_REFILLED] += ctl[CTL_R + cohort];
-    unsigned long long consumed = ctl[CTL_CONSUMED], backed = ctl[CTL_BACKED];
-    unsigned long long want = consumed > backed ? consumed - backed : 0;
-    if (want > P) { backed = consumed - P; want = P; }       // demand beyond a fully fresh pool is not owed later
-    if (want > (unsigned long long)slice) want = (unsigned long long)slice;
-    want -= want % QS_ENVS_PER_WAVE;
-    if (want < 32) want = 0;                                  // not worth two waves yet
-    ctl[CTL_BACKED] = backed + want;
-    ctl[CTL_R + cohort] = want;
+    __syncthreads();
+    int2* dst = stage_jobs + (size_t)cohort * slice;
+    for (int i = threadIdx.x; i < s_n; i += blockDim.x) dst[i] = la.jobs[(unsigned)(s_head + (unsigned long long)i) & la.qmask];
+    __syncthreads();
+    if (threadIdx.x == 0) { ctl[CTL_Q_HEAD] = s_head + (unsigned long long)s_n; ctl[CTL_R + cohort] = (unsigned long long)s_n; }
+}
+// Settle lanes paused (qs_settle_lanes(h, 0)): the jobs of the settles in progress go back into the ring (in front: they are the oldest)
+__global__ void k_lookahead_requeue(unsigned long long* __restrict__ ctl, LookAhead la, const int2* __restrict__ stage_jobs, int slice) {
+    if (blockIdx.x || threadIdx.x) return;
+    for (int c = QS_COHORTS - 1; c >= 0; c--) {
+        const int n = (int)ctl[CTL_R + c];
+        for (int i = n - 1; i >= 0; i--) {
+            if (ctl[CTL_Q_TAIL] - ctl[CTL_Q_HEAD] > (unsigned long long)la.qmask) { ctl[CTL_DROPPED] += 1; continue; }
+            ctl[CTL_Q_HEAD] -= 1;
+            la.jobs[(unsigned)ctl[CTL_Q_HEAD] & la.qmask] = stage_jobs[(size_t)c * slice + i];
+        }
+        ctl[CTL_R + c] = 0;
+    }
 }
 
-// QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297); all settles run side by side.
+// QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297).  An environment whose look-ahead slot holds the coming episode
+// takes it; the others settle side by side.
 template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ obs_keep,
-                                                      unsigned long long* __restrict__ stats, const float* __restrict__ states) {
+                                                      unsigned long long* __restrict__ stats, const float* __restrict__ states, LookAhead la) {
     using E = Env<LaneDev, CONE>;
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
@@ -323,12 +389,18 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
     const bool valid = env < cfg.n_envs;
     const bool sel = valid && (mask == nullptr || mask[env] != 0);
     if (!__any(sel)) return;
-    tile_load(s_rec, recs, first, cfg.n_envs, tile_extent(cfg, false));
+    tile_load(s_rec, recs, first, cfg.n_envs, QS_REC_END);   // the whole record: what comes back is written as a whole
     const int od = cfg.obs_dim;
     __syncthreads();
     float* rec = s_rec + slot * QS_REC_END;
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = (uint32_t)((valid ? env : 0) + cfg.env_id_offset);
+    const float* ahead = nullptr;
+    if (sel) {
+        ahead = lookahead_take(la, stats, env, qs::f2i(rec[R_EPISODE]) + 1, states == nullptr);   // (also queues what the window lacks after this reset)
+        if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
+    }
+    bool write_back = false;
     if (states) {   // reference-state initialisation (gym_env.py:278-297 with robot_desired_state set): randomizers, then the given
                     // rigid-body state instead of spawn + settle, then the task / sensor / filter reset of every reset
         if (sel) {
@@ -347,38 +419,54 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
         LaneDev::sync();
         if (sel)   // no settle ran, so _last_action and with it the filter history stay zero (gym_env.py:284, 267-269)
             for (int i = threadIdx.x & 3; i < 12 + 24 + 24; i += 4) rec[R_LAST_ACTION + i] = 0.0f;
-        if (sel && (threadIdx.x & 3) == 0) atomicAdd(&stats[1], 1ull);
+        write_back = sel;
     } else {
-        // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);
-        // quads that are not selected work on their LDS copy and simply do not write it back
-        E::reset(cfg, rec, ob, gid, true);
-        if (sel && (threadIdx.x & 3) == 0) { atomicAdd(&stats[0], (unsigned long long)cfg.settle_steps); atomicAdd(&stats[1], 1ull); }
+        if (ahead) copy_settled(rec, ahead, cfg.payload_soft != 0);
+        LaneDev::sync();
+        if (ahead) {
+            E::reset(cfg, rec, ob, gid, false);
+            float* g = recs + (size_t)env * QS_REC;
+            for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];
+            for (int i = threadIdx.x & 3; i < od; i += 4) obs_keep[(size_t)env * od + i] = ob[i];
+        }
+        const bool settle = sel && !ahead;
+        if (__any(settle)) {
+            // every quad of the wave runs the settle (identical control flow keeps the wave votes of the solver valid);
+            // quads that do not need it work on their LDS copy and simply do not write it back
+            __syncthreads();
+            E::reset(cfg, rec, ob, gid, true);
+            if (settle && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
+        }
+        write_back = settle;
     }
     __syncthreads();
-    if (sel) {
+    if (write_back) {
         float* g = recs + (size_t)env * QS_REC;
         for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];
         for (int i = threadIdx.x & 3; i < od; i += 4) obs_keep[(size_t)env * od + i] = ob[i];
     }
 }
 
-// Pre-settled reset states: entry p = reset of a virtual environment id 0x40000000 + p (its own parameter draw).
-template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_pool_fill(const qs_config* __restrict__ cfgp, float* __restrict__ pool, int first, int size, int generation) {
+// The look-ahead slots at qs_create: entry j = the reset of environment j % N to episode j / N (episodes 0 .. K - 1), all side by side.
+template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_lookahead_fill(const qs_config* __restrict__ cfgp, LookAhead la) {
     using E = Env<LaneDev, CONE>;
     __shared__ __attribute__((aligned(16))) float s_rec[QS_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_obs[QS_ENVS_PER_WAVE * QS_MAX_OBS];
     const qs_config& cfg = *cfgp;
-    const int slot = threadIdx.x >> 2, p = first + blockIdx.x * QS_ENVS_PER_WAVE + slot;   // entries [first, size) of the pool
+    const int slot = threadIdx.x >> 2;
+    const long long j = (long long)blockIdx.x * QS_ENVS_PER_WAVE + slot, total = (long long)cfg.n_envs * la.K;
+    const int env = (int)((j < total ? j : 0) % cfg.n_envs), episode = (int)((j < total ? j : 0) / cfg.n_envs);
     float* rec = s_rec + slot * QS_REC_END;
     for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) rec[i] = 0.0f;
     LaneDev::sync();
-    if ((threadIdx.x & 3) == 0) rec[R_EPISODE] = qs::i2f(generation - 1);
+    if ((threadIdx.x & 3) == 0) rec[R_EPISODE] = qs::i2f(episode - 1);
     LaneDev::sync();
-    E::reset(cfg, rec, s_obs + slot * QS_MAX_OBS, 0x40000000u + (uint32_t)p, true);
+    E::reset(cfg, rec, s_obs + slot * QS_MAX_OBS, (uint32_t)(env + cfg.env_id_offset), true);
     LaneDev::sync();
-    if (p < size) {
-        float* g = pool + (size_t)p * QS_REC;
-        for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];
+    if (j < total) {
+        float* g = la.slots + ((size_t)env * la.K + (size_t)(episode % la.K)) * QS_REC;
+        for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];     // (R_EPISODE = episode: the slot's tag)
+        if (episode == la.K - 1 && (threadIdx.x & 3) == 0) la.queued[env] = la.K - 1;
     }
 }
 
@@ -422,18 +510,19 @@ struct qs_handle {
     float* d_rec;
     float* d_obs;       // last observation of every environment [N, obs_dim]
     float* d_term_obs;  // [N, obs_dim]
-    float* d_pool;      // pre-settled reset states the step kernel draws from
-    float* d_pool_back; // streaming refill: staging records that are being settled by the extra workgroups of k_step
-    int pool_size, pool_generation;
-    int streaming;
-    long long tick;         // qs_step launches since streaming was switched on
-    int cohort_generation[QS_COHORTS];
+    LookAhead la;       // look-ahead reset states (cfg.reset_lookahead)
+    float* d_staging;   // records being settled by the extra workgroups of k_step (settle lanes), QS_COHORTS slices
+    int2* d_stage_jobs; // whose reset each staging record is
+    int slice;          // staging records per cohort
+    int lanes_on;
+    long long tick;         // qs_step launches since the settle lanes were switched on
     float* trace_rows; int trace_env;
     float* d_demo; int demo_len;   // qs_set_demo
     int n_simd, step_variant;   // SIMDs of the device; 0 = pick k_step / k_step_dense by grid size, 1 / 2 = forced (QS_STEP_VARIANT)
     unsigned long long* d_stats;
     hipEvent_t ev0, ev1;
-    int timing;
+    int timing;             // qs_enable_timing: 1 = armed (the next launch records ev0), 2 = ev0 recorded
+    long long timed_launches;
 };
 
 static int sensor_dim(int s) {
@@ -465,6 +554,7 @@ int qs_create(const qs_config* cfg, int device, qs_handle** out) {
         QS_FAIL(-1, "the DEMO tasks compare the policy's action with a recorded one: they need an RL action space (not CPG, not raw commands)");
     if (cfg->task < 0 || cfg->task > QS_TASK_CONT_JUMPING_FORWARD_DEMO) QS_FAIL(-1, "unknown task id %d", cfg->task);
     if (cfg->friction_cone != 0 && cfg->friction_cone != 1) QS_FAIL(-1, "friction_cone must be 0 (pyramid) or 1 (implicit cone), got %d", cfg->friction_cone);
+    if (cfg->reset_lookahead < 0 || cfg->reset_lookahead > 64) QS_FAIL(-1, "reset_lookahead must be between 0 (settle inside the step) and 64 reset states per environment, got %d", cfg->reset_lookahead);
     if (cfg->motor_control_mode == QS_MOTOR_TORQUE && cfg->rl_interface)  // gym_env.py:167-168
         QS_FAIL(-1, "the motor control mode TORQUE not implemented yet for RL Gym interface.");
     int od = 0;
@@ -508,13 +598,31 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
     QS_HIP(hipEventCreate(&h->ev1));
     hipLaunchKernelGGL(k_init, dim3(n_waves(cfg->n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec);
     QS_HIP(hipGetLastError());
-    h->pool_size = 0;
-    if (cfg->reset_pool > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
-        h->pool_size = cfg->reset_pool;
-        QS_HIP(hipMalloc(&h->d_pool, (size_t)h->pool_size * QS_REC * sizeof(float)));
-        if (cfg->friction_cone) hipLaunchKernelGGL((k_pool_fill<true>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, 0);
-        else hipLaunchKernelGGL((k_pool_fill<false>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, 0);
+    // look-ahead reset states: K slots per environment, filled for episodes 0 .. K - 1 before anything steps; not under QS_RAND_KEEP, where
+    // a reset's parameters are whatever qs_set_params wrote last (the settle cannot be computed ahead of that)
+    memset(&h->la, 0, sizeof(h->la));
+    if (cfg->reset_lookahead > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
+        const int K = cfg->reset_lookahead;
+        h->la.K = K;
+        size_t ring = 1024;
+        while (ring < 2 * n * (size_t)K) ring <<= 1;       // at most K jobs of an environment wait at a time (plus stale ones after stalls)
+        h->la.qmask = (unsigned)(ring - 1);
+        // a cohort settles at most `slice` records at a time: enough lanes for every environment to reset once per epoch and cohort
+        h->slice = (int)((n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE);
+        if (h->slice < QS_MAX_SLICE) h->slice = QS_MAX_SLICE;
+        if (h->slice > 65536) h->slice = 65536;
+        QS_HIP(hipMalloc(&h->la.slots, n * K * QS_REC * sizeof(float)));
+        QS_HIP(hipMalloc(&h->la.queued, n * sizeof(int)));
+        QS_HIP(hipMalloc(&h->la.jobs, ring * sizeof(int2)));
+        QS_HIP(hipMalloc(&h->d_staging, (size_t)QS_COHORTS * h->slice * QS_REC * sizeof(float)));
+        QS_HIP(hipMalloc(&h->d_stage_jobs, (size_t)QS_COHORTS * h->slice * sizeof(int2)));
+        QS_HIP(hipMemsetAsync(h->d_staging, 0, (size_t)QS_COHORTS * h->slice * QS_REC * sizeof(float), h->stream));
+        QS_HIP(hipMemsetAsync(h->d_stage_jobs, 0, (size_t)QS_COHORTS * h->slice * sizeof(int2), h->stream));
+        const unsigned fill_grid = (unsigned)((n * K + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE);
+        if (cfg->friction_cone) hipLaunchKernelGGL((k_lookahead_fill<true>), dim3(fill_grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->la);
+        else hipLaunchKernelGGL((k_lookahead_fill<false>), dim3(fill_grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->la);
         QS_HIP(hipGetLastError());
+        h->lanes_on = 1;
     }
     QS_HIP(hipStreamSynchronize(h->stream));
     return 0;
@@ -525,8 +633,11 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     QS_ON_DEVICE(h);
     hipStreamSynchronize(h->stream);
     hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
-    if (h->d_pool) hipFree(h->d_pool);
-    if (h->d_pool_back) hipFree(h->d_pool_back);
+    if (h->la.slots) hipFree(h->la.slots);
+    if (h->la.queued) hipFree(h->la.queued);
+    if (h->la.jobs) hipFree(h->la.jobs);
+    if (h->d_staging) hipFree(h->d_staging);
+    if (h->d_stage_jobs) hipFree(h->d_stage_jobs);
     if (h->d_demo) hipFree(h->d_demo);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -534,13 +645,13 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
 }
 
 int qs_set_stream(qs_handle* h, void* s) { if (!h) QS_FAIL(-1, "null handle"); h->stream = (hipStream_t)s; return 0; }
-int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle"); h->timing = on; return 0; }
+int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle"); h->timing = on ? 1 : 0; h->timed_launches = 0; return 0; }
 
 int qs_reset(qs_handle* h, const uint8_t* mask) {
     if (!h) QS_FAIL(-1, "null handle");
     QS_ON_DEVICE(h);
-    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_reset<true>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
-    else hipLaunchKernelGGL((k_reset<false>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr);
+    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_reset<true>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr, h->la);
+    else hipLaunchKernelGGL((k_reset<false>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, (const float*)nullptr, h->la);
     QS_HIP(hipGetLastError());
     return 0;
 }
@@ -548,8 +659,8 @@ int qs_reset(qs_handle* h, const uint8_t* mask) {
 int qs_reset_to(qs_handle* h, const uint8_t* mask, const float* states) {
     if (!h || !states) QS_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);
-    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_reset<true>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
-    else hipLaunchKernelGGL((k_reset<false>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states);
+    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_reset<true>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states, h->la);
+    else hipLaunchKernelGGL((k_reset<false>), dim3(n_waves(h->cfg.n_envs)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_rec, mask, h->d_obs, h->d_stats, states, h->la);
     QS_HIP(hipGetLastError());
     return 0;
 }
@@ -561,27 +672,16 @@ int qs_get_obs(qs_handle* h, float* obs) {
     return 0;
 }
 
-int qs_pool_streaming(qs_handle* h, int on, uint64_t* refilled) {
+int qs_settle_lanes(qs_handle* h, int on) {
     if (!h) QS_FAIL(-1, "null handle");
     QS_ON_DEVICE(h);
-    // a cohort settles whole pairs of waves (k_pool_plan: at least 32 records), so each of the QS_COHORTS slices must hold that many
-    if (on && h->pool_size < QS_COHORTS * 2 * QS_ENVS_PER_WAVE) QS_FAIL(-1, "streaming refill needs a reset pool of at least %d entries (cfg.reset_pool)", QS_COHORTS * 2 * QS_ENVS_PER_WAVE);
-    if (on && !h->d_pool_back) QS_HIP(hipMalloc(&h->d_pool_back, (size_t)h->pool_size * QS_REC * sizeof(float)));
-    if (on && !h->streaming) {          // resets that happened while streaming was off are not owed
-        QS_HIP(hipMemcpyAsync(&h->d_stats[CTL_BACKED], &h->d_stats[CTL_CONSUMED], sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
-        h->tick = 0;
-    }
-    if (!on && h->streaming) {   // settles in progress are dropped
-        hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, 0, 0, 1);
+    if (h->la.K == 0) { if (on) QS_FAIL(-1, "this handle keeps no look-ahead reset states (cfg.reset_lookahead = 0, or QS_RAND_KEEP)"); return 0; }
+    if (!on && h->lanes_on) {   // settles in progress are dropped, their jobs go back to the front of the queue
+        hipLaunchKernelGGL(k_lookahead_requeue, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->la, h->d_stage_jobs, h->slice);
         QS_HIP(hipGetLastError());
     }
-    h->streaming = on ? 1 : 0;
-    if (refilled) {
-        unsigned long long v = 0;
-        QS_HIP(hipStreamSynchronize(h->stream));
-        QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_REFILLED], sizeof(v), hipMemcpyDeviceToHost));
-        *refilled = v;
-    }
+    if (on && !h->lanes_on) h->tick = 0;
+    h->lanes_on = on ? 1 : 0;
     return 0;
 }
 
@@ -599,7 +699,6 @@ int qs_step_fused(qs_handle* h, const float* actions, float* fused) {
 
 static int launch_step(qs_handle* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     QS_ON_DEVICE(h);
-    PoolView pv; pv.pool = h->d_pool; pv.size = h->pool_size;
     SettleLanes lanes;
     memset(&lanes, 0, sizeof(lanes));
     lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.waves_per_cohort = 1; lanes.slice = 0;
@@ -607,51 +706,47 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     DemoTab demo; demo.rows = h->d_demo; demo.length = h->demo_len;
     if (E::demo_task(h->cfg.task) && !h->d_demo) QS_FAIL(-1, "the DEMO tasks need a demonstration: qs_set_demo first");
     int grid = lanes.n_env_waves;
-    if (h->streaming) {
+    if (h->la.K > 0 && h->lanes_on) {
         // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder);
         // cohort c runs the same schedule c * epoch / QS_COHORTS launches later
         const int rep = h->cfg.action_repeat, epoch = (h->cfg.settle_steps + rep - 1) / rep;
-        // a cohort settles at most QS_MAX_SLICE records at a time, whatever the size of the pool: the launch then carries at most
-        // QS_COHORTS * QS_MAX_SLICE / 16 extra workgroups (640), enough for 40 resets per step, and a large pool (few stale draws) costs no
-        // idle workgroups (a 65536-entry pool with slices of a fifth of it: 4096 of them, -20 % env-steps/s)
-        const int slice = min((h->pool_size / QS_COHORTS) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE, QS_MAX_SLICE);
-        lanes.staging = h->d_pool_back; lanes.slice = slice; lanes.waves_per_cohort = slice / QS_ENVS_PER_WAVE;
+        const int slice = h->slice;
+        lanes.staging = h->d_staging; lanes.stage_jobs = h->d_stage_jobs; lanes.slice = slice; lanes.waves_per_cohort = slice / QS_ENVS_PER_WAVE;
         // With one wave per SIMD a launch of more waves than SIMDs runs in two rounds.  While the environments leave at least
         // QS_COHORTS x 64 SIMDs free (room to settle 20 resets' worth per step) the settle lanes are trimmed to the free SIMDs and the
-        // one-wave-per-SIMD kernel stays; beyond that the two-waves-per-SIMD build takes the whole launch (below).
+        // one-wave-per-SIMD kernel stays; beyond that the two-waves-per-SIMD build takes the whole launch (below), with at most QS_MAX_SLICE
+        // records per cohort unless the environments are more than that (jobs beyond a cohort's lanes wait in the ring for the next cohort).
         const int free_simd = h->n_simd - lanes.n_env_waves;
-        if (h->step_variant != 2 && free_simd / QS_COHORTS >= 64 && lanes.waves_per_cohort > free_simd / QS_COHORTS) lanes.waves_per_cohort = free_simd / QS_COHORTS;
+        if (h->step_variant != 2 && free_simd / QS_COHORTS >= 64) { if (lanes.waves_per_cohort > free_simd / QS_COHORTS) lanes.waves_per_cohort = free_simd / QS_COHORTS; }
         const int cohort_cap = lanes.waves_per_cohort * QS_ENVS_PER_WAVE;
         for (int c = 0; c < QS_COHORTS; c++) {
             const long long t = h->tick - (long long)c * epoch / QS_COHORTS;
             if (t < 0) continue;                       // not started yet: settle_n stays 0
             const int phase = (int)(t % epoch);
             if (phase == 0) {
-                hipLaunchKernelGGL(k_pool_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_pool_back, h->d_pool, h->pool_size, c, slice);
-                hipLaunchKernelGGL(k_pool_plan, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->pool_size, c, cohort_cap, 0);
-                h->pool_generation++;
-                h->cohort_generation[c] = h->pool_generation;
+                hipLaunchKernelGGL(k_lookahead_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_staging, h->d_stage_jobs, h->la, c, slice);
+                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(256), 0, h->stream, h->d_stats, h->la, h->d_stage_jobs, c, slice, cohort_cap);
             }
-            lanes.spawn[c] = phase == 0; lanes.last[c] = phase == epoch - 1; lanes.generation[c] = h->cohort_generation[c];
+            lanes.spawn[c] = phase == 0; lanes.last[c] = phase == epoch - 1;
             lanes.settle_n[c] = phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
         }
         grid += QS_COHORTS * lanes.waves_per_cohort;
         h->tick++;
     }
-    if (h->timing) hipEventRecord(h->ev0, h->stream);
+    if (h->timing == 1) { hipEventRecord(h->ev0, h->stream); h->timing = 2; }   // (after this step's publish / plan launches, if any)
+    if (h->timing) h->timed_launches++;
     // more waves than SIMDs: the two-waves-per-SIMD build of the same body (see k_step_dense) instead of a second round of one-wave-per-
     // SIMD workgroups (N = 12288 with its settle lanes: 0.109 ms in two rounds)
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && grid > h->n_simd);
     const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC_END : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), lds, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
-                                                 h->d_obs, h->d_term_obs, pv, h->d_stats, lanes, tap, demo)
-    const bool exact = h->cfg.auto_reset && h->pool_size == 0;   // finished environments settle inside the step
+                                                 h->d_obs, h->d_term_obs, h->la, h->d_stats, lanes, tap, demo)
+    const bool reset = h->cfg.auto_reset != 0;   // finished environments are reset inside the step
 #define QS_PICK(C, X) { if (dense) QS_LAUNCH_STEP((k_step_dense<C, X>)); else QS_LAUNCH_STEP((k_step<C, X>)); }
-    if (h->cfg.friction_cone) { if (exact) QS_PICK(true, true) else QS_PICK(true, false) }
-    else { if (exact) QS_PICK(false, true) else QS_PICK(false, false) }
+    if (h->cfg.friction_cone) { if (reset) QS_PICK(true, true) else QS_PICK(true, false) }
+    else { if (reset) QS_PICK(false, true) else QS_PICK(false, false) }
 #undef QS_PICK
 #undef QS_LAUNCH_STEP
-    if (h->timing) hipEventRecord(h->ev1, h->stream);
     QS_HIP(hipGetLastError());
     return 0;
 }
@@ -705,8 +800,16 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
     switch (which) {
     case QS_COUNTER_SETTLE_SUBSTEPS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_SETTLE_SUBSTEPS], sizeof(v), hipMemcpyDeviceToHost)); break;
     case QS_COUNTER_RESETS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_RESETS], sizeof(v), hipMemcpyDeviceToHost)); break;
-    case QS_COUNTER_POOL_CONSUMED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_CONSUMED], sizeof(v), hipMemcpyDeviceToHost)); break;
-    case QS_COUNTER_POOL_REFILLED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_REFILLED], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_LOOKAHEAD_SERVED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_SERVED], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_LOOKAHEAD_SETTLED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_SETTLED], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_RESET_STALLS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_STALLS], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_LOOKAHEAD_DROPPED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_DROPPED], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_LOOKAHEAD_BACKLOG: {
+        unsigned long long ht[2];
+        QS_HIP(hipMemcpy(ht, &h->d_stats[CTL_Q_TAIL], sizeof(ht), hipMemcpyDeviceToHost));   // tail, head
+        v = ht[0] - ht[1];
+        break;
+    }
     case QS_COUNTER_LIMIT_PATH_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_rare_path_substeps), sizeof(v))); break;
     case QS_COUNTER_SELF_NARROW_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_self_narrow_substeps), sizeof(v))); break;
     default: QS_FAIL(-1, "unknown counter %d", which);
@@ -717,21 +820,14 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
 
 int qs_last_step_kernel_ms(qs_handle* h, float* ms) {
     if (!h || !ms) QS_FAIL(-1, "null argument");
-    if (!h->timing) QS_FAIL(-1, "timing is off (qs_enable_timing)");
+    if (h->timing != 2 || h->timed_launches <= 0) QS_FAIL(-1, "no step has been launched since qs_enable_timing(h, 1)");
     QS_ON_DEVICE(h);
+    QS_HIP(hipEventRecord(h->ev1, h->stream));
     QS_HIP(hipEventSynchronize(h->ev1));
-    QS_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
-    return 0;
-}
-
-int qs_refresh_pool(qs_handle* h) {  // redraw the pre-settled reset states (new parameter draws)
-    if (!h) QS_FAIL(-1, "null handle");
-    QS_ON_DEVICE(h);
-    if (h->pool_size <= 0) return 0;
-    h->pool_generation++;
-    if (h->cfg.friction_cone) hipLaunchKernelGGL((k_pool_fill<true>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
-    else hipLaunchKernelGGL((k_pool_fill<false>), dim3(n_waves(h->pool_size)), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->d_pool, 0, h->pool_size, h->pool_generation);
-    QS_HIP(hipGetLastError());
+    float total = 0.0f;
+    QS_HIP(hipEventElapsedTime(&total, h->ev0, h->ev1));
+    *ms = total / (float)h->timed_launches;
+    h->timing = 1; h->timed_launches = 0;     // armed again: the next launch starts a new batch
     return 0;
 }
 

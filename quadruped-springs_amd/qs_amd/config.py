@@ -115,7 +115,7 @@ class QsConfig(C.Structure):
         ("obs_dim", C.c_int32), ("enable_springs", C.c_int32), ("enable_filter", C.c_int32),
         ("enable_interp", C.c_int32), ("action_repeat", C.c_int32), ("solver_iters", C.c_int32),
         ("settle_steps", C.c_int32), ("max_sim_steps", C.c_int32), ("randomizer_flags", C.c_int32),
-        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_pool", C.c_int32), ("env_id_offset", C.c_int32), ("wrapper_mode", C.c_int32),
+        ("noise_enabled", C.c_int32), ("auto_reset", C.c_int32), ("reset_lookahead", C.c_int32), ("env_id_offset", C.c_int32), ("wrapper_mode", C.c_int32),
         ("seed", C.c_uint64), ("dt", C.c_double), ("filt_b", C.c_double * 3), ("filt_a", C.c_double * 3), ("gravity", C.c_float),
         ("kp", C.c_float * 3), ("kd", C.c_float * 3), ("tau_max", C.c_float * 3),
         ("cmd_lo", C.c_float * 12), ("cmd_hi", C.c_float * 12),

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("QS_LIB_PATH") or os.path.join(_HERE, "libqs_hip.so") 
 EXPORTS = (
     "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_reset_to", "qs_get_obs", "qs_step", "qs_step_fused", "qs_get_state", "qs_set_state",
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
-    "qs_refresh_pool", "qs_pool_streaming", "qs_set_trace", "qs_counter", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
+    "qs_settle_lanes", "qs_set_trace", "qs_counter", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
     "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
 )
 
@@ -50,8 +50,7 @@ def load():
     lib.qs_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.qs_enable_timing.argtypes = [vp, i32]
     lib.qs_last_step_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    lib.qs_refresh_pool.argtypes = [vp]
-    lib.qs_pool_streaming.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    lib.qs_settle_lanes.argtypes = [vp, C.c_int]
     lib.qs_set_trace.argtypes = [vp, C.c_int, vp]
     lib.qs_set_demo.argtypes = [vp, vp, C.c_int]
     lib.qs_set_demo_counter.argtypes = [vp, vp, vp]

@@ -20,7 +20,10 @@ PARAM = dict(mu=0, spring_k=1, spring_b=2, kp=3, kd=4, all=5)
 
 
 class QuadrupedVecEnv(SB3VecEnv):
-    def __init__(self, num_envs=1, device=0, auto_reset=True, reset_pool=0, **env_kwargs):
+    def __init__(self, num_envs=1, device=0, auto_reset=True, reset_lookahead=None, **env_kwargs):
+        """reset_lookahead = K: every environment keeps the settled reset states of its next K episodes ready (computed by extra workgroups
+        of the step kernel while the environments step), so a reset is a copy; results are bitwise those of K = 0, where every reset runs
+        the reference's 2500-substep settle in place (gym_env.py:278-297, 323-329).  Default: 8 with auto_reset, 0 without."""
         import torch
 
         if not torch.cuda.is_available():
@@ -28,7 +31,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         self.torch = torch
         self.lib = _lib.load()
         self.cfg, self.meta = build_config(n_envs=num_envs, auto_reset=auto_reset, **env_kwargs)
-        self.cfg.reset_pool = int(reset_pool)
+        self.cfg.reset_lookahead = int((8 if auto_reset else 0) if reset_lookahead is None else reset_lookahead)
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", device)
         lay = self.meta["layout"]
@@ -146,7 +149,8 @@ class QuadrupedVecEnv(SB3VecEnv):
         _lib.check(self.lib.qs_stats(self.h, C.byref(a), C.byref(b)))
         return dict(settle_substeps=a.value, resets=b.value)
 
-    COUNTERS = dict(settle_substeps=0, resets=1, pool_consumed=2, pool_refilled=3, limit_path_substeps=4, self_narrow_substeps=5)
+    COUNTERS = dict(settle_substeps=0, resets=1, lookahead_served=2, lookahead_settled=3, limit_path_substeps=4, self_narrow_substeps=5,
+                    reset_stalls=6, lookahead_backlog=7, lookahead_dropped=8)
 
     def counter(self, which):
         v = C.c_uint64(0)
@@ -160,10 +164,6 @@ class QuadrupedVecEnv(SB3VecEnv):
         ms = C.c_float()
         _lib.check(self.lib.qs_last_step_kernel_ms(self.h, C.byref(ms)))
         return ms.value
-
-    def refresh_pool(self):
-        self._stream()
-        _lib.check(self.lib.qs_refresh_pool(self.h))
 
     TRACE_FIELDS = dict(time=(0, 1), base_position=(1, 4), base_quaternion=(4, 8), base_linear_velocity=(8, 11), base_angular_velocity=(11, 14),
                         joint_angles=(14, 26), joint_velocities=(26, 38), torques=(38, 50), spring_tau=(50, 62), feet_normal_forces=(62, 66),
@@ -242,12 +242,11 @@ class QuadrupedVecEnv(SB3VecEnv):
         cuts = np.cumsum([action_dim, num_joints, num_joints, 3, 4, 3, 3, 1])
         return [demo[a:b] for a, b in zip(np.concatenate(([0], cuts[:-1])), cuts)]
 
-    def pool_streaming(self, on=True):
-        """Demand-driven background refill of the reset pool (qs_pool_streaming); returns the number of entries re-settled so far."""
-        n = C.c_uint64(0)
+    def settle_lanes(self, on=True):
+        """Switch the settle lanes of the look-ahead resets on / off (qs_settle_lanes; on from construction).  Off: resets use up the
+        states that are ready, then settle in place."""
         self._stream()
-        _lib.check(self.lib.qs_pool_streaming(self.h, int(bool(on)), C.byref(n)))
-        return int(n.value)
+        _lib.check(self.lib.qs_settle_lanes(self.h, int(bool(on))))
 
     # ---- SB3 VecEnv surface (numpy)
     def reset(self):

@@ -281,11 +281,11 @@ def test_auto_reset_and_terminal_observation(torch_cuda):
     assert v.stats()["resets"] == seen + 32
 
 
-def test_pooled_reset_states_are_settled(torch_cuda):
+def test_lookahead_reset_states_are_settled(torch_cuda):
     _, v, cfg = make_pair(256, torch_cuda, oracle=False, auto_reset=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5)
     v.close()
     from qs_amd.vec_env import QuadrupedVecEnv
-    v = QuadrupedVecEnv(num_envs=256, auto_reset=True, reset_pool=128, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+    v = QuadrupedVecEnv(num_envs=256, auto_reset=True, reset_lookahead=4, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                         enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=False)
     v.reset()
     rng = np.random.default_rng(3)
@@ -301,14 +301,15 @@ def test_pooled_reset_states_are_settled(torch_cuda):
     assert n_done > 0
 
 
-def test_streaming_pool_refill(torch_cuda):
-    """Demand-driven refill: the pool entries consumed by auto-resets are re-settled by the settle lanes of k_step, fresh draws."""
+def test_lookahead_states_are_consumed_and_resettled(torch_cuda):
+    """Every reset takes its environment's own next state and queues the settle of the one K episodes ahead; the settle lanes of k_step
+    deliver them (fresh randomizer draws each), and with enough of them ahead nobody has to settle in place."""
     import time
     from qs_amd.vec_env import QuadrupedVecEnv
-    v = QuadrupedVecEnv(num_envs=1024, auto_reset=True, reset_pool=256, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+    v = QuadrupedVecEnv(num_envs=1024, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                         enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=False)
     v.reset()
-    assert v.pool_streaming(True) == 0
+    assert v.counter("lookahead_served") == 1024 and v.counter("lookahead_settled") == 0 and v.counter("lookahead_backlog") == 1024
     rng = np.random.default_rng(3)
     n_done, mus = 0, set()
     t0 = time.time()
@@ -321,15 +322,17 @@ def test_streaming_pool_refill(torch_cuda):
             st = v.get_state().cpu().numpy()[done]
             assert np.all(np.abs(st[:, 2] - 0.328) < 0.01) and np.abs(st[:, 7:13]).max() < 0.05   # settled, at rest
             mus.update(np.round(v.get_info("params").cpu().numpy()[done, 0], 6).tolist())
-        if v.pool_streaming(True) >= 1024 and n_done > 1200:
+        if v.counter("lookahead_settled") >= 2048 and n_done > 1200:
             break
-    refilled = v.pool_streaming(False)
-    resets = v.stats()["resets"] - 1024          # the initial reset() of every environment is not a pooled one
-    assert n_done > 1200 and refilled >= 1024
-    assert refilled <= resets   # never more than was consumed (demand above the pool's capacity is forgiven, not owed)
-    assert len(mus) > 256                        # more distinct friction draws than one pool generation holds
-    assert min(mus) >= 0.5 and max(mus) <= 1.0
-    v.step(rng.uniform(-1, 1, size=(1024, 6)).astype(np.float32))   # static pool again: stepping stays valid
+    resets = v.stats()["resets"]
+    served, settled, stalls, backlog = (v.counter(k) for k in ("lookahead_served", "lookahead_settled", "reset_stalls", "lookahead_backlog"))
+    assert n_done > 1200 and settled >= 2048
+    assert served + stalls == resets == n_done + 1024
+    assert settled + backlog <= resets       # one settle queued per reset; those in the lanes are neither delivered nor waiting
+    assert stalls == 0 and v.counter("lookahead_dropped") == 0
+    assert len(mus) > 1000 and min(mus) >= 0.5 and max(mus) <= 1.0     # every reset its own friction draw
+    v.settle_lanes(False)
+    v.step(rng.uniform(-1, 1, size=(1024, 6)).astype(np.float32))   # lanes off: stepping stays valid
     v.close()
 
 
@@ -342,10 +345,9 @@ def test_ragged_batch_sizes_stay_inside_their_arrays(torch_cuda, n):
     from qs_amd import lib as L
     from qs_amd.vec_env import QuadrupedVecEnv
     torch = torch_cuda
-    kw = dict(auto_reset=True, reset_pool=160, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+    kw = dict(auto_reset=True, reset_lookahead=3, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
               enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=9, noise=True, settle_steps=200)
     v, w = QuadrupedVecEnv(num_envs=n, **kw), QuadrupedVecEnv(num_envs=n + 23, **kw)
-    v.pool_streaming(True); w.pool_streaming(True)
     o, G = v.obs_dim, 8
     guard = dict(obs=torch.full((n + G, o), 777.0, device=v.device), rew=torch.full((n + G,), 777.0, device=v.device),
                  done=torch.full((n + G,), 77, dtype=torch.uint8, device=v.device), trunc=torch.full((n + G,), 77, dtype=torch.uint8, device=v.device),
@@ -356,7 +358,7 @@ def test_ragged_batch_sizes_stay_inside_their_arrays(torch_cuda, n):
     rng = np.random.default_rng(n)
     for i in range(60):
         a = rng.uniform(-1, 1, size=(n + 23, 6)).astype(np.float32)
-        a[:, 1::3] = -1.0; a[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5       # falls: auto-resets from the pool happen
+        a[:, 1::3] = -1.0; a[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5       # falls: auto-resets happen
         av = torch.as_tensor(a[:n].copy(), device=v.device)
         v._stream()
         if i % 2:
@@ -403,24 +405,68 @@ def test_trace_tap(torch_cuda):
     v.step(a)
 
 
-def test_streaming_refill_is_reproducible(torch_cuda):
-    """The settle lanes follow the sequence of step calls only: two handles stepping the same actions stay bitwise equal."""
+def test_lookahead_resets_are_bitwise_the_exact_resets(torch_cuda):
+    """reset() = randomizers + spawn + 2500-substep settle (gym_env.py:278-297) depends on (seed, environment, episode) only.  A handle
+    that computes those states K episodes ahead in the settle lanes (slices of action_repeat substeps through the step's own loop, other
+    wave-mates, other kernels) must produce the bits of the handle that settles every reset in place: observations, rewards, done and
+    truncation flags of every step, and the records' state and parameters at the end.  3100 steps: every environment goes through at
+    least three resets (the 10-s limit, gym_env.py:245), most through many more."""
     from qs_amd.vec_env import QuadrupedVecEnv
-    kw = dict(num_envs=512, auto_reset=True, reset_pool=256, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
-              enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=True, settle_steps=300)
-    a, b = QuadrupedVecEnv(**kw), QuadrupedVecEnv(**kw)
-    a.reset(); b.reset()
-    a.pool_streaming(True); b.pool_streaming(True)
+    torch = torch_cuda
+    n, steps = 512, 3100
+    kw = dict(num_envs=n, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+              enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5, noise=True)
+    a, b = QuadrupedVecEnv(reset_lookahead=8, **kw), QuadrupedVecEnv(reset_lookahead=0, **kw)
+    assert torch.equal(a.reset_tensor(), b.reset_tensor())
+    gen = torch.Generator(device=a.device).manual_seed(7)
+    acts = torch.rand((64, n, a.action_dim), generator=gen, device=a.device) * 2 - 1
+    resets = torch.zeros(n, dtype=torch.int64, device=a.device)
+    for t in range(steps):
+        oa, ra, da, ta = a.step_tensor(acts[t % 64])
+        ob, rb, db, tb = b.step_tensor(acts[t % 64])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ta, tb), f"step {t}"
+        resets += da.to(torch.int64)
+        if t % 500 == 0:
+            assert torch.equal(a.get_info("terminal_obs"), b.get_info("terminal_obs"))
+    assert int(resets.min()) >= 3, int(resets.min())
+    assert torch.equal(a.get_state(), b.get_state()) and torch.equal(a.get_info("params"), b.get_info("params"))
+    assert torch.equal(a.get_info("task"), b.get_info("task")) and torch.equal(a.get_info("counters"), b.get_info("counters"))
+    total = int(resets.sum())
+    assert a.counter("lookahead_served") + a.counter("reset_stalls") == total + n and b.counter("reset_stalls") == 0 == b.counter("lookahead_served")
+    assert a.counter("reset_stalls") == 0, a.counter("reset_stalls")
+    # the exact handle settled every reset in place; the look-ahead handle did the same work in its lanes (plus the K states ahead of everyone)
+    assert b.stats()["settle_substeps"] == (total + n) * 2500
+    print(f"{total} resets, min per environment {int(resets.min())}; look-ahead: {a.counter('lookahead_settled')} states delivered by the lanes, "
+          f"{a.stats()['settle_substeps']} settle substeps")
+    a.close(); b.close()
+
+
+def test_lookahead_falls_back_to_the_exact_reset_when_it_runs_dry(torch_cuda):
+    """Lanes off: the K states that are ready are used up, later resets settle in place (counted as stalls) -- same bits either way, also
+    after the lanes come back."""
+    from qs_amd.vec_env import QuadrupedVecEnv
+    torch = torch_cuda
+    n = 80
+    kw = dict(num_envs=n, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+              enable_action_filter=True, env_randomizer_mode="TEST_RANDOMIZER", seed=6, noise=True, settle_steps=300)
+    a, b = QuadrupedVecEnv(reset_lookahead=2, **kw), QuadrupedVecEnv(reset_lookahead=0, **kw)
+    a.settle_lanes(False)
+    assert torch.equal(a.reset_tensor(), b.reset_tensor())
     rng = np.random.default_rng(3)
     n_done = 0
-    for i in range(150):      # five 30-launch epochs
-        act = rng.uniform(-1, 1, size=(512, 6)).astype(np.float32)
+    for i in range(260):
+        if i == 150:
+            a.settle_lanes(True)
+        act = rng.uniform(-1, 1, size=(n, 6)).astype(np.float32)
         act[:, 1::3] = -1.0; act[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5
-        oa, ra, da, _ = a.step(act)
-        ob, rb, db, _ = b.step(act)
+        act[::3] = 0.0                                                # a third of them stays up: mixed waves
+        t = torch.as_tensor(act, device=a.device)
+        oa, ra, da, ta = a.step_tensor(t)
+        ob, rb, db, tb = b.step_tensor(t)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ta, tb), f"step {i}"
         n_done += int(da.sum())
-        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
-    assert n_done > 100 and a.pool_streaming(False) == b.pool_streaming(False) > 0
+    assert torch.equal(a.get_state(), b.get_state()) and torch.equal(a.get_info("params"), b.get_info("params"))
+    assert a.counter("reset_stalls") > 20 and a.counter("lookahead_served") > n + 20 and a.counter("lookahead_settled") > 20
     a.close(); b.close()
 
 
@@ -431,7 +477,7 @@ def test_device_vec_normalize(torch_cuda, training, norm_reward):
     from qs_amd.vec_env import QuadrupedVecEnv
     from qs_amd.vec_normalize import DeviceVecNormalize
     n = 1000   # not a multiple of the block size
-    venv = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_pool=64, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+    venv = QuadrupedVecEnv(num_envs=n, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                            enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5)
     env = DeviceVecNormalize(venv, training=training, norm_reward=norm_reward)
     ref = VecNormalizeRef(n, venv.obs_dim, training=training, norm_reward=norm_reward, moments_dtype=np.float64)
@@ -557,7 +603,7 @@ def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
 def test_fused_step_output(torch_cuda):
     """qs_step_fused writes [obs | reward | done + 2 truncated] rows: same numbers as the four arrays of qs_step."""
     from qs_amd.vec_env import QuadrupedVecEnv
-    kw = dict(num_envs=300, auto_reset=True, reset_pool=64, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
+    kw = dict(num_envs=300, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
               enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=5)
     a, b = QuadrupedVecEnv(**kw), QuadrupedVecEnv(**kw)
     a.reset(); b.reset()
@@ -582,7 +628,7 @@ def test_both_step_kernels_agree_bitwise(torch_cuda):
     """k_step (one wave per SIMD) and k_step_dense (two, with spills) are the same body: same results to the last bit; the
     automatic choice at the largest BASELINE.json launch size (65536 environments) is the dense one and stays physical."""
     from qs_amd.vec_env import QuadrupedVecEnv
-    kw = dict(num_envs=2048, auto_reset=True, reset_pool=512, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=True,
+    kw = dict(num_envs=2048, auto_reset=True, reset_lookahead=4, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=True,
               enable_action_filter=True, env_randomizer_mode="TEST_RANDOMIZER", seed=9)
     envs = []
     for variant in ("1", "2"):
@@ -602,7 +648,7 @@ def test_both_step_kernels_agree_bitwise(torch_cuda):
         n_done += int(da.sum())
     assert n_done > 50
     a.close(); b.close()
-    big = QuadrupedVecEnv(num_envs=65536, auto_reset=True, reset_pool=4096, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC",
+    big = QuadrupedVecEnv(num_envs=65536, auto_reset=True, reset_lookahead=2, task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC",
                           enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=2)
     big.reset_tensor()
     g = torch_cuda.Generator(device="cuda").manual_seed(0)
@@ -749,7 +795,7 @@ def test_rsi_vec_env_and_gym_view(torch_cuda, golden):
     L, n, d = len(demo), 64, 6
     with pytest.raises(ValueError, match="demo="):
         QuadrupedVecEnv(num_envs=4, **kw)
-    venv = ReferenceStateInitVecEnv(QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_pool=64, demo=demo, noise=False, seed=3, **kw), seed=11)
+    venv = ReferenceStateInitVecEnv(QuadrupedVecEnv(num_envs=n, auto_reset=True, demo=demo, noise=False, seed=3, **kw), seed=11)
     obs = venv.reset_tensor()
     st = venv.get_state().cpu().numpy()
     np.testing.assert_allclose(st, venv.demo_states(demo[venv.random_el], d), atol=1e-6)

@@ -1,5 +1,5 @@
 """Round-2 GPU tests (through the C ABI): contact response of the non-foot links, the calf self-collision rule, the device noise
-stream, the sharded exchange on RCCL, exact-mode auto-reset in partial waves, reuse of pooled reset states."""
+stream, the sharded exchange on RCCL, exact-mode auto-reset in partial waves, the parameter draws of look-ahead resets."""
 import os
 
 import numpy as np
@@ -234,7 +234,7 @@ def test_sharded_step_on_one_nccl_rank(torch_cuda):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         n = 512
-        kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, reset_pool=256, seed=3, noise=True)
+        kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, seed=3, noise=True)
         a, b = vec_env(n, **kw), vec_env(n, **kw)
         sh = ShardedVecEnv(a, learner_rank=0)
         o1 = sh.reset().clone()
@@ -262,10 +262,10 @@ def test_sharded_step_on_one_nccl_rank(torch_cuda):
 
 @pytest.mark.parametrize("n", [48, 23])
 def test_exact_auto_reset_in_a_partial_wave(torch_cuda, n):
-    """reset_pool = 0: a finished environment settles inside the step while its wave's other environments are done stepping.  Those
+    """reset_lookahead = 0: a finished environment settles inside the step while its wave's other environments are done stepping.  Those
     must come out exactly as in a run without any reset, and the reset ones as a reset of their own."""
     kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", seed=5, settle_steps=400)
-    a, b = vec_env(n, auto_reset=True, reset_pool=0, **kw), vec_env(n, auto_reset=False, **kw)
+    a, b = vec_env(n, auto_reset=True, reset_lookahead=0, **kw), vec_env(n, auto_reset=False, **kw)
     a.reset(); b.reset()
     s = b.get_state().cpu().numpy()
     fall = np.zeros(n, bool); fall[[1, 17, 18, n - 1]] = True
@@ -284,7 +284,7 @@ def test_exact_auto_reset_in_a_partial_wave(torch_cuda, n):
     # the reset ones: standing again, and a second run of the same thing gives the same bits
     sa = a.get_state().cpu().numpy()
     assert np.all(sa[fall, 2] > 0.2) and np.all(a.get_info("foot_contact").cpu().numpy()[fall] == 1)
-    c = vec_env(n, auto_reset=True, reset_pool=0, **kw)
+    c = vec_env(n, auto_reset=True, reset_lookahead=0, **kw)
     c.reset(); c.set_state(s)
     oc = c.step(act)[0]
     assert np.array_equal(oc, oa) and np.array_equal(c.get_state().cpu().numpy(), sa)
@@ -295,18 +295,18 @@ def test_exact_auto_reset_in_a_partial_wave(torch_cuda, n):
     a.close(); b.close(); c.close()
 
 
-def test_pooled_resets_rarely_reuse_a_stale_entry(torch_cuda):
-    """The pooled auto-reset draws entry Philox(env, episode) mod P.  Over 2000 steps at N = 8192 with the streaming refill on: how many
-    resets got an entry that another reset had already used and that was not re-settled in between (seen as an identical parameter
-    draw), and are the consumed draws distributed as the reference's randomizers prescribe (env_randomizer.py:67-83, 110-117, 287-289)."""
+def test_lookahead_resets_draw_their_own_parameters(torch_cuda):
+    """Every reset is the reference's own: its parameters are the draws of (seed, environment, episode) -- no two resets of a 2000-step run
+    at N = 8192 share a draw --, distributed as the reference's randomizers prescribe (env_randomizer.py:67-83, 110-117, 287-289); the
+    settle work of the run's resets is done inside the run, and nobody waits for it."""
     from scipy import stats
     torch = torch_cuda
-    n, steps, P = 8192, 2000, 65536
-    v = vec_env(n, env_randomizer_mode="TEST_RANDOMIZER", auto_reset=True, reset_pool=P, seed=11)
+    n, steps = 8192, 2000
+    v = vec_env(n, env_randomizer_mode="TEST_RANDOMIZER", auto_reset=True, reset_lookahead=16, seed=11)
     v.reset_tensor()
-    v.pool_streaming(True)
     gen = torch.Generator(device=v.device).manual_seed(2)
     draws = []
+    st0 = v.stats()
     for t in range(steps):
         act = torch.rand((n, v.action_dim), generator=gen, device=v.device) * 2 - 1
         _, _, done, _ = v.step_tensor(act)
@@ -315,20 +315,18 @@ def test_pooled_resets_rarely_reuse_a_stale_entry(torch_cuda):
             if len(idx):
                 draws.append(v.get_info("params")[idx].cpu().numpy())
     st = v.stats()
-    v.pool_streaming(False)
     d = np.concatenate(draws)
     assert len(d) > 3000, len(d)
     mu, k, b, m_leg, m_pay = d[:, 0], d[:, 1:4], d[:, 4:7], d[:, 17:20], d[:, 20]
     _, counts = np.unique(d.view(np.dtype((np.void, d.dtype.itemsize * d.shape[1]))), return_counts=True)
-    reused = int((counts - 1).sum())
-    print(f"pooled resets sampled: {len(d)}, of which {reused} ({100.0 * reused / len(d):.1f} %) drew an entry already used and not yet re-settled; "
-          f"settle work ratio {st['settle_substeps'] / max(1, st['resets'] * 2500):.2f}")
-    assert reused / len(d) < 0.10
+    assert int((counts - 1).sum()) == 0                   # every reset its own draw
+    ratio = (st["settle_substeps"] - st0["settle_substeps"]) / max(1, (st["resets"] - st0["resets"]) * 2500)
+    print(f"resets sampled: {len(d)}; settle work done in the run / settle work its resets are worth: {ratio:.2f}; stalls {v.counter('reset_stalls')}")
+    assert 0.7 < ratio < 1.3 and v.counter("reset_stalls") == 0
     for name, x, lo, hi in [("mu", mu, 0.5, 1.0), ("k_hip", k[:, 0], 18.0, 22.0), ("k_calf", k[:, 2], 27.0, 33.0), ("b", b[:, 1], 0.27, 0.33),
                             ("m_thigh", m_leg[:, 1], 0.828, 1.012), ("m_payload", m_pay, 0.0, 1.0)]:
-        u = np.unique(x)                                  # one value per distinct pool entry: the draws themselves
-        assert u.min() >= lo - 1e-6 and u.max() <= hi + 1e-6, name
-        p = stats.kstest((u - lo) / (hi - lo), "uniform").pvalue
+        assert x.min() >= lo - 1e-6 and x.max() <= hi + 1e-6, name
+        p = stats.kstest((x - lo) / (hi - lo), "uniform").pvalue
         assert p > 1e-3, (name, p)
     v.close()
 
@@ -346,14 +344,13 @@ LAYERS = {
 def test_info_block_is_optional_and_changes_nothing_else(torch_cuda, layer):
     """info_fields=False: the steps skip the stores of the records' info block (torques, foot forces and flags, pose cache) and move the
     shortest range of the record that the handle's layers need (qs_layout.h: wrapper machine, CPG state only where used).  Observations,
-    rewards, done flags and the state must be bit for bit those of the default handle, through falls and pooled auto-resets with the
-    streaming refill running; the getters of the info block fail loudly, the others keep working."""
+    rewards, done flags and the state must be bit for bit those of the default handle, through falls and look-ahead auto-resets with the
+    settle lanes running; the getters of the info block fail loudly, the others keep working."""
     torch = torch_cuda
     n = 200
-    kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, reset_pool=160, seed=4, noise=True)
+    kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, reset_lookahead=4, seed=4, noise=True)
     kw.update(LAYERS[layer])
     a, b = vec_env(n, info_fields=True, **kw), vec_env(n, info_fields=False, **kw)
-    a.pool_streaming(True); b.pool_streaming(True)
     assert torch.equal(a.reset_tensor(), b.reset_tensor())
     gen = torch.Generator(device=a.device).manual_seed(3)
     resets = 0
@@ -421,13 +418,13 @@ def test_soft_payload_parity(torch_cuda, model):
     assert 1e-3 < lam < 0.1, lam
 
 
-def test_soft_payload_through_pooled_auto_resets(torch_cuda):
-    """The pre-settled reset pool and the streaming refill carry the block with the robot: after hundreds of auto-resets every block
+def test_soft_payload_through_lookahead_auto_resets(torch_cuda):
+    """The look-ahead reset states and the settle lanes carry the block with the robot: after hundreds of auto-resets every block
     still sits on its pivot, and the motion stays what the welded model gives (same seed, same actions) to a fraction of a millimetre
     over the first steps."""
     import torch
     n = 256
-    kw = dict(env_randomizer_mode="TEST_RANDOMIZER", seed=9, auto_reset=True, reset_pool=320, settle_steps=500)
+    kw = dict(env_randomizer_mode="TEST_RANDOMIZER", seed=9, auto_reset=True, reset_lookahead=4, settle_steps=500)
     vs, vw = vec_env(n, payload="soft", **kw), vec_env(n, payload="weld", **kw)
     os_, ow = vs.reset_tensor(), vw.reset_tensor()
     assert (os_ - ow).abs().max() < 2e-3
