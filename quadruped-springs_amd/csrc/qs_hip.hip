@@ -190,7 +190,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     // CTL_R[cohort] is only written between launches (k_lookahead_plan)
     const int limit = settling ? cohort * lanes.slice + (int)stats[CTL_R + cohort] : cfg.n_envs;
     if (first >= limit) return;
-    const int settle_n = settling ? lanes.settle_n[cohort] : 0;
+    int settle_n = settling ? lanes.settle_n[cohort] : 0;
     if (settling && settle_n == 0) return;                               // cohort not started yet
     float* const base = settling ? lanes.staging : recs;
     const int slot = threadIdx.x >> 2;
@@ -201,7 +201,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     // the quad of an environment fetches its action row (lane l takes entries l, l + 4, l + 8) -- issued before the tile loads, whose
     // latency then covers it
     float a_pre[3] = {0.0f, 0.0f, 0.0f};
-    int2 job = make_int2(0, 0);                                          // settle lanes: whose reset this record is (environment, episode)
+    int2 job = make_int2(0, 0);                                          // a settle: whose reset this record is (environment, episode)
     if (!settling) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -209,8 +209,9 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
     } else job = lanes.stage_jobs[valid ? env : first];
-    const bool spawn = settling && lanes.spawn[cohort], last = settling && lanes.last[cohort];
-    const int load_extent = settling ? (spawn ? 0 : (cfg.payload_soft ? (int)TILE_ALL : (int)QS_SETTLE_END)) : tile_extent(cfg, false);
+    bool spawn = settling && lanes.spawn[cohort];
+    const bool last = settling && lanes.last[cohort];
+    int load_extent = settling ? (spawn ? 0 : (cfg.payload_soft ? (int)TILE_ALL : (int)QS_SETTLE_END)) : tile_extent(cfg, false);
     // (a settle's first slice writes parameters and spawn state itself and reads nothing; its last slice leaves a whole record behind,
     // of which only the settled fields mean anything: the rest is zero rather than whatever the LDS held)
     if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
@@ -228,88 +229,109 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     QS_PHASE(29)
     float* rec = s_rec + slot * ls;
     float* ob = s_obs + slot * QS_MAX_OBS;
-    if (cfg.info_fields && (threadIdx.x & 3) == 0) rec[QS_INFO_END - 1] = 0.0f;   // the pad float behind the info block, stored with it
+    if (cfg.info_fields && !settling && (threadIdx.x & 3) == 0) rec[QS_INFO_END - 1] = 0.0f;   // the pad float behind the info block, stored with it
     const uint32_t gid = (uint32_t)((settling ? job.x : env) + cfg.env_id_offset);
-    if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
-    const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
+    bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
-    float* const trow = any_trace && env == tap.env ? tap.rows : nullptr;
+    float* trow = any_trace && env == tap.env ? tap.rows : nullptr;
     typename E::StepOut r;
-    r.redo = true;
-    if (!cfg.payload_soft) {   // (the payload block's constraint rows are not in the common-path build)
-        typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
-        r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
+    bool any_reset = false;   // wave-uniform: a reset rewrote the parameters of some record of the tile
+    bool do_reset = false;    // this quad's environment ended its episode
+    const float* ahead = nullptr;   // ... and this is its settled reset state; null: it settles inside the step (second trip of the loop)
+    int next_episode = 0;
+    // The loop runs ONCE, except in a wave with such an environment: its second trip is the in-step settle -- the wave turns into what a
+    // settle lane is (spawn, then all settle_steps substeps through the same E::step(..., settle_n)), so that the fallback costs the kernel
+    // no second copy of the substep loop and produces the bits the lanes produce.
+    for (int trip = 0;; trip++) {
+        if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
+        r.redo = true;
+        if (!cfg.payload_soft) {   // (the payload block's constraint rows are not in the common-path build)
+            typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+            r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
+            if (__builtin_expect(r.redo, 0)) {
+                // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
+                // env step of the whole wave with the full build
+                __syncthreads();
+                if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
+                if (settling && (spawn || last)) zero_tile_tail(s_rec, load_extent, ls);
+                __syncthreads();
+                if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
+            }
+        }
         if (__builtin_expect(r.redo, 0)) {
-            // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
-            // env step of the whole wave with the full build
-            __syncthreads();
-            if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
-            if (spawn || last) zero_tile_tail(s_rec, load_extent, ls);
-            __syncthreads();
-            if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
+            r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
         }
-    }
-    if (__builtin_expect(r.redo, 0)) {
-        r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
-    }
-    QS_PHASE(14)
-    if (settling) {
-        if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
+        QS_PHASE(14)
+        if (settling) {
+            if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
+            __syncthreads();
+            // a slice of a settle changes the rigid-body state and the warm start; its first slice also drew the parameters, its last one
+            // leaves the info block's results (and n_invalid) that copy_settled hands to a reset
+            tile_store(s_rec, base, first, limit, spawn ? 0 : (int)QS_RW_BEGIN,
+                       cfg.payload_soft ? (int)TILE_ALL : (last ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
+            return;
+        }
+        if (!RESET || trip == 1) break;
+        const bool dn = r.done > 0.5f;
+        if (valid && (threadIdx.x & 3) == 0) {
+            if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
+            else {   // fused layout (qs_step_fused): one row [obs | reward | done + 2 * truncated] per environment
+                float* row = obs_out + (size_t)env * (od + 2);
+                row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
+            }
+        }
+        do_reset = dn && valid;
+        if (__builtin_expect(!__any(do_reset), 1)) break;
+        any_reset = true;
+        LaneDev::sync();
+        next_episode = qs::f2i(rec[R_EPISODE]) + 1;
+        if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
+            for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
+            if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
+            ahead = lookahead_take(la, stats, env, next_episode);
+        }
+        if (__builtin_expect(!__any(do_reset && !ahead), 1)) break;
+        // no settled state ahead (reset_lookahead = 0, or all K states used up faster than the lanes settle): what the step produced is
+        // published, then the WHOLE wave walks through the settle on its LDS copies (the solver's v_mfma_f32_4x4x1 ignores EXEC, so every
+        // quad takes part: the others settle a copy of their own next reset that nobody keeps) and only the stalled environments keep the result.
         __syncthreads();
-        // a slice of a settle changes the rigid-body state and the warm start; its first slice also drew the parameters, its last one
-        // leaves the info block's results (and n_invalid) that copy_settled hands to a reset
-        tile_store(s_rec, base, first, limit, spawn ? 0 : (int)QS_RW_BEGIN,
-                   cfg.payload_soft ? (int)TILE_ALL : (last ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
-        return;
+        tile_store(s_rec, recs, first, cfg.n_envs, QS_RW_BEGIN, tile_extent(cfg, true), ls);
+        obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
+        __syncthreads();
+        spawn = true; settle_n = cfg.settle_steps; job = make_int2(env, next_episode);
+        trow = nullptr; any_trace = false;
     }
-    const bool dn = r.done > 0.5f;
-    if (valid && (threadIdx.x & 3) == 0) {
-        if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
-        else {   // fused layout (qs_step_fused): one row [obs | reward | done + 2 * truncated] per environment
-            float* row = obs_out + (size_t)env * (od + 2);
-            row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
+    if (!RESET) {
+        const bool dn = r.done > 0.5f;
+        if (valid && (threadIdx.x & 3) == 0) {
+            if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
+            else {
+                float* row = obs_out + (size_t)env * (od + 2);
+                row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
+            }
         }
     }
-    bool any_reset = false;   // wave-uniform: a look-ahead reset rewrote the parameters of some record of the tile
-    if (RESET) {
-        const bool do_reset = dn && valid;
-        if (__builtin_expect(__any(do_reset), 0)) {
-            any_reset = true;
+    if (RESET && __builtin_expect(any_reset, 0)) {
+        // the rest of the reset: the environment's own settled state from its look-ahead slot -- or, after an in-step settle, what that left
+        // in the LDS copy --, then the task / sensor / filter reset
+        LaneDev::sync();
+        if (ahead) copy_settled(rec, ahead, cfg.payload_soft != 0);
+        LaneDev::sync();
+        if (do_reset) E::reset(cfg, rec, ob, gid, false);
+        if (__builtin_expect(spawn, 0)) {   // after an in-step settle the other quads' LDS copies are spent: the reset ones go back on their own
+            if (do_reset && !ahead && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
             LaneDev::sync();
-            const float* ahead = nullptr;
-            if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
-                for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
-                if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
-                ahead = lookahead_take(la, stats, env, qs::f2i(rec[R_EPISODE]) + 1);
-                if (ahead) copy_settled(rec, ahead, cfg.payload_soft != 0);
-            }
-            LaneDev::sync();
-            if (ahead) E::reset(cfg, rec, ob, gid, false);
-            const bool stalled = do_reset && !ahead;
-            if (__builtin_expect(__any(stalled), 0)) {
-                // no settled state ahead (reset_lookahead = 0, or all K slots used up faster than the lanes settle): the whole wave walks
-                // through the 2500-substep settle.  The settle's solver uses v_mfma_f32_4x4x1, which ignores EXEC, so it must not run
-                // under a divergent branch: what the step produced is published first, then EVERY quad runs the reset on its LDS copy (as
-                // k_reset does) and only the stalled environments keep the result.
-                __syncthreads();
-                tile_store(s_rec, recs, first, cfg.n_envs, 0, tile_extent(cfg, true), ls);
-                obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
-                __syncthreads();
-                E::reset(cfg, rec, ob, gid, true);
-                if (stalled && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
-                LaneDev::sync();
-                if (stalled) {
-                    float* g = recs + (size_t)env * QS_REC;
-                    const int end = tile_extent(cfg, true);       // (what lies behind it was neither loaded nor is it this handle's to write)
-                    for (int i = threadIdx.x & 3; i < end; i += 4) g[i] = i == QS_INFO_END - 1 ? 0.0f : rec[i];   // (the pad float of the info block)
-                    for (int i = threadIdx.x & 3; i < od; i += 4) {
-                        if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
-                        else obs_out[(size_t)env * (od + 2) + i] = ob[i];
-                        obs_keep[(size_t)env * od + i] = ob[i];
-                    }
+            if (do_reset) {
+                float* g = recs + (size_t)env * QS_REC;
+                const int end = tile_extent(cfg, true);
+                for (int i = threadIdx.x & 3; i < end; i += 4) g[i] = rec[i];
+                for (int i = threadIdx.x & 3; i < od; i += 4) {
+                    if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
+                    else obs_out[(size_t)env * (od + 2) + i] = ob[i];
+                    obs_keep[(size_t)env * od + i] = ob[i];
                 }
-                return;
             }
+            return;
         }
     }
     __syncthreads();

@@ -62,3 +62,33 @@ for flag_name, flags in (("hipHostMallocNonCoherent", 0x80000000), ("hipHostMall
 
     bench(f"{flag_name}: hipMemcpyAsync + sync only", only_copy)
     hip.hipHostFree(p)
+
+# (e) ordinary (cached, page-aligned) host memory made DMA-able with hipHostRegister: what the numpy path's result buffers are
+import mmap
+for flag_name, flags in (("hipHostRegisterDefault", 0), ("hipHostRegisterPortable|Mapped", 3)):
+    mm = mmap.mmap(-1, (nbytes + 4095) // 4096 * 4096)
+    host = np.frombuffer(mm, dtype=np.float32, count=N * O).reshape(N, O)
+    host[:] = 0
+    addr = C.c_void_p(C.addressof(C.c_char.from_buffer(mm)))
+    rc = hip.hipHostRegister(addr, C.c_size_t(len(mm)), C.c_uint(flags))
+    if rc != 0:
+        print(flag_name, "hipHostRegister failed", rc)
+        continue
+
+    def via_reg(addr=addr, host=host):
+        hip.hipMemcpyAsync(addr, C.c_void_p(src.data_ptr()), C.c_size_t(nbytes), C.c_int(2), C.c_void_p(stream))
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        return host.copy()
+
+    def reg_only(addr=addr, host=host):
+        hip.hipMemcpyAsync(addr, C.c_void_p(src.data_ptr()), C.c_size_t(nbytes), C.c_int(2), C.c_void_p(stream))
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        return host[:1]
+
+    bench(f"{flag_name}: hipMemcpyAsync + sync + copy", via_reg)
+    bench(f"{flag_name}: hipMemcpyAsync + sync only", reg_only)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        out = host.copy()
+    print(f"{flag_name}: host-side numpy copy of the registered block alone {(time.perf_counter() - t0) / 200 * 1e6:8.1f} us")
+    hip.hipHostUnregister(addr)

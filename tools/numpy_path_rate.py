@@ -2,7 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "quadruped-springs_amd"))
 import numpy as np, torch
 from qs_amd.vec_env import QuadrupedVecEnv
-env = QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_pool=4096, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+env = QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                       enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1)
 env.reset()
 a = np.random.default_rng(0).uniform(-1, 1, size=(8192, 6)).astype(np.float32)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output directories (kernel stats + one directory per --pmc pass) for one kernel, over ALL of its launches.
-usage: python tools/pmc_summary.py gpurun_out/prof_x k_step [bench.json pmc.json]
-With the last two arguments the per-launch averages are also written as the pmc.json that bench.py reads (roofline.traffic)."""
+"""Summarise rocprofv3 CSV output directories (kernel stats + one directory per --pmc pass) for one kernel.
+usage: python tools/pmc_summary.py gpurun_out/prof_x k_step [bench.json pmc.json] [--last N]
+--last N: counters averaged over the LAST N launches of the kernel only -- with N = the profiled command's --steps that is its timed
+region (the launches before it are preparation: staggered resets, pre-roll, warmup, whose settle load is not the steady state's).
+With bench.json pmc.json the per-launch averages are also written as the pmc.json that bench.py reads (roofline.traffic)."""
 import collections
 import csv
 import glob
@@ -9,8 +11,12 @@ import json
 import os
 import sys
 
-root, kernel = sys.argv[1], sys.argv[2]
-bench_json, out_json = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else (None, None)
+argv = list(sys.argv)
+last = 0
+if "--last" in argv:
+    i = argv.index("--last"); last = int(argv[i + 1]); del argv[i:i + 2]
+root, kernel = argv[1], argv[2]
+bench_json, out_json = (argv[3], argv[4]) if len(argv) > 4 else (None, None)
 
 
 def base(name):
@@ -40,6 +46,8 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), 
             names[base(r["Kernel_Name"])] += 1
             meta = r
     for c, v in d.items():
+        if last:
+            v = v[-last:]          # rows are in dispatch order
         avg[c] = (sum(v) / len(v), len(v))
         print(f"| {c} | {sum(v) / len(v):.6g} | {min(v):.6g} | {max(v):.6g} | {len(v)} |")
 if meta:
@@ -49,12 +57,12 @@ if out_json and avg:
     b = json.load(open(bench_json))
     c = b["config"]
     j = {"kernel": names.most_common(1)[0][0], "workload": c["workload"], "envs_per_gpu": c["envs_per_gpu"],
-         "reset_pool": int(c["reset"].split()[2]) if c["reset"].startswith("pool of") else 0, "settle_lanes": "settle lanes" in c["reset"],
+         "reset_lookahead": c["reset_lookahead"],
          "friction_model": c["friction_model"], "solver_residual_threshold": c["solver_residual_threshold"],
          "fetch_size_kb": avg["FETCH_SIZE"][0], "write_size_kb": avg["WRITE_SIZE"][0], "fetch_correction": 2.0,
          "sq_insts_valu": avg.get("SQ_INSTS_VALU", (None, 0))[0], "sq_waves": avg.get("SQ_WAVES", (None, 0))[0],
          "launches": avg["FETCH_SIZE"][1], "bench_value": b["value"], "bench_kernel_ms": b["roofline"]["kernel_ms"],
-         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, per-launch averages over ALL launches of the step kernel in "
+         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, per-launch averages over " + (f"the last {last} launches (the timed region)" if last else "ALL launches") + " of the step kernel in "
                  "the profiled command (same table as the *_kernel_trace_pmc.md next to this file); FETCH_SIZE doubled per MI355X_MICROARCH.md "
                  "(16-B-per-lane streaming reads are tallied at half their bytes on gfx950)"}
     json.dump(j, open(out_json, "w"), indent=1)

@@ -31,9 +31,8 @@ for variant in ("1", "2"):
     for kw in CASES:
         kw = dict(dict(enable_springs=True, enable_action_filter=True), **kw)
         n = 4096
-        env = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_pool=1024, seed=3, **kw)
+        env = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_lookahead=8, seed=3, **kw)
         env.reset_tensor()
-        env.pool_streaming(True)
         g = torch.Generator(device="cuda").manual_seed(1)
         dones = 0
         for i in range(steps):
@@ -52,5 +51,5 @@ for variant in ("1", "2"):
                 assert st[:, 2].min() > zmin and st[:, 2].max() < 3.0, (kw, i, float(st[:, 2].min()), float(st[:, 2].max()))
                 assert st[:, 7:13].abs().max() <= 30.2 and st[:, 25:].abs().max() <= 30.2, (kw, i)
         ninv = env.get_info("n_invalid").max().item()
-        print(f"variant {variant} {kw['task_env']:28s} ok: {steps} steps x {n} envs, {dones} episode ends, refilled {env.pool_streaming(False)}, max invalid contacts {ninv:.0f}")
+        print(f"variant {variant} {kw['task_env']:28s} ok: {steps} steps x {n} envs, {dones} episode ends, look-ahead states settled {env.counter('lookahead_settled')}, stalls {env.counter('reset_stalls')}, max invalid contacts {ninv:.0f}")
         env.close()

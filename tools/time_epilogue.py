@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "q
 import torch
 from qs_amd.vec_env import QuadrupedVecEnv
 def run(tag, **kw):
-    env = QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_pool=4096, enable_springs=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1, **kw)
+    env = QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_lookahead=8, enable_springs=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1, **kw)
     env.reset_tensor()
     a = torch.rand((16, 8192, env.action_dim), device="cuda") * 2 - 1
     for i in range(30): env.step_tensor(a[i % 16])

@@ -8,7 +8,7 @@ for iters in (30, 0, 10, 60):
         cfg, meta = orig(**kw); cfg.solver_iters = iters; return cfg, meta
     import qs_amd.vec_env as ve
     ve.build_config = bc
-    env = ve.QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_pool=4096, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+    env = ve.QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                              enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1)
     env.reset_tensor()
     a = torch.rand((16, 8192, 6), device="cuda") * 2 - 1

@@ -2,7 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.getcwd(), "quadruped-springs_amd"))
 import torch
 from qs_amd import DeviceVecNormalize, QuadrupedVecEnv
-venv = QuadrupedVecEnv(num_envs=8192, device=0, auto_reset=True, reset_pool=4096, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+venv = QuadrupedVecEnv(num_envs=8192, device=0, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                        enable_springs=True, enable_action_filter=True)
 env = DeviceVecNormalize(venv)
 obs = env.reset_tensor()
