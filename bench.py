@@ -43,13 +43,37 @@ def workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
+def usable_cores():
+    """Host threads this process can actually run at once: the affinity mask, cut down to the CPU-time quota of its cgroup when there is
+    one (cgroup v2 cpu.max, v1 cpu.cfs_quota_us).  Round 2's box showed 256 CPUs in the mask and gave ~8 CPUs' worth of time: 256 busy
+    threads then run at 3 % each."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible, quota = n, None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(math.floor(quota + 1e-9))))
+    return n, visible, quota
+
+
 def cpu_baseline(cfg_kwargs, budget_s=14.0):
     """The oracle (CPU restatement, float64, scalar C) timed on this box's host cores on a bounded sample of the same workload: 64
     environments per host thread, every thread stepping its own share without a barrier between steps (qso_rollout: independent workers
     are the CPU's best case -- a reset's in-place 2500-substep settle then delays only its own thread), once on ONE thread and once on
     all of them.  Also tries the reference's own PyBullet path."""
     import numpy as np
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, visible, quota = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)          # read by libgomp when the oracle library is loaded
     os.environ["OMP_WAIT_POLICY"] = "passive"
     from oracle.qso import Oracle
@@ -77,7 +101,7 @@ def cpu_baseline(cfg_kwargs, budget_s=14.0):
         ref = "pybullet importable, but the reference's QuadrupedGymEnv also needs gym and the reference tree, which the GPU box does not hold: not run"
     except Exception as e:  # noqa: BLE001
         ref = f"unavailable ({type(e).__name__}: pybullet==3.2.5 of the reference's setup.py:10 is not installed on this box)"
-    return dict(value=allt["rate"], unit="env-steps/s", cores=cores, kind="port",
+    return dict(value=allt["rate"], unit="env-steps/s", cores=cores, kind="port", cpus_in_affinity_mask=visible, cgroup_cpu_quota=quota,
                 single_thread=one["rate"], per_thread=allt["rate"] / cores,
                 parallel_efficiency=allt["rate"] / (cores * one["rate"]),
                 resets_in_sample=allt["resets"], settle_share_of_substeps=allt["settle_share"], single_thread_settle_share=one["settle_share"],

@@ -291,6 +291,9 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
             ahead = lookahead_take(la, stats, env, next_episode);
         }
         if (__builtin_expect(!__any(do_reset && !ahead), 1)) break;
+#ifdef QS_AB_NO_STALL   /* A/B builds only (tools/r03_ab.sh): no in-step settle, i.e. no second trip -- wrong for a stalled reset, fast to compare */
+        break;
+#endif
         // no settled state ahead (reset_lookahead = 0, or all K states used up faster than the lanes settle): what the step produced is
         // published, then the WHOLE wave walks through the settle on its LDS copies (the solver's v_mfma_f32_4x4x1 ignores EXEC, so every
         // quad takes part: the others settle a copy of their own next reset that nobody keeps) and only the stalled environments keep the result.
@@ -362,6 +365,10 @@ __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * QS_REC_END; i += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(i / QS_REC_END), f = (int)(i % QS_REC_END);
         const int2 job = jobs[e];
+        // a state whose episode the environment has reached or passed meanwhile (it settled in place: a stall) is of no use -- and must not
+        // land in a slot that a later episode's state, settled in the same cohort, is going to as well.  The live episodes of an environment
+        // (the K after its current one) have K different slots.
+        if (job.y <= la.queued[job.x] - la.K) continue;
         float* dst = la.slots + ((size_t)job.x * la.K + (size_t)(job.y % la.K)) * QS_REC;
         dst[f] = f == R_EPISODE ? qs::i2f(job.y) : src[(size_t)e * QS_REC + f];
     }
