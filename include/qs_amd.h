@@ -209,8 +209,7 @@ enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset
        QS_COUNTER_SELF_NARROW_SUBSTEPS = 5, /* wave-substeps whose self-collision broad phase found a calf close enough to another leg or
                                                the trunk to run the link-link tests (per process) */
        QS_COUNTER_RESET_STALLS = 6,         /* resets of a handle with reset_lookahead > 0 whose state was not ready: settled in place */
-       QS_COUNTER_LOOKAHEAD_BACKLOG = 7,    /* settles queued and not yet taken by a settle lane */
-       QS_COUNTER_LOOKAHEAD_DROPPED = 8     /* settles that found the queue full (re-queued by the environment's next reset) */ };
+       QS_COUNTER_LOOKAHEAD_BACKLOG = 7     /* reset states the environments' look-ahead windows lack and no settle lane has taken yet */ };
 int qs_counter(qs_handle* h, int which, uint64_t* value);
 /* Average duration of the step-kernel launches of a BATCH of qs_step calls, from two HIP events on the handle's stream: one recorded in
  * front of the first step launched after qs_enable_timing(h, 1), one recorded by qs_last_step_kernel_ms, which waits for it, returns
@@ -220,11 +219,12 @@ int qs_counter(qs_handle* h, int which, uint64_t* value);
 int qs_enable_timing(qs_handle* h, int on);
 int qs_last_step_kernel_ms(qs_handle* h, float* ms);
 /* The settle lanes of a handle with cfg.reset_lookahead > 0 (on from qs_create).  While on, every qs_step launch carries extra
- * workgroups that advance the queued resets (gym_env.py:278-297, 325-327: randomizer draws, spawn, 2500 substeps under the settling
- * command) by action_repeat substeps each, through the same substep loop as the environments; a finished one goes to its environment's
- * look-ahead slot.  An epoch = the settle_steps / action_repeat launches one settle takes; the lanes work in five cohorts that start a
- * fifth of an epoch apart.  Off: queued settles wait (the ones in progress start over when the lanes come back), resets use up the
- * states that are ready and then settle in place -- results do not change, only when the work is done. */
+ * workgroups that advance resets (gym_env.py:278-297, 325-327: randomizer draws, spawn, 2500 substeps under the settling command) by
+ * action_repeat substeps each, through the same substep loop as the environments; a finished one goes to its environment's look-ahead
+ * slot.  An epoch = the settle_steps / action_repeat launches one settle takes; the lanes work in five cohorts that start a fifth of an
+ * epoch apart, each taking at its start what the environments' windows lack (environment e in episode X wants X + 1 .. X + K).  Off:
+ * nothing is settled ahead (the settles in progress start over when the lanes come back), resets use up the states that are ready and
+ * then settle in place -- results do not change, only when the work is done. */
 int qs_settle_lanes(qs_handle* h, int on);
 /* Per-substep trace tap for ONE environment (evaluation_wrapper.py:14,36-41 set_sub_step_callback; monitor_state.py:66-85):
  * while set, every qs_step writes action_repeat rows of QS_TRACE_DIM floats into `rows` (device memory, caller owned), one per

@@ -90,20 +90,19 @@ __device__ __forceinline__ void obs_store(const float* s_obs, int nrow, int od, 
 // one settle: counted as a stall) settles inside the step as with K = 0 -- every output is bitwise what reset_lookahead = 0 produces.
 struct LookAhead {
     float* slots;           // [N][K] records
-    int* queued;            // [N]: last episode of each environment whose settle has been queued
-    int2* jobs;             // ring of (environment, episode) waiting for a settle lane; head / tail in the handle's counters
-    unsigned qmask;         // ring size - 1 (a power of two)
+    int* cur;               // [N]: the episode each environment is in (written by every reset; what the planning scan reads)
+    int* handed;            // [N]: last episode of each environment whose settle a lane has taken (or that was settled at create)
     int K;
 };
 // Settle lanes: workgroups beyond the environments' ones advance records of a staging area through a reset's settle, one slice of substeps
 // per launch; ctl = the counters in qs_handle::d_stats.  The staging area is split into QS_COHORTS slices whose settles start QS_COHORTS-th
-// of an epoch (= the launches one settle takes) apart, so that queued jobs wait at most epoch / QS_COHORTS launches for a lane.
+// of an epoch (= the launches one settle takes) apart, so that a wanted state waits at most epoch / QS_COHORTS launches for a lane.
 #define QS_COHORTS 5
 #define QS_MAX_SLICE 2048
 struct SettleLanes { float* staging; const int2* stage_jobs; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
 struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
-enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_Q_TAIL = 4, CTL_Q_HEAD = 5, CTL_STALLS = 6, CTL_DROPPED = 7,
+enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
        CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
 
 // settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines)
@@ -115,32 +114,21 @@ __device__ __forceinline__ void copy_settled(float* rec, const float* src, bool 
     for (int i = R_FOOT_FORCE + lane; i < R_TAU_SPRING + 12; i += 4) rec[i] = src[i];    // contact results, torques
     if (lane == 0) rec[R_N_INVALID] = src[R_N_INVALID];
 }
-// A reset of `env` to episode X (called by the four lanes of its quad): the slot that holds the settled state of that episode, or null when
-// it is not there (yet); lane 0 queues the settles that the window X + 1 .. X + K now lacks (normally the one of episode X + K).
-__device__ __forceinline__ const float* lookahead_take(const LookAhead& la, unsigned long long* __restrict__ ctl, int env, int X, bool count = true) {
-    if (la.K == 0) return nullptr;
+// A reset of `env` to episode X (called by the four lanes of its quad): copies the slot of that episode into the record -- all of its loads
+// go out together with the one of the slot's tag, ONE trip to memory on the path of a wave that every launch waits for -- and says
+// whether the slot held that episode (if not, the in-step settle overwrites what was copied).  Nothing is queued here: the planning
+// scan of the settle lanes reads `cur`.
+__device__ __forceinline__ bool lookahead_take(const LookAhead& la, unsigned long long* __restrict__ ctl, float* rec, int env, int X, bool block, bool count = true) {
+    if (la.K == 0) return false;
     const float* slot = la.slots + ((size_t)env * la.K + (size_t)(X % la.K)) * QS_REC;
-    const bool ready = qs::f2i(slot[R_EPISODE]) == X;
+    const float tag = slot[R_EPISODE];
+    copy_settled(rec, slot, block);
+    const bool ready = qs::f2i(tag) == X;
     if ((threadIdx.x & 3) == 0) {
-        const int q = la.queued[env], to = X + la.K;
-        int Y = (q > X ? q : X) + 1;
-        for (; Y <= to; Y++) {
-            unsigned long long t = ctl[CTL_Q_TAIL];
-            bool room;
-            for (;;) {      // reserve a ring entry unless the ring is full (then the job is not queued now: the next reset tries again)
-                room = t - ctl[CTL_Q_HEAD] <= (unsigned long long)la.qmask;
-                if (!room) break;
-                const unsigned long long seen = atomicCAS(&ctl[CTL_Q_TAIL], t, t + 1);
-                if (seen == t) break;
-                t = seen;
-            }
-            if (!room) { atomicAdd(&ctl[CTL_DROPPED], 1ull); break; }
-            la.jobs[(unsigned)t & la.qmask] = make_int2(env, Y);
-        }
-        if (Y - 1 > q) la.queued[env] = Y - 1;
+        la.cur[env] = X;
         if (count) atomicAdd(&ctl[ready ? CTL_SERVED : CTL_STALLS], 1ull);
     }
-    return ready ? slot : nullptr;
+    return ready;
 }
 __device__ __forceinline__ void zero_tile_tail(float* lds, int from, int stride) {   // floats [from, stride) of the 16 records in LDS
     const int per = stride - from;
@@ -237,7 +225,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     typename E::StepOut r;
     bool any_reset = false;   // wave-uniform: a reset rewrote the parameters of some record of the tile
     bool do_reset = false;    // this quad's environment ended its episode
-    const float* ahead = nullptr;   // ... and this is its settled reset state; null: it settles inside the step (second trip of the loop)
+    bool ahead = false;       // ... and its settled reset state was ready; if not, it settles inside the step (second trip of the loop)
     int next_episode = 0;
     // The loop runs ONCE, except in a wave with such an environment: its second trip is the in-step settle -- the wave turns into what a
     // settle lane is (spawn, then all settle_steps substeps through the same E::step(..., settle_n)), so that the fallback costs the kernel
@@ -288,7 +276,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
         if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
             for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
             if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
-            ahead = lookahead_take(la, stats, env, next_episode);
+            ahead = lookahead_take(la, stats, rec, env, next_episode, cfg.payload_soft != 0);
         }
         if (__builtin_expect(!__any(do_reset && !ahead), 1)) break;
 #ifdef QS_AB_NO_STALL   /* A/B builds only (tools/r03_ab.sh): no in-step settle, i.e. no second trip -- wrong for a stalled reset, fast to compare */
@@ -298,7 +286,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
         // published, then the WHOLE wave walks through the settle on its LDS copies (the solver's v_mfma_f32_4x4x1 ignores EXEC, so every
         // quad takes part: the others settle a copy of their own next reset that nobody keeps) and only the stalled environments keep the result.
         __syncthreads();
-        tile_store(s_rec, recs, first, cfg.n_envs, QS_RW_BEGIN, tile_extent(cfg, true), ls);
+        tile_store(s_rec, recs, first, cfg.n_envs, 0, tile_extent(cfg, true), ls);
         obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
         __syncthreads();
         spawn = true; settle_n = cfg.settle_steps; job = make_int2(env, next_episode);
@@ -315,11 +303,13 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
         }
     }
     if (RESET && __builtin_expect(any_reset, 0)) {
-        // the rest of the reset: the environment's own settled state from its look-ahead slot -- or, after an in-step settle, what that left
-        // in the LDS copy --, then the task / sensor / filter reset
+        // the rest of the reset on the settled state in the record (from the environment's look-ahead slot -- copied once more where an
+        // in-step settle of the wave went over it --, or what its own in-step settle left there): the task / sensor / filter reset
         LaneDev::sync();
-        if (ahead) copy_settled(rec, ahead, cfg.payload_soft != 0);
-        LaneDev::sync();
+        if (__builtin_expect(spawn, 0)) {
+            if (ahead) copy_settled(rec, la.slots + ((size_t)env * la.K + (size_t)(next_episode % la.K)) * QS_REC, cfg.payload_soft != 0);
+            LaneDev::sync();
+        }
         if (do_reset) E::reset(cfg, rec, ob, gid, false);
         if (__builtin_expect(spawn, 0)) {   // after an in-step settle the other quads' LDS copies are spent: the reset ones go back on their own
             if (do_reset && !ahead && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
@@ -356,7 +346,7 @@ template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 1) void k
 template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, RESET, 2>(QS_STEP_PASS); }
 
 // Settle lanes, between two settles of a cohort (an epoch = the launches one settle takes): the staging records that finished settling go
-// to the look-ahead slots of their environments (the settled fields of copy_settled; R_EPISODE marks the slot as holding that episode) ...
+// to the look-ahead slots of their environments (R_EPISODE marks the slot as holding that episode) ...
 __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const float* __restrict__ staging, const int2* __restrict__ stage_jobs,
                                     LookAhead la, int cohort, int slice) {
     const int n = (int)ctl[CTL_R + cohort];
@@ -366,42 +356,51 @@ __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const 
         const int e = (int)(i / QS_REC_END), f = (int)(i % QS_REC_END);
         const int2 job = jobs[e];
         // a state whose episode the environment has reached or passed meanwhile (it settled in place: a stall) is of no use -- and must not
-        // land in a slot that a later episode's state, settled in the same cohort, is going to as well.  The live episodes of an environment
-        // (the K after its current one) have K different slots.
-        if (job.y <= la.queued[job.x] - la.K) continue;
+        // land in a slot that a later episode's state is going to as well.  The live episodes of an environment (the K after its current
+        // one) have K different slots.
+        if (job.y <= la.cur[job.x]) continue;
         float* dst = la.slots + ((size_t)job.x * la.K + (size_t)(job.y % la.K)) * QS_REC;
         dst[f] = f == R_EPISODE ? qs::i2f(job.y) : src[(size_t)e * QS_REC + f];
     }
 }
-// ... then the cohort takes the jobs that wait in the ring, at most `cap` (the lanes the launch geometry gives it).
-__global__ void k_lookahead_plan(unsigned long long* __restrict__ ctl, LookAhead la, int2* __restrict__ stage_jobs, int cohort, int slice, int cap) {
-    __shared__ unsigned long long s_head;
-    __shared__ int s_n;
-    if (threadIdx.x == 0) {
-        ctl[CTL_SETTLED] += ctl[CTL_R + cohort];
-        const unsigned long long head = ctl[CTL_Q_HEAD], tail = ctl[CTL_Q_TAIL];
-        unsigned long long n = tail - head;
-        if (n > (unsigned long long)cap) n = (unsigned long long)cap;
-        s_head = head; s_n = (int)n;
-    }
+// ... then the cohort takes what the environments' windows lack: environment e in episode X wants the states of X + 1 .. X + K; those up to
+// handed[e] are settled or being settled.  One block scans all environments, starting at a rotating offset (when more is wanted than the
+// cohort has lanes -- `cap` --, the rest waits for the next cohort, and nobody waits for ever).  cap = 0: count only (the backlog counter).
+__global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __restrict__ ctl, LookAhead la, int n_envs, int2* __restrict__ stage_jobs, int cohort,
+                                                          int slice, int cap, int offset) {
+    __shared__ int s_count, s_want;
+    if (threadIdx.x == 0) { s_count = 0; s_want = 0; if (cap > 0) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
     __syncthreads();
     int2* dst = stage_jobs + (size_t)cohort * slice;
-    for (int i = threadIdx.x; i < s_n; i += blockDim.x) dst[i] = la.jobs[(unsigned)(s_head + (unsigned long long)i) & la.qmask];
-    __syncthreads();
-    if (threadIdx.x == 0) { ctl[CTL_Q_HEAD] = s_head + (unsigned long long)s_n; ctl[CTL_R + cohort] = (unsigned long long)s_n; }
-}
-// Settle lanes paused (qs_settle_lanes(h, 0)): the jobs of the settles in progress go back into the ring (in front: they are the oldest)
-__global__ void k_lookahead_requeue(unsigned long long* __restrict__ ctl, LookAhead la, const int2* __restrict__ stage_jobs, int slice) {
-    if (blockIdx.x || threadIdx.x) return;
-    for (int c = QS_COHORTS - 1; c >= 0; c--) {
-        const int n = (int)ctl[CTL_R + c];
-        for (int i = n - 1; i >= 0; i--) {
-            if (ctl[CTL_Q_TAIL] - ctl[CTL_Q_HEAD] > (unsigned long long)la.qmask) { ctl[CTL_DROPPED] += 1; continue; }
-            ctl[CTL_Q_HEAD] -= 1;
-            la.jobs[(unsigned)ctl[CTL_Q_HEAD] & la.qmask] = stage_jobs[(size_t)c * slice + i];
-        }
-        ctl[CTL_R + c] = 0;
+    for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
+        const int e = (i + offset) % n_envs;
+        const int X = la.cur[e];
+        int h = la.handed[e];
+        if (h < X) h = X;
+        const int want = X + la.K - h;
+        if (want <= 0) continue;
+        atomicAdd(&s_want, want);
+        if (cap <= 0) continue;
+        const int at = atomicAdd(&s_count, want);
+        int took = 0;
+        for (int j = 0; j < want && at + j < cap; j++) { dst[at + j] = make_int2(e, h + 1 + j); took++; }
+        if (took) la.handed[e] = h + took;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = s_count < cap ? s_count : cap;
+        if (cap > 0) ctl[CTL_R + cohort] = (unsigned long long)n;
+        ctl[CTL_BACKLOG] = (unsigned long long)(s_want - (cap > 0 ? n : 0));
+    }
+}
+// Settle lanes switched off (qs_settle_lanes(h, 0)): the settles in progress are dropped; their states count as not handed out again
+__global__ void k_lookahead_requeue(unsigned long long* __restrict__ ctl, LookAhead la, const int2* __restrict__ stage_jobs, int slice) {
+    for (int c = 0; c < QS_COHORTS; c++) {
+        const int n = (int)ctl[CTL_R + c];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const int2 job = stage_jobs[(size_t)c * slice + i]; atomicMin(&la.handed[job.x], job.y - 1); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) for (int c = 0; c < QS_COHORTS; c++) ctl[CTL_R + c] = 0;
 }
 
 // QuadrupedGymEnv.reset for the masked environments (gym_env.py:278-297).  An environment whose look-ahead slot holds the coming episode
@@ -424,9 +423,10 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
     float* rec = s_rec + slot * QS_REC_END;
     float* ob = s_obs + slot * QS_MAX_OBS;
     const uint32_t gid = (uint32_t)((valid ? env : 0) + cfg.env_id_offset);
-    const float* ahead = nullptr;
+    bool ahead = false;
     if (sel) {
-        ahead = lookahead_take(la, stats, env, qs::f2i(rec[R_EPISODE]) + 1, states == nullptr);   // (also queues what the window lacks after this reset)
+        if (states == nullptr) ahead = lookahead_take(la, stats, rec, env, qs::f2i(rec[R_EPISODE]) + 1, cfg.payload_soft != 0);
+        else if (la.K > 0 && (threadIdx.x & 3) == 0) la.cur[env] = qs::f2i(rec[R_EPISODE]) + 1;   // (the look-ahead window moves on all the same)
         if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
     }
     bool write_back = false;
@@ -450,7 +450,6 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_reset(const
             for (int i = threadIdx.x & 3; i < 12 + 24 + 24; i += 4) rec[R_LAST_ACTION + i] = 0.0f;
         write_back = sel;
     } else {
-        if (ahead) copy_settled(rec, ahead, cfg.payload_soft != 0);
         LaneDev::sync();
         if (ahead) {
             E::reset(cfg, rec, ob, gid, false);
@@ -495,7 +494,7 @@ template <bool CONE> __global__ __launch_bounds__(QS_WAVE, 1) void k_lookahead_f
     if (j < total) {
         float* g = la.slots + ((size_t)env * la.K + (size_t)(episode % la.K)) * QS_REC;
         for (int i = threadIdx.x & 3; i < QS_REC_END; i += 4) g[i] = rec[i];     // (R_EPISODE = episode: the slot's tag)
-        if (episode == la.K - 1 && (threadIdx.x & 3) == 0) la.queued[env] = la.K - 1;
+        if (episode == la.K - 1 && (threadIdx.x & 3) == 0) { la.handed[env] = la.K - 1; la.cur[env] = -1; }
     }
 }
 
@@ -633,16 +632,13 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
     if (cfg->reset_lookahead > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
         const int K = cfg->reset_lookahead;
         h->la.K = K;
-        size_t ring = 1024;
-        while (ring < 2 * n * (size_t)K) ring <<= 1;       // at most K jobs of an environment wait at a time (plus stale ones after stalls)
-        h->la.qmask = (unsigned)(ring - 1);
         // a cohort settles at most `slice` records at a time: enough lanes for every environment to reset once per epoch and cohort
         h->slice = (int)((n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE);
         if (h->slice < QS_MAX_SLICE) h->slice = QS_MAX_SLICE;
         if (h->slice > 65536) h->slice = 65536;
         QS_HIP(hipMalloc(&h->la.slots, n * K * QS_REC * sizeof(float)));
-        QS_HIP(hipMalloc(&h->la.queued, n * sizeof(int)));
-        QS_HIP(hipMalloc(&h->la.jobs, ring * sizeof(int2)));
+        QS_HIP(hipMalloc(&h->la.cur, n * sizeof(int)));
+        QS_HIP(hipMalloc(&h->la.handed, n * sizeof(int)));
         QS_HIP(hipMalloc(&h->d_staging, (size_t)QS_COHORTS * h->slice * QS_REC * sizeof(float)));
         QS_HIP(hipMalloc(&h->d_stage_jobs, (size_t)QS_COHORTS * h->slice * sizeof(int2)));
         QS_HIP(hipMemsetAsync(h->d_staging, 0, (size_t)QS_COHORTS * h->slice * QS_REC * sizeof(float), h->stream));
@@ -663,8 +659,8 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     hipStreamSynchronize(h->stream);
     hipFree(h->d_cfg); hipFree(h->d_rec); hipFree(h->d_obs); hipFree(h->d_term_obs); hipFree(h->d_stats);
     if (h->la.slots) hipFree(h->la.slots);
-    if (h->la.queued) hipFree(h->la.queued);
-    if (h->la.jobs) hipFree(h->la.jobs);
+    if (h->la.cur) hipFree(h->la.cur);
+    if (h->la.handed) hipFree(h->la.handed);
     if (h->d_staging) hipFree(h->d_staging);
     if (h->d_stage_jobs) hipFree(h->d_stage_jobs);
     if (h->d_demo) hipFree(h->d_demo);
@@ -706,7 +702,7 @@ int qs_settle_lanes(qs_handle* h, int on) {
     QS_ON_DEVICE(h);
     if (h->la.K == 0) { if (on) QS_FAIL(-1, "this handle keeps no look-ahead reset states (cfg.reset_lookahead = 0, or QS_RAND_KEEP)"); return 0; }
     if (!on && h->lanes_on) {   // settles in progress are dropped, their jobs go back to the front of the queue
-        hipLaunchKernelGGL(k_lookahead_requeue, dim3(1), dim3(1), 0, h->stream, h->d_stats, h->la, h->d_stage_jobs, h->slice);
+        hipLaunchKernelGGL(k_lookahead_requeue, dim3(1), dim3(256), 0, h->stream, h->d_stats, h->la, h->d_stage_jobs, h->slice);
         QS_HIP(hipGetLastError());
     }
     if (on && !h->lanes_on) h->tick = 0;
@@ -754,7 +750,8 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
             const int phase = (int)(t % epoch);
             if (phase == 0) {
                 hipLaunchKernelGGL(k_lookahead_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_staging, h->d_stage_jobs, h->la, c, slice);
-                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(256), 0, h->stream, h->d_stats, h->la, h->d_stage_jobs, c, slice, cohort_cap);
+                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, c, slice, cohort_cap,
+                                   (int)((h->tick / (epoch / QS_COHORTS > 0 ? epoch / QS_COHORTS : 1)) * 4099 % h->cfg.n_envs));
             }
             lanes.spawn[c] = phase == 0; lanes.last[c] = phase == epoch - 1;
             lanes.settle_n[c] = phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
@@ -832,13 +829,14 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
     case QS_COUNTER_LOOKAHEAD_SERVED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_SERVED], sizeof(v), hipMemcpyDeviceToHost)); break;
     case QS_COUNTER_LOOKAHEAD_SETTLED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_SETTLED], sizeof(v), hipMemcpyDeviceToHost)); break;
     case QS_COUNTER_RESET_STALLS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_STALLS], sizeof(v), hipMemcpyDeviceToHost)); break;
-    case QS_COUNTER_LOOKAHEAD_DROPPED: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_DROPPED], sizeof(v), hipMemcpyDeviceToHost)); break;
-    case QS_COUNTER_LOOKAHEAD_BACKLOG: {
-        unsigned long long ht[2];
-        QS_HIP(hipMemcpy(ht, &h->d_stats[CTL_Q_TAIL], sizeof(ht), hipMemcpyDeviceToHost));   // tail, head
-        v = ht[0] - ht[1];
+    case QS_COUNTER_LOOKAHEAD_BACKLOG:
+        if (h->la.K > 0) {   // a counting pass of the planning scan
+            hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, 0, h->slice, 0, 0);
+            QS_HIP(hipGetLastError());
+            QS_HIP(hipStreamSynchronize(h->stream));
+            QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_BACKLOG], sizeof(v), hipMemcpyDeviceToHost));
+        }
         break;
-    }
     case QS_COUNTER_LIMIT_PATH_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_rare_path_substeps), sizeof(v))); break;
     case QS_COUNTER_SELF_NARROW_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_self_narrow_substeps), sizeof(v))); break;
     default: QS_FAIL(-1, "unknown counter %d", which);

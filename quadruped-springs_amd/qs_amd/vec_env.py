@@ -150,7 +150,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         return dict(settle_substeps=a.value, resets=b.value)
 
     COUNTERS = dict(settle_substeps=0, resets=1, lookahead_served=2, lookahead_settled=3, limit_path_substeps=4, self_narrow_substeps=5,
-                    reset_stalls=6, lookahead_backlog=7, lookahead_dropped=8)
+                    reset_stalls=6, lookahead_backlog=7)
 
     def counter(self, which):
         v = C.c_uint64(0)

@@ -328,8 +328,8 @@ def test_lookahead_states_are_consumed_and_resettled(torch_cuda):
     served, settled, stalls, backlog = (v.counter(k) for k in ("lookahead_served", "lookahead_settled", "reset_stalls", "lookahead_backlog"))
     assert n_done > 1200 and settled >= 2048
     assert served + stalls == resets == n_done + 1024
-    assert settled + backlog <= resets       # one settle queued per reset; those in the lanes are neither delivered nor waiting
-    assert stalls == 0 and v.counter("lookahead_dropped") == 0
+    assert settled + backlog <= resets       # one state wanted per reset; those in the lanes are neither delivered nor waiting
+    assert stalls == 0
     assert len(mus) > 1000 and min(mus) >= 0.5 and max(mus) <= 1.0     # every reset its own friction draw
     v.settle_lanes(False)
     v.step(rng.uniform(-1, 1, size=(1024, 6)).astype(np.float32))   # lanes off: stepping stays valid
