@@ -198,6 +198,25 @@ int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets);
  * buffer a sharded run all-gathers to the learner rank (one collective per step, qs_amd/sharded.py), written by the step
  * kernel itself instead of being packed from four arrays afterwards. */
 int qs_step_fused(qs_handle* h, const float* actions, float* fused);
+/* ---- Host (numpy) path: the SB3 consumer of load_model.py:113-133 hands over HOST arrays.  qs_host_step_begin = VecEnv.step_async:
+ * `actions` is a host array [N, action_dim] (any memory; copied before the call returns); the H2D copy, the step and ONE D2H copy of
+ * the results are enqueued on the handle's stream.  qs_host_step_end = VecEnv.step_wait: waits for them and points `out` at the
+ * results in page-locked host memory owned by the handle: two blocks alternate, so the arrays of a step stay valid until the end of the
+ * NEXT step.  terminal_rows: the observations of the environments that ended their episode in this step BEFORE their auto-reset
+ * (SB3: infos[i]["terminal_observation"]) as a compact list -- row r = [environment index (int32 bits), observation], in no particular
+ * order; the number of rows is the number of set `done` flags, of which the list holds the first terminal_cap (256, or N if smaller):
+ * a step that ends more episodes than that reads the rest with qs_get_info(QS_INFO_TERMINAL_OBS). */
+typedef struct qs_host_result {
+    const float* obs;            /* [N, obs_dim] */
+    const float* rew;            /* [N] */
+    const uint8_t* done;         /* [N] 0 / 1 */
+    const uint8_t* truncated;    /* [N] 0 / 1: done by the time limit, not by the task (gym_env.py:245-246) */
+    const float* terminal_rows;  /* [terminal_cap, 1 + obs_dim] */
+    int32_t terminal_cap;
+} qs_host_result;
+int qs_host_step_begin(qs_handle* h, const float* actions);
+int qs_host_step_end(qs_handle* h, qs_host_result* out);
+
 /* Telemetry counters (synchronises the stream). */
 enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset, in-step settles, settle lanes) */
        QS_COUNTER_RESETS = 1,               /* environment resets */

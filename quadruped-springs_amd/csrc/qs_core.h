@@ -1180,6 +1180,20 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
     _Pragma("unroll") for (int i = 0; i < 6; i++) (A).Ld[i] = Ld[i];                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int i = 0; i < 6; i++) (A).BK[j][i] = BK[j][i]; \
     _Pragma("unroll") for (int i = 0; i < 9; i++) (A).R[i] = R[i];
+        // The full build's wave on a rare path: the environments that have NO rare row of their own (no joint at a stop, no link on the
+        // floor) still get the result of the common-path solver -- bit for bit what the common-path build gives them in a wave without
+        // such a neighbour --, computed on a copy next to the many-rows solve; only the environments with rare rows take that one's.
+        // (Both solvers run for the whole wave: their MFMAs and wave votes must not sit under a divergent branch.)
+        State s_c = s; Out o_c = o;
+        if (HOT) {
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+            else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+        } else if (!soft) {
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R);
+            else solve_and_integrate<3, false>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R);
+        }
+        // this environment has rare rows of its own and takes the many-rows solver's result (every environment under payload_soft)
+        const M rare_mine = soft ? qgt(one, zero) : qgt(T::quad_sum(qflag(qor(any_lim, any_extra))), V(0.5f));
         if (!HOT && T::any(any_extra)) {
             // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
             // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
@@ -1240,9 +1254,13 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             if (CALLS) solve_with_limits_call<1>(cfg, Pr.mu, s, o, a);
             else solve_with_limits<1>(cfg, Pr.mu, s, o, a);
             if (soft) payload_integrate(cfg, blk, a.pay);
-        } else {
-            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
-            else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+        }
+        if (!HOT) {   // (in a wave without any rare row: the common-path result for everybody)
+#pragma unroll
+            for (int j = 0; j < 3; j++) s.qd[j] = qsel(rare_mine, s.qd[j], s_c.qd[j]);
+            s.vang = mk3<V>(qsel(rare_mine, s.vang.x, s_c.vang.x), qsel(rare_mine, s.vang.y, s_c.vang.y), qsel(rare_mine, s.vang.z, s_c.vang.z));
+            s.vlin = mk3<V>(qsel(rare_mine, s.vlin.x, s_c.vlin.x), qsel(rare_mine, s.vlin.y, s_c.vlin.y), qsel(rare_mine, s.vlin.z, s_c.vlin.z));
+            s.warm = qsel(rare_mine, s.warm, s_c.warm); o.foot_force = qsel(rare_mine, o.foot_force, o_c.foot_force);
         }
 #undef QS_RARE_COMMON
 #undef QS_LIMIT_ROWS

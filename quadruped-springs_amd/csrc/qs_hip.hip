@@ -102,8 +102,12 @@ struct LookAhead {
 struct SettleLanes { float* staging; const int2* stage_jobs; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
 struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
+// Host path (qs_host_step_*): the terminal observations of the step as a compact list [cap][1 + obs_dim] (environment index as int bits,
+// observation) behind the result block, so that ONE device-to-host copy brings everything a VecEnv.step_wait returns.  The list's
+// fill count alternates between two counters: a step counts in cnt[parity] and clears the other one for the next step.
+struct TermTail { float* rows; int cap, parity; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
-       CTL_R = 8 /* one per cohort */, CTL_N = 8 + QS_COHORTS };
+       CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_N = 10 + QS_COHORTS };
 
 // settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines)
 __device__ __forceinline__ void copy_settled(float* rec, const float* src, bool block) {
@@ -160,7 +164,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, LookAhead la,
-                                                 unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo) {
+                                                 unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo, TermTail tail) {
     using E = Env<LaneDev, CONE, false, WAVES == 1>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
     using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
@@ -171,6 +175,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     float* const s_obs = s_dyn + QS_ENVS_PER_WAVE * ls;
     float* const s_act = s_obs + QS_ENVS_PER_WAVE * QS_MAX_OBS;
     QS_PHASE_BEGIN
+    if (RESET && tail.rows && blockIdx.x == 0 && threadIdx.x == 0) stats[CTL_TERM_CNT + (tail.parity ^ 1)] = 0ull;
     const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles staging records
     const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
     const int first = settling ? cohort * lanes.slice + (((int)blockIdx.x - lanes.n_env_waves) % lanes.waves_per_cohort) * QS_ENVS_PER_WAVE
@@ -276,6 +281,16 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
         if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
             for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
             if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
+            if (tail.rows) {   // host path: also as a row of the compact list
+                int at = 0;
+                if ((threadIdx.x & 3) == 0) at = (int)atomicAdd(&stats[CTL_TERM_CNT + tail.parity], 1ull);
+                at = __shfl(at, (int)(threadIdx.x & ~3u));
+                if (at < tail.cap) {
+                    float* row = tail.rows + (size_t)at * (od + 1);
+                    if ((threadIdx.x & 3) == 0) row[0] = qs::i2f(env);
+                    for (int i = threadIdx.x & 3; i < od; i += 4) row[1 + i] = ob[i];
+                }
+            }
             ahead = lookahead_take(la, stats, rec, env, next_episode, cfg.payload_soft != 0);
         }
         if (__builtin_expect(!__any(do_reset && !ahead), 1)) break;
@@ -335,8 +350,8 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
 
 #define QS_STEP_ARGS const qs_config* __restrict__ cfgp, float* __restrict__ recs, const float* __restrict__ actions, float* __restrict__ obs_out,    \
                      float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep, \
-                     float* __restrict__ term_obs, LookAhead la, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo
-#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, la, stats, lanes, tap, demo
+                     float* __restrict__ term_obs, LookAhead la, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo, TermTail tail
+#define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, la, stats, lanes, tap, demo, tail
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
 template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, RESET, 1>(QS_STEP_PASS); }
@@ -530,6 +545,7 @@ thread_local char qs_g_err[512] = "";   // shared with qs_norm.hip
 #define QS_FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
 #define QS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) QS_FAIL(-2, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
+struct HostPath;
 struct qs_handle {
     qs_config cfg;
     int device;
@@ -548,6 +564,8 @@ struct qs_handle {
     float* d_demo; int demo_len;   // qs_set_demo
     int n_simd, step_variant;   // SIMDs of the device; 0 = pick k_step / k_step_dense by grid size, 1 / 2 = forced (QS_STEP_VARIANT)
     unsigned long long* d_stats;
+    TermTail tail;          // set for the launch of a host-path step
+    struct HostPath* host;  // qs_host_step_*: pinned buffers and the device result block (allocated at first use)
     hipEvent_t ev0, ev1;
     int timing;             // qs_enable_timing: 1 = armed (the next launch records ev0), 2 = ev0 recorded
     long long timed_launches;
@@ -653,6 +671,7 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
     return 0;
 }
 
+static void host_path_free(qs_handle* h);
 void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null members are skipped)
     if (!h) return;
     QS_ON_DEVICE(h);
@@ -664,6 +683,7 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     if (h->d_staging) hipFree(h->d_staging);
     if (h->d_stage_jobs) hipFree(h->d_stage_jobs);
     if (h->d_demo) hipFree(h->d_demo);
+    host_path_free(h);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     delete h;
@@ -729,6 +749,8 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.waves_per_cohort = 1; lanes.slice = 0;
     TraceTap tap; tap.rows = h->trace_rows; tap.env = h->trace_env;
     DemoTab demo; demo.rows = h->d_demo; demo.length = h->demo_len;
+    TermTail tail = h->tail;
+    memset(&h->tail, 0, sizeof(h->tail));       // (set by qs_host_step_begin for its own launch only)
     if (E::demo_task(h->cfg.task) && !h->d_demo) QS_FAIL(-1, "the DEMO tasks need a demonstration: qs_set_demo first");
     int grid = lanes.n_env_waves;
     if (h->la.K > 0 && h->lanes_on) {
@@ -766,7 +788,7 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && grid > h->n_simd);
     const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC_END : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), lds, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
-                                                 h->d_obs, h->d_term_obs, h->la, h->d_stats, lanes, tap, demo)
+                                                 h->d_obs, h->d_term_obs, h->la, h->d_stats, lanes, tap, demo, tail)
     const bool reset = h->cfg.auto_reset != 0;   // finished environments are reset inside the step
 #define QS_PICK(C, X) { if (dense) QS_LAUNCH_STEP((k_step_dense<C, X>)); else QS_LAUNCH_STEP((k_step<C, X>)); }
     if (h->cfg.friction_cone) { if (reset) QS_PICK(true, true) else QS_PICK(true, false) }
@@ -774,6 +796,94 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
 #undef QS_PICK
 #undef QS_LAUNCH_STEP
     QS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ host (numpy) path: VecEnv.step_async / step_wait on HOST arrays
+// load_model.py:113-133 drives the environment with numpy arrays.  One step of that path = copy of the actions into pinned staging +
+// H2D, the step kernel writing observations / rewards / flags into ONE device block (with the step's terminal observations as a
+// compact list behind them), ONE D2H copy of that block into page-locked ordinary host memory (hipHostRegister: the DMA engine writes it,
+// the host reads it at cache speed -- hipHostMalloc'ed memory read three times slower on the test box, tools/host_copy_rate.py).  Two
+// host blocks alternate, so the arrays of one step stay valid during the next.
+struct HostPath {
+    size_t bytes, off_rew, off_done, off_trunc, off_tail;
+    int cap;                 // rows of the compact terminal list
+    uint8_t* d_block;
+    uint8_t* h_block[2];
+    float* h_act; float* d_act;
+    int cur, parity, pending;
+    hipEvent_t ev;
+};
+static void host_path_free(qs_handle* h) {
+    HostPath* p = h->host;
+    if (!p) return;
+    for (int k = 0; k < 2; k++) if (p->h_block[k]) { hipHostUnregister(p->h_block[k]); free(p->h_block[k]); }
+    if (p->h_act) { hipHostUnregister(p->h_act); free(p->h_act); }
+    if (p->d_block) hipFree(p->d_block);
+    if (p->d_act) hipFree(p->d_act);
+    if (p->ev) hipEventDestroy(p->ev);
+    delete p;
+    h->host = nullptr;
+}
+static int host_path_init(qs_handle* h) {
+    if (h->host) return 0;
+    HostPath* p = new (std::nothrow) HostPath();
+    if (!p) QS_FAIL(-4, "out of host memory");
+    memset(p, 0, sizeof(*p));
+    h->host = p;
+    const size_t n = (size_t)h->cfg.n_envs, o = (size_t)h->cfg.obs_dim, d = (size_t)h->cfg.action_dim;
+    p->cap = (int)(n < 256 ? n : 256);
+    p->off_rew = n * o * 4; p->off_done = p->off_rew + n * 4; p->off_trunc = p->off_done + n;
+    p->off_tail = (p->off_trunc + n + 15) / 16 * 16;
+    p->bytes = p->off_tail + (size_t)p->cap * (o + 1) * 4;
+    const size_t page = 4096, hb = (p->bytes + page - 1) / page * page, ab = (n * d * 4 + page - 1) / page * page;
+    for (int k = 0; k < 2; k++) {
+        void* m = nullptr;
+        if (posix_memalign(&m, page, hb) != 0) QS_FAIL(-4, "out of host memory");
+        memset(m, 0, hb);
+        p->h_block[k] = (uint8_t*)m;
+        QS_HIP(hipHostRegister(m, hb, hipHostRegisterDefault));
+    }
+    void* m = nullptr;
+    if (posix_memalign(&m, page, ab) != 0) QS_FAIL(-4, "out of host memory");
+    memset(m, 0, ab);
+    p->h_act = (float*)m;
+    QS_HIP(hipHostRegister(m, ab, hipHostRegisterDefault));
+    QS_HIP(hipMalloc(&p->d_block, p->bytes));
+    QS_HIP(hipMemset(p->d_block, 0, p->bytes));
+    QS_HIP(hipMalloc(&p->d_act, n * d * 4));
+    QS_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
+    return 0;
+}
+
+int qs_host_step_begin(qs_handle* h, const float* actions_host) {
+    if (!h || !actions_host) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
+    if (int rc = host_path_init(h)) return rc;
+    HostPath* p = h->host;
+    if (p->pending) QS_FAIL(-1, "qs_host_step_begin: the previous step has not been collected (qs_host_step_end)");
+    const size_t n = (size_t)h->cfg.n_envs, d = (size_t)h->cfg.action_dim;
+    memcpy(p->h_act, actions_host, n * d * 4);
+    QS_HIP(hipMemcpyAsync(p->d_act, p->h_act, n * d * 4, hipMemcpyHostToDevice, h->stream));
+    p->cur ^= 1; p->parity ^= 1;
+    h->tail.rows = (float*)(p->d_block + p->off_tail); h->tail.cap = p->cap; h->tail.parity = p->parity;
+    if (int rc = launch_step(h, p->d_act, (float*)p->d_block, (float*)(p->d_block + p->off_rew), p->d_block + p->off_done, p->d_block + p->off_trunc)) return rc;
+    QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
+    QS_HIP(hipEventRecord(p->ev, h->stream));
+    p->pending = 1;
+    return 0;
+}
+
+int qs_host_step_end(qs_handle* h, qs_host_result* out) {
+    if (!h || !out) QS_FAIL(-1, "null argument");
+    HostPath* p = h->host;
+    if (!p || !p->pending) QS_FAIL(-1, "qs_host_step_end without qs_host_step_begin");
+    QS_ON_DEVICE(h);
+    QS_HIP(hipEventSynchronize(p->ev));
+    p->pending = 0;
+    const uint8_t* b = p->h_block[p->cur];
+    out->obs = (const float*)b; out->rew = (const float*)(b + p->off_rew); out->done = b + p->off_done; out->truncated = b + p->off_trunc;
+    out->terminal_rows = (const float*)(b + p->off_tail); out->terminal_cap = p->cap;
     return 0;
 }
 

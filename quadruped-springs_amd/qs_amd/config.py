@@ -132,6 +132,13 @@ class QsConfig(C.Structure):
     ]
 
 
+def decode_flags(flags):
+    """The last column of a fused result row is done + 2 * truncated (include/qs_amd.h, qs_step_fused): 0 running, 1 terminated,
+    3 truncated (gym_env.py:245-246: truncation is a done without termination).  Returns (done, truncated) as booleans; works on
+    torch tensors and numpy arrays alike.  The one decoder for QuadrupedVecEnv and ShardedVecEnv."""
+    return flags > 0.5, flags > 2.5
+
+
 def butter2_lowpass(fc, fs):
     """Coefficients of scipy.signal.butter(2, [fc/(fs/2)]) (utils/action_filter.py:191-213) in closed form
     (bilinear transform of the 2nd-order Butterworth prototype with pre-warping)."""

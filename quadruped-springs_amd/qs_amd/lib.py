@@ -12,9 +12,17 @@ LIB_PATH = os.environ.get("QS_LIB_PATH") or os.path.join(_HERE, "libqs_hip.so") 
 EXPORTS = (
     "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_reset_to", "qs_get_obs", "qs_step", "qs_step_fused", "qs_get_state", "qs_set_state",
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
-    "qs_settle_lanes", "qs_set_trace", "qs_counter", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
+    "qs_settle_lanes", "qs_host_step_begin", "qs_host_step_end", "qs_set_trace", "qs_counter", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
     "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
 )
+
+
+
+class HostResult(C.Structure):
+    """qs_host_result (include/qs_amd.h): where the results of a host-path step lie in the handle's page-locked host memory."""
+    _fields_ = [("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p), ("terminal_rows", C.c_void_p),
+                ("terminal_cap", C.c_int32)]
+
 
 _lib = None
 
@@ -51,6 +59,8 @@ def load():
     lib.qs_enable_timing.argtypes = [vp, i32]
     lib.qs_last_step_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.qs_settle_lanes.argtypes = [vp, C.c_int]
+    lib.qs_host_step_begin.argtypes = [vp, vp]
+    lib.qs_host_step_end.argtypes = [vp, C.POINTER(HostResult)]
     lib.qs_set_trace.argtypes = [vp, C.c_int, vp]
     lib.qs_set_demo.argtypes = [vp, vp, C.c_int]
     lib.qs_set_demo_counter.argtypes = [vp, vp, vp]

@@ -13,12 +13,7 @@ environment is any object with `step_tensor` / `reset_tensor` (tests plug in the
 import torch
 import torch.distributed as dist
 
-
-def decode_flags(flags):
-    """The last column of a fused result row is done + 2 * truncated (include/qs_amd.h, qs_step_fused): 0 running, 1 terminated,
-    3 truncated (gym_env.py:245-246: truncation is a done without termination).  Returns (done, truncated) as booleans; works on
-    torch tensors and numpy arrays alike.  The one decoder for QuadrupedVecEnv.step_wait and ShardedVecEnv."""
-    return flags > 0.5, flags > 2.5
+from .config import decode_flags  # noqa: F401  (re-exported: the decoder of the fused rows' flag column)
 
 
 class ShardedVecEnv:

@@ -10,7 +10,6 @@ import numpy as np
 
 from . import lib as _lib
 from .config import DEMO_FILES, OBSERVATION_EPS, build_config
-from .sharded import decode_flags
 from .spaces import Box, SB3VecEnv
 
 INFO = dict(foot_force=0, foot_contact=1, torque=2, spring_torque=3, task=4, n_invalid=5, params=6, counters=7,
@@ -20,10 +19,12 @@ PARAM = dict(mu=0, spring_k=1, spring_b=2, kp=3, kd=4, all=5)
 
 
 class QuadrupedVecEnv(SB3VecEnv):
-    def __init__(self, num_envs=1, device=0, auto_reset=True, reset_lookahead=None, **env_kwargs):
+    def __init__(self, num_envs=1, device=0, auto_reset=True, reset_lookahead=None, copy_outputs=True, **env_kwargs):
         """reset_lookahead = K: every environment keeps the settled reset states of its next K episodes ready (computed by extra workgroups
         of the step kernel while the environments step), so a reset is a copy; results are bitwise those of K = 0, where every reset runs
-        the reference's 2500-substep settle in place (gym_env.py:278-297, 323-329).  Default: 8 with auto_reset, 0 without."""
+        the reference's 2500-substep settle in place (gym_env.py:278-297, 323-329).  Default: 8 with auto_reset, 0 without.
+        copy_outputs=False: step() / step_wait() return views of the page-locked result block instead of copies (valid until the end of
+        the next step: two blocks alternate)."""
         import torch
 
         if not torch.cuda.is_available():
@@ -48,7 +49,8 @@ class QuadrupedVecEnv(SB3VecEnv):
             self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self._trunc = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self._act = torch.zeros((n, d), dtype=torch.float32, device=self.device)
-        self._actions = None
+        self._views, self._infos, self._dirty = {}, [{} for _ in range(self.num_envs)], []
+        self.copy_outputs = bool(copy_outputs)
         self._trace = None
         self._closed = False
         self.render_mode = None
@@ -253,31 +255,69 @@ class QuadrupedVecEnv(SB3VecEnv):
         return self.reset_tensor().cpu().numpy().copy()
 
     def step_async(self, actions):
-        self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.action_dim)
+        """VecEnv.step_async: the actions go to the device and the step and the copy of its results back are enqueued (qs_host_step_begin);
+        nothing is waited for."""
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.size != self.num_envs * self.action_dim:
+            raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {a.shape}")
+        self._stream()
+        _lib.check(self.lib.qs_host_step_begin(self.h, a.ctypes.data_as(C.c_void_p)))
+
+    def _host_views(self, res):
+        """numpy views of the result block qs_host_step_end points at (one set per host block: two alternate)."""
+        key = res.obs
+        views = self._views.get(key)
+        if views is None:
+            n, o = self.num_envs, self.obs_dim
+            f32, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+            views = (np.ctypeslib.as_array(C.cast(res.obs, f32), shape=(n, o)), np.ctypeslib.as_array(C.cast(res.rew, f32), shape=(n,)),
+                     np.ctypeslib.as_array(C.cast(res.done, u8), shape=(n,)).view(np.bool_),
+                     np.ctypeslib.as_array(C.cast(res.truncated, u8), shape=(n,)).view(np.bool_),
+                     np.ctypeslib.as_array(C.cast(res.terminal_rows, f32), shape=(res.terminal_cap, o + 1)))
+            self._views[key] = views
+        return views
 
     def step_wait(self):
-        # host (SB3 numpy) path: one H2D copy of the actions, one step with the fused output row, ONE D2H copy of [N, o + 2].
-        # (Pinned staging was tried and dropped: reading the pinned result on the host ran at ~160 MB/s on the test box.)
-        if getattr(self, "_d_fused", None) is None:
-            self._d_fused = self.torch.zeros((self.num_envs, self.obs_dim + 2), dtype=self.torch.float32, device=self.device)
-        self._act.copy_(self.torch.from_numpy(self._actions))
-        res = self.step_fused(self._act, self._d_fused).cpu().numpy()
-        obs, rew = res[:, : self.obs_dim].copy(), res[:, self.obs_dim].copy()
-        done, trunc = decode_flags(res[:, self.obs_dim + 1])
-        infos = [{} for _ in range(self.num_envs)]
-        if done.any():
-            term = self.get_info("terminal_obs").cpu().numpy() if self.cfg.auto_reset else obs
-            for i in np.nonzero(done)[0]:
-                infos[i]["TimeLimit.truncated"] = bool(trunc[i])  # gym_env.py:246
-                infos[i]["terminal_observation"] = term[i].copy()
+        """VecEnv.step_wait: (obs [N, o] float32, rewards [N] float32, dones [N] bool, infos) -- the SB3 convention of load_model.py:113-133:
+        finished environments are already reset, their last observation is infos[i]["terminal_observation"], infos[i]["TimeLimit.truncated"]
+        says whether the time limit ended the episode (gym_env.py:246).  One H2D copy, the step, ONE D2H copy into page-locked host memory;
+        the arrays returned are copies of it (copy_outputs=False: views, valid until the end of the NEXT step).  `infos` is ONE list
+        of N dicts kept by the environment: per step only the dicts of environments that had something to say are emptied and refilled."""
+        res = _lib.HostResult()
+        _lib.check(self.lib.qs_host_step_end(self.h, C.byref(res)))
+        obs, rew, done, trunc, term = self._host_views(res)
+        if self.copy_outputs:
+            obs, rew, done = obs.copy(), rew.copy(), done.copy()
+        infos = self._infos
+        for i in self._dirty:
+            infos[i].clear()
+        dirty = self._dirty = []
+        idx = np.flatnonzero(done)
+        if idx.size:
+            if not self.cfg.auto_reset:
+                for i in idx.tolist():
+                    infos[i]["TimeLimit.truncated"] = bool(trunc[i]); infos[i]["terminal_observation"] = obs[i].copy()
+            else:
+                rows = term[: idx.size] if idx.size <= term.shape[0] else None
+                if rows is None:    # more episode ends than the compact list holds: the per-environment array
+                    full = self.get_info("terminal_obs").cpu().numpy()
+                    for i in idx.tolist():
+                        infos[i]["TimeLimit.truncated"] = bool(trunc[i]); infos[i]["terminal_observation"] = full[i]
+                else:
+                    rows = rows.copy()
+                    envs = rows[:, 0].view(np.int32)
+                    for k, i in enumerate(envs.tolist()):
+                        infos[i]["TimeLimit.truncated"] = bool(trunc[i]); infos[i]["terminal_observation"] = rows[k, 1:]
+            dirty.extend(idx.tolist())
         if self.cfg.wrapper_mode:
             # the reference's LandingWrapper / GoToRestWrapper loop over env.step inside one wrapper.step; here every inner
             # step is one launch and the ones whose action was scripted are flagged, so a learner can mask them out.  Only the
             # environments in a scripted phase get the keys (read them with infos[i].get("scripted", False)).
             w = self.get_info("wrapper").cpu().numpy()
-            for i in np.nonzero((w[:, 0] > 0.5) | (w[:, 1] > 0.5))[0]:
+            for i in np.nonzero((w[:, 0] > 0.5) | (w[:, 1] > 0.5))[0].tolist():
                 infos[i]["scripted"] = bool(w[i, 1])
                 infos[i]["phase"] = PHASE[int(w[i, 0])]
+                dirty.append(i)
         return obs, rew, done, infos
 
     def step(self, actions):
