@@ -165,7 +165,11 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, LookAhead la,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo, TermTail tail) {
+#ifdef QS_AB_NO_CALLS
+    using E = Env<LaneDev, CONE, false, false>;
+#else
     using E = Env<LaneDev, CONE, false, WAVES == 1>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
+#endif
     using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -194,14 +198,15 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     // the quad of an environment fetches its action row (lane l takes entries l, l + 4, l + 8) -- issued before the tile loads, whose
     // latency then covers it
     float a_pre[3] = {0.0f, 0.0f, 0.0f};
-    int2 job = make_int2(0, 0);                                          // a settle: whose reset this record is (environment, episode)
+    int2 job0 = make_int2(0, 0);                                         // settle lanes: whose reset this record is (environment, episode)
     if (!settling) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int k = (int)(threadIdx.x & 3u) + 4 * j;
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
-    } else job = lanes.stage_jobs[valid ? env : first];
+    } else job0 = lanes.stage_jobs[valid ? env : first];
+    const int2 job = job0;
     bool spawn = settling && lanes.spawn[cohort];
     const bool last = settling && lanes.last[cohort];
     int load_extent = settling ? (spawn ? 0 : (cfg.payload_soft ? (int)TILE_ALL : (int)QS_SETTLE_END)) : tile_extent(cfg, false);
@@ -224,9 +229,9 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     float* ob = s_obs + slot * QS_MAX_OBS;
     if (cfg.info_fields && !settling && (threadIdx.x & 3) == 0) rec[QS_INFO_END - 1] = 0.0f;   // the pad float behind the info block, stored with it
     const uint32_t gid = (uint32_t)((settling ? job.x : env) + cfg.env_id_offset);
-    bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
+    const bool any_trace0 = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
-    float* trow = any_trace && env == tap.env ? tap.rows : nullptr;
+    float* const trow0 = any_trace0 && env == tap.env ? tap.rows : nullptr;
     typename E::StepOut r;
     bool any_reset = false;   // wave-uniform: a reset rewrote the parameters of some record of the tile
     bool do_reset = false;    // this quad's environment ended its episode
@@ -234,9 +239,14 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     int next_episode = 0;
     // The loop runs ONCE, except in a wave with such an environment: its second trip is the in-step settle -- the wave turns into what a
     // settle lane is (spawn, then all settle_steps substeps through the same E::step(..., settle_n)), so that the fallback costs the kernel
-    // no second copy of the substep loop and produces the bits the lanes produce.
+    // no second copy of the substep loop and produces the bits the lanes produce.  Only wave-uniform scalars travel along the back edge
+    // (what the second trip needs per lane lies in the LDS records; what the code behind the loop needs of the first trip is parked in
+    // the action rows, which a settle does not read): a per-lane value alive around the loop would cost the common path a register.
     for (int trip = 0;; trip++) {
-        if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
+        float* const trow = trip ? nullptr : trow0;
+        const bool any_trace = trip ? false : any_trace0;
+        const int spawn_episode = (RESET && trip) ? qs::f2i(rec[R_EPISODE]) + 1 : job.y;
+        if (spawn) { E::settle_spawn(cfg, rec, gid, spawn_episode); LaneDev::sync(); }
         r.redo = true;
         if (!cfg.payload_soft) {   // (the payload block's constraint rows are not in the common-path build)
             typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
@@ -248,7 +258,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
                 if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
                 if (settling && (spawn || last)) zero_tile_tail(s_rec, load_extent, ls);
                 __syncthreads();
-                if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
+                if (spawn) { E::settle_spawn(cfg, rec, gid, spawn_episode); LaneDev::sync(); }
             }
         }
         if (__builtin_expect(r.redo, 0)) {
@@ -264,7 +274,12 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
                        cfg.payload_soft ? (int)TILE_ALL : (last ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
             return;
         }
-        if (!RESET || trip == 1) break;
+        if (!RESET) break;
+        if (trip == 1) {   // the in-step settle is done: what the first trip found, from where it was parked
+            const float* park = s_act + slot * 12;
+            do_reset = park[0] > 0.5f; ahead = park[1] > 0.5f; next_episode = qs::f2i(park[2]); any_reset = true;
+            break;
+        }
         const bool dn = r.done > 0.5f;
         if (valid && (threadIdx.x & 3) == 0) {
             if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
@@ -304,8 +319,9 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
         tile_store(s_rec, recs, first, cfg.n_envs, 0, tile_extent(cfg, true), ls);
         obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
         __syncthreads();
-        spawn = true; settle_n = cfg.settle_steps; job = make_int2(env, next_episode);
-        trow = nullptr; any_trace = false;
+        if ((threadIdx.x & 3) == 0) { float* park = s_act + slot * 12; park[0] = do_reset ? 1.0f : 0.0f; park[1] = ahead ? 1.0f : 0.0f; park[2] = qs::i2f(next_episode); }
+        __syncthreads();
+        spawn = true; settle_n = cfg.settle_steps;
     }
     if (!RESET) {
         const bool dn = r.done > 0.5f;
@@ -387,19 +403,25 @@ __global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __r
     if (threadIdx.x == 0) { s_count = 0; s_want = 0; if (cap > 0) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
     __syncthreads();
     int2* dst = stage_jobs + (size_t)cohort * slice;
-    for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
-        const int e = (i + offset) % n_envs;
-        const int X = la.cur[e];
-        int h = la.handed[e];
-        if (h < X) h = X;
-        const int want = X + la.K - h;
-        if (want <= 0) continue;
-        atomicAdd(&s_want, want);
-        if (cap <= 0) continue;
-        const int at = atomicAdd(&s_count, want);
-        int took = 0;
-        for (int j = 0; j < want && at + j < cap; j++) { dst[at + j] = make_int2(e, h + 1 + j); took++; }
-        if (took) la.handed[e] = h + took;
+    // two passes: first the environments that are running low (fewer than half of their K states ready or on the way: after a burst of
+    // resets -- e.g. everybody at the 10-s limit in one step -- the ones that fall every few steps must not wait behind the rest), then
+    // everybody else while lanes remain
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
+            const int e = (i + offset) % n_envs;
+            const int X = la.cur[e];
+            int h = la.handed[e];
+            if (h < X) h = X;
+            const int want = X + la.K - h;
+            if (want <= 0 || (2 * want > la.K) != (pass == 0)) continue;
+            atomicAdd(&s_want, want);
+            if (cap <= 0) continue;
+            const int at = atomicAdd(&s_count, want);
+            int took = 0;
+            for (int j = 0; j < want && at + j < cap; j++) { dst[at + j] = make_int2(e, h + 1 + j); took++; }
+            if (took) la.handed[e] = h + took;
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -25,15 +25,26 @@ class QuadrupedVecEnv(SB3VecEnv):
         the reference's 2500-substep settle in place (gym_env.py:278-297, 323-329).  Default: 8 with auto_reset, 0 without.
         copy_outputs=False: step() / step_wait() return views of the page-locked result block instead of copies (valid until the end of
         the next step: two blocks alternate)."""
+        cfg, meta = build_config(n_envs=num_envs, auto_reset=auto_reset, **env_kwargs)
+        cfg.reset_lookahead = int((8 if auto_reset else 0) if reset_lookahead is None else reset_lookahead)
+        self._setup(cfg, meta, device, copy_outputs)
+
+    @classmethod
+    def from_config(cls, cfg, meta, device=0, copy_outputs=True):
+        """A handle for a qs_config built (and possibly edited) by the caller: build_config(...) -> (cfg, meta)."""
+        self = cls.__new__(cls)
+        self._setup(cfg, meta, device, copy_outputs)
+        return self
+
+    def _setup(self, cfg, meta, device, copy_outputs):
         import torch
 
         if not torch.cuda.is_available():
             raise RuntimeError("QuadrupedVecEnv needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
         self.torch = torch
         self.lib = _lib.load()
-        self.cfg, self.meta = build_config(n_envs=num_envs, auto_reset=auto_reset, **env_kwargs)
-        self.cfg.reset_lookahead = int((8 if auto_reset else 0) if reset_lookahead is None else reset_lookahead)
-        self.num_envs = int(num_envs)
+        self.cfg, self.meta = cfg, meta
+        self.num_envs = int(cfg.n_envs)
         self.device = torch.device("cuda", device)
         lay = self.meta["layout"]
         self.observation_space = Box(lay["low"] - OBSERVATION_EPS, lay["high"] + OBSERVATION_EPS, dtype=np.float32)  # gym_env.py:160-164
@@ -41,6 +52,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         self.action_space = Box(-np.ones(d), np.ones(d), dtype=np.float32)                                       # gym_env.py:179-182
         self.action_dim, self.obs_dim = d, self.cfg.obs_dim
         self.h = C.c_void_p()
+        self._closed = False
         _lib.check(self.lib.qs_create(C.byref(self.cfg), device, C.byref(self.h)))
         n, o = self.num_envs, self.obs_dim
         with torch.cuda.device(self.device):
@@ -52,7 +64,6 @@ class QuadrupedVecEnv(SB3VecEnv):
         self._views, self._infos, self._dirty = {}, [{} for _ in range(self.num_envs)], []
         self.copy_outputs = bool(copy_outputs)
         self._trace = None
-        self._closed = False
         self.render_mode = None
         self.demo_list, self.demo_length = None, 0
         if self.meta["task_env"] in DEMO_FILES:

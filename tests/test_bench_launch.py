@@ -49,3 +49,43 @@ def test_metric_name_follows_the_workload():
     m = bench.metric_name("config3_8192", kw3, 8192, 2, 0)
     assert "continuous-jumping-forward" in m and "jump-in-place" not in m and "x 2" in m
     assert "N=4096" in bench.metric_name("jump_in_place_8192", kw, 4096, 1, 0)
+
+
+def test_visible_gpus_counts_without_a_hip_call(tmp_path, monkeypatch):
+    """The launcher counts devices from the KFD topology (CPUs are nodes with simd_count 0) and honours *_VISIBLE_DEVICES."""
+    sys.path.insert(0, REPO)
+    import bench
+    for i, simd in enumerate((0, 1024, 1024, 0, 1024)):
+        d = tmp_path / str(i); d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_listdir, real_open = os.listdir, open
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    monkeypatch.setattr(os, "listdir", lambda p: real_listdir(str(tmp_path)) if p == root else real_listdir(p))
+    import builtins
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace(root, str(tmp_path)), *a, **k))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
+
+
+def test_scale_table_reads_what_scale_sh_writes(tmp_path):
+    """tools/scale.sh appends {"mode", "n_gpus", "line"} rows; tools/scale_table.py computes the efficiencies from the per-N values."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import scale_table
+    def line(n, value, envs, scaling="weak"):
+        return {"metric": "m", "value": value, "unit": "env-steps/s", "n_gpus": n, "steps": 1000, "warmup": 50, "ms_per_step": 8192 * n / value * 1e3,
+                "higher_is_better": True, "scaling": scaling, "config": {"envs_per_gpu": envs, "rccl_ranks": n, "rank_ms_per_step_min_max": [0.07, 0.08], "stalls": 0}}
+    rows = [dict(mode="weak", n_gpus=1, line=line(1, 100e6, 8192)), dict(mode="weak", n_gpus=8, line=line(8, 760e6, 8192)),
+            dict(mode="strong", n_gpus=1, line=line(1, 300e6, 65536, "strong")), dict(mode="strong", n_gpus=8, line=line(8, 800e6, 8192, "strong")),
+            dict(mode="sharded", n_gpus=2, line=None, error="see sharded_2.err")]
+    p = tmp_path / "scale.jsonl"
+    p.write_text("\n".join(json.dumps(r) for r in rows) + "\n")
+    t = scale_table.table(scale_table.parse(str(p)))
+    eff = {(r["mode"], r["n_gpus"]): r.get("efficiency") for r in t}
+    assert abs(eff[("weak", 8)] - 0.95) < 1e-9 and abs(eff[("strong", 8)] - 800 / 2400) < 1e-9 and eff[("weak", 1)] == 1.0
+    assert t[-1]["value"] is None and "sharded_2.err" in t[-1]["error"]
+    # and the script itself hands bench.py the flags the table relies on
+    sh = open(os.path.join(REPO, "tools", "scale.sh")).read()
+    assert "--total-envs 65536" in sh and "--workload config4_sharded" in sh and "scale_table.py" in sh

@@ -33,28 +33,11 @@ def make_pair(n, torch, oracle=True, **kw):
     kw.setdefault("noise", False)
     auto_reset = kw.pop("auto_reset", False)
     keep = kw.pop("keep_params", False)
-    v = QuadrupedVecEnv.__new__(QuadrupedVecEnv)
-    # build by hand so that cfg can be edited before qs_create
-    import ctypes as C
-    from qs_amd import lib as L
-    from qs_amd.config import build_config, OBSERVATION_EPS
-    from qs_amd.spaces import Box
-    cfg, meta = build_config(n_envs=n, auto_reset=auto_reset, **kw)
+    from qs_amd.config import build_config
+    cfg, meta = build_config(n_envs=n, auto_reset=auto_reset, **kw)     # built by hand so that cfg can be edited before qs_create
     if keep:
         cfg.randomizer_flags |= 8
-    v.torch, v.lib, v.cfg, v.meta, v.num_envs = torch, L.load(), cfg, meta, n
-    v.device = torch.device("cuda", 0)
-    v.action_dim, v.obs_dim = cfg.action_dim, cfg.obs_dim
-    v.observation_space = Box(meta["layout"]["low"] - OBSERVATION_EPS, meta["layout"]["high"] + OBSERVATION_EPS)
-    v.action_space = Box(-np.ones(cfg.action_dim), np.ones(cfg.action_dim))
-    v.h = C.c_void_p()
-    L.check(v.lib.qs_create(C.byref(cfg), 0, C.byref(v.h)))
-    v._obs = torch.zeros((n, cfg.obs_dim), dtype=torch.float32, device=v.device)
-    v._rew = torch.zeros(n, dtype=torch.float32, device=v.device)
-    v._done = torch.zeros(n, dtype=torch.uint8, device=v.device)
-    v._trunc = torch.zeros(n, dtype=torch.uint8, device=v.device)
-    v._act = torch.zeros((n, cfg.action_dim), dtype=torch.float32, device=v.device)
-    v._actions, v._closed, v.render_mode = None, False, None
+    v = QuadrupedVecEnv.from_config(cfg, meta)
     return (Oracle(cfg) if oracle else None), v, cfg
 
 
