@@ -165,11 +165,12 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, LookAhead la,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo, TermTail tail) {
-#ifdef QS_AB_NO_CALLS
+    // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch).  The full build's many-rows solver is inlined
+    // (CALLS = false) in both kernels: as a real function (round 2's one-wave-per-SIMD build) it takes State / Out by reference, which
+    // keeps them in memory around the call, and expressions that then span a store and a load are no longer contracted into the FMAs
+    // the common-path build forms -- the redo of a wave gave its other 15 environments different last bits than the common-path build
+    // (tests/test_gpu_round2.py::test_results_do_not_depend_on_wave_mates); it also measured 4 % slower on the headline.
     using E = Env<LaneDev, CONE, false, false>;
-#else
-    using E = Env<LaneDev, CONE, false, WAVES == 1>;   // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch)
-#endif
     using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];

@@ -30,13 +30,14 @@ class QuadrupedVecEnv(SB3VecEnv):
         self._setup(cfg, meta, device, copy_outputs)
 
     @classmethod
-    def from_config(cls, cfg, meta, device=0, copy_outputs=True):
-        """A handle for a qs_config built (and possibly edited) by the caller: build_config(...) -> (cfg, meta)."""
+    def from_config(cls, cfg, meta, device=0, copy_outputs=True, load_demo=True):
+        """A handle for a qs_config built (and possibly edited) by the caller: build_config(...) -> (cfg, meta).  load_demo=False leaves
+        the demonstration of a DEMO task to a later set_demo()."""
         self = cls.__new__(cls)
-        self._setup(cfg, meta, device, copy_outputs)
+        self._setup(cfg, meta, device, copy_outputs, load_demo)
         return self
 
-    def _setup(self, cfg, meta, device, copy_outputs):
+    def _setup(self, cfg, meta, device, copy_outputs, load_demo=True):
         import torch
 
         if not torch.cuda.is_available():
@@ -66,7 +67,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         self._trace = None
         self.render_mode = None
         self.demo_list, self.demo_length = None, 0
-        if self.meta["task_env"] in DEMO_FILES:
+        if load_demo and self.meta["task_env"] in DEMO_FILES:
             if self.meta["demo"] is None:
                 self.close()
                 raise ValueError(f"task {self.meta['task_env']} imitates a demonstration: pass demo=<array [L, action_dim + 38] or path of the "

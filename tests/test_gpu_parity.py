@@ -37,7 +37,7 @@ def make_pair(n, torch, oracle=True, **kw):
     cfg, meta = build_config(n_envs=n, auto_reset=auto_reset, **kw)     # built by hand so that cfg can be edited before qs_create
     if keep:
         cfg.randomizer_flags |= 8
-    v = QuadrupedVecEnv.from_config(cfg, meta)
+    v = QuadrupedVecEnv.from_config(cfg, meta, load_demo=False)
     return (Oracle(cfg) if oracle else None), v, cfg
 
 

@@ -41,6 +41,20 @@ for name, kw in (("default", {}), ("views_no_info_block", dict(copy_outputs=Fals
           f"{N / dt_dev / 1e6:.1f} M; {dones} episode ends in 200 steps, {term} with terminal_observation; stalls {env.counter('reset_stalls')}")
     out[name] = dict(ms_per_step=dt * 1e3, env_steps_per_s=N / dt, device_tensor_env_steps_per_s=N / dt_dev, keywords=kw)
     if name == "default":
+        # where the time goes: step_async (copy into pinned staging + enqueue), the wait inside step_wait, the host-side rest of step_wait
+        import ctypes as C
+        from qs_amd import lib as L
+        tb = tw = tp = 0.0
+        for i in range(300):
+            t0 = time.perf_counter(); env.step_async(acts[i % 64]); t1 = time.perf_counter()
+            res = L.HostResult(); L.check(env.lib.qs_host_step_end(env.h, C.byref(res))); t2 = time.perf_counter()
+            env.lib.qs_host_step_begin(env.h, acts[(i + 1) % 64].ctypes.data_as(C.c_void_p))     # (keeps the begin / end pairing for the real step_wait)
+            env.step_wait(); t3 = time.perf_counter()
+            tb += t1 - t0; tw += t2 - t1
+        for i in range(300):
+            env.step_async(acts[i % 64]); t0 = time.perf_counter(); env.step_wait(); tp += time.perf_counter() - t0
+        print(f"   step_async {tb / 300 * 1e6:.1f} us, wait for kernel + copies {tw / 300 * 1e6:.1f} us, whole step_wait {tp / 300 * 1e6:.1f} us per step")
+        out[name]["breakdown_us"] = dict(step_async=tb / 300 * 1e6, wait=tw / 300 * 1e6, step_wait=tp / 300 * 1e6)
         pr = cProfile.Profile(); pr.enable()
         for i in range(200):
             env.step(acts[i % 64])
