@@ -32,10 +32,10 @@ for name, kw in (("default", {}), ("views_no_info_block", dict(copy_outputs=Fals
         obs, rew, done, infos = env.step(acts[i % 64])
         dones += int(done.sum()); term += sum(1 for k in np.flatnonzero(done) if "terminal_observation" in infos[k])
     # the device-tensor path of the same handle, for comparison
-    a_dev = torch.as_tensor(acts[:8], device=env.device)
+    a_dev = torch.as_tensor(acts, device=env.device)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     for i in range(steps):
-        env.step_tensor(a_dev[i % 8])
+        env.step_tensor(a_dev[i % 64])
     torch.cuda.synchronize(); dt_dev = (time.perf_counter() - t1) / steps
     print(f"{name}: numpy VecEnv.step path {dt * 1e3:.3f} ms/step = {N / dt / 1e6:.1f} M env-steps/s; device-tensor path {dt_dev * 1e3:.3f} ms/step = "
           f"{N / dt_dev / 1e6:.1f} M; {dones} episode ends in 200 steps, {term} with terminal_observation; stalls {env.counter('reset_stalls')}")
