@@ -35,6 +35,19 @@ for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=Tru
         n = base(r["Name"])
         if n.startswith("k_") or float(r["Percentage"]) > 1:
             print(f"| {n[:50]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {r['Percentage']} |")
+# per-dispatch durations of the kernel trace: the same average restricted to the last N launches (the timed region of the profiled command)
+trace_avg_us = None
+for f in glob.glob(os.path.join(root, "**", "*_kernel_trace.csv"), recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if wanted(r.get("Kernel_Name", ""))]
+    if rows and "Start_Timestamp" in rows[0]:
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        sel = d[-last:] if last else d
+        trace_avg_us = sum(sel) / len(sel)
+        srt = sorted(sel)
+        print(f"\n{kernel}: {len(d)} launches in the kernel trace; " + (f"the last {len(sel)} (the timed region)" if last else "all of them") +
+              f": average {trace_avg_us:.2f} us, min {srt[0]:.2f}, median {srt[len(srt) // 2]:.2f}, 99th percentile {srt[int(len(srt) * 0.99)]:.2f}, max {srt[-1]:.2f} us")
+    break
 print()
 print("| counter | per-launch avg | min | max | launches |\n|---|---|---|---|---|")
 meta, avg, names = None, {}, collections.Counter()
@@ -61,7 +74,7 @@ if out_json and avg:
          "friction_model": c["friction_model"], "solver_residual_threshold": c["solver_residual_threshold"],
          "fetch_size_kb": avg["FETCH_SIZE"][0], "write_size_kb": avg["WRITE_SIZE"][0], "fetch_correction": 2.0,
          "sq_insts_valu": avg.get("SQ_INSTS_VALU", (None, 0))[0], "sq_waves": avg.get("SQ_WAVES", (None, 0))[0],
-         "launches": avg["FETCH_SIZE"][1], "bench_value": b["value"], "bench_kernel_ms": b["roofline"]["kernel_ms"],
+         "launches": avg["FETCH_SIZE"][1], "bench_value": b["value"], "bench_kernel_ms": b["roofline"]["kernel_ms"], "rocprof_kernel_us_timed_region": trace_avg_us,
          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, per-launch averages over " + (f"the last {last} launches (the timed region)" if last else "ALL launches") + " of the step kernel in "
                  "the profiled command (same table as the *_kernel_trace_pmc.md next to this file); FETCH_SIZE doubled per MI355X_MICROARCH.md "
                  "(16-B-per-lane streaming reads are tallied at half their bytes on gfx950)"}

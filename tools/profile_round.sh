@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/rNN_<tag>_*: one unprofiled bench line, kernel trace + stats, then one PMC pass per counter group
-# (never combined with sys / hip / hsa traces).  Every table and the pmc.json are computed from ALL launches of the step kernel; the
-# raw per-launch CSVs are deleted afterwards (nothing is re-summarised from a trimmed sample).
+# (never combined with sys / hip / hsa traces).  The counter averages and the pmc.json cover the LAST 1000 launches of the step kernel = the timed
+# region of the profiled command (the launches before it are preparation: staggered resets, pre-roll, warmup); the kernel stats CSV is
+# rocprofv3's own, over all launches.  The raw per-launch CSVs are deleted afterwards.
 #   bash tools/profile_round.sh <tag> [bench.py flags]     on the GPU box; results in gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-d}; shift || true
@@ -9,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1000 --warmup 50 --no-cpu-baseline $*"
+ARGS="--steps 1000 --warmup 50 --no-cpu-baseline --no-info-line $*"
 python3 $REPO/bench.py $ARGS 2> "$OUT/bench.err" | tail -1 > "$OUT/bench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
 i=0
@@ -18,7 +19,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BU
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python3 $REPO/bench.py $ARGS > "$OUT/pmc$i.log" 2>&1
 done
 cd "$REPO"
-python3 tools/pmc_summary.py "$OUT" k_step "$OUT/bench.json" "$OUT/pmc.json" > "$OUT/summary.md" 2>&1
+python3 tools/pmc_summary.py "$OUT" k_step "$OUT/bench.json" "$OUT/pmc.json" --last 1000 > "$OUT/summary.md" 2>&1
 cp $(find "$OUT/trace" -name "*_kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
 rm -rf "$OUT/trace" "$OUT"/pmc[0-9] "$OUT"/*.log
 du -sh "$OUT"; cat "$OUT/summary.md"; cut -c1-300 "$OUT/bench.json"

@@ -10,6 +10,8 @@
 //           and the Delassus block.  A hands its 9 bias values and the contact flags to B through LDS (s_barrier), B computes the
 //           accelerations, the rows' right-hand sides, the sweeps, delta v and the integration, and hands the new state (19 values per
 //           lane) back through LDS for A's next substep (second s_barrier).
+// Both kernels claim the whole register file of a SIMD (256 VGPR + 256 AGPR, like k_step) so that the dispatcher can put no two waves on
+// one SIMD: without that the probe's small kernels are packed two to a SIMD and measure something else.
 // Every wave runs ITER dependent substeps (the state feeds back) and wave 0 of workgroup 0 reports cycles per substep; results of the
 // two mappings are compared.  `--extra W` adds W more workgroups of the same kind to the launch: the settle lanes of the look-ahead
 // resets (185 waves' worth at the benchmark's reset rate), which in the mono mapping run on SIMDs the environments leave idle and in the
@@ -350,6 +352,7 @@ __device__ __forceinline__ void store_result(Result& r, const St& s) {
 
 // ------------------------------------------------------------------ mono: one wave does everything
 __global__ __launch_bounds__(64, 1) void k_mono(const float* __restrict__ in, Result* __restrict__ out, unsigned long long* cycles, int n_wg) {
+    asm volatile("" ::: "v255", "a255");               // one wave per SIMD, as the product kernel
     const int wg = blockIdx.x % n_wg;                  // extra workgroups (settle lanes) repeat the environments' inputs
     const int env = wg * 16 + (threadIdx.x >> 2);
     St s; load_state(in + (size_t)env * 40, s);
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(64, 1) void k_mono(const float* __restrict__ in, Re
 
 // ------------------------------------------------------------------ split: wave 0 = A (bias + collision), wave 1 = B (mass matrix side, then everything after the join)
 __global__ __launch_bounds__(128, 1) void k_split(const float* __restrict__ in, Result* __restrict__ out, unsigned long long* cycles, int n_wg) {
+    asm volatile("" ::: "v255", "a255");
     __shared__ float x_bias[64 * 12];      // A -> B: C[3], Cb[6], dist, active, n_invalid
     __shared__ float x_state[64 * 20];     // B -> A: the new state
     const int wg = blockIdx.x % n_wg, lane = threadIdx.x & 63;
@@ -378,7 +382,9 @@ __global__ __launch_bounds__(128, 1) void k_split(const float* __restrict__ in, 
     St s; load_state(in + (size_t)env * 40, s);
     V mtot; const SIf I0 = base_inertia(mtot);
     const unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long acc_own = 0, acc_wait = 0, acc_tail = 0;      // wave's own work up to the join, wait at the join, B: after the join
     for (int it = 0; it < ITER; it++) {
+        const unsigned long long ta = __builtin_readcyclecounter();
         Pre P; prereq(s, P);
         if (!roleB) {
             BiasOut b; role_bias(s, P, I0, b);
@@ -388,8 +394,10 @@ __global__ __launch_bounds__(128, 1) void k_split(const float* __restrict__ in, 
 #pragma unroll
             for (int k = 0; k < 6; k++) xb[64 * (3 + k)] = b.Cb[k];
             xb[64 * 9] = b.dist; xb[64 * 10] = b.active; xb[64 * 11] = b.n_invalid;
+            const unsigned long long tb = __builtin_readcyclecounter();
             __syncthreads();                    // join: B picks the bias up
             __syncthreads();                    // B has finished the substep
+            acc_own += tb - ta; acc_wait += __builtin_readcyclecounter() - tb;
             const float* xs = x_state + lane;
             s.pos = mk3<V>(xs[0], xs[64], xs[128]); s.qx = xs[192]; s.qy = xs[256]; s.qz = xs[320]; s.qw = xs[384];
             s.vlin = mk3<V>(xs[448], xs[512], xs[576]); s.vang = mk3<V>(xs[640], xs[704], xs[768]);
@@ -399,7 +407,10 @@ __global__ __launch_bounds__(128, 1) void k_split(const float* __restrict__ in, 
         } else {
             V tau[3]; pd_torque(s, tau);
             MassOut m; role_mass(s, P, I0, mtot, m);
+            T::opaque(m.Ap[0][0]);
+            const unsigned long long tb = __builtin_readcyclecounter();
             __syncthreads();                    // join
+            const unsigned long long tc = __builtin_readcyclecounter();
             BiasOut b; const float* xb = x_bias + lane;
 #pragma unroll
             for (int k = 0; k < 3; k++) b.C[k] = xb[64 * k];
@@ -414,12 +425,14 @@ __global__ __launch_bounds__(128, 1) void k_split(const float* __restrict__ in, 
             for (int j = 0; j < 3; j++) { xs[64 * (13 + j)] = s.q[j]; xs[64 * (16 + j)] = s.qd[j]; }
             xs[64 * 19] = s.warm;
             __syncthreads();
+            acc_own += tb - ta; acc_wait += tc - tb; acc_tail += __builtin_readcyclecounter() - tc;
         }
         T::opaque(s.q[0]);
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (roleB && (int)blockIdx.x < n_wg) store_result(out[blockIdx.x * 64 + lane], s);
-    if (blockIdx.x == 0 && threadIdx.x == 64) cycles[0] = (t1 - t0) / ITER;
+    if (blockIdx.x == 0 && threadIdx.x == 64) { cycles[0] = (t1 - t0) / ITER; cycles[1] = acc_own / ITER; cycles[2] = acc_wait / ITER; cycles[3] = acc_tail / ITER; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cycles[4] = acc_own / ITER; cycles[5] = acc_wait / ITER; }
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -445,15 +458,15 @@ int main(int argc, char** argv) {
     }
     float* d_in; Result *d_m, *d_s; unsigned long long* d_c;
     CK(hipMalloc(&d_in, in.size() * 4)); CK(hipMalloc(&d_m, (size_t)n_env * 4 * sizeof(Result))); CK(hipMalloc(&d_s, (size_t)n_env * 4 * sizeof(Result)));
-    CK(hipMalloc(&d_c, 16));
+    CK(hipMalloc(&d_c, 64));
     CK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    unsigned long long cm = 0, cs = 0; float msm = 0, mss = 0;
+    unsigned long long cm = 0, cs = 0, det[8] = {0}; float msm = 0, mss = 0;
     for (int rep = 0; rep < 4; rep++) {
         hipEventRecord(e0); hipLaunchKernelGGL(k_mono, dim3(n_wg + extra), dim3(64), 0, 0, d_in, d_m, d_c, n_wg); hipEventRecord(e1);
         CK(hipDeviceSynchronize()); hipEventElapsedTime(&msm, e0, e1); CK(hipMemcpy(&cm, d_c, 8, hipMemcpyDeviceToHost));
         hipEventRecord(e0); hipLaunchKernelGGL(k_split, dim3(n_wg + extra), dim3(128), 0, 0, d_in, d_s, d_c, n_wg); hipEventRecord(e1);
-        CK(hipDeviceSynchronize()); hipEventElapsedTime(&mss, e0, e1); CK(hipMemcpy(&cs, d_c, 8, hipMemcpyDeviceToHost));
+        CK(hipDeviceSynchronize()); hipEventElapsedTime(&mss, e0, e1); CK(hipMemcpy(det, d_c, 48, hipMemcpyDeviceToHost)); cs = det[0];
     }
     std::vector<Result> rm((size_t)n_env * 4), rs((size_t)n_env * 4);
     CK(hipMemcpy(rm.data(), d_m, rm.size() * sizeof(Result), hipMemcpyDeviceToHost));
@@ -465,7 +478,7 @@ int main(int argc, char** argv) {
             worst = fmax(worst, fabs((double)rm[i].st[k] - rs[i].st[k])); scale = fmax(scale, fabs((double)rm[i].st[k]));
         }
     printf("{\"n_env\": %d, \"substeps\": %d, \"sweeps\": %d, \"extra_workgroups\": %d, \"mono\": {\"waves\": %d, \"cycles_per_substep\": %llu, \"kernel_ms\": %.4f, \"us_per_substep\": %.3f}, "
-           "\"split\": {\"waves\": %d, \"cycles_per_substep\": %llu, \"kernel_ms\": %.4f, \"us_per_substep\": %.3f}, \"max_abs_difference\": %.3e, \"max_abs_value\": %.3e, \"nan\": %d}\n",
-           n_env, ITER, SWEEPS, extra, n_wg + extra, cm, msm, msm * 1e3 / ITER, 2 * (n_wg + extra), cs, mss, mss * 1e3 / ITER, worst, scale, nan);
+           "\"split\": {\"waves\": %d, \"cycles_per_substep\": %llu, \"kernel_ms\": %.4f, \"us_per_substep\": %.3f, \"B_before_join\": %llu, \"B_waits_for_A\": %llu, \"B_after_join\": %llu, \"A_before_join\": %llu, \"A_waits_for_B\": %llu}, \"max_abs_difference\": %.3e, \"max_abs_value\": %.3e, \"nan\": %d}\n",
+           n_env, ITER, SWEEPS, extra, n_wg + extra, cm, msm, msm * 1e3 / ITER, 2 * (n_wg + extra), cs, mss, mss * 1e3 / ITER, det[1], det[2], det[3], det[4], det[5], worst, scale, nan);
     return 0;
 }
