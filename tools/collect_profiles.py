@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copy what a GPU call of tools/r02_gpu_profiles.sh left under gpurun_out/ into profiles/ (tracked), named per round and tag.
-usage: python tools/collect_profiles.py gpurun_out/r02p gpurun_out/prof_r02a r02_a"""
+"""Copy what a GPU call of tools/r03_gpu_profiles.sh (r02_gpu_profiles.sh) left under gpurun_out/ into profiles/ (tracked), named per round and tag.
+usage: python tools/collect_profiles.py gpurun_out/r03p gpurun_out/prof_r03a r03_a"""
 import os
 import shutil
 import sys
@@ -25,4 +25,6 @@ for src, name, title in (("phase_cycles.txt", "phase_cycles.md", "Cycles per pha
         body = [l for l in open(os.path.join(run, src)).read().splitlines() if "amdgpu.ids" not in l]
         with open(os.path.join(dst, f"{tag}_{name}"), "w") as f:
             f.write(f"# {title}\n\n```\n" + "\n".join(body) + "\n```\n")
+if os.path.exists(os.path.join(run, "split_probe.jsonl")):
+    shutil.copy(os.path.join(run, "split_probe.jsonl"), os.path.join(dst, f"{tag}_split_probe.jsonl"))
 print(sorted(x for x in os.listdir(dst) if x.startswith(tag)))
