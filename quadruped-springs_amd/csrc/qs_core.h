@@ -258,7 +258,9 @@ template <> struct Rng<LaneEmu> {
 // CALLS (full build of the one-wave-per-SIMD kernel only): the many-rows solvers are real functions, so that their register needs stay out of
 // the allocation of the full build's own common path (a device function cannot be given a register budget, so the two-waves-per-SIMD
 // kernel inlines them).
-template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> struct Sim {
+// SOFT (HOT builds): the common-path build ALSO holds the payload block's six rows (cfg.payload_soft), next to the twelve foot rows in
+// solve_and_integrate<.., PAY>; without it a common-path build gives up on every substep of such a handle and the full build does the work.
+template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool SOFT = false> struct Sim {
     using V = typename T::V;
     using M = typename T::M;
     using V3v = V3<V>;
@@ -338,13 +340,25 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
     }
 
     struct Row { V jq[3], u[3], w[6], rhs, dinv, act, diag; };
+    // the six rows of the payload block's fixed constraint (cfg.payload_soft, see solve_with_limits)
+    struct PayRows {
+        V w[6][6], rhs[6], dinv[6], diag[6];   // base side (whitened), right-hand side x dinv, 1 / A_kk, A_kk
+        V3v rB; V mI, mM, act;                  // block centre -> pivot (world), 1 / inertia, 1 / mass, 1 while the block exists
+        V lam[6]; V3v dw, dv;                   // results: impulses, the block's velocity change (world)
+    };
 
     // One stepSimulation() (gym_env.py:218-219) under joint torques tau[3] per leg.
     // TRACK: follow PyBullet's solverResidualThreshold -- an environment whose sweep changed no row velocity by more than
     // sqrt(threshold) is frozen (its residuals are zeroed, so later sweeps leave it untouched) and the wave leaves the
     // loop when all of its 16 environments are frozen.  Without TRACK every sweep is executed.
-    template <int NR, bool TRACK> static QS_FN void solve_and_integrate(const qs_config& cfg, V mu, State& s, Out& o, const Row* rows,
-                                                            const V* Lc, const V* Ld, const V (*BK)[6], const V* R) {
+    // PAY (cfg.payload_soft with every robot of interest on its feet): the six rows of the payload block's fixed constraint ride along with
+    // the twelve foot rows.  They stay in velocity space as in solve_with_limits (replicated over the quad: y = the base part of J^T lambda
+    // in the Cholesky factor's whitened coordinates, here kept up to date by six v_fmac_dpp per foot-row delta), swept where Bullet sorts
+    // them (in front of the normals; forwards on odd sweeps, backwards on even ones); a payload delta moves the lane's own foot candidates
+    // through the precomputed couplings Apc[k][c] = -dinv_c (w_c . pw_k).  Same rows, clamps and order as the many-rows solver, at a
+    // third of its instructions per sweep.
+    template <int NR, bool TRACK, bool PAY = false> static QS_FN void solve_and_integrate(const qs_config& cfg, V mu, State& s, Out& o, const Row* rows,
+                                                            const V* Lc, const V* Ld, const V (*BK)[6], const V* R, PayRows* pq = nullptr) {
         constexpr int NT = 4 * NR;
         const float dt = (float)cfg.dt;
         // Delassus columns of the own rows, pre-scaled by the own row's 1/diag:
@@ -418,6 +432,26 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         }
         QS_PHASE_G(9)
         const V big = V(1e10f), zero = V(0.0f);
+        // payload rows (PAY): state of the velocity-space part
+        V py[PAY ? 6 : 1], plam[PAY ? 6 : 1], Apc[PAY ? 6 : 1][NR];
+        V3v pja[PAY ? 3 : 1], dwb = mk3<V>(zero, zero, zero), dvb = mk3<V>(zero, zero, zero);
+        V plive = V(1.0f);
+        const V pbound = V(500.0f * (float)cfg.dt);
+        if (PAY) {
+            const PayRows& q = *pq;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { py[PAY ? i : 0] = T::quad_sum(rows[0].w[i] * (s.warm * cfg.warmstart * rows[0].act)); plam[PAY ? i : 0] = zero; }
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+#pragma unroll
+                for (int c = 0; c < NR; c++) {
+                    V t = rows[c].w[0] * q.w[k][0];
+#pragma unroll
+                    for (int i = 1; i < 6; i++) t = t + rows[c].w[i] * q.w[k][i];
+                    Apc[PAY ? k : 0][c] = -(t * rows[c].dinv);
+                }
+            pja[0] = mk3<V>(zero, -q.rB.z, q.rB.y); pja[PAY ? 1 : 0] = mk3<V>(q.rB.z, zero, -q.rB.x); pja[PAY ? 2 : 0] = mk3<V>(-q.rB.y, q.rB.x, zero);   // -(rB x e_k)
+        }
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
         // (the implicit cone's projection is not idempotent in floating point: once an environment is frozen its friction bound is lifted,
         // so that the sweeps the rest of the wave still needs leave it exactly alone and no result depends on the wave's other environments)
@@ -442,6 +476,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         lam_all[i_] = lam_all[i_] + dk;                                                                                \
         if (NR == 3 && QS_PGS_PACKED) { T::fma2(Ap[i_][0], Ap[i_][1], dk, res[0], res[1]); res[2] = res[2] + Ap[i_][2] * dk; }      \
         else { _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk; }                     \
+        if (PAY) { _Pragma("unroll") for (int i = 0; i < 6; i++) py[PAY ? i : 0] = T::template fma_bcast<K>(rows[RR].w[i], dk, py[PAY ? i : 0]); } \
         if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
             // Implicit cone friction (CONE; resolveConeFrictionConstraintRows): the two friction rows of foot K from the same
@@ -456,8 +491,40 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         lam_all[ia_] = lam_all[ia_] + da; lam_all[ib_] = lam_all[ib_] + db;                                             \
         /* two chained FMAs per candidate (not res + (a da + b db): one instruction and one level of the dependency chain less) */ \
         _Pragma("unroll") for (int c = 0; c < NR; c++) { res[c] = res[c] + Ap[ia_][c] * da; res[c] = res[c] + Ap[ib_][c] * db; } \
+        if (PAY) { _Pragma("unroll") for (int i = 0; i < 6; i++) {                                                     \
+            py[PAY ? i : 0] = T::template fma_bcast<K>(rows[1].w[i], da, py[PAY ? i : 0]);                             \
+            py[PAY ? i : 0] = T::template fma_bcast<K>(rows[2].w[i], db, py[PAY ? i : 0]); } }                         \
         if (TRACK) dvmax = T::absmax_mul2(dvmax, da, diag_all[TRACK ? ia_ : 0], db, diag_all[TRACK ? ib_ : 0]);           \
     }
+            // payload row P (0..2: the pivot along world axis P, 3..5: the frames' relative rotation), replicated over the quad
+#define QS_PAYROW(P)                                                                                                   \
+    {                                                                                                                  \
+        const PayRows& q_ = *pq;                                                                                        \
+        V rel = (P) < 3 ? dot(pja[PAY ? (P) % 3 : 0], dwb) - ((P) == 0 ? dvb.x : (P) == 1 ? dvb.y : dvb.z)             \
+                        : -((P) == 3 ? dwb.x : (P) == 4 ? dwb.y : dwb.z);                                              \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) rel = rel + q_.w[P][i] * py[PAY ? i : 0];                        \
+        V cand = qmin(qmax(plam[PAY ? (P) : 0] + (q_.rhs[P] - q_.dinv[P] * rel), -pbound), pbound);                    \
+        V dl = (cand - plam[PAY ? (P) : 0]) * (plive * q_.act);                                                        \
+        plam[PAY ? (P) : 0] = plam[PAY ? (P) : 0] + dl;                                                                \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) py[PAY ? i : 0] = py[PAY ? i : 0] + q_.w[P][i] * dl;             \
+        _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Apc[PAY ? (P) : 0][c] * dl;                   \
+        if ((P) < 3) {                                                                                                 \
+            dwb = dwb + pja[PAY ? (P) % 3 : 0] * (q_.mI * dl);                                                         \
+            if ((P) == 0) dvb.x = dvb.x - q_.mM * dl;                                                                  \
+            if ((P) == 1) dvb.y = dvb.y - q_.mM * dl;                                                                  \
+            if ((P) == 2) dvb.z = dvb.z - q_.mM * dl;                                                                  \
+        } else {                                                                                                       \
+            if ((P) == 3) dwb.x = dwb.x - q_.mI * dl;                                                                  \
+            if ((P) == 4) dwb.y = dwb.y - q_.mI * dl;                                                                  \
+            if ((P) == 5) dwb.z = dwb.z - q_.mI * dl;                                                                  \
+        }                                                                                                              \
+        if (TRACK) dvmax = qmax(dvmax, qabs(dl * q_.diag[P]));                                                         \
+    }
+            if (PAY) {
+                if (it & 1) { QS_PAYROW(0) QS_PAYROW(1) QS_PAYROW(2) QS_PAYROW(3) QS_PAYROW(4) QS_PAYROW(5) }
+                else { QS_PAYROW(5) QS_PAYROW(4) QS_PAYROW(3) QS_PAYROW(2) QS_PAYROW(1) QS_PAYROW(0) }
+            }
+#undef QS_PAYROW
             QS_ROW_UPDATE(0, 0, 0) QS_ROW_UPDATE(1, 0, 0) QS_ROW_UPDATE(2, 0, 0) QS_ROW_UPDATE(3, 0, 0)
             if (NR == 3 && CONE) {
                 QS_PAIR_UPDATE(0) QS_PAIR_UPDATE(1) QS_PAIR_UPDATE(2) QS_PAIR_UPDATE(3)
@@ -469,6 +536,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
 #undef QS_ROW_UPDATE
             if (TRACK) {
                 M conv = qle(dvmax, thr);
+                if (PAY) plive = qsel(conv, zero, plive);     // a frozen environment's payload deltas are dropped
                 if (CONE) mu_c = qsel(conv, V(1e30f), mu_c);
                 // frozen environment: make clamp(cand) == lam for its rows from now on
 #pragma unroll
@@ -488,12 +556,20 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
 
         // delta v = H^-1 J^T lambda :  dv_b = L^-T sum_i w_i lam_i ;  dqd = sum_own u_r lam_r - (B K)^T dv_b
         V z[6];
+        if (PAY) {   // the base part of J^T lambda was kept up to date for the payload rows (foot rows and payload rows together)
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            V t = rows[0].w[i] * lam_own[0];
+            for (int i = 0; i < 6; i++) z[i] = py[PAY ? i : 0];
 #pragma unroll
-            for (int r = 1; r < NR; r++) t = t + rows[r].w[i] * lam_own[r];
-            z[i] = T::quad_sum(t);
+            for (int k = 0; k < 6; k++) pq->lam[k] = plam[PAY ? k : 0];
+            pq->dw = dwb; pq->dv = dvb;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                V t = rows[0].w[i] * lam_own[0];
+#pragma unroll
+                for (int r = 1; r < NR; r++) t = t + rows[r].w[i] * lam_own[r];
+                z[i] = T::quad_sum(t);
+            }
         }
         ltsolve6<V>(Lc, Ld, z);
 #pragma unroll
@@ -533,11 +609,6 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
     // cfg.joint_erp), swept with the joint-limit rows as Bullet sorts them (after them forwards, before them backwards).  They have no
     // joint part and touch every lane's y alike, so every lane of the quad computes them redundantly: no broadcast.  The block's side
     // of a row is analytic (isotropic inertia mI^-1, mass mM^-1, lever rB): J = (-(rB x e_k), -e_k) resp. (-e_k, 0).
-    struct PayRows {
-        V w[6][6], rhs[6], dinv[6], diag[6];   // base side (whitened), right-hand side x dinv, 1 / A_kk, A_kk
-        V3v rB; V mI, mM, act;                  // block centre -> pivot (world), 1 / inertia, 1 / mass, 1 while the block exists
-        V lam[6]; V3v dw, dv;                   // results: impulses, the block's velocity change (world)
-    };
     template <int NCP> struct RareArgs { Row rows[3 * NCP + 3]; V Sm[21], Ld[6], BK[3][6], R[9]; PayRows pay; bool has_pay; };
     template <int NCP> static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, RareArgs<NCP>& a) {
         constexpr int NRW = 3 * NCP + 3, LIM = 3 * NCP;
@@ -870,14 +941,22 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         for (int k = 0; k < 6; k++) T::st(blk, B_LAM + k, q.lam[k]);
     }
 
+    // results of the block's rows: the many-rows solver's for an environment with rare rows of its own, the common-path solver's otherwise
+    static QS_FN void keep_rare_payload(PayRows& c, const PayRows& r, M rare_mine) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c.lam[k] = qsel(rare_mine, r.lam[k], c.lam[k]);
+        c.dw = mk3<V>(qsel(rare_mine, r.dw.x, c.dw.x), qsel(rare_mine, r.dw.y, c.dw.y), qsel(rare_mine, r.dw.z, c.dw.z));
+        c.dv = mk3<V>(qsel(rare_mine, r.dv.x, c.dv.x), qsel(rare_mine, r.dv.y, c.dv.y), qsel(rare_mine, r.dv.z, c.dv.z));
+    }
+
     // `detect`: classify the contacts of the non-foot links, the payload block and the link-link pairs (o.n_invalid).  The reference reads
     // GetContactInfo after the LAST stepSimulation of an env step (task_base.py:137-147 via gym_env.py:241-245), so the callers ask for it
     // there only -- unless cfg.body_contacts, where those links' heights decide in every substep whether they push back.
     // `blk`: the payload block's state in the record (R_BLOCK) under cfg.payload_soft, nullptr otherwise
     static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true, float* blk = nullptr) {
         using namespace go1;
-        if (HOT && cfg.payload_soft) return true;   // the block's constraint rows live on the many-rows path
-        const bool soft = !HOT && cfg.payload_soft && blk != nullptr;
+        if (HOT && !SOFT && cfg.payload_soft) return true;   // this build holds no payload rows
+        const bool soft = (!HOT || SOFT) && cfg.payload_soft && blk != nullptr;
         Model P;
         {   // opaque copies keep the compiler from hoisting the 24 leg constants out of the substep loop (where they would
             // occupy registers for the whole env step); rebuilding them is ~40 multiplications per substep
@@ -1175,7 +1254,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
     }
 #define QS_RARE_COMMON(A)                                                                                              \
     (A).has_pay = soft;                                                                                                \
-    if (soft) payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, (A).pay);                                          \
+    if (soft) (A).pay = pay_c;   /* (the rows; the results in it are overwritten) */                                   \
     _Pragma("unroll") for (int i = 0; i < 21; i++) (A).Sm[i] = Sm[i];                                                  \
     _Pragma("unroll") for (int i = 0; i < 6; i++) (A).Ld[i] = Ld[i];                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int i = 0; i < 6; i++) (A).BK[j][i] = BK[j][i]; \
@@ -1185,15 +1264,26 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
         // such a neighbour --, computed on a copy next to the many-rows solve; only the environments with rare rows take that one's.
         // (Both solvers run for the whole wave: their MFMAs and wave votes must not sit under a divergent branch.)
         State s_c = s; Out o_c = o;
-        if (HOT) {
+        PayRows pay_c;      // cfg.payload_soft: the block's six rows (built once: payload_rows also applies gravity to the block), then the
+                            // common-path solver's results for them
+        if (HOT && SOFT) {      // (a handle without the block does not launch this build)
+            payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R, &pay_c);
+            else solve_and_integrate<3, false, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R, &pay_c);
+            payload_integrate(cfg, blk, pay_c);
+        } else if (HOT) {
             if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
             else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
         } else if (!soft) {
             if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R);
             else solve_and_integrate<3, false>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R);
+        } else {
+            payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R, &pay_c);
+            else solve_and_integrate<3, false, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R, &pay_c);
         }
-        // this environment has rare rows of its own and takes the many-rows solver's result (every environment under payload_soft)
-        const M rare_mine = soft ? qgt(one, zero) : qgt(T::quad_sum(qflag(qor(any_lim, any_extra))), V(0.5f));
+        // this environment has rare rows of its own and takes the many-rows solver's result
+        const M rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, any_extra))), V(0.5f));
         if (!HOT && T::any(any_extra)) {
             // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
             // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
@@ -1243,8 +1333,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             QS_RARE_COMMON(a)
             if (CALLS) solve_with_limits_call<3>(cfg, Pr.mu, s, o, a);
             else solve_with_limits<3>(cfg, Pr.mu, s, o, a);
-            if (soft) payload_integrate(cfg, blk, a.pay);
-        } else if (!HOT && (soft || T::any(any_lim))) {
+            if (soft) keep_rare_payload(pay_c, a.pay, rare_mine);
+        } else if (!HOT && T::any(any_lim)) {
             T::count_rare_path();
             QS_LIMIT_ROWS(rows + 3)
             RareArgs<1> a;
@@ -1253,7 +1343,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             QS_RARE_COMMON(a)
             if (CALLS) solve_with_limits_call<1>(cfg, Pr.mu, s, o, a);
             else solve_with_limits<1>(cfg, Pr.mu, s, o, a);
-            if (soft) payload_integrate(cfg, blk, a.pay);
+            if (soft) keep_rare_payload(pay_c, a.pay, rare_mine);
         }
         if (!HOT) {   // (in a wave without any rare row: the common-path result for everybody)
 #pragma unroll
@@ -1261,6 +1351,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false> stru
             s.vang = mk3<V>(qsel(rare_mine, s.vang.x, s_c.vang.x), qsel(rare_mine, s.vang.y, s_c.vang.y), qsel(rare_mine, s.vang.z, s_c.vang.z));
             s.vlin = mk3<V>(qsel(rare_mine, s.vlin.x, s_c.vlin.x), qsel(rare_mine, s.vlin.y, s_c.vlin.y), qsel(rare_mine, s.vlin.z, s_c.vlin.z));
             s.warm = qsel(rare_mine, s.warm, s_c.warm); o.foot_force = qsel(rare_mine, o.foot_force, o_c.foot_force);
+            if (soft) payload_integrate(cfg, blk, pay_c);
         }
 #undef QS_RARE_COMMON
 #undef QS_LIMIT_ROWS

@@ -157,9 +157,8 @@ __global__ __launch_bounds__(QS_WAVE, 1) void k_init(const qs_config* __restrict
 
 // QuadrupedGymEnv.step for 16 environments per wave (gym_env.py:227-256); auto-reset per the SB3 VecEnv convention.
 // The body is compiled twice (k_step / k_step_dense below) under different register budgets.
-// RESET: the build for handles with cfg.auto_reset (a finished environment takes its look-ahead slot, or settles inside the step when
-// that is not ready / reset_lookahead = 0); handles without auto-reset leave that code out
-template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
+// SOFT: the build for handles with cfg.payload_soft whose common-path part holds the payload block's rows (qs_core.h; implicit cone only)
+template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ void step_body(const qs_config* __restrict__ cfgp, float* __restrict__ recs,
                                                  const float* __restrict__ actions, float* __restrict__ obs_out,
                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
@@ -171,7 +170,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     // the common-path build forms -- the redo of a wave gave its other 15 environments different last bits than the common-path build
     // (tests/test_gpu_round2.py::test_results_do_not_depend_on_wave_mates); it also measured 4 % slower on the headline.
     using E = Env<LaneDev, CONE, false, false>;
-    using EH = Env<LaneDev, CONE, true>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
+    using EH = Env<LaneDev, CONE, true, false, SOFT>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const qs_config& cfg = *cfgp;
@@ -180,7 +179,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     float* const s_obs = s_dyn + QS_ENVS_PER_WAVE * ls;
     float* const s_act = s_obs + QS_ENVS_PER_WAVE * QS_MAX_OBS;
     QS_PHASE_BEGIN
-    if (RESET && tail.rows && blockIdx.x == 0 && threadIdx.x == 0) stats[CTL_TERM_CNT + (tail.parity ^ 1)] = 0ull;
+    if (tail.rows && blockIdx.x == 0 && threadIdx.x == 0) stats[CTL_TERM_CNT + (tail.parity ^ 1)] = 0ull;
     const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles staging records
     const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
     const int first = settling ? cohort * lanes.slice + (((int)blockIdx.x - lanes.n_env_waves) % lanes.waves_per_cohort) * QS_ENVS_PER_WAVE
@@ -188,7 +187,7 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     // CTL_R[cohort] is only written between launches (k_lookahead_plan)
     const int limit = settling ? cohort * lanes.slice + (int)stats[CTL_R + cohort] : cfg.n_envs;
     if (first >= limit) return;
-    int settle_n = settling ? lanes.settle_n[cohort] : 0;
+    const int settle_n = settling ? lanes.settle_n[cohort] : 0;
     if (settling && settle_n == 0) return;                               // cohort not started yet
     float* const base = settling ? lanes.staging : recs;
     const int slot = threadIdx.x >> 2;
@@ -199,18 +198,16 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     // the quad of an environment fetches its action row (lane l takes entries l, l + 4, l + 8) -- issued before the tile loads, whose
     // latency then covers it
     float a_pre[3] = {0.0f, 0.0f, 0.0f};
-    int2 job0 = make_int2(0, 0);                                         // settle lanes: whose reset this record is (environment, episode)
+    int2 job = make_int2(0, 0);                                          // settle lanes: whose reset this record is (environment, episode)
     if (!settling) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int k = (int)(threadIdx.x & 3u) + 4 * j;
             if (k < d && valid) a_pre[j] = actions[(size_t)env * d + k];
         }
-    } else job0 = lanes.stage_jobs[valid ? env : first];
-    const int2 job = job0;
-    bool spawn = settling && lanes.spawn[cohort];
-    const bool last = settling && lanes.last[cohort];
-    int load_extent = settling ? (spawn ? 0 : (cfg.payload_soft ? (int)TILE_ALL : (int)QS_SETTLE_END)) : tile_extent(cfg, false);
+    } else job = lanes.stage_jobs[valid ? env : first];
+    const bool spawn = settling && lanes.spawn[cohort], last = settling && lanes.last[cohort];
+    const int load_extent = settling ? (spawn ? 0 : (cfg.payload_soft ? (int)TILE_ALL : (int)QS_SETTLE_END)) : tile_extent(cfg, false);
     // (a settle's first slice writes parameters and spawn state itself and reads nothing; its last slice leaves a whole record behind,
     // of which only the settled fields mean anything: the rest is zero rather than whatever the LDS held)
     if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
@@ -230,133 +227,95 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
     float* ob = s_obs + slot * QS_MAX_OBS;
     if (cfg.info_fields && !settling && (threadIdx.x & 3) == 0) rec[QS_INFO_END - 1] = 0.0f;   // the pad float behind the info block, stored with it
     const uint32_t gid = (uint32_t)((settling ? job.x : env) + cfg.env_id_offset);
-    const bool any_trace0 = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
+    if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
+    const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
-    float* const trow0 = any_trace0 && env == tap.env ? tap.rows : nullptr;
+    float* const trow = any_trace && env == tap.env ? tap.rows : nullptr;
     typename E::StepOut r;
-    bool any_reset = false;   // wave-uniform: a reset rewrote the parameters of some record of the tile
-    bool do_reset = false;    // this quad's environment ended its episode
-    bool ahead = false;       // ... and its settled reset state was ready; if not, it settles inside the step (second trip of the loop)
-    int next_episode = 0;
-    // The loop runs ONCE, except in a wave with such an environment: its second trip is the in-step settle -- the wave turns into what a
-    // settle lane is (spawn, then all settle_steps substeps through the same E::step(..., settle_n)), so that the fallback costs the kernel
-    // no second copy of the substep loop and produces the bits the lanes produce.  Only wave-uniform scalars travel along the back edge
-    // (what the second trip needs per lane lies in the LDS records; what the code behind the loop needs of the first trip is parked in
-    // the action rows, which a settle does not read): a per-lane value alive around the loop would cost the common path a register.
-    for (int trip = 0;; trip++) {
-        float* const trow = trip ? nullptr : trow0;
-        const bool any_trace = trip ? false : any_trace0;
-        const int spawn_episode = (RESET && trip) ? qs::f2i(rec[R_EPISODE]) + 1 : job.y;
-        if (spawn) { E::settle_spawn(cfg, rec, gid, spawn_episode); LaneDev::sync(); }
-        r.redo = true;
-        if (!cfg.payload_soft) {   // (the payload block's constraint rows are not in the common-path build)
-            typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
-            r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
-            if (__builtin_expect(r.redo, 0)) {
-                // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
-                // env step of the whole wave with the full build
-                __syncthreads();
-                if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
-                if (settling && (spawn || last)) zero_tile_tail(s_rec, load_extent, ls);
-                __syncthreads();
-                if (spawn) { E::settle_spawn(cfg, rec, gid, spawn_episode); LaneDev::sync(); }
-            }
-        }
+    r.redo = true;
+    if (SOFT || !cfg.payload_soft) {   // (a payload_soft handle under the friction pyramid: its rows are in no common-path build)
+        typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+        r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
         if (__builtin_expect(r.redo, 0)) {
-            r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
-        }
-        QS_PHASE(14)
-        if (settling) {
-            if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
+            // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
+            // env step of the whole wave with the full build
             __syncthreads();
-            // a slice of a settle changes the rigid-body state and the warm start; its first slice also drew the parameters, its last one
-            // leaves the info block's results (and n_invalid) that copy_settled hands to a reset
-            tile_store(s_rec, base, first, limit, spawn ? 0 : (int)QS_RW_BEGIN,
-                       cfg.payload_soft ? (int)TILE_ALL : (last ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
-            return;
-        }
-        if (!RESET) break;
-        if (trip == 1) {   // the in-step settle is done: what the first trip found, from where it was parked
-            const float* park = s_act + slot * 12;
-            do_reset = park[0] > 0.5f; ahead = park[1] > 0.5f; next_episode = qs::f2i(park[2]); any_reset = true;
-            break;
-        }
-        const bool dn = r.done > 0.5f;
-        if (valid && (threadIdx.x & 3) == 0) {
-            if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
-            else {   // fused layout (qs_step_fused): one row [obs | reward | done + 2 * truncated] per environment
-                float* row = obs_out + (size_t)env * (od + 2);
-                row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
-            }
-        }
-        do_reset = dn && valid;
-        if (__builtin_expect(!__any(do_reset), 1)) break;
-        any_reset = true;
-        LaneDev::sync();
-        next_episode = qs::f2i(rec[R_EPISODE]) + 1;
-        if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
-            for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
-            if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
-            if (tail.rows) {   // host path: also as a row of the compact list
-                int at = 0;
-                if ((threadIdx.x & 3) == 0) at = (int)atomicAdd(&stats[CTL_TERM_CNT + tail.parity], 1ull);
-                at = __shfl(at, (int)(threadIdx.x & ~3u));
-                if (at < tail.cap) {
-                    float* row = tail.rows + (size_t)at * (od + 1);
-                    if ((threadIdx.x & 3) == 0) row[0] = qs::i2f(env);
-                    for (int i = threadIdx.x & 3; i < od; i += 4) row[1 + i] = ob[i];
-                }
-            }
-            ahead = lookahead_take(la, stats, rec, env, next_episode, cfg.payload_soft != 0);
-        }
-        if (__builtin_expect(!__any(do_reset && !ahead), 1)) break;
-#ifdef QS_AB_NO_STALL   /* A/B builds only (tools/r03_ab.sh): no in-step settle, i.e. no second trip -- wrong for a stalled reset, fast to compare */
-        break;
-#endif
-        // no settled state ahead (reset_lookahead = 0, or all K states used up faster than the lanes settle): what the step produced is
-        // published, then the WHOLE wave walks through the settle on its LDS copies (the solver's v_mfma_f32_4x4x1 ignores EXEC, so every
-        // quad takes part: the others settle a copy of their own next reset that nobody keeps) and only the stalled environments keep the result.
-        __syncthreads();
-        tile_store(s_rec, recs, first, cfg.n_envs, 0, tile_extent(cfg, true), ls);
-        obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
-        __syncthreads();
-        if ((threadIdx.x & 3) == 0) { float* park = s_act + slot * 12; park[0] = do_reset ? 1.0f : 0.0f; park[1] = ahead ? 1.0f : 0.0f; park[2] = qs::i2f(next_episode); }
-        __syncthreads();
-        spawn = true; settle_n = cfg.settle_steps;
-    }
-    if (!RESET) {
-        const bool dn = r.done > 0.5f;
-        if (valid && (threadIdx.x & 3) == 0) {
-            if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
-            else {
-                float* row = obs_out + (size_t)env * (od + 2);
-                row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
-            }
+            if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
+            if (spawn || last) zero_tile_tail(s_rec, load_extent, ls);
+            __syncthreads();
+            if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
         }
     }
-    if (RESET && __builtin_expect(any_reset, 0)) {
-        // the rest of the reset on the settled state in the record (from the environment's look-ahead slot -- copied once more where an
-        // in-step settle of the wave went over it --, or what its own in-step settle left there): the task / sensor / filter reset
-        LaneDev::sync();
-        if (__builtin_expect(spawn, 0)) {
-            if (ahead) copy_settled(rec, la.slots + ((size_t)env * la.K + (size_t)(next_episode % la.K)) * QS_REC, cfg.payload_soft != 0);
-            LaneDev::sync();
+    if (__builtin_expect(r.redo, 0)) {
+        r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+    }
+    QS_PHASE(14)
+    if (settling) {
+        if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
+        __syncthreads();
+        // a slice of a settle changes the rigid-body state and the warm start; its first slice also drew the parameters, its last one
+        // leaves the info block's results (and n_invalid) that copy_settled hands to a reset
+        tile_store(s_rec, base, first, limit, spawn ? 0 : (int)QS_RW_BEGIN,
+                   cfg.payload_soft ? (int)TILE_ALL : (last ? (int)TILE_INFO : (int)QS_SETTLE_END), ls);
+        return;
+    }
+    const bool dn = r.done > 0.5f;
+    if (valid && (threadIdx.x & 3) == 0) {
+        if (rew_out) { rew_out[env] = r.reward; done_out[env] = dn ? 1 : 0; trunc_out[env] = r.trunc > 0.5f ? 1 : 0; }
+        else {   // fused layout (qs_step_fused): one row [obs | reward | done + 2 * truncated] per environment
+            float* row = obs_out + (size_t)env * (od + 2);
+            row[od] = r.reward; row[od + 1] = (dn ? 1.0f : 0.0f) + (r.trunc > 0.5f ? 2.0f : 0.0f);
         }
-        if (do_reset) E::reset(cfg, rec, ob, gid, false);
-        if (__builtin_expect(spawn, 0)) {   // after an in-step settle the other quads' LDS copies are spent: the reset ones go back on their own
-            if (do_reset && !ahead && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
+    }
+    bool any_reset = false;   // wave-uniform: a reset rewrote the parameters of some record of the tile
+    if (cfg.auto_reset) {   // a finished environment takes its look-ahead state, or settles here when that is not ready / reset_lookahead = 0
+        const bool do_reset = dn && valid;
+        if (__builtin_expect(__any(do_reset), 0)) {
+            any_reset = true;
             LaneDev::sync();
-            if (do_reset) {
-                float* g = recs + (size_t)env * QS_REC;
-                const int end = tile_extent(cfg, true);
-                for (int i = threadIdx.x & 3; i < end; i += 4) g[i] = rec[i];
-                for (int i = threadIdx.x & 3; i < od; i += 4) {
-                    if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
-                    else obs_out[(size_t)env * (od + 2) + i] = ob[i];
-                    obs_keep[(size_t)env * od + i] = ob[i];
+            bool ahead = false;   // this environment's settled reset state was ready
+            if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
+                for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
+                if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
+                if (tail.rows) {   // host path: also as a row of the compact list
+                    int at = 0;
+                    if ((threadIdx.x & 3) == 0) at = (int)atomicAdd(&stats[CTL_TERM_CNT + tail.parity], 1ull);
+                    at = __shfl(at, (int)(threadIdx.x & ~3u));
+                    if (at < tail.cap) {
+                        float* row = tail.rows + (size_t)at * (od + 1);
+                        if ((threadIdx.x & 3) == 0) row[0] = qs::i2f(env);
+                        for (int i = threadIdx.x & 3; i < od; i += 4) row[1 + i] = ob[i];
+                    }
                 }
+                ahead = lookahead_take(la, stats, rec, env, qs::f2i(rec[R_EPISODE]) + 1, cfg.payload_soft != 0);
             }
-            return;
+            LaneDev::sync();
+            if (__builtin_expect(__any(do_reset && !ahead), 0)) {
+                // no settled state ahead (reset_lookahead = 0, or all K states used up faster than the lanes settle): the settle happens here,
+                // in the kernel's full build (cold code behind the step).  Its solver's v_mfma_f32_4x4x1 ignores EXEC, so it must not run
+                // under a divergent branch: what the step produced is published first, then EVERY quad runs the reset on its LDS copy (as
+                // k_reset does) and only the resetting environments keep the result -- one whose state was ready gets from its own settle the
+                // very bits it had copied from its slot.
+                __syncthreads();
+                tile_store(s_rec, recs, first, cfg.n_envs, QS_RW_BEGIN, tile_extent(cfg, true), ls);
+                obs_store(s_obs, min(QS_ENVS_PER_WAVE, cfg.n_envs - first), od, first, obs_out, rew_out == nullptr, obs_keep);
+                __syncthreads();
+                E::reset(cfg, rec, ob, gid, true);
+                if (do_reset && !ahead && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)cfg.settle_steps);
+                LaneDev::sync();
+                if (do_reset) {
+                    float* g = recs + (size_t)env * QS_REC;
+                    const int end = tile_extent(cfg, true);
+                    for (int i = threadIdx.x & 3; i < end; i += 4) g[i] = rec[i];
+                    for (int i = threadIdx.x & 3; i < od; i += 4) {
+                        if (rew_out) obs_out[(size_t)env * od + i] = ob[i];
+                        else obs_out[(size_t)env * (od + 2) + i] = ob[i];
+                        obs_keep[(size_t)env * od + i] = ob[i];
+                    }
+                }
+                return;
+            }
+            if (do_reset) E::reset(cfg, rec, ob, gid, false);
         }
     }
     __syncthreads();
@@ -371,11 +330,11 @@ template <bool CONE, bool RESET, int WAVES> static __device__ __forceinline__ vo
 #define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, la, stats, lanes, tap, demo, tail
 // One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
 // wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
-template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, RESET, 1>(QS_STEP_PASS); }
+template <bool CONE, bool SOFT> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, 1, SOFT>(QS_STEP_PASS); }
 // Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
 // issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
 // (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
-template <bool CONE, bool RESET> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, RESET, 2>(QS_STEP_PASS); }
+template <bool CONE, bool SOFT> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, 2, SOFT>(QS_STEP_PASS); }
 
 // Settle lanes, between two settles of a cohort (an epoch = the launches one settle takes): the staging records that finished settling go
 // to the look-ahead slots of their environments (R_EPISODE marks the slot as holding that episode) ...
@@ -812,10 +771,10 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC_END : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), lds, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
                                                  h->d_obs, h->d_term_obs, h->la, h->d_stats, lanes, tap, demo, tail)
-    const bool reset = h->cfg.auto_reset != 0;   // finished environments are reset inside the step
-#define QS_PICK(C, X) { if (dense) QS_LAUNCH_STEP((k_step_dense<C, X>)); else QS_LAUNCH_STEP((k_step<C, X>)); }
-    if (h->cfg.friction_cone) { if (reset) QS_PICK(true, true) else QS_PICK(true, false) }
-    else { if (reset) QS_PICK(false, true) else QS_PICK(false, false) }
+#define QS_PICK(C, S) { if (dense) QS_LAUNCH_STEP((k_step_dense<C, S>)); else QS_LAUNCH_STEP((k_step<C, S>)); }
+    if (h->cfg.friction_cone && h->cfg.payload_soft) QS_PICK(true, true)
+    else if (h->cfg.friction_cone) QS_PICK(true, false)
+    else QS_PICK(false, false)
 #undef QS_PICK
 #undef QS_LAUNCH_STEP
     QS_HIP(hipGetLastError());

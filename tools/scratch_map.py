@@ -16,7 +16,7 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.check_call(["hipcc"] + FLAGS + ["-I" + os.path.join(REPO, "include"), "-save-temps", "-o", "t.so",
                                                os.path.join(REPO, "quadruped-springs_amd", "csrc", "qs_hip.hip")], cwd=d, stderr=subprocess.DEVNULL)
     lines = open(os.path.join(d, "qs_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
-for name in ("_Z6k_stepILb1ELb1EE", "_Z6k_stepILb1ELb0EE", "_Z12k_step_denseILb1ELb1EE"):
+for name in ("_Z6k_stepILb1ELb0EE", "_Z6k_stepILb1ELb1EE", "_Z12k_step_denseILb1ELb0EE"):   # <CONE, SOFT>
     st = [i for i, l in enumerate(lines) if l.startswith(name) and l.split(";")[0].rstrip().endswith(":")][0]
     en = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))
     f = lines[st:en]
