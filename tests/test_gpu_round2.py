@@ -497,3 +497,33 @@ def test_results_do_not_depend_on_wave_mates(torch_cuda, neighbour):
         assert np.array_equal(v.get_info("foot_force").cpu().numpy()[twins], v.get_info("foot_force").cpu().numpy()[twins + 16])
     assert v.counter("limit_path_substeps") > rare0 + 20       # wave 0 did take the rare path
     v.close()
+
+
+def test_a_fallen_robot_does_not_depend_on_its_wave_mates_either(torch_cuda):
+    """The other direction: the SAME fallen robot in two waves whose other 15 environments stand, fly or lie differently --
+    which rows of the many-rows solver are skipped as empty in the whole wave and when the wave leaves the sweeps differ, its bits must not."""
+    n = 32
+    v = vec_env(n, **RAW)
+    v.reset()
+    rng = np.random.default_rng(21)
+    s = v.get_state().cpu().numpy()
+    k0, k1 = 5, 16 + 9                                                       # the same robot, lane position differs too
+    lying = fallen_states(s[:1], rng)[0]
+    lying[2] = 0.09
+    mates = fallen_states(s[16:], np.random.default_rng(22))                # wave 1: everybody else lies about in other attitudes ...
+    s[16:] = mates
+    s[20:24, 2] = 0.6                                                        # ... or is in the air
+    s[k0] = lying; s[k1] = lying                                             # wave 0: 15 standing robots around it
+    v.set_state(s)
+    rare0 = v.counter("limit_path_substeps")
+    for t in range(40):
+        tau = rng.uniform(-4, 4, size=(n, 12)).astype(np.float32)
+        tau[k1] = tau[k0]
+        obs = v.step(tau)[0]
+        st = v.get_state().cpu().numpy()
+        assert np.array_equal(st[k0], st[k1]), f"step {t}"
+        assert np.array_equal(obs[k0], obs[k1]), f"step {t}"
+    ff = v.get_info("foot_force").cpu().numpy()
+    assert np.array_equal(ff[k0], ff[k1])
+    assert st[k0, 2] < 0.12 and v.counter("limit_path_substeps") > rare0 + 100
+    v.close()
