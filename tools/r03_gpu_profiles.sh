@@ -14,7 +14,7 @@ run pyramid_resid0 --friction-model pyramid --solver-residual-threshold 0 --no-c
 run cone_resid0 --solver-residual-threshold 0 --no-cpu-baseline --no-info-line
 run n4096 --envs-per-gpu 4096 --no-cpu-baseline --no-info-line
 run n16384 --envs-per-gpu 16384 --no-cpu-baseline --no-info-line
-run n65536 --envs-per-gpu 65536 --reset-lookahead 8 --no-cpu-baseline --no-info-line
+run n65536 --envs-per-gpu 65536 --no-cpu-baseline --no-info-line
 run masses_weld --env-kw env_randomizer_mode=MASS_RANDOMIZER --no-cpu-baseline --no-info-line
 run masses_soft --env-kw env_randomizer_mode=MASS_RANDOMIZER payload=soft --steps 100 --warmup 20 --preroll 200 --no-cpu-baseline --no-info-line
 python tools/numpy_path_rate.py $OUT/numpy_path.json 2>&1 | grep "numpy VecEnv\|step_async"
