@@ -790,9 +790,11 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
 struct HostPath {
     size_t bytes, off_rew, off_done, off_trunc, off_tail;
     int cap;                 // rows of the compact terminal list
-    uint8_t* d_block;
+    int zero_copy;           // the step kernel reads the actions from / writes the results to the page-locked host memory itself
+    uint8_t* d_block;        // (copy mode) the device result block
     uint8_t* h_block[2];
-    float* h_act; float* d_act;
+    uint8_t* hd_block[2];    // (zero-copy mode) device addresses of the host blocks
+    float* h_act; float* d_act; float* hd_act;
     int cur, parity, pending;
     hipEvent_t ev;
 };
@@ -818,22 +820,32 @@ static int host_path_init(qs_handle* h) {
     p->off_rew = n * o * 4; p->off_done = p->off_rew + n * 4; p->off_trunc = p->off_done + n;
     p->off_tail = (p->off_trunc + n + 15) / 16 * 16;
     p->bytes = p->off_tail + (size_t)p->cap * (o + 1) * 4;
+    // QS_HOST_PATH=copy: H2D copy of the actions and D2H copy of a device result block around the step (two DMA operations on the stream);
+    // default: zero copy -- the page-locked host buffers are mapped into the device's address space and the kernel reads its 24 B of
+    // actions per environment and writes its rows over PCIe itself, the waves that finish first while the others still compute
+    const char* mode = getenv("QS_HOST_PATH");
+    p->zero_copy = !(mode && strcmp(mode, "copy") == 0);
+    const unsigned flags = p->zero_copy ? hipHostRegisterMapped : hipHostRegisterDefault;
     const size_t page = 4096, hb = (p->bytes + page - 1) / page * page, ab = (n * d * 4 + page - 1) / page * page;
     for (int k = 0; k < 2; k++) {
         void* m = nullptr;
         if (posix_memalign(&m, page, hb) != 0) QS_FAIL(-4, "out of host memory");
         memset(m, 0, hb);
         p->h_block[k] = (uint8_t*)m;
-        QS_HIP(hipHostRegister(m, hb, hipHostRegisterDefault));
+        QS_HIP(hipHostRegister(m, hb, flags));
+        if (p->zero_copy) QS_HIP(hipHostGetDevicePointer((void**)&p->hd_block[k], m, 0));
     }
     void* m = nullptr;
     if (posix_memalign(&m, page, ab) != 0) QS_FAIL(-4, "out of host memory");
     memset(m, 0, ab);
     p->h_act = (float*)m;
-    QS_HIP(hipHostRegister(m, ab, hipHostRegisterDefault));
-    QS_HIP(hipMalloc(&p->d_block, p->bytes));
-    QS_HIP(hipMemset(p->d_block, 0, p->bytes));
-    QS_HIP(hipMalloc(&p->d_act, n * d * 4));
+    QS_HIP(hipHostRegister(m, ab, flags));
+    if (p->zero_copy) QS_HIP(hipHostGetDevicePointer((void**)&p->hd_act, m, 0));
+    else {
+        QS_HIP(hipMalloc(&p->d_block, p->bytes));
+        QS_HIP(hipMemset(p->d_block, 0, p->bytes));
+        QS_HIP(hipMalloc(&p->d_act, n * d * 4));
+    }
     QS_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
     return 0;
 }
@@ -846,11 +858,13 @@ int qs_host_step_begin(qs_handle* h, const float* actions_host) {
     if (p->pending) QS_FAIL(-1, "qs_host_step_begin: the previous step has not been collected (qs_host_step_end)");
     const size_t n = (size_t)h->cfg.n_envs, d = (size_t)h->cfg.action_dim;
     memcpy(p->h_act, actions_host, n * d * 4);
-    QS_HIP(hipMemcpyAsync(p->d_act, p->h_act, n * d * 4, hipMemcpyHostToDevice, h->stream));
     p->cur ^= 1; p->parity ^= 1;
-    h->tail.rows = (float*)(p->d_block + p->off_tail); h->tail.cap = p->cap; h->tail.parity = p->parity;
-    if (int rc = launch_step(h, p->d_act, (float*)p->d_block, (float*)(p->d_block + p->off_rew), p->d_block + p->off_done, p->d_block + p->off_trunc)) return rc;
-    QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
+    uint8_t* blk = p->zero_copy ? p->hd_block[p->cur] : p->d_block;
+    const float* act = p->zero_copy ? p->hd_act : p->d_act;
+    if (!p->zero_copy) QS_HIP(hipMemcpyAsync(p->d_act, p->h_act, n * d * 4, hipMemcpyHostToDevice, h->stream));
+    h->tail.rows = (float*)(blk + p->off_tail); h->tail.cap = p->cap; h->tail.parity = p->parity;
+    if (int rc = launch_step(h, act, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, blk + p->off_trunc)) return rc;
+    if (!p->zero_copy) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
     QS_HIP(hipEventRecord(p->ev, h->stream));
     p->pending = 1;
     return 0;

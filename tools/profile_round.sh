@@ -20,6 +20,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BU
 done
 cd "$REPO"
 python3 tools/pmc_summary.py "$OUT" k_step "$OUT/bench.json" "$OUT/pmc.json" --last 1000 > "$OUT/summary.md" 2>&1
+{ echo; echo "(rocprofv3's VGPR / AGPR / scratch columns above come from its dispatch records: it reports the architected VGPR half only.  The code object itself -- tools/kernel_resources.py on the library that ran:)"; echo '```'; python3 tools/kernel_resources.py k_step; echo '```'; } >> "$OUT/summary.md" 2>&1
 cp $(find "$OUT/trace" -name "*_kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
 rm -rf "$OUT/trace" "$OUT"/pmc[0-9] "$OUT"/*.log
 du -sh "$OUT"; cat "$OUT/summary.md"; cut -c1-300 "$OUT/bench.json"
