@@ -199,9 +199,12 @@ int qs_stats(qs_handle* h, uint64_t* settle_substeps, uint64_t* resets);
  * kernel itself instead of being packed from four arrays afterwards. */
 int qs_step_fused(qs_handle* h, const float* actions, float* fused);
 /* ---- Host (numpy) path: the SB3 consumer of load_model.py:113-133 hands over HOST arrays.  qs_host_step_begin = VecEnv.step_async:
- * `actions` is a host array [N, action_dim] (any memory; copied before the call returns); the H2D copy, the step and ONE D2H copy of
- * the results are enqueued on the handle's stream.  qs_host_step_end = VecEnv.step_wait: waits for them and points `out` at the
- * results in page-locked host memory owned by the handle: two blocks alternate, so the arrays of a step stay valid until the end of the
+ * `actions` is a host array [N, action_dim] (any memory; copied into page-locked staging before the call returns); the step is enqueued on
+ * the handle's stream with its action and result pointers IN that page-locked host memory, mapped into the device's address space: the
+ * kernel reads its 24 B of actions per environment and writes its result rows over PCIe itself, the waves that finish first while the
+ * others still compute (QS_HOST_PATH=copy in the environment: an H2D and a D2H copy around the step instead; 47 against 57 M env-steps/s
+ * at N = 8192).  qs_host_step_end = VecEnv.step_wait: waits for the step and points `out` at the results in page-locked host memory
+ * owned by the handle: two blocks alternate, so the arrays of a step stay valid until the end of the
  * NEXT step.  terminal_rows: the observations of the environments that ended their episode in this step BEFORE their auto-reset
  * (SB3: infos[i]["terminal_observation"]) as a compact list -- row r = [environment index (int32 bits), observation], in no particular
  * order; the number of rows is the number of set `done` flags, of which the list holds the first terminal_cap (256, or N if smaller):
