@@ -315,9 +315,7 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
                 }
                 return;
             }
-#ifndef QS_AB_FREE_RESET   /* A/B builds only: what the launch would gain if the task / sensor / filter part of a reset cost nothing (wrong results) */
             if (do_reset) E::reset(cfg, rec, ob, gid, false);
-#endif
         }
     }
     __syncthreads();
