@@ -99,7 +99,8 @@ struct LookAhead {
 // of an epoch (= the launches one settle takes) apart, so that a wanted state waits at most epoch / QS_COHORTS launches for a lane.
 #define QS_COHORTS 5
 #define QS_MAX_SLICE 2048
-struct SettleLanes { float* staging; const int2* stage_jobs; int n_env_waves, waves_per_cohort, slice; int spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS]; };
+struct SettleLanes { float* staging; const int2* stage_jobs; int n_env_waves, slice; int wave0[QS_COHORTS + 1] /* first settle wave of each cohort */,
+                     spawn[QS_COHORTS], last[QS_COHORTS], settle_n[QS_COHORTS]; };
 struct TraceTap { float* rows; int env; };
 struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonstration of the DEMO tasks
 // Host path (qs_host_step_*): the terminal observations of the step as a compact list [cap][1 + obs_dim] (environment index as int bits,
@@ -181,9 +182,11 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
     QS_PHASE_BEGIN
     if (tail.rows && blockIdx.x == 0 && threadIdx.x == 0) stats[CTL_TERM_CNT + (tail.parity ^ 1)] = 0ull;
     const bool settling = (int)blockIdx.x >= lanes.n_env_waves;          // wave-uniform: this workgroup settles staging records
-    const int cohort = settling ? ((int)blockIdx.x - lanes.n_env_waves) / lanes.waves_per_cohort : 0;
-    const int first = settling ? cohort * lanes.slice + (((int)blockIdx.x - lanes.n_env_waves) % lanes.waves_per_cohort) * QS_ENVS_PER_WAVE
-                               : (int)blockIdx.x * QS_ENVS_PER_WAVE;
+    const int sw = (int)blockIdx.x - lanes.n_env_waves;                  // settle lanes: which of them
+    int cohort = 0;
+#pragma unroll
+    for (int c = 1; c < QS_COHORTS; c++) cohort += settling && sw >= lanes.wave0[c] ? 1 : 0;
+    const int first = settling ? cohort * lanes.slice + (sw - lanes.wave0[cohort]) * QS_ENVS_PER_WAVE : (int)blockIdx.x * QS_ENVS_PER_WAVE;
     // CTL_R[cohort] is only written between launches (k_lookahead_plan)
     const int limit = settling ? cohort * lanes.slice + (int)stats[CTL_R + cohort] : cfg.n_envs;
     if (first >= limit) return;
@@ -358,15 +361,35 @@ __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const 
 // handed[e] are settled or being settled.  One block scans all environments, starting at a rotating offset (when more is wanted than the
 // cohort has lanes -- `cap` --, the rest waits for the next cohort, and nobody waits for ever).  cap = 0: count only (the backlog counter).
 __global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __restrict__ ctl, LookAhead la, int n_envs, int2* __restrict__ stage_jobs, int cohort,
-                                                          int slice, int cap, int offset) {
-    __shared__ int s_count, s_want;
-    if (threadIdx.x == 0) { s_count = 0; s_want = 0; if (cap > 0) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
+                                                          int slice, int take, int offset) {
+    __shared__ int s_count, s_want, s_cap;
+    if (threadIdx.x == 0) { s_count = 0; s_want = 0; if (take) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
     __syncthreads();
+    // what all windows lack together
+    for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
+        const int X = la.cur[i];
+        int h = la.handed[i];
+        if (h < X) h = X;
+        const int want = X + la.K - h;
+        if (want > 0) atomicAdd(&s_want, want);
+    }
+    __syncthreads();
+    // The cohort takes ALL of it, up to the lanes the launch carries for it (`slice`).  In the benchmark's steady state that is ~36 waves
+    // per cohort, 180 settling waves next to the 512 stepping ones: one round of the one-wave-per-SIMD kernel.  A burst (everybody at the
+    // 10-s limit in one step) or the start of a training run (every robot falls within a few dozen steps: the settle work is a multiple
+    // of the stepping work) puts more waves into the launch than the chip has SIMDs, and the launch runs in several rounds -- which
+    // costs what the work weighs, whereas a reset that finds no state ready settles inside a step at 170 steps' time.  Decided HERE, on
+    // the device: the host launches ahead of the GPU by hundreds of steps and knows nothing current.  (Round 3's first version trimmed
+    // the lanes to the idle SIMDs from the host: 0.6 M env-steps/s under a policy that throws every robot down every 38 steps, 3 - 7 M
+    // with a third of the backlog per cohort, tools/falling_policy_rate.py.)
+    if (threadIdx.x == 0) { int c = s_want < slice ? s_want : slice; c = (c + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE; if (c > slice) c = slice; s_cap = take ? c : 0; }
+    __syncthreads();
+    const int cap = s_cap;
     int2* dst = stage_jobs + (size_t)cohort * slice;
     // two passes: first the environments that are running low (fewer than half of their K states ready or on the way: after a burst of
     // resets -- e.g. everybody at the 10-s limit in one step -- the ones that fall every few steps must not wait behind the rest), then
     // everybody else while lanes remain
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < 2 && cap > 0; pass++) {
         for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
             const int e = (i + offset) % n_envs;
             const int X = la.cur[e];
@@ -374,8 +397,6 @@ __global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __r
             if (h < X) h = X;
             const int want = X + la.K - h;
             if (want <= 0 || (2 * want > la.K) != (pass == 0)) continue;
-            atomicAdd(&s_want, want);
-            if (cap <= 0) continue;
             const int at = atomicAdd(&s_count, want);
             int took = 0;
             for (int j = 0; j < want && at + j < cap; j++) { dst[at + j] = make_int2(e, h + 1 + j); took++; }
@@ -383,11 +404,10 @@ __global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __r
         }
         __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         const int n = s_count < cap ? s_count : cap;
-        if (cap > 0) ctl[CTL_R + cohort] = (unsigned long long)n;
-        ctl[CTL_BACKLOG] = (unsigned long long)(s_want - (cap > 0 ? n : 0));
+        if (take) ctl[CTL_R + cohort] = (unsigned long long)n;
+        ctl[CTL_BACKLOG] = (unsigned long long)(s_want - n);
     }
 }
 // Settle lanes switched off (qs_settle_lanes(h, 0)): the settles in progress are dropped; their states count as not handed out again
@@ -632,10 +652,11 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
     if (cfg->reset_lookahead > 0 && !(cfg->randomizer_flags & QS_RAND_KEEP)) {
         const int K = cfg->reset_lookahead;
         h->la.K = K;
-        // a cohort settles at most `slice` records at a time: enough lanes for every environment to reset once per epoch and cohort
-        h->slice = (int)((n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE);
+        // a cohort settles at most `slice` records at a time: 2 N -- with five cohorts per epoch of 250 launches that is room for every
+        // environment to fall every 25 steps (the start of a training run); a launch only carries the lanes the backlog asks for
+        h->slice = (int)((2 * n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE);
         if (h->slice < QS_MAX_SLICE) h->slice = QS_MAX_SLICE;
-        if (h->slice > 65536) h->slice = 65536;
+        if (h->slice > 131072) h->slice = 131072;
         QS_HIP(hipMalloc(&h->la.slots, n * K * QS_REC * sizeof(float)));
         QS_HIP(hipMalloc(&h->la.cur, n * sizeof(int)));
         QS_HIP(hipMalloc(&h->la.handed, n * sizeof(int)));
@@ -643,6 +664,7 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
         QS_HIP(hipMalloc(&h->d_stage_jobs, (size_t)QS_COHORTS * h->slice * sizeof(int2)));
         QS_HIP(hipMemsetAsync(h->d_staging, 0, (size_t)QS_COHORTS * h->slice * QS_REC * sizeof(float), h->stream));
         QS_HIP(hipMemsetAsync(h->d_stage_jobs, 0, (size_t)QS_COHORTS * h->slice * sizeof(int2), h->stream));
+
         const unsigned fill_grid = (unsigned)((n * K + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE);
         if (cfg->friction_cone) hipLaunchKernelGGL((k_lookahead_fill<true>), dim3(fill_grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->la);
         else hipLaunchKernelGGL((k_lookahead_fill<false>), dim3(fill_grid), dim3(QS_WAVE), 0, h->stream, h->d_cfg, h->la);
@@ -728,46 +750,50 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     QS_ON_DEVICE(h);
     SettleLanes lanes;
     memset(&lanes, 0, sizeof(lanes));
-    lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.waves_per_cohort = 1; lanes.slice = 0;
+    lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.slice = 0;
     TraceTap tap; tap.rows = h->trace_rows; tap.env = h->trace_env;
     DemoTab demo; demo.rows = h->d_demo; demo.length = h->demo_len;
     TermTail tail = h->tail;
     memset(&h->tail, 0, sizeof(h->tail));       // (set by qs_host_step_begin for its own launch only)
     if (E::demo_task(h->cfg.task) && !h->d_demo) QS_FAIL(-1, "the DEMO tasks need a demonstration: qs_set_demo first");
     int grid = lanes.n_env_waves;
+    bool lanes_fit = true;      // the environments' waves and the lanes' usual share fit the SIMDs
     if (h->la.K > 0 && h->lanes_on) {
         // one settle = settle_steps substeps = `epoch` launches of action_repeat substeps (the last one takes the remainder);
         // cohort c runs the same schedule c * epoch / QS_COHORTS launches later
         const int rep = h->cfg.action_repeat, epoch = (h->cfg.settle_steps + rep - 1) / rep;
         const int slice = h->slice;
-        lanes.staging = h->d_staging; lanes.stage_jobs = h->d_stage_jobs; lanes.slice = slice; lanes.waves_per_cohort = slice / QS_ENVS_PER_WAVE;
-        // With one wave per SIMD a launch of more waves than SIMDs runs in two rounds.  While the environments leave at least
-        // QS_COHORTS x 64 SIMDs free (room to settle 20 resets' worth per step) the settle lanes are trimmed to the free SIMDs and the
-        // one-wave-per-SIMD kernel stays; beyond that the two-waves-per-SIMD build takes the whole launch (below), with at most QS_MAX_SLICE
-        // records per cohort unless the environments are more than that (jobs beyond a cohort's lanes wait in the ring for the next cohort).
+        lanes.staging = h->d_staging; lanes.stage_jobs = h->d_stage_jobs; lanes.slice = slice;
+        // Every launch carries the lanes of five full cohorts (a workgroup beyond its cohort's jobs leaves at once: 5120 of them at
+        // N = 8192 cost the launch 0.4 %); how many of them work is decided on the device (k_lookahead_plan).  The kernel: one wave per
+        // SIMD while the environments' waves and the lanes' usual load fit the SIMDs, the two-waves-per-SIMD build beyond.
         const int free_simd = h->n_simd - lanes.n_env_waves;
-        if (h->step_variant != 2 && free_simd / QS_COHORTS >= 64) { if (lanes.waves_per_cohort > free_simd / QS_COHORTS) lanes.waves_per_cohort = free_simd / QS_COHORTS; }
-        const int cohort_cap = lanes.waves_per_cohort * QS_ENVS_PER_WAVE;
+        const int cohort_waves = slice / QS_ENVS_PER_WAVE;
+        int base_waves = cohort_waves;
+        if (h->step_variant != 2 && free_simd / QS_COHORTS >= 64 && base_waves > free_simd / QS_COHORTS) base_waves = free_simd / QS_COHORTS;
+        lanes_fit = n_waves(h->cfg.n_envs) + QS_COHORTS * base_waves <= h->n_simd;
         for (int c = 0; c < QS_COHORTS; c++) {
             const long long t = h->tick - (long long)c * epoch / QS_COHORTS;
+            lanes.wave0[c] = c * cohort_waves;
             if (t < 0) continue;                       // not started yet: settle_n stays 0
             const int phase = (int)(t % epoch);
             if (phase == 0) {
                 hipLaunchKernelGGL(k_lookahead_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_staging, h->d_stage_jobs, h->la, c, slice);
-                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, c, slice, cohort_cap,
+                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, c, slice, 1,
                                    (int)((h->tick / (epoch / QS_COHORTS > 0 ? epoch / QS_COHORTS : 1)) * 4099 % h->cfg.n_envs));
             }
             lanes.spawn[c] = phase == 0; lanes.last[c] = phase == epoch - 1;
             lanes.settle_n[c] = phase == epoch - 1 ? h->cfg.settle_steps - rep * (epoch - 1) : rep;
         }
-        grid += QS_COHORTS * lanes.waves_per_cohort;
+        lanes.wave0[QS_COHORTS] = QS_COHORTS * cohort_waves;
+        grid += lanes.wave0[QS_COHORTS];
         h->tick++;
     }
     if (h->timing == 1) { hipEventRecord(h->ev0, h->stream); h->timing = 2; }   // (after this step's publish / plan launches, if any)
     if (h->timing) h->timed_launches++;
     // more waves than SIMDs: the two-waves-per-SIMD build of the same body (see k_step_dense) instead of a second round of one-wave-per-
     // SIMD workgroups (N = 12288 with its settle lanes: 0.109 ms in two rounds)
-    const bool dense = h->step_variant == 2 || (h->step_variant == 0 && grid > h->n_simd);
+    const bool dense = h->step_variant == 2 || (h->step_variant == 0 && (lanes.n_env_waves > h->n_simd || !lanes_fit));
     const size_t lds = (size_t)QS_ENVS_PER_WAVE * ((h->cfg.payload_soft ? QS_REC_END : QS_INFO_END) + QS_MAX_OBS + 12) * sizeof(float);
 #define QS_LAUNCH_STEP(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(QS_WAVE), lds, h->stream, h->d_cfg, h->d_rec, actions, obs, rew, done, trunc, \
                                                  h->d_obs, h->d_term_obs, h->la, h->d_stats, lanes, tap, demo, tail)

@@ -22,11 +22,11 @@ class QuadrupedVecEnv(SB3VecEnv):
     def __init__(self, num_envs=1, device=0, auto_reset=True, reset_lookahead=None, copy_outputs=True, **env_kwargs):
         """reset_lookahead = K: every environment keeps the settled reset states of its next K episodes ready (computed by extra workgroups
         of the step kernel while the environments step), so a reset is a copy; results are bitwise those of K = 0, where every reset runs
-        the reference's 2500-substep settle in place (gym_env.py:278-297, 323-329).  Default: 8 with auto_reset, 0 without.
+        the reference's 2500-substep settle in place (gym_env.py:278-297, 323-329).  Default: 16 with auto_reset (N x 16 x 1152 bytes), 0 without.
         copy_outputs=False: step() / step_wait() return views of the page-locked result block instead of copies (valid until the end of
         the next step: two blocks alternate)."""
         cfg, meta = build_config(n_envs=num_envs, auto_reset=auto_reset, **env_kwargs)
-        cfg.reset_lookahead = int((8 if auto_reset else 0) if reset_lookahead is None else reset_lookahead)
+        cfg.reset_lookahead = int((16 if auto_reset else 0) if reset_lookahead is None else reset_lookahead)
         self._setup(cfg, meta, device, copy_outputs)
 
     @classmethod
