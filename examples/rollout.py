@@ -29,7 +29,7 @@ def main():
     args = ap.parse_args()
     env_kwargs = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", action_space_mode="SYMMETRIC", motor_control_mode="PD",
                       enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER")   # an args.yml of the reference
-    venv = QuadrupedVecEnv(num_envs=args.envs, device=0, auto_reset=True, reset_lookahead=8, wrapper=args.wrapper, **env_kwargs)
+    venv = QuadrupedVecEnv(num_envs=args.envs, device=0, auto_reset=True, wrapper=args.wrapper, **env_kwargs)
     env = DeviceVecNormalize(venv, training=True, norm_reward=True)   # VecNormalize.load(stats_path, env) in the reference
     rng = np.random.default_rng(0)
     returns, lengths, ep_ret, ep_len = [], [], np.zeros(args.envs), np.zeros(args.envs, int)

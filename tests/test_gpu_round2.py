@@ -527,3 +527,30 @@ def test_a_fallen_robot_does_not_depend_on_its_wave_mates_either(torch_cuda):
     assert np.array_equal(ff[k0], ff[k1])
     assert st[k0, 2] < 0.25 and v.counter("limit_path_substeps") > rare0 + 100
     v.close()
+
+
+def test_lookahead_keeps_up_with_robots_that_fall_all_the_time(torch_cuda):
+    """The start of a training run: every robot is thrown down within a few dozen steps, so the resets' settle work is a multiple of the
+    stepping work.  The settle lanes size themselves on the device (every cohort takes what the environments' windows lack), so with
+    K = 16 states per environment nobody has to settle inside a step -- round 3's first version (lanes trimmed to the idle SIMDs by the
+    host) fell to 0.6 M env-steps/s here with hundreds of stalls per step."""
+    torch = torch_cuda
+    n, steps = 4096, 1200
+    v = vec_env(n, env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, reset_lookahead=16, seed=3, info_fields=False)
+    v.reset_tensor()
+    gen = torch.Generator(device=v.device).manual_seed(1)
+    acts = torch.rand((64, n, v.action_dim), generator=gen, device=v.device) * 2 - 1
+    acts[:, :, 1::3] = -1.0
+    acts[0::2, :, 2::3] = 1.0; acts[1::2, :, 2::3] = -0.5
+    import time
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        v.step_tensor(acts[i % 64])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    resets = v.counter("resets") - n
+    print(f"{resets / steps:.1f} resets per step, {v.counter('reset_stalls')} stalls, {n * steps / dt / 1e6:.1f} M env-steps/s, "
+          f"settle substeps per env substep {v.counter('settle_substeps') / (n * steps * 10):.2f}")
+    assert resets / steps > 60                      # every environment every ~40 steps
+    assert v.counter("reset_stalls") == 0
+    assert n * steps / dt > 5e6
+    v.close()

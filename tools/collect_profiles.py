@@ -20,7 +20,8 @@ for src, name in (("summary.md", "static_pool_kernel_trace_pmc.md"), ("pmc.json"
     if os.path.exists(os.path.join(static, src)):
         shutil.copy(os.path.join(static, src), os.path.join(dst, f"{tag}_{name}"))
 for src, name, title in (("phase_cycles.txt", "phase_cycles.md", "Cycles per phase of one physics substep (tools/phase_profile.py, -DQS_PROFILE_PHASES build of the same source)"),
-                         ("rare_path.txt", "rare_path.md", "Step time when waves take the many-rows solver (tools/time_rare_path.py: NO_TASK, raw torques, N = 8192)")):
+                         ("rare_path.txt", "rare_path.md", "Step time when waves take the many-rows solver (tools/time_rare_path.py: NO_TASK, raw torques, N = 8192)"),
+                         ("falling_policy.txt", "falling_policy.md", "Look-ahead resets under a policy that throws every robot down every ~38 steps (tools/falling_policy_rate.py, N = 8192)")):
     if os.path.exists(os.path.join(run, src)):
         body = [l for l in open(os.path.join(run, src)).read().splitlines() if "amdgpu.ids" not in l]
         with open(os.path.join(dst, f"{tag}_{name}"), "w") as f:

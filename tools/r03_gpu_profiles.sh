@@ -19,6 +19,7 @@ run masses_weld --env-kw env_randomizer_mode=MASS_RANDOMIZER --no-cpu-baseline -
 run masses_soft --env-kw env_randomizer_mode=MASS_RANDOMIZER payload=soft --steps 100 --warmup 20 --preroll 200 --no-cpu-baseline --no-info-line
 python tools/numpy_path_rate.py $OUT/numpy_path.json 2>&1 | grep "numpy VecEnv\|step_async"
 python tools/time_rare_path.py > $OUT/rare_path.txt 2>&1; grep "ms per step" $OUT/rare_path.txt
+python tools/falling_policy_rate.py 16 2>&1 | grep "K =" > $OUT/falling_policy.txt; cat $OUT/falling_policy.txt
 for x in 0 185; do ./tools/bin/split_probe --extra $x; done > $OUT/split_probe.jsonl 2>&1; cat $OUT/split_probe.jsonl
 bash tools/profile_round.sh ${2:-r03a} > $OUT/profile.log 2>&1
 tail -30 $OUT/profile.log

@@ -31,7 +31,7 @@ for variant in ("1", "2"):
     for kw in CASES:
         kw = dict(dict(enable_springs=True, enable_action_filter=True), **kw)
         n = 4096
-        env = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_lookahead=8, seed=3, **kw)
+        env = QuadrupedVecEnv(num_envs=n, auto_reset=True, seed=3, **kw)
         env.reset_tensor()
         g = torch.Generator(device="cuda").manual_seed(1)
         dones = 0
