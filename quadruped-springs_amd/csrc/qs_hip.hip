@@ -358,56 +358,49 @@ __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const 
     }
 }
 // ... then the cohort takes what the environments' windows lack: environment e in episode X wants the states of X + 1 .. X + K; those up to
-// handed[e] are settled or being settled.  One block scans all environments, starting at a rotating offset (when more is wanted than the
-// cohort has lanes -- `cap` --, the rest waits for the next cohort, and nobody waits for ever).  cap = 0: count only (the backlog counter).
+// handed[e] are settled or being settled.  One block scans all environments, starting at a rotating offset, in two passes:
+//   1. the URGENT ones -- more than a quarter of the window missing (K = 16: fewer than 12 states ready or on the way) -- get all they lack,
+//      whatever that takes (up to the `slice` records the launch carries lanes for).  That is the start of a training run: every robot
+//      falls within a few dozen steps, the settle work is a multiple of the stepping work, the launch runs in several rounds -- which
+//      costs what the work weighs, whereas a reset that finds no state ready settles inside a step at 170 steps' time;
+//   2. the others share what is left of `base_cap` = the SIMDs the environments' waves leave idle: after a burst (everybody at the 10-s
+//      limit in the same step -- the usual picture when all environments of a learner start together) nobody is short of states, and
+//      working the burst off over a few cohorts costs the launches nothing, where taking it at once would double their time for an epoch.
+// Decided HERE, on the device: the host launches ahead of the GPU by hundreds of steps and knows nothing current (round 3's first version
+// trimmed the lanes to the idle SIMDs from the host: 0.6 M env-steps/s under a policy that throws every robot down every 38 steps, against
+// 33.6 M; tools/falling_policy_rate.py).  take = 0: count only (the backlog counter).
 __global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __restrict__ ctl, LookAhead la, int n_envs, int2* __restrict__ stage_jobs, int cohort,
-                                                          int slice, int take, int offset) {
-    __shared__ int s_count, s_want, s_cap;
-    if (threadIdx.x == 0) { s_count = 0; s_want = 0; if (take) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
+                                                          int slice, int base_cap, int take, int offset) {
+    __shared__ int s_count, s_want, s_urgent;
+    if (threadIdx.x == 0) { s_count = 0; s_want = 0; s_urgent = 0; if (take) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
     __syncthreads();
-    // what all windows lack together
-    for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
-        const int X = la.cur[i];
-        int h = la.handed[i];
-        if (h < X) h = X;
-        const int want = X + la.K - h;
-        if (want > 0) atomicAdd(&s_want, want);
-    }
-    __syncthreads();
-    // The cohort takes ALL of it, up to the lanes the launch carries for it (`slice`).  In the benchmark's steady state that is ~36 waves
-    // per cohort, 180 settling waves next to the 512 stepping ones: one round of the one-wave-per-SIMD kernel.  A burst (everybody at the
-    // 10-s limit in one step) or the start of a training run (every robot falls within a few dozen steps: the settle work is a multiple
-    // of the stepping work) puts more waves into the launch than the chip has SIMDs, and the launch runs in several rounds -- which
-    // costs what the work weighs, whereas a reset that finds no state ready settles inside a step at 170 steps' time.  Decided HERE, on
-    // the device: the host launches ahead of the GPU by hundreds of steps and knows nothing current.  (Round 3's first version trimmed
-    // the lanes to the idle SIMDs from the host: 0.6 M env-steps/s under a policy that throws every robot down every 38 steps, 3 - 7 M
-    // with a third of the backlog per cohort, tools/falling_policy_rate.py.)
-    if (threadIdx.x == 0) { int c = s_want < slice ? s_want : slice; c = (c + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE * QS_ENVS_PER_WAVE; if (c > slice) c = slice; s_cap = take ? c : 0; }
-    __syncthreads();
-    const int cap = s_cap;
     int2* dst = stage_jobs + (size_t)cohort * slice;
-    // two passes: first the environments that are running low (fewer than half of their K states ready or on the way: after a burst of
-    // resets -- e.g. everybody at the 10-s limit in one step -- the ones that fall every few steps must not wait behind the rest), then
-    // everybody else while lanes remain
-    for (int pass = 0; pass < 2 && cap > 0; pass++) {
+    for (int pass = 0; pass < 2; pass++) {
+        const int cap = take ? (pass == 0 ? slice : (s_count > base_cap ? 0 : base_cap)) : 0;     // (s_count: what the urgent pass took; read after the barrier)
         for (int i = threadIdx.x; i < n_envs; i += blockDim.x) {
             const int e = (i + offset) % n_envs;
             const int X = la.cur[e];
             int h = la.handed[e];
             if (h < X) h = X;
             const int want = X + la.K - h;
-            if (want <= 0 || (2 * want > la.K) != (pass == 0)) continue;
+            if (want <= 0 || (4 * want > la.K) != (pass == 0)) continue;
+            atomicAdd(&s_want, want);
+            if (cap <= 0) continue;
             const int at = atomicAdd(&s_count, want);
             int took = 0;
             for (int j = 0; j < want && at + j < cap; j++) { dst[at + j] = make_int2(e, h + 1 + j); took++; }
             if (took) la.handed[e] = h + took;
         }
         __syncthreads();
+        if (threadIdx.x == 0 && pass == 0) { if (s_count > slice) s_count = slice; s_urgent = s_count; }    // (requests beyond the slice were not served)
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const int n = s_count < cap ? s_count : cap;
+        int n = s_count;
+        const int lim = s_urgent > base_cap ? s_urgent : base_cap;       // the second pass stopped at base_cap, unless the first had gone beyond it already
+        if (n > lim) n = lim;
         if (take) ctl[CTL_R + cohort] = (unsigned long long)n;
-        ctl[CTL_BACKLOG] = (unsigned long long)(s_want - n);
+        ctl[CTL_BACKLOG] = (unsigned long long)(s_want - (take ? n : 0));
     }
 }
 // Settle lanes switched off (qs_settle_lanes(h, 0)): the settles in progress are dropped; their states count as not handed out again
@@ -765,8 +758,9 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
         const int slice = h->slice;
         lanes.staging = h->d_staging; lanes.stage_jobs = h->d_stage_jobs; lanes.slice = slice;
         // Every launch carries the lanes of five full cohorts (a workgroup beyond its cohort's jobs leaves at once: 5120 of them at
-        // N = 8192 cost the launch 0.4 %); how many of them work is decided on the device (k_lookahead_plan).  The kernel: one wave per
-        // SIMD while the environments' waves and the lanes' usual load fit the SIMDs, the two-waves-per-SIMD build beyond.
+        // N = 8192 cost the launch 0.4 %); how many of them work is decided on the device (k_lookahead_plan): normally what fits the SIMDs
+        // the environments leave idle (base_waves per cohort: the one-wave-per-SIMD kernel then runs the launch in one round), more
+        // when environments run short of states.
         const int free_simd = h->n_simd - lanes.n_env_waves;
         const int cohort_waves = slice / QS_ENVS_PER_WAVE;
         int base_waves = cohort_waves;
@@ -779,7 +773,7 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
             const int phase = (int)(t % epoch);
             if (phase == 0) {
                 hipLaunchKernelGGL(k_lookahead_publish, dim3(128), dim3(256), 0, h->stream, h->d_stats, h->d_staging, h->d_stage_jobs, h->la, c, slice);
-                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, c, slice, 1,
+                hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, c, slice, base_waves * QS_ENVS_PER_WAVE, 1,
                                    (int)((h->tick / (epoch / QS_COHORTS > 0 ? epoch / QS_COHORTS : 1)) * 4099 % h->cfg.n_envs));
             }
             lanes.spawn[c] = phase == 0; lanes.last[c] = phase == epoch - 1;
@@ -963,7 +957,7 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
     case QS_COUNTER_RESET_STALLS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_STALLS], sizeof(v), hipMemcpyDeviceToHost)); break;
     case QS_COUNTER_LOOKAHEAD_BACKLOG:
         if (h->la.K > 0) {   // a counting pass of the planning scan
-            hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, 0, h->slice, 0, 0);
+            hipLaunchKernelGGL(k_lookahead_plan, dim3(1), dim3(1024), 0, h->stream, h->d_stats, h->la, h->cfg.n_envs, h->d_stage_jobs, 0, h->slice, 0, 0, 0);
             QS_HIP(hipGetLastError());
             QS_HIP(hipStreamSynchronize(h->stream));
             QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_BACKLOG], sizeof(v), hipMemcpyDeviceToHost));

@@ -89,3 +89,24 @@ def test_scale_table_reads_what_scale_sh_writes(tmp_path):
     # and the script itself hands bench.py the flags the table relies on
     sh = open(os.path.join(REPO, "tools", "scale.sh")).read()
     assert "--total-envs 65536" in sh and "--workload config4_sharded" in sh and "scale_table.py" in sh
+
+
+def test_usable_cores_follow_the_cgroup_quota(monkeypatch):
+    """The CPU baseline uses as many threads as the box grants CPU time for: the affinity mask cut to the cgroup quota (the GPU box of
+    round 3: 256 CPUs in the mask, cpu.max = "1600000 100000" = 16)."""
+    sys.path.insert(0, REPO)
+    import bench
+    import builtins, io
+    real_open = builtins.open
+    def fake(path, *a, **k):
+        if str(path) == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO(fake.content)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    fake.content = "1600000 100000\n"
+    assert bench.usable_cores() == (16, 256, 16.0)
+    fake.content = "max 100000\n"
+    assert bench.usable_cores()[0] == 256
+    fake.content = "50000 100000\n"           # half a CPU: still one thread
+    assert bench.usable_cores()[0] == 1

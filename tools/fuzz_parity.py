@@ -3,7 +3,9 @@
 wrapper x solver settings x record options, each for a reset and a few re-seated steps (what tests/test_gpu_parity.py does for its fixed
 list of cases).  Prints every configuration that deviates.  usage: python tools/fuzz_parity.py [cases] [seed] [fallen]
 With "fallen": NO_TASK with the links' contact response on, two thirds of the robots thrown onto trunk / hips / thighs / calves in random
-attitudes with random joint angles under raw random torques -- the many-rows solver path (12 rows per leg, joint stops, payload rows)."""
+attitudes with random joint angles under raw random torques -- the many-rows solver path (12 rows per leg, joint stops, payload rows).
+With "lookahead": no oracle -- random configurations with auto-reset, one handle with K look-ahead states per environment (K random) against
+one that settles every reset in place (K = 0), rough actions, every output of every step compared BITWISE."""
 import os
 import sys
 
@@ -12,6 +14,50 @@ import numpy as np
 from qs_amd import config as C
 from qs_amd.vec_env import QuadrupedVecEnv
 from oracle.qso import Oracle
+
+def run_lookahead(cases, seed, verbose=True):
+    import torch
+    rng = np.random.default_rng(seed)
+    tasks = [t for t in C.TASKS if not t.endswith("_DEMO")]
+    wrappers = [None, None, None, "LANDING", "GO_TO_REST", "LANDING2", "LANDING_BACKFLIP", "LANDING_BACKFLIP2", "LANDING_CONTINUOUS"]
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    bad, ran = [], 0
+    for case in range(cases):
+        kw = dict(task_env=pick(tasks), observation_space_mode=pick(list(C.SENSOR_BUNDLES)), action_space_mode=pick(list(C.ACTION_SPACE_MODES)),
+                  motor_control_mode=pick(["PD", "PD", "CARTESIAN_PD"]), env_randomizer_mode=pick(list(C.RANDOMIZERS)), wrapper=pick(wrappers),
+                  friction_model=pick(["cone", "cone", "pyramid"]), solver_residual_threshold=pick([0.0, 1e-7]), enable_springs=bool(rng.integers(2)),
+                  enable_action_filter=bool(rng.integers(2)), info_fields=bool(rng.integers(2)), payload=pick(["weld", "weld", "soft"]),
+                  seed=int(rng.integers(1000)), settle_steps=int(pick([100, 200, 300])), noise=bool(rng.integers(2)))
+        n, K = int(pick([5, 16, 37, 64])), int(pick([1, 2, 3, 5, 16]))
+        try:
+            a, b = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_lookahead=K, **kw), QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_lookahead=0, **kw)
+        except (ValueError, KeyError, RuntimeError):
+            continue
+        ran += 1
+        try:
+            assert torch.equal(a.reset_tensor(), b.reset_tensor()), "reset observation"
+            d = a.action_dim
+            resets = 0
+            for i in range(int(pick([60, 120]))):
+                act = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+                if d in (6, 12) and (i // 8) % 3 != 2:
+                    act[:, 1::3] = -1.0; act[:, 2::3] = 1.0 if (i // 8) % 2 else -0.5       # violent leg motions: falls, resets
+                t = torch.as_tensor(act, device=a.device)
+                ra, rb = a.step_tensor(t), b.step_tensor(t)
+                for name, x, y in zip(("obs", "reward", "done", "truncated"), ra, rb):
+                    assert torch.equal(x, y), f"{name} step {i}"
+                resets += int(ra[2].sum())
+            assert torch.equal(a.get_state(), b.get_state()), "final state"
+            assert torch.equal(a.get_info("params"), b.get_info("params")) and torch.equal(a.get_info("task"), b.get_info("task")), "final parameters / task"
+            if verbose and case % 20 == 0:
+                print(f"case {case}: n {n} K {K} {kw['task_env']} {kw['wrapper']} payload {kw['payload']}: {resets} resets, {a.counter('reset_stalls')} stalls, bitwise equal")
+        except AssertionError as e:
+            bad.append((case, kw, str(e).strip().splitlines()[0:3]))
+            if verbose:
+                print(f"case {case}: n {n} K {K} {kw}\n   {bad[-1][2]}")
+        a.close(); b.close()
+    return ran, bad
+
 
 def run(cases, seed, verbose=True, fallen=False):
     rng = np.random.default_rng(seed)
@@ -91,5 +137,9 @@ def run(cases, seed, verbose=True, fallen=False):
 
 
 if __name__ == "__main__":
+    if "lookahead" in sys.argv[3:]:
+        ran, bad = run_lookahead(int(sys.argv[1]), int(sys.argv[2]))
+        print(f"{ran} configurations ran, {len(bad)} deviated")
+        sys.exit(1 if bad else 0)
     ran, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0, fallen="fallen" in sys.argv[3:])
     print(f"{ran} configurations ran, {len(bad)} deviated")
