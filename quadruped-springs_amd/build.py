@@ -34,8 +34,14 @@ def build(force=False, verbose=False):
     # v_max_f32 x, x canonicalisations in front of every fmin / fmax / med3 can go (+5 % measured); reassociation and the rest of
     # -ffast-math are NOT enabled (measured slower, and the summation order is part of the parity with the host emulation).
     # -amdgpu-mfma-vgpr-form: the 4x4x1 MFMAs of the Delassus block write VGPRs, no v_accvgpr_read per result (+1 % at N = 8192).
+    # -ffp-contract=on (hipcc's default is "fast"): which multiply of an expression is fused into an FMA is decided by the front end, per
+    # source expression, and not by the back end per inlined copy.  Under "fast" the step's two builds (common path / full), the settle
+    # loops of k_reset and of the settle lanes, ... are separate inlined copies of the same templates, and for expressions with two
+    # candidate products the back end's choice depended on the copy's surroundings: the copies agreed bit for bit under the implicit cone
+    # and differed in the last bit under the friction pyramid and with payload="soft" (round 3, tools/diag/r03_lanes.py) -- the
+    # look-ahead resets and the independence of wave-mates need them to agree.  Costs 1.7 % on the headline (cross-statement fusions).
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
-           "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math",
+           "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
            "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
            "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("QS_HIPCC_EXTRA", "").split() + [
            "-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]

@@ -461,16 +461,20 @@ def test_random_configurations_against_the_oracle(torch_cuda):
     assert ran >= 25 and not bad, bad[:2]
 
 
+@pytest.mark.parametrize("variant", [dict(), dict(friction_model="pyramid"), dict(payload="soft", env_randomizer_mode="MASS_RANDOMIZER", seed=3),
+                                     dict(friction_model="pyramid", solver_residual_threshold=0.0)], ids=["cone", "pyramid", "soft", "pyramid_resid0"])
 @pytest.mark.parametrize("neighbour", ["fallen", "joint_limit"])
-def test_results_do_not_depend_on_wave_mates(torch_cuda, neighbour):
+def test_results_do_not_depend_on_wave_mates(torch_cuda, neighbour, variant):
     """A wave in which some environment needs a rare path (a link on the floor, a joint at its stop) gives up its common-path attempt and
     repeats the env step of all its 16 environments with the full build of the step.  The other 15 must come out of that
     with the bits the common-path build gives them in a wave without such a neighbour: environment k of wave 0 (with the neighbour) against
     its twin k + 16 of wave 1 (same state, same actions, no neighbour), step after step."""
     torch = torch_cuda
     n = 32
-    v = vec_env(n, **RAW)                     # NO_TASK: body_contacts "auto" is on, nothing ends the episode
+    v = vec_env(n, **dict(RAW, **variant))    # NO_TASK: body_contacts "auto" is on, nothing ends the episode
     v.reset()
+    if "payload" in variant:                  # twins carry the same payload
+        par = v.get_info("params").cpu().numpy(); par[16:] = par[:16]; v.set_params("all", par)
     rng = np.random.default_rng(11)
     s = v.get_state().cpu().numpy()
     s[16:] = s[:16]
