@@ -86,9 +86,8 @@ def run(cases, seed, verbose=True, fallen=False):
             continue
         ran += 1
         o = Oracle(v.cfg, "f32")
-        o64 = Oracle(v.cfg, "f64") if fallen else None   # yardstick: how far the oracle's own two precisions part from the same state
-        if o64 is not None:
-            o64.reset()
+        o64 = Oracle(v.cfg, "f64")   # yardstick: how far the oracle's own two precisions part from the same state
+        o64.reset()
         try:
             oo, ov = o.reset(), v.reset()
             np.testing.assert_allclose(ov, oo, atol=2e-3, err_msg="reset observation")
@@ -111,23 +110,22 @@ def run(cases, seed, verbose=True, fallen=False):
                 vo, rv, dv, infos = v.step(a)
                 so, sv = o.get_state(), v.get_state().cpu().numpy()
                 slack = np.zeros((n, 1))
-                if o64 is not None:
-                    # flailing fallen robots switch support points and stick / slip within an env step: chaotic at the rounding level.  An
-                    # environment may deviate by what the oracle's float64 build deviates from its float32 build from the same state (x 5)
-                    o64.set_state(s.astype(np.float64)); o64.step(a)
-                    s64 = o64.get_state()
-                    slack = 5.0 * np.abs(s64 - so).max(axis=1, keepdims=True)
+                # contacts that stick / slip or make / break within an env step are chaotic at the rounding level (flailing fallen robots most of
+                # all).  An environment may deviate by what the oracle's float64 build deviates from its float32 build from the same state (x 5)
+                o64.set_state(s.astype(np.float64)); o64.step(a)
+                s64 = o64.get_state()
+                slack = 5.0 * np.abs(s64 - so).max(axis=1, keepdims=True)
                 assert (np.abs(sv[:, :7] - so[:, :7]) <= 5e-5 + slack).all(), f"pose step {i}: {np.abs(sv[:, :7] - so[:, :7]).max():.2e} (slack {slack.max():.1e})"
                 assert (np.abs(sv[:, 13:25] - so[:, 13:25]) <= 2e-4 + slack).all(), f"q step {i}: {np.abs(sv[:, 13:25] - so[:, 13:25]).max():.2e} (slack {slack.max():.1e})"
                 assert (np.abs(sv[:, 7:13] - so[:, 7:13]) <= 2e-2 + 10 * slack).all(), f"base velocity step {i}"
-                if o64 is not None:
+                if fallen:
                     continue
                 np.testing.assert_array_equal(dv, do, err_msg=f"done step {i}")
                 np.testing.assert_allclose(rv, ro, atol=1e-3, rtol=5e-3, err_msg=f"reward step {i}")
                 np.testing.assert_allclose(vo, oo, atol=1e-1, err_msg=f"obs step {i}")
                 if do.any():
                     m = do.astype(np.uint8)
-                    o.reset(m); v.reset_tensor(mask=m)
+                    o.reset(m); v.reset_tensor(mask=m); o64.reset(m)
         except AssertionError as e:
             bad.append((case, kw, str(e).strip().splitlines()[0:6]))
             if verbose:
