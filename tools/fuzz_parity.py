@@ -115,8 +115,17 @@ def run(cases, seed, verbose=True, fallen=False):
                 o64.set_state(s.astype(np.float64)); o64.step(a)
                 s64 = o64.get_state()
                 slack = 5.0 * np.abs(s64 - so).max(axis=1, keepdims=True)
-                assert (np.abs(sv[:, :7] - so[:, :7]) <= 5e-5 + slack).all(), f"pose step {i}: {np.abs(sv[:, :7] - so[:, :7]).max():.2e} (slack {slack.max():.1e})"
-                assert (np.abs(sv[:, 13:25] - so[:, 13:25]) <= 2e-4 + slack).all(), f"q step {i}: {np.abs(sv[:, 13:25] - so[:, 13:25]).max():.2e} (slack {slack.max():.1e})"
+                # ... and an environment in which a foot sits inside the contact threshold without carrying load is AT a make / break boundary:
+                # rounding decides on which side the next substep falls (seen once in ~300 configurations: 4e-4 rad in one joint)
+                boundary = ((o.get_info(1) > 0.5) & (o.get_info(0) <= 0.0)).any(axis=1, keepdims=True)
+                slack = slack + 2e-3 * boundary
+                def worst(d, tol):
+                    e = int(np.argmax((d - tol - slack).max(axis=1)))
+                    return (f"{d[e].max():.2e} in environment {e} (its float64 / float32 spread x 5: {slack[e, 0]:.1e}; contacts {o.get_info(1)[e].astype(int).tolist()}, "
+                            f"foot forces {np.round(o.get_info(0)[e], 1).tolist()})")
+                dp, dq = np.abs(sv[:, :7] - so[:, :7]), np.abs(sv[:, 13:25] - so[:, 13:25])
+                assert (dp <= 5e-5 + slack).all(), f"pose step {i}: " + worst(dp, 5e-5)
+                assert (dq <= 2e-4 + slack).all(), f"q step {i}: " + worst(dq, 2e-4)
                 assert (np.abs(sv[:, 7:13] - so[:, 7:13]) <= 2e-2 + 10 * slack).all(), f"base velocity step {i}"
                 if fallen:
                     continue
