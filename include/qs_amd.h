@@ -202,7 +202,7 @@ int qs_step_fused(qs_handle* h, const float* actions, float* fused);
  * `actions` is a host array [N, action_dim] (any memory; copied into page-locked staging before the call returns); the step is enqueued on
  * the handle's stream with its action and result pointers IN that page-locked host memory, mapped into the device's address space: the
  * kernel reads its 24 B of actions per environment and writes its result rows over PCIe itself, the waves that finish first while the
- * others still compute (QS_HOST_PATH=copy in the environment: an H2D and a D2H copy around the step instead; 47 against 57 M env-steps/s
+ * others still compute (QS_HOST_PATH=copy in the environment: an H2D and a D2H copy around the step instead; 47 against 55 M env-steps/s
  * at N = 8192).  qs_host_step_end = VecEnv.step_wait: waits for the step and points `out` at the results in page-locked host memory
  * owned by the handle: two blocks alternate, so the arrays of a step stay valid until the end of the
  * NEXT step.  terminal_rows: the observations of the environments that ended their episode in this step BEFORE their auto-reset
