@@ -558,3 +558,41 @@ def test_lookahead_keeps_up_with_robots_that_fall_all_the_time(torch_cuda):
     assert v.counter("reset_stalls") == 0
     assert n * steps / dt > 5e6
     v.close()
+
+
+@pytest.mark.parametrize("mode", ["zero_copy", "copy"])
+def test_host_path_terminal_observations_and_views(torch_cuda, mode, monkeypatch):
+    """The numpy path (qs_host_step_begin / _end): results arrive in page-locked host memory (written by the kernel itself, or by one D2H
+    copy under QS_HOST_PATH=copy); the terminal observations come as a compact list of at most 256 rows with the per-environment array as
+    the fallback when more episodes end in one step; copy_outputs=False hands out views of two alternating blocks."""
+    torch = torch_cuda
+    if mode == "copy":
+        monkeypatch.setenv("QS_HOST_PATH", "copy")
+    n = 1024
+    kw = dict(env_randomizer_mode="GROUND_RANDOMIZER", auto_reset=True, seed=2, noise=True)
+    a, b = vec_env(n, copy_outputs=False, **kw), vec_env(n, **kw)      # a: numpy path with views, b: device path
+    oa, ob = a.reset(), b.reset_tensor().cpu().numpy()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(4)
+    prev = None
+    for t in range(40):
+        act = rng.uniform(-1, 1, size=(n, 6)).astype(np.float32)
+        if t in (10, 25):                     # everybody falls at once: 1024 episode ends in one step, four times the compact list
+            s = b.get_state().cpu().numpy(); s[:, 2] = 0.05; s[:, 3:7] = [0.7071, 0, 0, 0.7071]
+            a.set_state(s); b.set_state(s)
+        if t == 30:                           # ... and a few: the compact list alone
+            s = b.get_state().cpu().numpy(); s[::97, 2] = 0.05; s[::97, 3:7] = [0.7071, 0, 0, 0.7071]
+            a.set_state(s); b.set_state(s)
+        obs, rew, done, infos = a.step(act)
+        ob, rb, db, tb = (x.cpu().numpy() for x in b.step_tensor(torch.as_tensor(act, device=b.device)))
+        assert np.array_equal(obs, ob) and np.array_equal(rew, rb) and np.array_equal(done, db.astype(bool))
+        term = b.get_info("terminal_obs").cpu().numpy()
+        for i in np.flatnonzero(done):
+            assert np.array_equal(infos[i]["terminal_observation"], term[i]) and infos[i]["TimeLimit.truncated"] == bool(tb[i])
+        assert all(not infos[i] for i in np.flatnonzero(~done))
+        if t in (10, 25):
+            assert done.all()
+        if prev is not None:                  # the views of the step before are still that step's results
+            assert np.array_equal(prev[0], prev[1])
+        prev = (obs, obs.copy())
+    a.close(); b.close()
