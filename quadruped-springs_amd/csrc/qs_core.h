@@ -85,7 +85,22 @@ template <class V> struct V3 { V x, y, z; };
 template <class V> QS_FN V3<V> mk3(V x, V y, V z) { V3<V> r; r.x = x; r.y = y; r.z = z; return r; }
 template <class V> QS_FN V3<V> operator+(V3<V> a, V3<V> b) { return mk3<V>(a.x + b.x, a.y + b.y, a.z + b.z); }
 template <class V> QS_FN V3<V> operator-(V3<V> a, V3<V> b) { return mk3<V>(a.x - b.x, a.y - b.y, a.z - b.z); }
-template <class V> QS_FN V3<V> operator*(V3<V> a, V s) { return mk3<V>(a.x * s, a.y * s, a.z * s); }
+// a * s is kept as the pair (a, s) until it is used: `p + a * s`, `p - a * s`, `a * s + b * t` then are ONE expression per component
+// and the front end contracts each into an FMA (-ffp-contract=on fuses within an expression only; through two operator functions the
+// product and the sum were a v_mul and a v_add -- 88 of them per substep).  Anywhere else the pair converts to the plain product.
+template <class V> struct V3s {
+    V3<V> a; V s;
+    QS_FN operator V3<V>() const { return mk3<V>(a.x * s, a.y * s, a.z * s); }
+    QS_FN V3<V> v() const { return mk3<V>(a.x * s, a.y * s, a.z * s); }
+};
+template <class V> QS_FN V3s<V> operator*(V3<V> a, V s) { V3s<V> r; r.a = a; r.s = s; return r; }
+template <class V> QS_FN V3s<V> operator*(V3s<V> a, V t) { V3s<V> r; r.a = a.v(); r.s = t; return r; }
+template <class V> QS_FN V3<V> operator+(V3<V> p, V3s<V> q) { return mk3<V>(p.x + q.a.x * q.s, p.y + q.a.y * q.s, p.z + q.a.z * q.s); }
+template <class V> QS_FN V3<V> operator+(V3s<V> q, V3<V> p) { return mk3<V>(q.a.x * q.s + p.x, q.a.y * q.s + p.y, q.a.z * q.s + p.z); }
+template <class V> QS_FN V3<V> operator-(V3<V> p, V3s<V> q) { return mk3<V>(p.x - q.a.x * q.s, p.y - q.a.y * q.s, p.z - q.a.z * q.s); }
+template <class V> QS_FN V3<V> operator-(V3s<V> q, V3<V> p) { return mk3<V>(q.a.x * q.s - p.x, q.a.y * q.s - p.y, q.a.z * q.s - p.z); }
+template <class V> QS_FN V3<V> operator+(V3s<V> p, V3s<V> q) { return mk3<V>(p.a.x * p.s + q.a.x * q.s, p.a.y * p.s + q.a.y * q.s, p.a.z * p.s + q.a.z * q.s); }
+template <class V> QS_FN V3<V> operator-(V3s<V> p, V3s<V> q) { return mk3<V>(p.a.x * p.s - q.a.x * q.s, p.a.y * p.s - q.a.y * q.s, p.a.z * p.s - q.a.z * q.s); }
 template <class V> QS_FN V dot(V3<V> a, V3<V> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 template <class V> QS_FN V3<V> cross(V3<V> a, V3<V> b) { return mk3<V>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 template <class V> struct S3 { V xx, xy, xz, yy, yz, zz; };
