@@ -473,6 +473,12 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         V mu_c = mu;
         for (int it = 0; it < cfg.solver_iters; it++) {
             V dvmax = zero;   // largest |row velocity change| of this sweep (replicated over the quad)
+            // (PAY) the impulse changes of the lane's OWN foot rows in this sweep.  The payload rows read J^T lambda's base part (py) at the
+            // start of a sweep only, the foot rows do not read it at all (their candidates move with Ap / Apc directly): so the foot rows'
+            // share is added once per sweep, each lane summing its own three rows and one quad_sum per component -- 48 instructions where
+            // 144 broadcast-multiply-adds (every row's delta times lane K's row vector, fetched by DPP) used to keep py current row by row.
+            V own_d[PAY ? NR : 1];
+            if (PAY) { _Pragma("unroll") for (int r = 0; r < NR; r++) own_d[PAY ? r : 0] = zero; }
             // Row (K, RR): every lane clamps the candidate of ITS row RR, lane K's result is the real one; one DPP-fused
             // subtract fetches it (delta = bcast_K(cand) - lam), the replicated impulse is advanced and the candidates of the
             // lane's own rows move by Ap * delta.
@@ -491,7 +497,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         lam_all[i_] = lam_all[i_] + dk;                                                                                \
         if (NR == 3 && QS_PGS_PACKED) { T::fma2(Ap[i_][0], Ap[i_][1], dk, res[0], res[1]); res[2] = res[2] + Ap[i_][2] * dk; }      \
         else { _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Ap[i_][c] * dk; }                     \
-        if (PAY) { _Pragma("unroll") for (int i = 0; i < 6; i++) py[PAY ? i : 0] = T::template fma_bcast<K>(rows[RR].w[i], dk, py[PAY ? i : 0]); } \
+        if (PAY) own_d[PAY ? (RR) : 0] = qsel(T::is_leg(K), dk, own_d[PAY ? (RR) : 0]);                                 \
         if (TRACK) dvmax = qmax(dvmax, qabs(dk * diag_all[TRACK ? i_ : 0]));                                           \
     }
             // Implicit cone friction (CONE; resolveConeFrictionConstraintRows): the two friction rows of foot K from the same
@@ -506,9 +512,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         lam_all[ia_] = lam_all[ia_] + da; lam_all[ib_] = lam_all[ib_] + db;                                             \
         /* two chained FMAs per candidate (not res + (a da + b db): one instruction and one level of the dependency chain less) */ \
         _Pragma("unroll") for (int c = 0; c < NR; c++) { res[c] = res[c] + Ap[ia_][c] * da; res[c] = res[c] + Ap[ib_][c] * db; } \
-        if (PAY) { _Pragma("unroll") for (int i = 0; i < 6; i++) {                                                     \
-            py[PAY ? i : 0] = T::template fma_bcast<K>(rows[1].w[i], da, py[PAY ? i : 0]);                             \
-            py[PAY ? i : 0] = T::template fma_bcast<K>(rows[2].w[i], db, py[PAY ? i : 0]); } }                         \
+        if (PAY) { own_d[PAY ? 1 : 0] = qsel(T::is_leg(K), da, own_d[PAY ? 1 : 0]); own_d[PAY ? 2 : 0] = qsel(T::is_leg(K), db, own_d[PAY ? 2 : 0]); } \
         if (TRACK) dvmax = T::absmax_mul2(dvmax, da, diag_all[TRACK ? ia_ : 0], db, diag_all[TRACK ? ib_ : 0]);           \
     }
             // payload row P (0..2: the pivot along world axis P, 3..5: the frames' relative rotation), replicated over the quad
@@ -549,6 +553,15 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             }
 #undef QS_PAIR_UPDATE
 #undef QS_ROW_UPDATE
+            if (PAY) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    V t = rows[0].w[i] * own_d[0];
+#pragma unroll
+                    for (int r = 1; r < NR; r++) t = t + rows[r].w[i] * own_d[PAY ? r : 0];
+                    py[PAY ? i : 0] = py[PAY ? i : 0] + T::quad_sum(t);
+                }
+            }
             if (TRACK) {
                 M conv = qle(dvmax, thr);
                 if (PAY) plive = qsel(conv, zero, plive);     // a frozen environment's payload deltas are dropped
