@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     # loops of k_reset and of the settle lanes, ... are separate inlined copies of the same templates, and for expressions with two
     # candidate products the back end's choice depended on the copy's surroundings: the copies agreed bit for bit under the implicit cone
     # and differed in the last bit under the friction pyramid and with payload="soft" (round 3, tools/diag/r03_lanes.py) -- the
-    # look-ahead resets and the independence of wave-mates need them to agree.  Costs 1.7 % on the headline (cross-statement fusions).
+    # look-ahead resets and the independence of wave-mates need them to agree.  Cost 1.7 % on the headline at first (cross-statement fusions); 0.8 % since p + a * s on vectors is one expression (V3s, qs_core.h).
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
            "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
            "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
