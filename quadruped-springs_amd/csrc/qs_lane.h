@@ -107,8 +107,10 @@ struct LaneDev {
     template <int K> static QS_DEV float bcast(float x) { return dpp<K * 0x55>(x); }
     // value of lane (l ^ K) of the quad, K = 1..3: quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
     template <int K> static QS_DEV float xorl(float x) { return dpp<K == 1 ? 0xB1 : (K == 2 ? 0x4E : 0x1B)>(x); }
-    // acc + bcast<K>(d) * a as ONE v_fmac_f32_dpp: the DPP move is given the accumulator as its (ignored, bound_ctrl) old
-    // value so that the three uses per row are not merged into one shared v_mov_dpp, which the DPP combiner could not fold
+    // acc + bcast<K>(d) * a.  (gfx950 can encode this as one v_fmac_f32_dpp, but hipcc 7.2's DPP combiner folds a v_mov_dpp into adds,
+    // subtracts and max only, not into the tied-accumulator FMA: this is a v_mov_b32_dpp and a v_fmac_f32, whatever `old` value the move is
+    // given -- checked in the ISA in round 3.  Writing the instruction in inline asm would need its own s_nop against the DPP read hazard,
+    // which the hazard recognizer does not see inside asm.  The common-path solver therefore avoids per-row broadcast FMAs: qs_core.h, own_d.)
     template <int K> static QS_DEV float fma_bcast(float d, float a, float acc) {
         float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, d), K * 0x55, 0xF, 0xF, true));
         return fmaf(b, a, acc);

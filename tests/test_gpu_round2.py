@@ -596,3 +596,16 @@ def test_host_path_terminal_observations_and_views(torch_cuda, mode, monkeypatch
             assert np.array_equal(prev[0], prev[1])
         prev = (obs, obs.copy())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("cmd", [["examples/rollout.py", "--envs", "256", "--steps", "60"],
+                                 ["examples/rollout.py", "--envs", "256", "--steps", "60", "--device-policy", "--wrapper", "LANDING"],
+                                 ["examples/imitation.py", "--envs", "128", "--steps", "40"],
+                                 ["examples/cpg_gait.py", "--envs", "64", "--seconds", "0.5"]])
+def test_examples_run(torch_cuda, cmd):
+    """The example programs (the reference's load_model.py loop, the imitation smoke test, the CPG driver) run to the end on the GPU."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, cmd[0])] + cmd[1:], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
