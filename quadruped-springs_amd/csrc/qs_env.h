@@ -635,9 +635,12 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
                 for (int j = 0; j < 3; j++) { V e = T::ld_leg(a, j, 3) - act_last[12 + j]; n2 = n2 + e * e; }
                 n2 = T::quad_sum(n2);
             } else {
+                V av[12];   // (a row is d + 38 floats: entries 0..11 exist for every d; all loads go out together, not one trip to memory per term)
+#pragma unroll
+                for (int k = 0; k < 12; k++) av[k] = T::ld(a, k);
 #pragma unroll
                 for (int k = 0; k < 12; k++)
-                    if (k < d) { V e = T::ld(a, k) - act_last[k]; n2 = n2 + e * e; }
+                    if (k < d) { V e = av[k] - act_last[k]; n2 = n2 + e * e; }
             }
             reward = qexp(qsqrt(n2) * (-0.35f)) / (V((float)demo_len) - start);
             cnt = cnt + 1.0f;

@@ -33,50 +33,95 @@ __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) {
     return QS_HOT;
 }
 // `stride`: floats between two records in LDS (QS_REC_END, or QS_INFO_END in the step kernels of handles without the payload block's state)
+//
+// All moves are BATCHED: every round's load is issued before the first result is used (global -> registers -> LDS on the way in, LDS ->
+// registers -> global on the way out).  Written as a rolled loop each round was `global_load_dwordx4; s_waitcnt vmcnt(0); ds_write_b128`:
+// eleven trips to memory one after the other, 5.7 k cycles = 2.3 us at the entry of every launch whatever N (256 environments as well as
+// 8192: a latency chain, not a bandwidth burst -- tools/phase_profile.py, profiles/r03_e_phase_cycles.md); batched it is one trip.
+// PER > 0: float4s per record known at compile time (the index split is a multiply-shift and the rounds need no predicate when they divide).
+template <int PER> __device__ __forceinline__ void tile_load_rounds(float4* __restrict__ dst, const float4* __restrict__ src, int nenv, int stride4, int per_rt) {
+    constexpr int MAX_PER = QS_REC_END / 4;
+    constexpr int ROUNDS = PER > 0 ? (QS_ENVS_PER_WAVE * PER + QS_WAVE - 1) / QS_WAVE : (QS_ENVS_PER_WAVE * MAX_PER + QS_WAVE - 1) / QS_WAVE;
+    const int per = PER > 0 ? PER : per_rt, total = QS_ENVS_PER_WAVE * per;
+    const unsigned inv = ((1u << 20) + (unsigned)per - 1u) / (unsigned)per;      // i / per = (i * inv) >> 20, exact for i * per < 2^20
+    float4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = (int)threadIdx.x + r * QS_WAVE;
+        // (every round loads -- beyond the range, the tile's first float4 again -- and only the LDS write is predicated: an array element
+        // assigned under a condition would send the whole array to scratch)
+        const bool in = (PER > 0 && (QS_ENVS_PER_WAVE * PER) % QS_WAVE == 0) || i < total;
+        const int e = PER > 0 ? i / PER : (int)(((unsigned)i * inv) >> 20), o = i - e * per;
+        v[r] = src[in ? (e < nenv ? e : 0) * (QS_REC / 4) + o : 0];   /* tail quads replay the tile's first record (never stored) */
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = (int)threadIdx.x + r * QS_WAVE;
+        if ((PER > 0 && (QS_ENVS_PER_WAVE * PER) % QS_WAVE == 0) || i < total) {
+            const int e = PER > 0 ? i / PER : (int)(((unsigned)i * inv) >> 20), o = i - e * per;
+            dst[e * stride4 + o] = v[r];
+        }
+    }
+}
 __device__ __forceinline__ void tile_load(float* lds, const float* __restrict__ g, int first_env, int n_envs, int extent, int stride = QS_REC_END) {
-    // Only the hot block [0, QS_HOT) of each record is fetched (the info block behind it is written, never read back, by a step).
-    // (the rounds pipeline as written; the ~6 k cycles this takes at kernel entry are the burst of all waves fetching their
-    // records at once -- ~9 MB per launch at ~3 TB/s -- not a per-load latency chain: holding all rounds in registers first
-    // was measured slower)
+    // Only the leading range [0, extent) of each record is fetched (QS_HOT by default: the info block behind it is written, never read
+    // back, by a step).
     const float4* src = reinterpret_cast<const float4*>(g + (size_t)first_env * QS_REC);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
-    // (the usual extent as a constant: the index split is a multiply-shift instead of a division by a runtime value)
-#define QS_TILE_LOAD_LOOP(PER)                                                                                         \
-    for (int i = threadIdx.x; i < QS_ENVS_PER_WAVE * (PER); i += QS_WAVE) {                                            \
-        const int e = i / (PER), o = i - e * (PER);                                                                    \
-        dst[e * (stride / 4) + o] = src[(e < nenv ? e : 0) * (QS_REC / 4) + o];  /* tail quads replay the tile's first record (never stored) */ \
+    if (extent == QS_HOT) tile_load_rounds<QS_HOT / 4>(dst, src, nenv, stride / 4, 0);
+    else if (extent == QS_SETTLE_END) tile_load_rounds<QS_SETTLE_END / 4>(dst, src, nenv, stride / 4, 0);
+    else tile_load_rounds<0>(dst, src, nenv, stride / 4, extent / 4);
+}
+template <int PER> __device__ __forceinline__ void tile_store_rounds(float4* __restrict__ dst, const float4* __restrict__ src, int nenv, int stride4, int b4, int per_rt) {
+    constexpr int MAX_PER = QS_REC_END / 4;
+    constexpr int ROUNDS = PER > 0 ? (QS_ENVS_PER_WAVE * PER + QS_WAVE - 1) / QS_WAVE : (QS_ENVS_PER_WAVE * MAX_PER + QS_WAVE - 1) / QS_WAVE;
+    const int per = PER > 0 ? PER : per_rt, total = nenv * per;
+    const unsigned inv = ((1u << 20) + (unsigned)per - 1u) / (unsigned)per;
+    float4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = (int)threadIdx.x + r * QS_WAVE;
+        const int e = PER > 0 ? i / PER : (int)(((unsigned)i * inv) >> 20), o = i - e * per + b4;
+        v[r] = src[i < total ? e * stride4 + o : 0];
     }
-    if (extent == QS_HOT) { QS_TILE_LOAD_LOOP(QS_HOT / 4) }
-    else { const int per = extent / 4; QS_TILE_LOAD_LOOP(per) }
-#undef QS_TILE_LOAD_LOOP
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = (int)threadIdx.x + r * QS_WAVE;
+        if (i < total) { const int e = PER > 0 ? i / PER : (int)(((unsigned)i * inv) >> 20), o = i - e * per + b4; dst[e * (QS_REC / 4) + o] = v[r]; }
+    }
 }
 __device__ __forceinline__ void tile_store(const float* lds, float* __restrict__ g, int first_env, int n_envs, int begin, int end, int stride = QS_REC_END) {
     float4* dst = reinterpret_cast<float4*>(g + (size_t)first_env * QS_REC);
     const float4* src = reinterpret_cast<const float4*>(lds);
-    const int b4 = begin / 4;
     const int nenv = min(QS_ENVS_PER_WAVE, n_envs - first_env);
-#define QS_TILE_STORE_LOOP(PER)                                                                                        \
-    for (int i = threadIdx.x; i < nenv * (PER); i += QS_WAVE) {                                                        \
-        const int e = i / (PER), o = i - e * (PER) + b4;                                                               \
-        dst[e * (QS_REC / 4) + o] = src[e * (stride / 4) + o];                                                         \
-    }
-    if (begin == QS_RW_BEGIN && end == QS_HOT) { QS_TILE_STORE_LOOP((QS_HOT - QS_RW_BEGIN) / 4) }
-    else { const int per = (end - begin) / 4; QS_TILE_STORE_LOOP(per) }
-#undef QS_TILE_STORE_LOOP
+    if (begin == QS_RW_BEGIN && end == QS_HOT) tile_store_rounds<(QS_HOT - QS_RW_BEGIN) / 4>(dst, src, nenv, stride / 4, QS_RW_BEGIN / 4, 0);
+    else if (begin == QS_RW_BEGIN && end == QS_SETTLE_END) tile_store_rounds<(QS_SETTLE_END - QS_RW_BEGIN) / 4>(dst, src, nenv, stride / 4, QS_RW_BEGIN / 4, 0);
+    else tile_store_rounds<0>(dst, src, nenv, stride / 4, begin / 4, (end - begin) / 4);
 }
 
 // the observation rows of the tile (LDS, QS_MAX_OBS apart) to the caller's rows ([N, od], or [N, od + 2] in the fused layout) and the
 // handle's own copy.  i / od by multiply-shift: exact for i < 16 * 64, od <= 64 with inv = ceil(2^16 / od) (one division per wave
-// instead of two per element)
+// instead of two per element).  Batched like the tile moves: the LDS reads of all rounds first, then the stores.
 __device__ __forceinline__ void obs_store(const float* s_obs, int nrow, int od, int first, float* __restrict__ obs_out, bool fused, float* __restrict__ obs_keep) {
     const unsigned inv = (65536u + (unsigned)od - 1u) / (unsigned)od;
-    const int row = fused ? od + 2 : od;
-    for (int i = threadIdx.x; i < nrow * od; i += QS_WAVE) {
+    const int row = fused ? od + 2 : od, total = nrow * od;
+    constexpr int ROUNDS = QS_ENVS_PER_WAVE * QS_MAX_OBS / QS_WAVE;
+    float v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = (int)threadIdx.x + r * QS_WAVE;
         const int e = (int)(((unsigned)i * inv) >> 16), o = i - e * od;
-        const float v = s_obs[e * QS_MAX_OBS + o];
-        obs_out[(size_t)(first + e) * row + o] = v;
-        obs_keep[(size_t)first * od + i] = v;
+        v[r] = s_obs[i < total ? e * QS_MAX_OBS + o : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = (int)threadIdx.x + r * QS_WAVE;
+        if (i < total) {
+            const int e = (int)(((unsigned)i * inv) >> 16), o = i - e * od;
+            obs_out[(size_t)(first + e) * row + o] = v[r];
+            obs_keep[(size_t)first * od + i] = v[r];
+        }
     }
 }
 
@@ -110,14 +155,45 @@ struct TermTail { float* rows; int cap, parity; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
        CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_N = 10 + QS_COHORTS };
 
-// settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines)
-__device__ __forceinline__ void copy_settled(float* rec, const float* src, bool block) {
+// settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines), and the slot's tag.
+// Every load is issued before the first value is used: as four rolled loops (`rec[i] = src[i]`) the copy was a load, a wait and an LDS write
+// per element -- about twenty trips to memory, one after the other, on the path of the wave that every launch waits for (round 3: found in
+// the ISA; the launch got 2 us shorter).
+__device__ __forceinline__ float copy_settled(float* rec, const float* __restrict__ src, bool block) {
+    static_assert(R_PARAMS == 0 && R_PARAMS + QS_PARAM_DIM == R_POS, "parameters and rigid-body state are one range");
     const int lane = threadIdx.x & 3;
-    if (block) for (int i = R_BLOCK + lane; i < R_BLOCK + QS_BLOCK_DIM; i += 4) rec[i] = src[i];   // the payload block settled with the robot
-    for (int i = R_POS + lane; i < R_WARM + 4; i += 4) rec[i] = src[i];                  // rigid-body state + warm start
-    for (int i = R_PARAMS + lane; i < R_PARAMS + QS_PARAM_DIM; i += 4) rec[i] = src[i];  // params
-    for (int i = R_FOOT_FORCE + lane; i < R_TAU_SPRING + 12; i += 4) rec[i] = src[i];    // contact results, torques
-    if (lane == 0) rec[R_N_INVALID] = src[R_N_INVALID];
+    constexpr int END_A = R_WARM + 4, NA = (END_A + 3) / 4;                   // [0, 65): parameters, rigid-body state, warm start
+    constexpr int NB = (R_TAU_SPRING + 12 - R_FOOT_FORCE) / 4;               // [211, 243): contact results, torques
+    constexpr int NC = QS_BLOCK_DIM / 4;                                      // the payload block settled with the robot
+    static_assert((R_TAU_SPRING + 12 - R_FOOT_FORCE) % 4 == 0 && QS_BLOCK_DIM % 4 == 0, "whole rounds");
+    float a[NA], b[NB], c[NC];
+#pragma unroll
+    for (int k = 0; k < NA; k++) { const int i = lane + 4 * k; a[k] = src[i < END_A ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < NB; k++) b[k] = src[R_FOOT_FORCE + lane + 4 * k];
+    const float ninv = src[R_N_INVALID], tag = src[R_EPISODE];
+    if (block) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) c[k] = src[R_BLOCK + lane + 4 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < NA; k++) { const int i = lane + 4 * k; if (i < END_A) rec[i] = a[k]; }
+#pragma unroll
+    for (int k = 0; k < NB; k++) rec[R_FOOT_FORCE + lane + 4 * k] = b[k];
+    if (lane == 0) rec[R_N_INVALID] = ninv;
+    if (block) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) rec[R_BLOCK + lane + 4 * k] = c[k];
+    }
+    return tag;
+}
+// rows of at most QS_MAX_OBS floats from LDS to global memory by the four lanes of a quad, the LDS reads of all rounds first
+__device__ __forceinline__ void quad_row_store(float* __restrict__ dst, const float* row, int n) {
+    float v[QS_MAX_OBS / 4];
+#pragma unroll
+    for (int k = 0; k < QS_MAX_OBS / 4; k++) { const int i = (int)(threadIdx.x & 3) + 4 * k; v[k] = row[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < QS_MAX_OBS / 4; k++) { const int i = (int)(threadIdx.x & 3) + 4 * k; if (i < n) dst[i] = v[k]; }
 }
 // A reset of `env` to episode X (called by the four lanes of its quad): copies the slot of that episode into the record -- all of its loads
 // go out together with the one of the slot's tag, ONE trip to memory on the path of a wave that every launch waits for -- and says
@@ -126,8 +202,7 @@ __device__ __forceinline__ void copy_settled(float* rec, const float* src, bool 
 __device__ __forceinline__ bool lookahead_take(const LookAhead& la, unsigned long long* __restrict__ ctl, float* rec, int env, int X, bool block, bool count = true) {
     if (la.K == 0) return false;
     const float* slot = la.slots + ((size_t)env * la.K + (size_t)(X % la.K)) * QS_REC;
-    const float tag = slot[R_EPISODE];
-    copy_settled(rec, slot, block);
+    const float tag = copy_settled(rec, slot, block);
     const bool ready = qs::f2i(tag) == X;
     if ((threadIdx.x & 3) == 0) {
         la.cur[env] = X;
@@ -278,7 +353,7 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
             LaneDev::sync();
             bool ahead = false;   // this environment's settled reset state was ready
             if (do_reset) {  // keep the terminal observation (SB3: infos[i]["terminal_observation"])
-                for (int i = threadIdx.x & 3; i < od; i += 4) term_obs[(size_t)env * od + i] = ob[i];
+                quad_row_store(term_obs + (size_t)env * od, ob, od);
                 if ((threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_RESETS], 1ull);
                 if (tail.rows) {   // host path: also as a row of the compact list
                     int at = 0;
@@ -287,7 +362,7 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
                     if (at < tail.cap) {
                         float* row = tail.rows + (size_t)at * (od + 1);
                         if ((threadIdx.x & 3) == 0) row[0] = qs::i2f(env);
-                        for (int i = threadIdx.x & 3; i < od; i += 4) row[1 + i] = ob[i];
+                        quad_row_store(row + 1, ob, od);
                     }
                 }
                 ahead = lookahead_take(la, stats, rec, env, qs::f2i(rec[R_EPISODE]) + 1, cfg.payload_soft != 0);

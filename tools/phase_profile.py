@@ -14,10 +14,11 @@ from qs_amd.vec_env import QuadrupedVecEnv
 
 NAMES = {1: "base rotation, velocities", 2: "leg kinematics", 3: "link inertias", 4: "RNEA bias", 5: "CRBA (B, D, K)", 6: "Schur + Cholesky",
          7: "accelerations, v*", 8: "collision", 9: "contact rows + Delassus", 10: "PGS sweeps", 11: "delta v", 12: "integrate positions"}
-env = QuadrupedVecEnv(num_envs=8192, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+env = QuadrupedVecEnv(num_envs=N, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                       enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1)
 env.reset_tensor()
-a = torch.rand((16, 8192, 6), device="cuda") * 2 - 1
+a = torch.rand((16, N, 6), device="cuda") * 2 - 1
 for i in range(20):
     env.step_tensor(a[i % 16])
 out = (C.c_uint64 * 48)()
