@@ -39,6 +39,10 @@ __device__ __forceinline__ int tile_extent(const qs_config& cfg, bool store) {
 // eleven trips to memory one after the other, 5.7 k cycles = 2.3 us at the entry of every launch whatever N (256 environments as well as
 // 8192: a latency chain, not a bandwidth burst -- tools/phase_profile.py, profiles/r03_e_phase_cycles.md); batched it is one trip.
 // PER > 0: float4s per record known at compile time (the index split is a multiply-shift and the rounds need no predicate when they divide).
+// (keeps a batch of loaded values in front of the predicated stores that consume them: without a use of its own the compiler sinks each
+// load into its store's branch, one memory trip per round again)
+__device__ __forceinline__ void keep_loaded(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+__device__ __forceinline__ void keep_loaded(float v) { asm volatile("" ::"v"(v)); }
 template <int PER> __device__ __forceinline__ void tile_load_rounds(float4* __restrict__ dst, const float4* __restrict__ src, int nenv, int stride4, int per_rt) {
     constexpr int MAX_PER = QS_REC_END / 4;
     constexpr int ROUNDS = PER > 0 ? (QS_ENVS_PER_WAVE * PER + QS_WAVE - 1) / QS_WAVE : (QS_ENVS_PER_WAVE * MAX_PER + QS_WAVE - 1) / QS_WAVE;
@@ -53,6 +57,10 @@ template <int PER> __device__ __forceinline__ void tile_load_rounds(float4* __re
         const bool in = (PER > 0 && (QS_ENVS_PER_WAVE * PER) % QS_WAVE == 0) || i < total;
         const int e = PER > 0 ? i / PER : (int)(((unsigned)i * inv) >> 20), o = i - e * per;
         v[r] = src[in ? (e < nenv ? e : 0) * (QS_REC / 4) + o : 0];   /* tail quads replay the tile's first record (never stored) */
+    }
+    if (!(PER > 0 && (QS_ENVS_PER_WAVE * PER) % QS_WAVE == 0)) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) keep_loaded(v[r]);
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
@@ -86,6 +94,8 @@ template <int PER> __device__ __forceinline__ void tile_store_rounds(float4* __r
         v[r] = src[i < total ? e * stride4 + o : 0];
     }
 #pragma unroll
+    for (int r = 0; r < ROUNDS; r++) keep_loaded(v[r]);
+#pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
         const int i = (int)threadIdx.x + r * QS_WAVE;
         if (i < total) { const int e = PER > 0 ? i / PER : (int)(((unsigned)i * inv) >> 20), o = i - e * per + b4; dst[e * (QS_REC / 4) + o] = v[r]; }
@@ -114,6 +124,8 @@ __device__ __forceinline__ void obs_store(const float* s_obs, int nrow, int od, 
         const int e = (int)(((unsigned)i * inv) >> 16), o = i - e * od;
         v[r] = s_obs[i < total ? e * QS_MAX_OBS + o : 0];
     }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) keep_loaded(v[r]);
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
         const int i = (int)threadIdx.x + r * QS_WAVE;
@@ -192,6 +204,8 @@ __device__ __forceinline__ void quad_row_store(float* __restrict__ dst, const fl
     float v[QS_MAX_OBS / 4];
 #pragma unroll
     for (int k = 0; k < QS_MAX_OBS / 4; k++) { const int i = (int)(threadIdx.x & 3) + 4 * k; v[k] = row[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < QS_MAX_OBS / 4; k++) keep_loaded(v[k]);
 #pragma unroll
     for (int k = 0; k < QS_MAX_OBS / 4; k++) { const int i = (int)(threadIdx.x & 3) + 4 * k; if (i < n) dst[i] = v[k]; }
 }
