@@ -18,6 +18,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 env = QuadrupedVecEnv(num_envs=N, auto_reset=True, reset_lookahead=8, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                       enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1)
 env.reset_tensor()
+if os.environ.get("QS_PP_LANES") == "0":
+    env.settle_lanes(False)      # (round 3: with the lanes, substeps 0-5 of a step take 16.7 k cycles and substep 6 -- when the settle waves leave -- 19.1 k; without them all ten take 17.0 k; the sums agree)
 a = torch.rand((16, N, 6), device="cuda") * 2 - 1
 for i in range(20):
     env.step_tensor(a[i % 16])
