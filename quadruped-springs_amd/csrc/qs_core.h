@@ -448,24 +448,47 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         QS_PHASE_G(9)
         const V big = V(1e10f), zero = V(0.0f);
         // payload rows (PAY): state of the velocity-space part
-        V py[PAY ? 6 : 1], plam[PAY ? 6 : 1], Apc[PAY ? 6 : 1][NR];
-        V3v pja[PAY ? 3 : 1], dwb = mk3<V>(zero, zero, zero), dvb = mk3<V>(zero, zero, zero);
+        // prel[P]: the velocity along payload row P under the impulses so far (what the row's clamp looks at); a delta of row Q moves it by
+        // App[Q][P] = pw_Q . pw_P + the block's own response (1 / mass on the pivot rows, 1 / inertia on the rotation rows and through the
+        // lever rB on the pivot rows), a delta of foot row c of this lane by Cpc[P][c] = w_c . pw_P; Apc = -dinv_c Cpc moves the foot
+        // candidates.  J^T lambda's base part and the block's velocity change are put together from the impulses after the sweeps.
+        V prel[PAY ? 6 : 1], plam[PAY ? 6 : 1], Apc[PAY ? 6 : 1][NR], Cpc[PAY ? 6 : 1][NR], App[PAY ? 6 : 1][PAY ? 6 : 1];
+        V3v pja[PAY ? 3 : 1];
         V plive = V(1.0f);
         const V pbound = V(500.0f * (float)cfg.dt);
         if (PAY) {
             const PayRows& q = *pq;
+            V py0[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { py[PAY ? i : 0] = T::quad_sum(rows[0].w[i] * (s.warm * cfg.warmstart * rows[0].act)); plam[PAY ? i : 0] = zero; }
+            for (int i = 0; i < 6; i++) { py0[i] = T::quad_sum(rows[0].w[i] * (s.warm * cfg.warmstart * rows[0].act)); plam[PAY ? i : 0] = zero; }
 #pragma unroll
-            for (int k = 0; k < 6; k++)
+            for (int k = 0; k < 6; k++) {
 #pragma unroll
                 for (int c = 0; c < NR; c++) {
                     V t = rows[c].w[0] * q.w[k][0];
 #pragma unroll
                     for (int i = 1; i < 6; i++) t = t + rows[c].w[i] * q.w[k][i];
+                    Cpc[PAY ? k : 0][c] = t;
                     Apc[PAY ? k : 0][c] = -(t * rows[c].dinv);
                 }
+                V r0 = q.w[k][0] * py0[0];
+#pragma unroll
+                for (int i = 1; i < 6; i++) r0 = r0 + q.w[k][i] * py0[i];
+                prel[PAY ? k : 0] = r0;                                   // the warm-started normal impulses' share
+            }
             pja[0] = mk3<V>(zero, -q.rB.z, q.rB.y); pja[PAY ? 1 : 0] = mk3<V>(q.rB.z, zero, -q.rB.x); pja[PAY ? 2 : 0] = mk3<V>(-q.rB.y, q.rB.x, zero);   // -(rB x e_k)
+#pragma unroll
+            for (int P = 0; P < 6; P++)
+#pragma unroll
+                for (int Q = P; Q < 6; Q++) {
+                    V t = q.w[P][0] * q.w[Q][0];
+#pragma unroll
+                    for (int i = 1; i < 6; i++) t = t + q.w[P][i] * q.w[Q][i];
+                    if (Q < 3) { t = t + q.mI * dot(pja[PAY ? P : 0], pja[PAY ? Q : 0]); if (P == Q) t = t + q.mM; }             // pivot x pivot
+                    else if (P < 3) { const V3v jp = pja[PAY ? P : 0]; t = t - q.mI * (Q == 3 ? jp.x : Q == 4 ? jp.y : jp.z); }   // pivot x rotation
+                    else if (P == Q) t = t + q.mI;                                                                              // rotation x rotation
+                    App[PAY ? P : 0][PAY ? Q : 0] = t; App[PAY ? Q : 0][PAY ? P : 0] = t;
+                }
         }
         const V thr = V(sqrtf(cfg.solver_residual_threshold));
         // (the implicit cone's projection is not idempotent in floating point: once an environment is frozen its friction bound is lifted,
@@ -519,26 +542,14 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
 #define QS_PAYROW(P)                                                                                                   \
     {                                                                                                                  \
         const PayRows& q_ = *pq;                                                                                        \
-        V rel = (P) < 3 ? dot(pja[PAY ? (P) % 3 : 0], dwb) - ((P) == 0 ? dvb.x : (P) == 1 ? dvb.y : dvb.z)             \
-                        : -((P) == 3 ? dwb.x : (P) == 4 ? dwb.y : dwb.z);                                              \
-        _Pragma("unroll") for (int i = 0; i < 6; i++) rel = rel + q_.w[P][i] * py[PAY ? i : 0];                        \
-        V cand = qmin(qmax(plam[PAY ? (P) : 0] + (q_.rhs[P] - q_.dinv[P] * rel), -pbound), pbound);                    \
-        V dl = (cand - plam[PAY ? (P) : 0]) * (plive * q_.act);                                                        \
+        V cand = clampv<V>(plam[PAY ? (P) : 0] + (q_.rhs[P] - q_.dinv[P] * prel[PAY ? (P) : 0]), -pbound, pbound);     \
+        V dl = (cand - plam[PAY ? (P) : 0]) * pla;                                                                     \
         plam[PAY ? (P) : 0] = plam[PAY ? (P) : 0] + dl;                                                                \
-        _Pragma("unroll") for (int i = 0; i < 6; i++) py[PAY ? i : 0] = py[PAY ? i : 0] + q_.w[P][i] * dl;             \
+        _Pragma("unroll") for (int k = 0; k < 6; k++) prel[PAY ? k : 0] = prel[PAY ? k : 0] + App[PAY ? (P) : 0][PAY ? k : 0] * dl; \
         _Pragma("unroll") for (int c = 0; c < NR; c++) res[c] = res[c] + Apc[PAY ? (P) : 0][c] * dl;                   \
-        if ((P) < 3) {                                                                                                 \
-            dwb = dwb + pja[PAY ? (P) % 3 : 0] * (q_.mI * dl);                                                         \
-            if ((P) == 0) dvb.x = dvb.x - q_.mM * dl;                                                                  \
-            if ((P) == 1) dvb.y = dvb.y - q_.mM * dl;                                                                  \
-            if ((P) == 2) dvb.z = dvb.z - q_.mM * dl;                                                                  \
-        } else {                                                                                                       \
-            if ((P) == 3) dwb.x = dwb.x - q_.mI * dl;                                                                  \
-            if ((P) == 4) dwb.y = dwb.y - q_.mI * dl;                                                                  \
-            if ((P) == 5) dwb.z = dwb.z - q_.mI * dl;                                                                  \
-        }                                                                                                              \
         if (TRACK) dvmax = qmax(dvmax, qabs(dl * q_.diag[P]));                                                         \
     }
+            const V pla = PAY ? plive * pq->act : zero;   // (a frozen environment's payload deltas are dropped)
             if (PAY) {
                 if (it & 1) { QS_PAYROW(0) QS_PAYROW(1) QS_PAYROW(2) QS_PAYROW(3) QS_PAYROW(4) QS_PAYROW(5) }
                 else { QS_PAYROW(5) QS_PAYROW(4) QS_PAYROW(3) QS_PAYROW(2) QS_PAYROW(1) QS_PAYROW(0) }
@@ -555,11 +566,11 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
 #undef QS_ROW_UPDATE
             if (PAY) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    V t = rows[0].w[i] * own_d[0];
+                for (int k = 0; k < 6; k++) {
+                    V t = Cpc[PAY ? k : 0][0] * own_d[0];
 #pragma unroll
-                    for (int r = 1; r < NR; r++) t = t + rows[r].w[i] * own_d[PAY ? r : 0];
-                    py[PAY ? i : 0] = py[PAY ? i : 0] + T::quad_sum(t);
+                    for (int r = 1; r < NR; r++) t = t + Cpc[PAY ? k : 0][r] * own_d[PAY ? r : 0];
+                    prel[PAY ? k : 0] = prel[PAY ? k : 0] + T::quad_sum(t);
                 }
             }
             if (TRACK) {
@@ -584,12 +595,25 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
 
         // delta v = H^-1 J^T lambda :  dv_b = L^-T sum_i w_i lam_i ;  dqd = sum_own u_r lam_r - (B K)^T dv_b
         V z[6];
-        if (PAY) {   // the base part of J^T lambda was kept up to date for the payload rows (foot rows and payload rows together)
+        if (PAY) {   // the base part of J^T lambda: the foot rows' as without the block, plus the payload rows'; the block's velocity change
+            const PayRows& q = *pq;
 #pragma unroll
-            for (int i = 0; i < 6; i++) z[i] = py[PAY ? i : 0];
+            for (int i = 0; i < 6; i++) {
+                V t = rows[0].w[i] * lam_own[0];
+#pragma unroll
+                for (int r = 1; r < NR; r++) t = t + rows[r].w[i] * lam_own[r];
+                V zp = q.w[0][i] * plam[0];
+#pragma unroll
+                for (int k = 1; k < 6; k++) zp = zp + q.w[k][i] * plam[PAY ? k : 0];
+                z[i] = T::quad_sum(t) + zp;
+            }
 #pragma unroll
             for (int k = 0; k < 6; k++) pq->lam[k] = plam[PAY ? k : 0];
-            pq->dw = dwb; pq->dv = dvb;
+            V3v dwb = pja[0] * (q.mI * plam[0]);
+            dwb = dwb + pja[PAY ? 1 : 0] * (q.mI * plam[PAY ? 1 : 0]);
+            dwb = dwb + pja[PAY ? 2 : 0] * (q.mI * plam[PAY ? 2 : 0]);
+            dwb = dwb - mk3<V>(plam[PAY ? 3 : 0], plam[PAY ? 4 : 0], plam[PAY ? 5 : 0]) * q.mI;
+            pq->dw = dwb; pq->dv = mk3<V>(-(q.mM * plam[0]), -(q.mM * plam[PAY ? 1 : 0]), -(q.mM * plam[PAY ? 2 : 0]));
         } else {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
