@@ -138,6 +138,11 @@ def run(cases, seed, verbose=True, fallen=False):
                 assert (dp <= 5e-5 + slack).all(), f"pose step {i}: " + worst(dp, 5e-5)
                 assert (dq <= 2e-4 + slack).all(), f"q step {i}: " + worst(dq, 2e-4)
                 dvel = np.abs(sv[:, 7:13] - so[:, 7:13])
+                if not (dvel <= 2e-2 + 10 * slack).all() and os.environ.get("QS_FUZZ_DUMP"):     # for tools/diag/r03_fuzz_case.py
+                    import pickle
+                    os.makedirs(os.environ["QS_FUZZ_DUMP"], exist_ok=True)
+                    with open(os.path.join(os.environ["QS_FUZZ_DUMP"], f"case{case}.pkl"), "wb") as f:
+                        pickle.dump(dict(kw=kw, n=n, state=s, action=a, env=int(np.argmax((dvel - 2e-2 - 10 * slack).max(axis=1)))), f)
                 assert (dvel <= 2e-2 + 10 * slack).all(), f"base velocity step {i}: " + worst(dvel, 2e-2)
                 if fallen:
                     continue
