@@ -123,7 +123,7 @@ def run(cases, seed, verbose=True, fallen=False):
                                    and (np.abs(sv[:, 7:13] - so[:, 7:13]) <= 2e-2 + 10 * slack).all()):
                     # a third yardstick before a flailing robot counts as a deviation: the float32 oracle itself from states 1e-6 away (stick / slip and
                     # joint-stop rows switch on rounding; the two precisions of the oracle can agree by luck where a third evaluation does not)
-                    for trial in range(4):
+                    for trial in range(12):
                         sp = s + 1e-6 * rng.standard_normal(s.shape) * np.maximum(np.abs(s), 1.0)
                         sp[:, 3:7] /= np.linalg.norm(sp[:, 3:7], axis=1, keepdims=True)
                         o64.set_state(sp.astype(np.float64)); o64.step(a)
