@@ -367,11 +367,11 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
     // sqrt(threshold) is frozen (its residuals are zeroed, so later sweeps leave it untouched) and the wave leaves the
     // loop when all of its 16 environments are frozen.  Without TRACK every sweep is executed.
     // PAY (cfg.payload_soft with every robot of interest on its feet): the six rows of the payload block's fixed constraint ride along with
-    // the twelve foot rows.  They stay in velocity space as in solve_with_limits (replicated over the quad: y = the base part of J^T lambda
-    // in the Cholesky factor's whitened coordinates, here kept up to date by six v_fmac_dpp per foot-row delta), swept where Bullet sorts
-    // them (in front of the normals; forwards on odd sweeps, backwards on even ones); a payload delta moves the lane's own foot candidates
-    // through the precomputed couplings Apc[k][c] = -dinv_c (w_c . pw_k).  Same rows, clamps and order as the many-rows solver, at a
-    // third of its instructions per sweep.
+    // the twelve foot rows, in impulse space like them (replicated over the quad: the rows' relative velocities prel[6], moved by a payload
+    // delta through the 6 x 6 block App and by the foot rows' deltas of a sweep, together, at its end), swept where Bullet sorts them (in
+    // front of the normals; forwards on odd sweeps, backwards on even ones); a payload delta moves the lane's own foot candidates through
+    // the precomputed couplings Apc[k][c] = -dinv_c (w_c . pw_k).  Same rows, clamps and order as the many-rows solver (which keeps them
+    // in velocity space), at a quarter of its instructions per sweep.
     template <int NR, bool TRACK, bool PAY = false> static QS_FN void solve_and_integrate(const qs_config& cfg, V mu, State& s, Out& o, const Row* rows,
                                                             const V* Lc, const V* Ld, const V (*BK)[6], const V* R, PayRows* pq = nullptr) {
         constexpr int NT = 4 * NR;
