@@ -329,7 +329,7 @@ def main():
         # (config.settle_work_ratio says how much of it this particular run did).
         # Untimed preparation: put the environments at evenly spread episode phases, as in the steady state of a training run
         # (they would otherwise all hit the 1000-step limit of gym_env.py:35 in the same step: one burst of N resets).
-        groups = 16
+        groups = 125    # (16 groups left a burst of several hundred time-limit resets every 62 steps: a 20-step timed region either held one or did not)
         ids = torch.arange(n, device=dev)
         for gidx in range(groups):
             env.reset_tensor((ids % groups == gidx).to(torch.uint8))
@@ -342,19 +342,27 @@ def main():
             local_step(acts[i % n_act])
         for i in range(args.warmup):
             step_fn(acts[i % n_act])
+        # the counters in front of the timed region: a stream-ordered snapshot into device memory behind the last warmup step, read after the
+        # region (the synchronising reads that stood here left the device idle long enough for the region's first launch to start ~100 us
+        # late, 5 us per step of a 20-step region)
+        snap0 = env.counters_snapshot()
         barrier()
-        c0 = {k: env.counter(k) for k in ("settle_substeps", "resets", "lookahead_served", "lookahead_settled", "reset_stalls", "limit_path_substeps",
-                                          "self_narrow_substeps")}
         # the step kernel's launches of the timed region between two HIP events on the kernel's own stream (qs_enable_timing: one event in
         # front of the first launch, one behind the last): per-launch duration for the roofline, measured over the timed region itself
         env.enable_timing(True)
         t0 = time.perf_counter()
         for i in range(args.steps):
             step_fn(acts[i % n_act])
+        t_loop = time.perf_counter()
         kernel_ms = env.last_step_kernel_ms()      # records the closing event here, in stream order, and waits for it
+        t_ev = time.perf_counter()
         barrier()
         elapsed = time.perf_counter() - t0
+        if os.environ.get("QS_BENCH_DEBUG"):
+            print(f"[debug] loop {1e6 * (t_loop - t0):.0f} us, event wait {1e6 * (t_ev - t_loop):.0f} us, barrier {1e6 * (elapsed - (t_ev - t0)):.0f} us, kernel_ms x K {1e3 * kernel_ms * args.steps:.0f} us", file=sys.stderr)
         env.enable_timing(False)
+        c0 = {k: int(v) for k, v in zip(("settle_substeps", "resets", "lookahead_served", "lookahead_settled", "limit_path_substeps", "self_narrow_substeps",
+                                         "reset_stalls"), snap0.cpu().tolist())}
         c1 = {k: env.counter(k) for k in c0}
         backlog = env.counter("lookahead_backlog") if args.reset_lookahead else 0
         local_elapsed = None

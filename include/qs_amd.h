@@ -233,6 +233,10 @@ enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset
        QS_COUNTER_RESET_STALLS = 6,         /* resets of a handle with reset_lookahead > 0 whose state was not ready: settled in place */
        QS_COUNTER_LOOKAHEAD_BACKLOG = 7     /* reset states the environments' look-ahead windows lack and no settle lane has taken yet */ };
 int qs_counter(qs_handle* h, int which, uint64_t* value);
+/* The counters 0 .. 6 as they stand at this point of the handle's stream, copied to `dev_out[8]` (DEVICE memory; entry 7 is left alone) by
+ * copies enqueued on the stream: nothing is waited for.  For a reader that wants the counters of a region without idling the device in
+ * front of it (bench.py: a synchronising read right before a short timed region made its first launch ~100 us late). */
+int qs_counters_async(qs_handle* h, uint64_t* dev_out);
 /* Average duration of the step-kernel launches of a BATCH of qs_step calls, from two HIP events on the handle's stream: one recorded in
  * front of the first step launched after qs_enable_timing(h, 1), one recorded by qs_last_step_kernel_ms, which waits for it, returns
  * elapsed milliseconds / launches since the first event and starts the next batch.  For bench.py's roofline leg: the figure covers the

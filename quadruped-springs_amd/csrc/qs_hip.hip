@@ -1033,6 +1033,19 @@ int qs_set_trace(qs_handle* h, int env, float* rows) {
     return 0;
 }
 
+int qs_counters_async(qs_handle* h, uint64_t* dev_out) {
+    if (!h || !dev_out) QS_FAIL(-1, "null argument");
+    QS_ON_DEVICE(h);
+    static_assert(CTL_SETTLE_SUBSTEPS == QS_COUNTER_SETTLE_SUBSTEPS && CTL_RESETS == QS_COUNTER_RESETS && CTL_SERVED == QS_COUNTER_LOOKAHEAD_SERVED &&
+                  CTL_SETTLED == QS_COUNTER_LOOKAHEAD_SETTLED && CTL_STALLS == QS_COUNTER_RESET_STALLS, "the handle's counters sit at their public indices");
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(dev_out);
+    QS_HIP(hipMemcpyAsync(out, h->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+    QS_HIP(hipMemcpyAsync(out + QS_COUNTER_RESET_STALLS, h->d_stats + CTL_STALLS, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+    QS_HIP(hipMemcpyFromSymbolAsync(out + QS_COUNTER_LIMIT_PATH_SUBSTEPS, HIP_SYMBOL(qs_rare_path_substeps), sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice, h->stream));
+    QS_HIP(hipMemcpyFromSymbolAsync(out + QS_COUNTER_SELF_NARROW_SUBSTEPS, HIP_SYMBOL(qs_self_narrow_substeps), sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
 int qs_counter(qs_handle* h, int which, uint64_t* value) {
     if (!h || !value) QS_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);

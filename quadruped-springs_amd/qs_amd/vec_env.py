@@ -171,6 +171,14 @@ class QuadrupedVecEnv(SB3VecEnv):
         _lib.check(self.lib.qs_counter(self.h, self.COUNTERS[which] if isinstance(which, str) else int(which), C.byref(v)))
         return int(v.value)
 
+    def counters_snapshot(self):
+        """The counters as they stand at this point of the stream, in a device tensor [8] (int64; index = COUNTERS, entry 7 unused) -- no
+        synchronisation: read it (.cpu()) whenever convenient."""
+        out = self.torch.zeros(8, dtype=self.torch.int64, device=self.device)
+        self._stream()
+        _lib.check(self.lib.qs_counters_async(self.h, self._ptr(out)))
+        return out
+
     def enable_timing(self, on=True):
         _lib.check(self.lib.qs_enable_timing(self.h, int(on)))
 
