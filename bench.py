@@ -354,12 +354,12 @@ def main():
         for i in range(args.steps):
             step_fn(acts[i % n_act])
         t_loop = time.perf_counter()
-        kernel_ms = env.last_step_kernel_ms()      # records the closing event here, in stream order, and waits for it
-        t_ev = time.perf_counter()
+        env.enable_timing(2)                        # the closing event, in stream order behind the last launch; waited for after the region
         barrier()
         elapsed = time.perf_counter() - t0
+        kernel_ms = env.last_step_kernel_ms()
         if os.environ.get("QS_BENCH_DEBUG"):
-            print(f"[debug] loop {1e6 * (t_loop - t0):.0f} us, event wait {1e6 * (t_ev - t_loop):.0f} us, barrier {1e6 * (elapsed - (t_ev - t0)):.0f} us, kernel_ms x K {1e3 * kernel_ms * args.steps:.0f} us", file=sys.stderr)
+            print(f"[debug] launching {1e6 * (t_loop - t0):.0f} us, until the barrier returned {1e6 * elapsed:.0f} us, kernel_ms x K {1e3 * kernel_ms * args.steps:.0f} us", file=sys.stderr)
         env.enable_timing(False)
         c0 = {k: int(v) for k, v in zip(("settle_substeps", "resets", "lookahead_served", "lookahead_settled", "limit_path_substeps", "self_narrow_substeps",
                                          "reset_stalls"), snap0.cpu().tolist())}

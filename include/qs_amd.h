@@ -241,7 +241,9 @@ int qs_counters_async(qs_handle* h, uint64_t* dev_out);
  * front of the first step launched after qs_enable_timing(h, 1), one recorded by qs_last_step_kernel_ms, which waits for it, returns
  * elapsed milliseconds / launches since the first event and starts the next batch.  For bench.py's roofline leg: the figure covers the
  * timed region itself and includes the gaps between back-to-back launches, so it can never be shorter than the kernel's own duration nor
- * longer than the wall time per step (a pair of events around every single 0.07-ms launch read 5 % high). */
+ * longer than the wall time per step (a pair of events around every single 0.07-ms launch read 5 % high).  qs_enable_timing(h, 2) closes
+ * the batch without waiting: the closing event is recorded on the stream there and qs_last_step_kernel_ms, whenever it is called, waits for
+ * that one (a caller that times the region on its own clock keeps the wait out of it). */
 int qs_enable_timing(qs_handle* h, int on);
 int qs_last_step_kernel_ms(qs_handle* h, float* ms);
 /* The settle lanes of a handle with cfg.reset_lookahead > 0 (on from qs_create).  While on, every qs_step launch carries extra

@@ -776,7 +776,18 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
 }
 
 int qs_set_stream(qs_handle* h, void* s) { if (!h) QS_FAIL(-1, "null handle"); h->stream = (hipStream_t)s; return 0; }
-int qs_enable_timing(qs_handle* h, int on) { if (!h) QS_FAIL(-1, "null handle"); h->timing = on ? 1 : 0; h->timed_launches = 0; return 0; }
+int qs_enable_timing(qs_handle* h, int on) {
+    if (!h) QS_FAIL(-1, "null handle");
+    if (on == 2) {   // close the batch: the closing event goes onto the stream now, qs_last_step_kernel_ms waits for it later
+        if (h->timing != 2 || h->timed_launches <= 0) QS_FAIL(-1, "no step has been launched since qs_enable_timing(h, 1)");
+        QS_ON_DEVICE(h);
+        QS_HIP(hipEventRecord(h->ev1, h->stream));
+        h->timing = 3;
+        return 0;
+    }
+    h->timing = on ? 1 : 0; h->timed_launches = 0;
+    return 0;
+}
 
 int qs_reset(qs_handle* h, const uint8_t* mask) {
     if (!h) QS_FAIL(-1, "null handle");
@@ -873,7 +884,7 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
         h->tick++;
     }
     if (h->timing == 1) { hipEventRecord(h->ev0, h->stream); h->timing = 2; }   // (after this step's publish / plan launches, if any)
-    if (h->timing) h->timed_launches++;
+    if (h->timing == 1 || h->timing == 2) h->timed_launches++;
     // more waves than SIMDs: the two-waves-per-SIMD build of the same body (see k_step_dense) instead of a second round of one-wave-per-
     // SIMD workgroups (N = 12288 with its settle lanes: 0.109 ms in two rounds)
     const bool dense = h->step_variant == 2 || (h->step_variant == 0 && (lanes.n_env_waves > h->n_simd || !lanes_fit));
@@ -1075,9 +1086,9 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
 
 int qs_last_step_kernel_ms(qs_handle* h, float* ms) {
     if (!h || !ms) QS_FAIL(-1, "null argument");
-    if (h->timing != 2 || h->timed_launches <= 0) QS_FAIL(-1, "no step has been launched since qs_enable_timing(h, 1)");
+    if ((h->timing != 2 && h->timing != 3) || h->timed_launches <= 0) QS_FAIL(-1, "no step has been launched since qs_enable_timing(h, 1)");
     QS_ON_DEVICE(h);
-    QS_HIP(hipEventRecord(h->ev1, h->stream));
+    if (h->timing == 2) QS_HIP(hipEventRecord(h->ev1, h->stream));     // (3: qs_enable_timing(h, 2) recorded it already)
     QS_HIP(hipEventSynchronize(h->ev1));
     float total = 0.0f;
     QS_HIP(hipEventElapsedTime(&total, h->ev0, h->ev1));

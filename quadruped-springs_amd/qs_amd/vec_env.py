@@ -180,6 +180,9 @@ class QuadrupedVecEnv(SB3VecEnv):
         return out
 
     def enable_timing(self, on=True):
+        """True / False: arm / disarm the batch timing of the step kernel; 2: close the batch now (the closing event goes onto the stream,
+        last_step_kernel_ms() waits for it whenever it is called)."""
+        self._stream()
         _lib.check(self.lib.qs_enable_timing(self.h, int(on)))
 
     def last_step_kernel_ms(self):
