@@ -267,20 +267,20 @@ template <> struct Rng<LaneEmu> {
 // CONE: friction model of the contact rows, a compile-time choice so that neither variant costs the other registers or a branch:
 // false = pyramid with Bullet's skip rule, true = implicit cone (qs_config::friction_cone; the kernels are built for both).
 // HOT: the build of the substep that holds the common path ONLY.  Where a wave would need one of the rare paths (a joint at its stop,
-// a non-foot link on the plane, the link-link tests of the self-collision rule) substep() gives up and returns true instead: the step
-// kernel then repeats the whole env step of that wave with the full build (HOT = false), whose rare code thus sits outside the hot
-// loop and costs it neither registers nor schedule (measured: inlined into the loop the rare code took 20 % off the headline).
-// CALLS (full build of the one-wave-per-SIMD kernel only): the many-rows solvers are real functions, so that their register needs stay out of
-// the allocation of the full build's own common path (a device function cannot be given a register budget, so the two-waves-per-SIMD
-// kernel inlines them).
+// a non-foot link on the plane, the link-link tests of the self-collision rule) substep() gives up, leaves the state as it found it and
+// returns true: the env step of that wave then goes on FROM THAT SUBSTEP in the full build (HOT = false; Env::step), whose rare code thus
+// sits behind the hot loop and costs it neither registers nor schedule (measured: inlined into the loop the rare code took 20 % off the
+// headline).  (Rounds 2-3 repeated the whole env step with the full build: a rare-path wave paid up to two steps' time.)
+// CALLS: unused since round 4 (rounds 2-3: the many-rows solvers as real functions in the one-wave-per-SIMD kernel).
 // SOFT (HOT builds): the common-path build ALSO holds the payload block's six rows (cfg.payload_soft), next to the twelve foot rows in
 // solve_and_integrate<.., PAY>; without it a common-path build gives up on every substep of such a handle and the full build does the work.
-template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool SOFT = false> struct Sim {
+// the values a substep works on: one set of types for every build of Sim (an env step may start in the common-path build and go on in
+// the full one, qs_env.h)
+template <class T> struct SimTypes {
     using V = typename T::V;
     using M = typename T::M;
     using V3v = V3<V>;
     using Spv = Sp<V>;
-
     struct State {          // registers carried through the substeps of one env step
         V3v pos; V qx, qy, qz, qw; V3v vlin, vang;  // replicated over the quad
         V q[3], qd[3];                              // own leg
@@ -300,6 +300,28 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
     struct Out {            // results of the last substep
         V tau_pd[3], tau_spring[3], foot_force, foot_contact, n_invalid;
     };
+    struct Row { V jq[3], u[3], w[6], rhs, dinv, act, diag; };
+    // the six rows of the payload block's fixed constraint (cfg.payload_soft, see integrate_rare)
+    struct PayRows {
+        V w[6][6], rhs[6], dinv[6], diag[6];   // base side (whitened), right-hand side x dinv, 1 / A_kk, A_kk
+        V3v rB; V mI, mM, act;                  // block centre -> pivot (world), 1 / inertia, 1 / mass, 1 while the block exists
+        V lam[6]; V3v dw, dv;                   // results: impulses, the block's velocity change (world)
+    };
+};
+
+#include "qs_rare.h"
+
+template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool SOFT = false> struct Sim : SimTypes<T> {
+    using V = typename T::V;
+    using M = typename T::M;
+    using V3v = V3<V>;
+    using Spv = Sp<V>;
+    using State = typename SimTypes<T>::State;
+    using Par = typename SimTypes<T>::Par;
+    using Model = typename SimTypes<T>::Model;
+    using Out = typename SimTypes<T>::Out;
+    using Row = typename SimTypes<T>::Row;
+    using PayRows = typename SimTypes<T>::PayRows;
 
     // per-env model from the randomizable masses (env_randomizer.py:56-83); a link of mass m has the inertia m x cfg.unit_inertia
     // (the host picks the rule: URDF tensor scaled with the mass, or Bullet's collision-shape inertia; qs_amd/config.py)
@@ -354,14 +376,6 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         }
     }
 
-    struct Row { V jq[3], u[3], w[6], rhs, dinv, act, diag; };
-    // the six rows of the payload block's fixed constraint (cfg.payload_soft, see solve_with_limits)
-    struct PayRows {
-        V w[6][6], rhs[6], dinv[6], diag[6];   // base side (whitened), right-hand side x dinv, 1 / A_kk, A_kk
-        V3v rB; V mI, mM, act;                  // block centre -> pivot (world), 1 / inertia, 1 / mass, 1 while the block exists
-        V lam[6]; V3v dw, dv;                   // results: impulses, the block's velocity change (world)
-    };
-
     // One stepSimulation() (gym_env.py:218-219) under joint torques tau[3] per leg.
     // TRACK: follow PyBullet's solverResidualThreshold -- an environment whose sweep changed no row velocity by more than
     // sqrt(threshold) is frozen (its residuals are zeroed, so later sweeps leave it untouched) and the wave leaves the
@@ -415,7 +429,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
 #pragma unroll
                 for (int r = 0; r < NR; r++)
 #pragma unroll
-                    for (int c = 0; c < NR; c++) T::outer_fma(rows[r].w[i], wc[c][i], acc[r][c]);
+                    for (int c = 0; c < NR; c++) { if (HOT) T::outer_fma(rows[r].w[i], wc[c][i], acc[r][c]); else T::outer_fma_valu(rows[r].w[i], wc[c][i], acc[r][c]); }
 #define QS_SCATTER(K)                                                                                                  \
     {                                                                                                                  \
         M own = T::is_leg(K);                                                                                          \
@@ -642,193 +656,68 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         s.vlin.z = clampv<V>(s.vlin.z + R[6] * z[3] + R[7] * z[4] + R[8] * z[5], -cap, cap);
     }
 
-    // The rare path: rows beyond the three foot-contact rows of a leg -- one row per violated joint limit (falls) and, with NCP = 3,
-    // normal + friction rows of up to two more support points of the leg (trunk corner, hip housing, thigh ends, knee end of the calf:
-    // a fallen robot rests on them).  Row layout of a leg: contact point c = 0 .. NCP-1 (0 = the foot) at rows 3c (normal), 3c + 1,
-    // 3c + 2 (friction), joint limits at rows 3 NCP + j.
-    //
-    // Same projected Gauss-Seidel as solve_and_integrate, in VELOCITY space: with y = sum_i w_i lambda_i (the base part of J^T lambda in the
-    // whitened coordinates of the Cholesky factor, replicated over the quad) and x = sum_{own rows} u_r lambda_r (the own leg's part) the
-    // velocity of row i along its own direction is w_i . y + jq_i . x, because A_ij = w_i . w_j + [same leg] jq_i . u_j.  A row update is
-    // then: that dot product (9 FMAs on the lane's own row data), clamp, one DPP broadcast of the owner's delta, y += w_owner delta (six
-    // v_fmac_dpp), x += u delta on the owner.  No (4 NRW) x NRW Delassus block is built or fetched: round 2's first version kept that block
-    // in scratch and spent ~0.4 ms per substep waiting for its rows (a fallen-robot wave: 4 ms per env step).  The row data (15 values
-    // x NRW) are loaded from the argument block once; in the one-wave-per-SIMD kernel this is a real function with its own registers.
-    // Rows that are empty in the whole wave are skipped (an empty row's update is exactly a no-op).
-    //
-    // cfg.payload_soft (quadruped.py:778-819): the payload block is a rigid body of its own, held on the base by a fixed constraint -- six
-    // more rows (three hold the block's pivot on the base origin, three hold the frames parallel; impulse bound 500 N x dt, ERP
-    // cfg.joint_erp), swept with the joint-limit rows as Bullet sorts them (after them forwards, before them backwards).  They have no
-    // joint part and touch every lane's y alike, so every lane of the quad computes them redundantly: no broadcast.  The block's side
-    // of a row is analytic (isotropic inertia mI^-1, mass mM^-1, lever rB): J = (-(rB x e_k), -e_k) resp. (-e_k, 0).
-    template <int NCP> struct RareArgs { Row rows[3 * NCP + 3]; V Sm[21], Ld[6], BK[3][6], R[9]; PayRows pay; bool has_pay; };
-    template <int NCP> static QS_FN void solve_with_limits(const qs_config& cfg, V mu, State& s, Out& o, RareArgs<NCP>& a) {
-        constexpr int NRW = 3 * NCP + 3, LIM = 3 * NCP;
+    // The rare path: rows beyond the three foot-contact rows of a leg -- one row per violated joint limit (falls), normal + friction rows
+    // of up to two more support points of the leg (trunk corner, hip housing, thigh ends, knee end of the calf: a fallen robot rests on
+    // them), the six rows of the payload block's fixed constraint (cfg.payload_soft, quadruped.py:778-819: three hold the block's pivot on
+    // the base origin, three hold the frames parallel; impulse bound 500 N x dt, ERP cfg.joint_erp; swept with the joint-limit rows as
+    // Bullet sorts them).  Row layout of a leg: contact point c = 0 .. 2 (0 = the foot) at rows 3c (normal), 3c + 1, 3c + 2 (friction), joint
+    // limits at rows 9 + j.  The solve itself is RareSolver (qs_rare.h): one environment at a time, one row per lane of the wave; this is
+    // what comes after it, in the quad layout again: delta v = H^-1 J^T lambda from the impulses lam[12] of the lane's rows (and the block's
+    // plam[6]):  dv_b = L^-T sum_i w_i lam_i ;  dqd = sum_own u_r lam_r - (B K)^T dv_b.
+    static QS_FN void integrate_rare(const qs_config& cfg, State& s, Out& o, const Row* xr, const V* lam, const V* Sm, const V* Ld, const V (*BK)[6], const V* R,
+                                     PayRows* pay, const V* plam) {
         const float dt = (float)cfg.dt;
-        const V zero = V(0.0f), big = V(1e10f);
-        Row rw[NRW];
-#pragma unroll
-        for (int r = 0; r < NRW; r++) rw[r] = a.rows[r];
-        // which rows exist at all in this wave: bit NRW K + R <=> row R of leg K is active in some environment (a friction row with its normal row)
-        unsigned long long on = 0ull;
-#pragma unroll
-        for (int r = 0; r < NRW; r++) {
-            const M act = qgt(rw[r < LIM ? r - r % 3 : r].act, V(0.5f));
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (T::any(qand(T::is_leg(k), act))) on |= 1ull << (NRW * k + r);
-        }
-        V lam[NRW], y[6], x[3];
-#pragma unroll
-        for (int r = 0; r < NRW; r++) lam[r] = zero;
-        // warm start: normal rows of the feet only, factor cfg.warmstart
-        lam[0] = s.warm * cfg.warmstart * rw[0].act;
-#pragma unroll
-        for (int i = 0; i < 6; i++) y[i] = T::quad_sum(rw[0].w[i] * lam[0]);
-#pragma unroll
-        for (int j = 0; j < 3; j++) x[j] = rw[0].u[j] * lam[0];
-        const bool track = cfg.solver_residual_threshold > 0.0f;
-        const V thr = V(sqrtf(cfg.solver_residual_threshold));
-        V live = V(1.0f);   // 0 once the environment is frozen (its residual passed under the threshold): its deltas are dropped
-        // payload rows (replicated)
-        const bool pay = a.has_pay;
-        V pw[6][6], prhs[6], pdinv[6], pdiag[6], plam[6], mI = zero, mM = zero, pact = zero;
-        V3v pja[6], dwb = mk3<V>(zero, zero, zero), dvb = mk3<V>(zero, zero, zero);
-        const V bound = V(500.0f * dt);
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            plam[k] = zero; prhs[k] = zero; pdinv[k] = zero; pdiag[k] = zero; pja[k] = mk3<V>(zero, zero, zero);
-#pragma unroll
-            for (int i = 0; i < 6; i++) pw[k][i] = zero;
-        }
-        if (pay) {
-            const PayRows& q = a.pay;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                prhs[k] = q.rhs[k]; pdinv[k] = q.dinv[k]; pdiag[k] = q.diag[k];
-#pragma unroll
-                for (int i = 0; i < 6; i++) pw[k][i] = q.w[k][i];
-            }
-            mI = q.mI; mM = q.mM; pact = q.act;
-            pja[0] = mk3<V>(zero, -q.rB.z, q.rB.y); pja[1] = mk3<V>(q.rB.z, zero, -q.rB.x); pja[2] = mk3<V>(-q.rB.y, q.rB.x, zero);   // -(rB x e_k)
-            pja[3] = mk3<V>(V(-1.0f), zero, zero); pja[4] = mk3<V>(zero, V(-1.0f), zero); pja[5] = mk3<V>(zero, zero, V(-1.0f));
-        }
-        // payload row P (0..2 linear along world axis P, 3..5 angular)
-#define QS_PROW(P)                                                                                                     \
-    {                                                                                                                  \
-        V rel = dot(pja[P], dwb) - ((P) == 0 ? dvb.x : (P) == 1 ? dvb.y : (P) == 2 ? dvb.z : zero);                    \
-        _Pragma("unroll") for (int i = 0; i < 6; i++) rel = rel + pw[P][i] * y[i];                                     \
-        V cand = qmin(qmax(plam[P] + (prhs[P] - pdinv[P] * rel), -bound), bound);                                      \
-        V dl = (cand - plam[P]) * (live * pact);                                                                       \
-        plam[P] = plam[P] + dl;                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 6; i++) y[i] = y[i] + pw[P][i] * dl;                                     \
-        dwb = dwb + pja[P] * (mI * dl);                                                                                \
-        if ((P) == 0) dvb.x = dvb.x - mM * dl;                                                                         \
-        if ((P) == 1) dvb.y = dvb.y - mM * dl;                                                                         \
-        if ((P) == 2) dvb.z = dvb.z - mM * dl;                                                                         \
-        if (track) dvmax = qmax(dvmax, qabs(dl * pdiag[P]));                                                           \
-    }
-        // the lane's own row R: unclamped candidate from the current velocities
-#define QS_RCAND(R) (lam[R] + (rw[R].rhs - rw[R].dinv * (rw[R].w[0] * y[0] + rw[R].w[1] * y[1] + rw[R].w[2] * y[2] + rw[R].w[3] * y[3] + rw[R].w[4] * y[4] + \
-                                                         rw[R].w[5] * y[5] + rw[R].jq[0] * x[0] + rw[R].jq[1] * x[1] + rw[R].jq[2] * x[2])))
-        // apply the delta of row (K, R): dl = the lane's own (clamped candidate - impulse); the owner's counts
-#define QS_RAPPLY(K, R, DL)                                                                                            \
-    {                                                                                                                  \
-        V d_ = T::template bcast<K>(DL);                                                                               \
-        V dk_ = qsel(T::is_leg(K), d_, zero);                                                                          \
-        lam[R] = lam[R] + dk_;                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 6; i++) y[i] = T::template fma_bcast<K>(rw[R].w[i], d_, y[i]);          \
-        _Pragma("unroll") for (int j = 0; j < 3; j++) x[j] = x[j] + rw[R].u[j] * dk_;                                  \
-        if (track) dvmax = qmax(dvmax, T::template bcast<K>(qabs((DL) * rw[R].diag)));                                 \
-    }
-        // one row update; KIND 0: unilateral [0, 1e10] (joint limit or contact normal), KIND 1: friction bounded by mu x the normal impulse
-        // of its contact point (row N0 of the same leg), left alone while that impulse is not positive (Bullet's rule)
-#define QS_RROW(K, R, KIND, N0)                                                                                        \
-    if ((on >> (NRW * (K) + (R))) & 1ull) {                                                                            \
-        V cand = QS_RCAND(R);                                                                                          \
-        if (KIND == 0) cand = qmin(qmax(cand, zero), big);                                                             \
-        else { V tot = lam[N0]; V lim = mu * tot; cand = qsel(qgt(tot, zero), qmin(qmax(cand, -lim), lim), lam[R]); }  \
-        V dl = (cand - lam[R]) * live;                                                                                 \
-        QS_RAPPLY(K, R, dl)                                                                                            \
-    }
-        // implicit cone friction: both friction rows of a contact point of leg K from the same velocities, projected onto the disc
-#define QS_RPAIR(K, N0)                                                                                                \
-    if ((on >> (NRW * (K) + (N0))) & 1ull) {                                                                           \
-        V ca = QS_RCAND((N0) + 1), cb = QS_RCAND((N0) + 2), lim = mu * lam[N0];                                      \
-        V r2 = ca * ca + cb * cb;                                                                                      \
-        V sc = qmin(lim * qrsqrt(qmax(r2, V(1e-30f))), V(1.0f));                                                       \
-        V da = (ca * sc - lam[(N0) + 1]) * live, db = (cb * sc - lam[(N0) + 2]) * live;                                \
-        QS_RAPPLY(K, (N0) + 1, da)                                                                                     \
-        QS_RAPPLY(K, (N0) + 2, db)                                                                                     \
-    }
-#define QS_RLEG_FWD(K) QS_RROW(K, LIM + 0, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 2, 0, 0)
-#define QS_RLEG_BWD(K) QS_RROW(K, LIM + 2, 0, 0) QS_RROW(K, LIM + 1, 0, 0) QS_RROW(K, LIM + 0, 0, 0)
-#define QS_RNORMALS(K) { QS_RROW(K, 0, 0, 0) if constexpr (NCP == 3) { QS_RROW(K, 3, 0, 3) QS_RROW(K, 6, 0, 6) } }
-#define QS_RFRICTION(K)                                                                                               \
-    {                                                                                                                  \
-        if (CONE) { QS_RPAIR(K, 0) if constexpr (NCP == 3) { QS_RPAIR(K, 3) QS_RPAIR(K, 6) } }                         \
-        else {                                                                                                         \
-            QS_RROW(K, 1, 1, 0) QS_RROW(K, 2, 1, 0)                                                                    \
-            if constexpr (NCP == 3) { QS_RROW(K, 4, 1, 3) QS_RROW(K, 5, 1, 3) QS_RROW(K, 7, 1, 6) QS_RROW(K, 8, 1, 6) } \
-        }                                                                                                              \
-    }
-        for (int it = 0; it < cfg.solver_iters; it++) {
-            V dvmax = zero;
-            // per sweep: 12 limit rows (forward on odd sweeps, backward on even ones), the normal rows (leg by leg, foot first), the friction rows
-            if (it & 1) {
-                QS_RLEG_FWD(0) QS_RLEG_FWD(1) QS_RLEG_FWD(2) QS_RLEG_FWD(3)
-                if (pay) { QS_PROW(0) QS_PROW(1) QS_PROW(2) QS_PROW(3) QS_PROW(4) QS_PROW(5) }
-            } else {
-                if (pay) { QS_PROW(5) QS_PROW(4) QS_PROW(3) QS_PROW(2) QS_PROW(1) QS_PROW(0) }
-                QS_RLEG_BWD(3) QS_RLEG_BWD(2) QS_RLEG_BWD(1) QS_RLEG_BWD(0)
-            }
-            QS_RNORMALS(0) QS_RNORMALS(1) QS_RNORMALS(2) QS_RNORMALS(3)
-            QS_RFRICTION(0) QS_RFRICTION(1) QS_RFRICTION(2) QS_RFRICTION(3)
-            if (track) {
-                M conv = qle(dvmax, thr);
-                live = qsel(conv, zero, live);
-                if (!T::any(qgt(live, V(0.5f)))) break;
-            }
-        }
-#undef QS_PROW
-#undef QS_RFRICTION
-#undef QS_RNORMALS
-#undef QS_RLEG_FWD
-#undef QS_RLEG_BWD
-#undef QS_RPAIR
-#undef QS_RROW
-#undef QS_RAPPLY
-#undef QS_RCAND
         o.foot_force = lam[0] * qrcp(dt);
         s.warm = lam[0];
-        if (pay) {
+        V z[6], x[3];
 #pragma unroll
-            for (int k = 0; k < 6; k++) a.pay.lam[k] = plam[k];
-            a.pay.dw = dwb; a.pay.dv = dvb;
+        for (int i = 0; i < 6; i++) {
+            V t = xr[0].w[i] * lam[0];
+#pragma unroll
+            for (int r = 1; r < 12; r++) t = t + xr[r].w[i] * lam[r];
+            z[i] = T::quad_sum(t);
         }
-        // delta v = H^-1 J^T lambda :  dv_b = L^-T y ;  dqd = x - (B K)^T dv_b
-        V z[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) z[i] = y[i];
-        ltsolve6<V>(a.Sm, a.Ld, z);
+        for (int j = 0; j < 3; j++) {
+            V t = xr[0].u[j] * lam[0];
+#pragma unroll
+            for (int r = 1; r < 12; r++) t = t + xr[r].u[j] * lam[r];
+            x[j] = t;
+        }
+        if (pay) {   // the block's rows: their base part of J^T lambda (they act on every lane's copy alike), the block's velocity change
+            PayRows& q = *pay;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                V zp = q.w[0][i] * plam[0];
+#pragma unroll
+                for (int k = 1; k < 6; k++) zp = zp + q.w[k][i] * plam[k];
+                z[i] = z[i] + zp;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) q.lam[k] = plam[k];
+            const V zero = V(0.0f);
+            const V3v ja0 = mk3<V>(zero, -q.rB.z, q.rB.y), ja1 = mk3<V>(q.rB.z, zero, -q.rB.x), ja2 = mk3<V>(-q.rB.y, q.rB.x, zero);   // -(rB x e_k)
+            V3v dwb = ja0 * (q.mI * plam[0]);
+            dwb = dwb + ja1 * (q.mI * plam[1]);
+            dwb = dwb + ja2 * (q.mI * plam[2]);
+            dwb = dwb - mk3<V>(plam[3], plam[4], plam[5]) * q.mI;
+            q.dw = dwb; q.dv = mk3<V>(-(q.mM * plam[0]), -(q.mM * plam[1]), -(q.mM * plam[2]));
+        }
+        ltsolve6<V>(Sm, Ld, z);
         const V cap = V(cfg.vel_cap);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             V t = x[j];
 #pragma unroll
-            for (int i = 0; i < 6; i++) t = t - a.BK[j][i] * z[i];
+            for (int i = 0; i < 6; i++) t = t - BK[j][i] * z[i];
             s.qd[j] = clampv<V>(s.qd[j] + t, -cap, cap);
         }
-        const V* R = a.R;
         s.vang.x = clampv<V>(s.vang.x + R[0] * z[0] + R[1] * z[1] + R[2] * z[2], -cap, cap);
         s.vang.y = clampv<V>(s.vang.y + R[3] * z[0] + R[4] * z[1] + R[5] * z[2], -cap, cap);
         s.vang.z = clampv<V>(s.vang.z + R[6] * z[0] + R[7] * z[1] + R[8] * z[2], -cap, cap);
         s.vlin.x = clampv<V>(s.vlin.x + R[0] * z[3] + R[1] * z[4] + R[2] * z[5], -cap, cap);
         s.vlin.y = clampv<V>(s.vlin.y + R[3] * z[3] + R[4] * z[4] + R[5] * z[5], -cap, cap);
         s.vlin.z = clampv<V>(s.vlin.z + R[6] * z[3] + R[7] * z[4] + R[8] * z[5], -cap, cap);
-    }
-    template <int NCP> static QS_NOINLINE void solve_with_limits_call(const qs_config& cfg, V mu, State& s, Out& o, RareArgs<NCP>& a) {
-        solve_with_limits<NCP>(cfg, mu, s, o, a);
     }
 
     // ---- link-link tests of the self-collision rule (rare path)
@@ -897,7 +786,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         return n;
     }
 
-    // returns true iff HOT and the wave needs a rare path (nothing it wrote is valid then).
+    // returns true iff HOT and the wave needs a rare path: `s` (and the payload block's state) is then as it came in, and the caller repeats
+    // this substep with the full build.
     // ---- cfg.payload_soft: the payload block as a body of its own (quadruped.py:778-819: createMultiBody(box of half extent 0.05) +
     // createConstraint(base, block, JOINT_FIXED, child pivot -delta) = a btMultiBodyFixedConstraint in the same PGS as the contacts)
     // puts the block where the constraint wants it, at the base's velocity (a reset's spawn, qs_set_state, qs_set_params)
@@ -1005,7 +895,13 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
     // GetContactInfo after the LAST stepSimulation of an env step (task_base.py:137-147 via gym_env.py:241-245), so the callers ask for it
     // there only -- unless cfg.body_contacts, where those links' heights decide in every substep whether they push back.
     // `blk`: the payload block's state in the record (R_BLOCK) under cfg.payload_soft, nullptr otherwise
-    static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true, float* blk = nullptr) {
+    // `scratch_row`: this environment's observation row in the wave's staging area (unused between two epilogues): the many-rows solve
+    // borrows the sixteen rows of the wave (RareSolver)
+    // `last`: the contact classification is READ after this substep (the last one of an env step: gym_env.py:241-245); the link-link tests of
+    // the self-collision rule only run then -- they decide nothing about the motion (round 4: with cfg.body_contacts they ran in every
+    // substep, 11 k cycles each for a robot lying on folded legs)
+    static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true, float* blk = nullptr, float* scratch_row = nullptr,
+                              bool last = true) {
         using namespace go1;
         if (HOT && !SOFT && cfg.payload_soft) return true;   // this build holds no payload rows
         const bool soft = (!HOT || SOFT) && cfg.payload_soft && blk != nullptr;
@@ -1144,24 +1040,6 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         for (int j = 0; j < 3; j++)
 #pragma unroll
             for (int i = 0; i < 6; i++) qdd[j] = qdd[j] - BK[j][i] * ab[i];
-        // ---- v* = v + dt a (world frame for the base; classical acceleration of the origin = a_lin + w x v)
-        const V cap = V(cfg.vel_cap);
-        {
-            V3v wxv = cross(v0.a, v0.l);
-            V3v al = mk3<V>(ab[3] + wxv.x, ab[4] + wxv.y, ab[5] + wxv.z);
-            s.vang.x = clampv<V>(s.vang.x + dt * (R[0] * ab[0] + R[1] * ab[1] + R[2] * ab[2]), -cap, cap);
-            s.vang.y = clampv<V>(s.vang.y + dt * (R[3] * ab[0] + R[4] * ab[1] + R[5] * ab[2]), -cap, cap);
-            s.vang.z = clampv<V>(s.vang.z + dt * (R[6] * ab[0] + R[7] * ab[1] + R[8] * ab[2]), -cap, cap);
-            s.vlin.x = clampv<V>(s.vlin.x + dt * (R[0] * al.x + R[1] * al.y + R[2] * al.z), -cap, cap);
-            s.vlin.y = clampv<V>(s.vlin.y + dt * (R[3] * al.x + R[4] * al.y + R[5] * al.z), -cap, cap);
-            s.vlin.z = clampv<V>(s.vlin.z + dt * (R[6] * al.x + R[7] * al.y + R[8] * al.z), -cap, cap);
-#pragma unroll
-            for (int j = 0; j < 3; j++) s.qd[j] = clampv<V>(s.qd[j] + dt * qdd[j], -cap, cap);
-        }
-        Spv vs;  // predicted base velocity in base coordinates
-        vs.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
-        vs.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
-
         QS_PHASE(7)
         // ---- collision: foot sphere vs plane z = 0 ; the other link primitives (trunk box, hip cylinder, thigh and calf boxes, payload
         // block) count as invalid contacts (quadruped.py:243-249) and, with cfg.body_contacts, push back on the rare path below
@@ -1198,7 +1076,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             o.n_invalid = T::quad_sum(n) + trunk + pay;
             if (cfg.body_contacts) any_extra = qor(qor(m_trunk, m_hip), qor(m_thigh, qlt(h_cf_hi, V(THR_CALF))));
         }
-        if (detect && cfg.self_collision) {
+        if (detect && last && cfg.self_collision) {
             // Link-link contacts count only when a calf is involved (quadruped.py:237-241).  Broad phase, every substep: extents of
             // the own calf and of the own whole leg towards the robot's centre planes, in mirrored coordinates (sy y: towards the own
             // side, fx x: towards the own end); thigh within 0.021 of its axis, calf and foot within 0.02, hip housing within 0.046.
@@ -1237,6 +1115,26 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
         if (HOT && __builtin_expect(T::any(qor(any_lim, any_extra)), 0)) return true;
+        // ---- v* = v + dt a (world frame for the base; classical acceleration of the origin = a_lin + w x v).  The first write to `s` of the
+        // substep: a HOT build's wave that gives up (above) hands the state back as it came, and the env step goes on in the full build from
+        // THIS substep (qs_env.h).  (The first version updated the velocities before the collision phase and kept the old ones for that
+        // case: 23 more AGPR copies in the hot loop, -2.5 % on the headline.)
+        const V cap = V(cfg.vel_cap);
+        {
+            V3v wxv = cross(v0.a, v0.l);
+            V3v al = mk3<V>(ab[3] + wxv.x, ab[4] + wxv.y, ab[5] + wxv.z);
+            s.vang.x = clampv<V>(s.vang.x + dt * (R[0] * ab[0] + R[1] * ab[1] + R[2] * ab[2]), -cap, cap);
+            s.vang.y = clampv<V>(s.vang.y + dt * (R[3] * ab[0] + R[4] * ab[1] + R[5] * ab[2]), -cap, cap);
+            s.vang.z = clampv<V>(s.vang.z + dt * (R[6] * ab[0] + R[7] * ab[1] + R[8] * ab[2]), -cap, cap);
+            s.vlin.x = clampv<V>(s.vlin.x + dt * (R[0] * al.x + R[1] * al.y + R[2] * al.z), -cap, cap);
+            s.vlin.y = clampv<V>(s.vlin.y + dt * (R[3] * al.x + R[4] * al.y + R[5] * al.z), -cap, cap);
+            s.vlin.z = clampv<V>(s.vlin.z + dt * (R[6] * al.x + R[7] * al.y + R[8] * al.z), -cap, cap);
+#pragma unroll
+            for (int j = 0; j < 3; j++) s.qd[j] = clampv<V>(s.qd[j] + dt * qdd[j], -cap, cap);
+        }
+        Spv vs;  // predicted base velocity in base coordinates
+        vs.a = mk3<V>(R[0] * s.vang.x + R[3] * s.vang.y + R[6] * s.vang.z, R[1] * s.vang.x + R[4] * s.vang.y + R[7] * s.vang.z, R[2] * s.vang.x + R[5] * s.vang.y + R[8] * s.vang.z);
+        vs.l = mk3<V>(R[0] * s.vlin.x + R[3] * s.vlin.y + R[6] * s.vlin.z, R[1] * s.vlin.x + R[4] * s.vlin.y + R[7] * s.vlin.z, R[2] * s.vlin.x + R[5] * s.vlin.y + R[8] * s.vlin.z);
         if (soft || T::any(qor(qor(act_m, any_lim), any_extra))) {
         QS_PHASE(8)
         // ---- constraint rows of this leg: 0 normal, 1 t1 = -y_world, 2 t2 = +x_world ; 3..5 joint limits (rare path)
@@ -1304,13 +1202,6 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         V rel = lim_sgn[j] * s.qd[j];                                                                                  \
         r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;                                  \
     }
-#define QS_RARE_COMMON(A)                                                                                              \
-    (A).has_pay = soft;                                                                                                \
-    if (soft) (A).pay = pay_c;   /* (the rows; the results in it are overwritten) */                                   \
-    _Pragma("unroll") for (int i = 0; i < 21; i++) (A).Sm[i] = Sm[i];                                                  \
-    _Pragma("unroll") for (int i = 0; i < 6; i++) (A).Ld[i] = Ld[i];                                                   \
-    _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int i = 0; i < 6; i++) (A).BK[j][i] = BK[j][i]; \
-    _Pragma("unroll") for (int i = 0; i < 9; i++) (A).R[i] = R[i];
         // The full build's wave on a rare path: the environments that have NO rare row of their own (no joint at a stop, no link on the
         // floor) still get the result of the common-path solver -- bit for bit what the common-path build gives them in a wave without
         // such a neighbour --, computed on a copy next to the many-rows solve; only the environments with rare rows take that one's.
@@ -1336,66 +1227,72 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         }
         // this environment has rare rows of its own and takes the many-rows solver's result
         const M rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, any_extra))), V(0.5f));
-        if (!HOT && T::any(any_extra)) {
-            // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
-            // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
+        QS_PHASE_G(39)
+        if (!HOT && T::any(rare_mine)) {
             T::count_rare_path();
-            RareArgs<3> a;
+            Row xr[12];   // this leg's rows: contact point c at 3c .. 3c + 2 (0 = the foot), joint limits at 9 + j
 #pragma unroll
-            for (int r = 0; r < 3; r++) a.rows[r] = rows[r];
-            const V bigh = V(1e9f);
-            V hh[5] = {qsel(qlt(h_trunk, V(THR_TRUNK)), h_trunk, bigh), qsel(qlt(h_hip, V(THR_HIP)), h_hip, bigh), qsel(qlt(h_th_hi, V(THR_THIGH)), h_th_hi, bigh),
-                       qsel(qlt(h_th_lo, V(THR_THIGH)), h_th_lo, bigh), qsel(qlt(h_cf_hi, V(THR_CALF)), h_cf_hi, bigh)};
-            if (!cfg.body_contacts) { for (int i = 0; i < 5; i++) hh[i] = bigh; }
-            // candidate points (base coordinates): lowest vertex of each primitive
-            V sgz = qsel(qlt(Rz.z, zero), -one, one), sga = qsel(qlt(az, zero), -one, one);
-            V sg2 = qsel(qlt(gx2, zero), -one, one), sg3 = qsel(qlt(gx3, zero), -one, one);
-            V rad = HIP_CYL_R * qrsqrt(qmax(one - az * az, V(1e-12f)));
-            V3v pc[5];
-            pc[0] = mk3<V>(fx * TRUNK_HALF[0], sy * TRUNK_HALF[1], sgz * (-TRUNK_HALF[2]));
-            pc[1] = p1 - Y * (sga * HIP_CYL_HALF_LEN) - (Rz - Y * az) * rad;
-            V3v toff = X2 * (sg2 * THIGH_HALF[0]) + Y * (sga * THIGH_HALF[1]);
-            pc[2] = p2 - toff; pc[3] = p3 - toff;
-            pc[4] = p3 - X3 * (sg3 * CALF_HALF[0]) - Y * (sga * CALF_HALF[1]);
-            const float depth[5] = {0.0f, 1.0f, 2.0f, 2.0f, 3.0f};   // joints of the leg that move the point
+            for (int r = 0; r < 3; r++) xr[r] = rows[r];
 #pragma unroll
-            for (int slot = 0; slot < 2; slot++) {
-                V best = hh[0], bi = zero;
+            for (int r = 3; r < 12; r++) {
+                Row& e_ = xr[r];
+                e_.rhs = zero; e_.dinv = zero; e_.act = zero; e_.diag = zero;
 #pragma unroll
-                for (int i = 1; i < 5; i++) { M m = qlt(hh[i], best); best = qsel(m, hh[i], best); bi = qsel(m, V((float)i), bi); }
-                bi = qsel(qlt(best, V(1e8f)), bi, V(4.0f));   // empty slot: any point that the joints move (an all-zero Jacobian has no 1 / diag)
-                V3v pt = pc[0]; V dep = V(depth[0]);
+                for (int i = 0; i < 6; i++) e_.w[i] = zero;
 #pragma unroll
-                for (int i = 1; i < 5; i++) {
-                    M m = qgt(bi, V(i - 0.5f));   // bi >= i: later candidates overwrite
-                    pt = mk3<V>(qsel(m, pc[i].x, pt.x), qsel(m, pc[i].y, pt.y), qsel(m, pc[i].z, pt.z));
-                    dep = qsel(m, V(depth[i]), dep);
-                }
-#pragma unroll
-                for (int i = 0; i < 5; i++) hh[i] = qsel(qand(qgt(bi, V(i - 0.5f)), qlt(bi, V(i + 0.5f))), bigh, hh[i]);   // taken
-                V act_x = qflag(qlt(best, V(1e8f)));
-                V dist_x = qsel(qlt(best, V(1e8f)), best, zero);
-                V f1 = qflag(qgt(dep, V(0.5f))), f2 = qflag(qgt(dep, V(1.5f))), f3 = qflag(qgt(dep, V(2.5f)));
-                V3v e1 = cross(ax1, pt - p1) * f1, e2 = cross(Y, pt - p2) * f2, e3 = cross(Y, pt - p3) * f3;
-                QS_CONTACT_ROW_AT(a.rows[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
-                QS_CONTACT_ROW_AT(a.rows[4 + 3 * slot], (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
-                QS_CONTACT_ROW_AT(a.rows[5 + 3 * slot], Rx, false, pt, e1, e2, e3, dist_x, act_x)
+                for (int i = 0; i < 3; i++) { e_.jq[i] = zero; e_.u[i] = zero; }
             }
-            QS_LIMIT_ROWS(a.rows + 9)
-            QS_RARE_COMMON(a)
-            if (CALLS) solve_with_limits_call<3>(cfg, Pr.mu, s, o, a);
-            else solve_with_limits<3>(cfg, Pr.mu, s, o, a);
-            if (soft) keep_rare_payload(pay_c, a.pay, rare_mine);
-        } else if (!HOT && T::any(any_lim)) {
-            T::count_rare_path();
-            QS_LIMIT_ROWS(rows + 3)
-            RareArgs<1> a;
+            if (T::any(any_extra)) {
+                // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
+                // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
+                const V bigh = V(1e9f);
+                V hh[5] = {qsel(qlt(h_trunk, V(THR_TRUNK)), h_trunk, bigh), qsel(qlt(h_hip, V(THR_HIP)), h_hip, bigh), qsel(qlt(h_th_hi, V(THR_THIGH)), h_th_hi, bigh),
+                           qsel(qlt(h_th_lo, V(THR_THIGH)), h_th_lo, bigh), qsel(qlt(h_cf_hi, V(THR_CALF)), h_cf_hi, bigh)};
+                // candidate points (base coordinates): lowest vertex of each primitive
+                V sgz = qsel(qlt(Rz.z, zero), -one, one), sga = qsel(qlt(az, zero), -one, one);
+                V sg2 = qsel(qlt(gx2, zero), -one, one), sg3 = qsel(qlt(gx3, zero), -one, one);
+                V rad = HIP_CYL_R * qrsqrt(qmax(one - az * az, V(1e-12f)));
+                V3v pc[5];
+                pc[0] = mk3<V>(fx * TRUNK_HALF[0], sy * TRUNK_HALF[1], sgz * (-TRUNK_HALF[2]));
+                pc[1] = p1 - Y * (sga * HIP_CYL_HALF_LEN) - (Rz - Y * az) * rad;
+                V3v toff = X2 * (sg2 * THIGH_HALF[0]) + Y * (sga * THIGH_HALF[1]);
+                pc[2] = p2 - toff; pc[3] = p3 - toff;
+                pc[4] = p3 - X3 * (sg3 * CALF_HALF[0]) - Y * (sga * CALF_HALF[1]);
+                const float depth[5] = {0.0f, 1.0f, 2.0f, 2.0f, 3.0f};   // joints of the leg that move the point
 #pragma unroll
-            for (int r = 0; r < 6; r++) a.rows[r] = rows[r];
-            QS_RARE_COMMON(a)
-            if (CALLS) solve_with_limits_call<1>(cfg, Pr.mu, s, o, a);
-            else solve_with_limits<1>(cfg, Pr.mu, s, o, a);
-            if (soft) keep_rare_payload(pay_c, a.pay, rare_mine);
+                for (int slot = 0; slot < 2; slot++) {
+                    V best = hh[0], bi = zero;
+#pragma unroll
+                    for (int i = 1; i < 5; i++) { M m = qlt(hh[i], best); best = qsel(m, hh[i], best); bi = qsel(m, V((float)i), bi); }
+                    if (!T::any(qlt(best, V(1e8f)))) break;   // nobody in the wave has a (second) support point: the slot's rows stay empty
+                    bi = qsel(qlt(best, V(1e8f)), bi, V(4.0f));   // empty slot: any point that the joints move (an all-zero Jacobian has no 1 / diag)
+                    V3v pt = pc[0]; V dep = V(depth[0]);
+#pragma unroll
+                    for (int i = 1; i < 5; i++) {
+                        M m = qgt(bi, V(i - 0.5f));   // bi >= i: later candidates overwrite
+                        pt = mk3<V>(qsel(m, pc[i].x, pt.x), qsel(m, pc[i].y, pt.y), qsel(m, pc[i].z, pt.z));
+                        dep = qsel(m, V(depth[i]), dep);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; i++) hh[i] = qsel(qand(qgt(bi, V(i - 0.5f)), qlt(bi, V(i + 0.5f))), bigh, hh[i]);   // taken
+                    V act_x = qflag(qlt(best, V(1e8f)));
+                    V dist_x = qsel(qlt(best, V(1e8f)), best, zero);
+                    V f1 = qflag(qgt(dep, V(0.5f))), f2 = qflag(qgt(dep, V(1.5f))), f3 = qflag(qgt(dep, V(2.5f)));
+                    V3v e1 = cross(ax1, pt - p1) * f1, e2 = cross(Y, pt - p2) * f2, e3 = cross(Y, pt - p3) * f3;
+                    QS_CONTACT_ROW_AT(xr[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
+                    QS_CONTACT_ROW_AT(xr[4 + 3 * slot], (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
+                    QS_CONTACT_ROW_AT(xr[5 + 3 * slot], Rx, false, pt, e1, e2, e3, dist_x, act_x)
+                }
+            }
+            if (T::any(any_lim)) { QS_LIMIT_ROWS(xr + 9) }
+            QS_PHASE_G(40)
+            V lam12[12], plam[6];
+            PayRows pay_r;
+            if (soft) pay_r = pay_c;   // (the rows; the results in it are overwritten)
+            RareSolver<T, CONE>::solve(cfg, Pr.mu, xr, soft ? &pay_r : nullptr, rare_mine, s.warm * cfg.warmstart * rows[0].act, T::wave_scratch(scratch_row), lam12, plam);
+            integrate_rare(cfg, s, o, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam);
+            if (soft) keep_rare_payload(pay_c, pay_r, rare_mine);
+            QS_PHASE_G(45)
         }
         if (!HOT) {   // (in a wave without any rare row: the common-path result for everybody)
 #pragma unroll

@@ -455,7 +455,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         default: return {false, false, false, false, 0, false};
         }
     }
-    struct StepOut { V reward, done, trunc; bool redo; };   // redo (HOT builds, wave-uniform): the wave needs the full build, nothing here is valid
+    struct StepOut { V reward, done, trunc; int resume; };   // resume >= 0 (HOT builds, wave-uniform): go on in the full build at that substep (see step)
 
     // One env.step(action) (gym_env.py:227-256).  `rec` = this environment's record, `act` = its action row,
     // `obs` = QS_MAX_OBS floats of staging for its observation.
@@ -477,9 +477,31 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         }
         T::st_leg(row, TR_FOOT_FORCE, 1, o.foot_force); T::st_leg(row, TR_FOOT_CONTACT, 1, o.foot_contact);
     }
+    // A HOT build's step hands over where a wave needs a rare path: substep k of the common-path build gives up, the step leaves the
+    // environment's state of that moment in the record, what the prologue produced in the (still unused) observation row -- ST_* below --
+    // and returns resume = k; the kernel then calls the FULL build's step<true>(..., k), which skips the prologue (the filter history and
+    // the scripted phases have moved on already), picks those values up and runs substeps k .. n - 1 and the epilogue.  The environments
+    // of the wave that have no rare row of their own get from the full build, bit for bit, what the common-path build gives them
+    // (qs_core.h), so nothing depends on where the switch happens.  (Rounds 2-3 fetched the records again and repeated the WHOLE env step in
+    // the full build: the wave that every launch waits for paid up to two steps' time.  Continuing inside the same function -- the full
+    // build's substep loop behind the hot one -- was tried first: the values live across both loops put ~30 scratch instructions into the
+    // hot loop, 112.1 -> 102.5 M env-steps/s.)
+    enum { ST_CMD = 0, ST_KP = 12, ST_KD = 15, ST_W = 18, ST_CPGP = 22, ST_CPGR = 28, ST_CPGTH = 32 };
+    static QS_FN void stash_state(float* rec, const typename S::State& s) {
+        T::st(rec, R_POS, s.pos.x); T::st(rec, R_POS + 1, s.pos.y); T::st(rec, R_POS + 2, s.pos.z);
+        T::st(rec, R_QUAT, s.qx); T::st(rec, R_QUAT + 1, s.qy); T::st(rec, R_QUAT + 2, s.qz); T::st(rec, R_QUAT + 3, s.qw);
+        T::st(rec, R_VLIN, s.vlin.x); T::st(rec, R_VLIN + 1, s.vlin.y); T::st(rec, R_VLIN + 2, s.vlin.z);
+        T::st(rec, R_VANG, s.vang.x); T::st(rec, R_VANG + 1, s.vang.y); T::st(rec, R_VANG + 2, s.vang.z);
+#pragma unroll
+        for (int j = 0; j < 3; j++) { T::st_leg(rec, R_Q + j, 3, s.q[j]); T::st_leg(rec, R_QD + j, 3, s.qd[j]); }
+        T::st_leg(rec, R_WARM, 1, s.warm);
+    }
+    template <bool RESUME = false>
     static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0,
-                              float* trace = nullptr, bool any_trace = false, const float* demo_rows = nullptr, int demo_len = 0) {
+                              float* trace = nullptr, bool any_trace = false, const float* demo_rows = nullptr, int demo_len = 0, int resume_k = 0) {
+        static_assert(!(RESUME && HOT), "an env step resumes in the full build");
         typename S::State s; typename S::Par P; typename S::Out o;
+        if (RESUME) T::sync();   // (the stash was written by other lanes of the quad)
         load_state(rec, s); load_par(cfg, rec, P);
         const int d = settle_n > 0 ? 0 : cfg.action_dim;
         // action: copy, filter (gym_env.py:229-234); every lane keeps the d replicated values plus its own-leg slice
@@ -502,7 +524,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         for (int k = 0; k < 15; k++) act_in[k] = act[k];
         // scripted phases of the landing / go-to-rest wrappers (one inner env.step per call)
         V w_phase = V(0.0f), w_timer = V(0.0f), w_end = V(0.0f), w_tstart = V(0.0f);
-        if (cfg.wrapper_mode != QS_WRAP_NONE && settle_n == 0) {
+        if (!RESUME && cfg.wrapper_mode != QS_WRAP_NONE && settle_n == 0) {
             const float* w = rec + R_WRAP;
             w_phase = T::ld(w, W_PHASE); w_timer = T::ld(w, W_TIMER); w_end = T::ld(w, W_END); w_tstart = T::ld(w, W_TSTART);
             const float env_dt = (float)((double)cfg.action_repeat * cfg.dt);
@@ -550,7 +572,18 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         V act_last[15];   // what env.step was given (after the scripted phases): _last_action, gym_env.py:230
 #pragma unroll
         for (int k = 0; k < 15; k++) act_last[k] = act[k];
-        if (d == 12) {  // DEFAULT space / raw commands: every lane filters the 3 entries of its own leg
+        if (RESUME) {   // what env.step was given is in the record already (R_LAST_ACTION), the filter has run
+#pragma unroll
+            for (int k = 0; k < 15; k++) act_last[k] = V(0.0f);
+            if (d == 12) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) act_last[12 + j] = T::ld_leg(rec, R_LAST_ACTION + j, 3);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    if (k < d) act_last[k] = T::ld(rec, R_LAST_ACTION + k);
+            }
+        } else if (d == 12) {  // DEFAULT space / raw commands: every lane filters the 3 entries of its own leg
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 V a = act[12 + j];
@@ -583,14 +616,27 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         V cmd[3];
         const bool cpg = cfg.action_space_mode == QS_ACT_CPG && settle_n == 0;
         V cpg_p[5], cpg_r = V(0.0f), cpg_th = V(0.0f);
-        if (settle_n > 0) {
+        if (RESUME) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { cmd[j] = T::ld_leg(obs, ST_CMD + j, 3); P.kp[j] = T::ld(obs, ST_KP + j); P.kd[j] = T::ld(obs, ST_KD + j); }
+            w_phase = T::ld(obs, ST_W); w_timer = T::ld(obs, ST_W + 1); w_end = T::ld(obs, ST_W + 2); w_tstart = T::ld(obs, ST_W + 3);
+#pragma unroll
+            for (int k = 0; k < 5; k++) cpg_p[k] = T::ld(obs, ST_CPGP + k);
+            cpg_r = T::ld_leg(obs, ST_CPGR, 1); cpg_th = T::ld_leg(obs, ST_CPGTH, 1);
+            T::sync();   // (the row is the wave's scratch from here on, until the epilogue writes the observation into it)
+        } else if (settle_n > 0) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) cpg_p[k] = V(0.0f);
 #pragma unroll
             for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
         } else if (cpg) {
 #pragma unroll
             for (int k = 0; k < 5; k++) cpg_p[k] = clampv<V>(act[k], V(-1.0f), V(1.0f)) * (0.5f * (cfg.cpg_hi[k] - cfg.cpg_lo[k])) + 0.5f * (cfg.cpg_hi[k] + cfg.cpg_lo[k]);
             cpg_r = T::ld_leg(rec, R_CPG, 1); cpg_th = T::ld_leg(rec, R_CPG + 4, 1);
+            cmd[0] = V(0.0f); cmd[1] = V(0.0f); cmd[2] = V(0.0f);   // (cpg_command sets them in every substep)
         } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) cpg_p[k] = V(0.0f);
             action_to_command(cfg, act, cmd);
         }
         int sim_step = f2i(rec[R_SIM_STEP]), env_step = f2i(rec[R_ENV_STEP]), total = f2i(rec[R_TOTAL_STEPS]);
@@ -598,18 +644,37 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
 #pragma unroll
         for (int j = 0; j < 3; j++) old_tau[j] = T::ld_leg(rec, R_NEW_TAU + j, 3);
         const int n_sub = settle_n > 0 ? settle_n : cfg.action_repeat;
-        for (int k = 0; k < n_sub; k++) {  // gym_env.py:236-237, 207-216
+        float* const blk = cfg.payload_soft ? rec + R_BLOCK : nullptr;
+        if (HOT) {
+            // what a resumed step needs of the prologue goes into the (still unused) observation row here, once per step and whether or not
+            // the step is ever handed over: 30 LDS writes -- stored only at the hand-over, these values stayed live for that cold block all
+            // through the hot loop (0.8 % of the headline)
+#pragma unroll
+            for (int j = 0; j < 3; j++) { T::st_leg(obs, ST_CMD + j, 3, cmd[j]); T::st(obs, ST_KP + j, P.kp[j]); T::st(obs, ST_KD + j, P.kd[j]); }
+            T::st(obs, ST_W, w_phase); T::st(obs, ST_W + 1, w_timer); T::st(obs, ST_W + 2, w_end); T::st(obs, ST_W + 3, w_tstart);
+#pragma unroll
+            for (int i = 0; i < 5; i++) T::st(obs, ST_CPGP + i, cpg_p[i]);
+        }
+        int k = RESUME ? resume_k : 0;
+        bool gave_up = false;   // (HOT builds, wave-uniform) substep k needs a rare path; `s` is as that substep found it
+        for (; k < n_sub; k++) {  // gym_env.py:236-237, 207-216
             V tau[3];
-            if (cpg) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate
+            if (cpg && !(RESUME && k == resume_k)) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate (a resumed substep's tick has happened)
             QS_PHASE_SUB_BEGIN
             S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
-            if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts, cfg.payload_soft ? rec + R_BLOCK : nullptr), 0)) { StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = true; return z; }
+            if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts, blk, obs, k == n_sub - 1), 0)) { gave_up = true; break; }
             QS_PHASE_SUB(k)
             if (__builtin_expect(any_trace, 0)) {
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
             }
         }
-        if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.redo = false; return z; }
+        if (HOT && __builtin_expect(gave_up, 0)) {   // hand over to the full build: the state of this moment (the rest of the stash is in place)
+            stash_state(rec, s);
+            if (cpg) { T::st_leg(obs, ST_CMD, 3, cmd[0]); T::st_leg(obs, ST_CMD + 1, 3, cmd[1]); T::st_leg(obs, ST_CMD + 2, 3, cmd[2]); T::st_leg(obs, ST_CPGR, 1, cpg_r); T::st_leg(obs, ST_CPGTH, 1, cpg_th); }
+            StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.resume = k;
+            return z;
+        }
+        if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.resume = -1; return z; }
         QS_PHASE(32)
         if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;
@@ -655,7 +720,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         reward = reward + qsel(qgt(done, V(0.5f)), task_reward_end(cfg, t, term, now), V(0.0f));  // :250-251
         QS_PHASE(35)
         StepOut r; r.reward = reward; r.done = done; r.trunc = qsel(qgt(term, V(0.5f)), V(0.0f), done);  // :246
-        r.redo = false;
+        r.resume = -1;
         if (cfg.wrapper_mode != QS_WRAP_NONE) {
             float* w = rec + R_WRAP;
             M running = qlt(done, V(0.5f));
@@ -795,7 +860,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             for (int j = 0; j < 3; j++) cmd[j] = T::ld_leg(cfg.settle_cmd, j, 3);
             for (int n = 0; n < cfg.settle_steps; n++) {
                 V tau[3]; S::actuate(cfg, P, s, cmd, o, tau, true);
-                S::substep(cfg, P, s, tau, o, n == cfg.settle_steps - 1 || cfg.body_contacts, cfg.payload_soft ? rec + R_BLOCK : nullptr);
+                S::substep(cfg, P, s, tau, o, n == cfg.settle_steps - 1 || cfg.body_contacts, cfg.payload_soft ? rec + R_BLOCK : nullptr, obs, n == cfg.settle_steps - 1);
             }
             store_state(rec, s, o);
         } else {  // the record already holds a settled state (copied from the pre-settled pool)

@@ -257,10 +257,10 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
     // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch).  The full build's many-rows solver is inlined
     // (CALLS = false) in both kernels: as a real function (round 2's one-wave-per-SIMD build) it takes State / Out by reference, which
     // keeps them in memory around the call, and expressions that then span a store and a load are no longer contracted into the FMAs
-    // the common-path build forms -- the redo of a wave gave its other 15 environments different last bits than the common-path build
+    // the common-path build forms -- a wave on a rare path gave its other 15 environments different last bits than the common-path build
     // (tests/test_gpu_round2.py::test_results_do_not_depend_on_wave_mates); it also measured 4 % slower on the headline.
-    using E = Env<LaneDev, CONE, false, false>;
-    using EH = Env<LaneDev, CONE, true, false, SOFT>;   // the common path only; gives up where a rare path is needed (qs_core.h, HOT)
+    using E = Env<LaneDev, CONE, false, false>;         // the full build: resets, in-step settle
+    using EH = Env<LaneDev, CONE, true, false, SOFT>;   // the env step: common-path substeps, then (rare) the full build's (qs_env.h, Env::step)
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const qs_config& cfg = *cfgp;
@@ -323,24 +323,15 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
     const bool any_trace = tap.rows != nullptr && !settling && tap.env >= first && tap.env < first + QS_ENVS_PER_WAVE;   // wave-uniform
     QS_PHASE(13)
     float* const trow = any_trace && env == tap.env ? tap.rows : nullptr;
+    // The env step starts in the common-path build; a wave in which some environment needs a rare path goes on in the full build from the
+    // substep where that shows (Env::step: the state of that moment is in the LDS record, the prologue's results in the observation row).
+    // A payload_soft handle under the friction pyramid has its block's rows in no common-path build: its first substep already hands over.
     typename E::StepOut r;
-    r.redo = true;
-    if (SOFT || !cfg.payload_soft) {   // (a payload_soft handle under the friction pyramid: its rows are in no common-path build)
-        typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
-        r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.redo = rh.redo;
-        if (__builtin_expect(r.redo, 0)) {
-            // some environment of this wave needs a rare path: fetch the records again (the attempt wrote into its LDS copy) and run the
-            // env step of the whole wave with the full build
-            __syncthreads();
-            if (load_extent > 0) tile_load(s_rec, base, first, limit, load_extent, ls);
-            if (spawn || last) zero_tile_tail(s_rec, load_extent, ls);
-            __syncthreads();
-            if (spawn) { E::settle_spawn(cfg, rec, gid, job.y); LaneDev::sync(); }
-        }
+    {
+        const typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+        r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.resume = rh.resume;
     }
-    if (__builtin_expect(r.redo, 0)) {
-        r = E::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
-    }
+    if (__builtin_expect(r.resume >= 0, 0)) r = E::template step<true>(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length, r.resume);
     QS_PHASE(14)
     if (settling) {
         if (valid && (threadIdx.x & 3) == 0) atomicAdd(&stats[CTL_SETTLE_SUBSTEPS], (unsigned long long)settle_n);
@@ -623,6 +614,16 @@ __global__ void k_task_info(const float* __restrict__ recs, int n, float* __rest
     for (int k = 46; k < QS_TASK_DIM; k++) o[k] = 0.0f;
 }
 
+#ifdef QS_ISA_ONLY
+// tools/isa_headline.py: device code of the named step kernels only (seconds instead of minutes), for reading the ISA
+#if defined(QS_ISA_PYRAMID)
+template __global__ void k_step<false, false>(QS_STEP_ARGS);
+#elif !defined(QS_ISA_DENSE)
+template __global__ void k_step<true, false>(QS_STEP_ARGS);
+#else
+template __global__ void k_step_dense<true, false>(QS_STEP_ARGS);
+#endif
+#else
 // ------------------------------------------------------------------ host side of the C ABI
 thread_local char qs_g_err[512] = "";   // shared with qs_norm.hip
 #define g_err qs_g_err
@@ -1241,3 +1242,4 @@ int qs_debug_phases(unsigned long long* out32, int reset) {
 #endif
 
 }  // extern "C"
+#endif  // QS_ISA_ONLY

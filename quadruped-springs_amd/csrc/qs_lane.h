@@ -12,6 +12,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include "../../include/qs_amd.h"   // QS_MAX_OBS
 
 #if defined(__HIPCC__)
 #define QS_FN __host__ __device__ __forceinline__
@@ -134,6 +135,14 @@ struct LaneDev {
     typedef float Acc4 __attribute__((ext_vector_type(4)));
     static QS_DEV Acc4 acc4_zero() { Acc4 z = {0.0f, 0.0f, 0.0f, 0.0f}; return z; }
     static QS_DEV void outer_fma(float a, float b, Acc4& acc) { acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0); }
+    // the same four products on the vector ALU (DPP broadcast + v_fma_f32): what the FULL build uses -- its register pressure spills MFMA
+    // accumulators, and ROCm 7.2's "Rewrite AGPR-Copy-MFMA" pass (at work under -amdgpu-mfma-vgpr-form) segfaults on spilled ones.
+    // Bitwise the MFMA's result (both are one fused multiply-add per element; tests/test_gpu_round2.py::test_results_do_not_depend_on_wave_mates
+    // holds the two builds to each other).
+    static QS_DEV void outer_fma_valu(float a, float b, Acc4& acc) {
+        acc[0] = fmaf(bcast<0>(a), b, acc[0]); acc[1] = fmaf(bcast<1>(a), b, acc[1]);
+        acc[2] = fmaf(bcast<2>(a), b, acc[2]); acc[3] = fmaf(bcast<3>(a), b, acc[3]);
+    }
     template <int K> static QS_DEV float acc4_get(const Acc4& acc) { return acc[K]; }
     static QS_DEV float bcast_dyn(float x, int k) { return __shfl(x, (int)((threadIdx.x & 60u) | (unsigned)k), 64); }  // rare path only
     static QS_DEV int leg() { return (int)(threadIdx.x & 3u); }
@@ -147,6 +156,8 @@ struct LaneDev {
     static QS_DEV void st(float* rec, int i, float v) { if ((threadIdx.x & 3u) == 0) rec[i] = v; }
     static QS_DEV float first(float x) { return x; }
     static QS_DEV void opaque(float& x) { asm volatile("" : "+v"(x)); }
+    // the wave's sixteen observation rows (LDS) from the row of this lane's environment
+    static QS_DEV float* wave_scratch(float* row) { return row - (size_t)(threadIdx.x >> 2) * QS_MAX_OBS; }
     static QS_DEV void count_rare_path() { if (threadIdx.x == 0) atomicAdd(&qs_rare_path_substeps, 1ull); }
     static QS_DEV void count_self_narrow() { if (threadIdx.x == 0) atomicAdd(&qs_self_narrow_substeps, 1ull); }
     // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
@@ -214,11 +225,13 @@ struct LaneEmu {
         return r;
     }
     static void fma2(V4 a0, V4 a1, V4 b, V4& c0, V4& c1) { for (int l = 0; l < 4; l++) { c0.v[l] = fmaf(a0.v[l], b.v[l], c0.v[l]); c1.v[l] = fmaf(a1.v[l], b.v[l], c1.v[l]); } }
+    static float* wave_scratch(float* row) { return row; }
     static void count_rare_path() {}
     static void count_self_narrow() {}
     struct Acc4 { V4 k[4]; };
     static Acc4 acc4_zero() { Acc4 z; for (int i = 0; i < 4; i++) z.k[i] = V4(0.0f); return z; }
     static void outer_fma(V4 a, V4 b, Acc4& acc) { for (int K = 0; K < 4; K++) for (int l = 0; l < 4; l++) acc.k[K].v[l] = fmaf(a.v[K], b.v[l], acc.k[K].v[l]); }
+    static void outer_fma_valu(V4 a, V4 b, Acc4& acc) { outer_fma(a, b, acc); }
     template <int K> static V4 acc4_get(const Acc4& acc) { return acc.k[K]; }
     static bool any(M4 m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
     static V4 ld_leg(const float* rec, int base, int stride) { V4 r; for (int i = 0; i < 4; i++) r.v[i] = rec[base + stride * i]; return r; }

@@ -1,0 +1,373 @@
+// qs_rare.h -- the many-rows contact solve: one environment at a time, ONE ROW PER LANE.
+//
+// Rows beyond the three foot-contact rows of a leg -- a row per violated joint limit, normal + friction rows of up to two more support
+// points per leg (trunk corner, hip housing, thigh ends, knee end of the calf: a fallen robot rests on them), the six rows of the payload
+// block's fixed constraint -- make up to 54 rows per environment.  The quad layout of the common path (one leg per lane, 16 environments
+// per wave) has no room for them: rounds 2-3 swept them in VELOCITY space, twelve row slots per lane, every slot's candidate recomputed by
+// nine FMAs in all four lanes of the quad for the one that owned it -- ~38 instructions per row and sweep, ~216 k cycles per substep of
+// a wave with ONE fallen robot (profiles/r03_g_rare_path.md), and the launch ends with its slowest wave.
+//
+// Here the wave turns to one environment with rare rows at a time (the others wait; they get the common-path solver's result anyway):
+//   * the environment's quad writes its rows to LDS; lane p of the wave takes the row of position p in Bullet's sweep order
+//     (limits, payload rows, normals, friction pairs -- RarePos below);
+//   * every lane builds ITS column of the Delassus matrix, A[j][p] = w_j . w_p + [same body part] a_j . b_p, pre-scaled by -1 / A_pp,
+//     into registers, the other rows' data fetched with v_readlane: up to 54 values;
+//   * projected Gauss-Seidel in impulse space on lane-private candidates, as in the common path: a row update is one v_med3 (every lane
+//     clamps its own candidate), a subtract, one v_readlane of the owner's delta into an SGPR and one v_fmac of it into every lane's
+//     candidate -- six instructions per unilateral row, eighteen per friction pair, only for rows that exist (they are packed into
+//     consecutive lanes);
+//   * the environment leaves the sweeps when ITS residual is under PyBullet's threshold (not when the wave's sixteen are);
+//   * the impulses go back to the quad through LDS, which turns them into velocities (Sim::substep).
+// Same rows, order, clamps and early exit as before (and as oracle/qso_phys.c); a result depends on the environment's own rows only.
+//
+// LDS: 54 rows x 16 floats + 64 impulses = 3.7 KB of the wave's observation rows, which nobody uses between two epilogues.
+// (included by qs_core.h inside namespace qs, after SimTypes)
+#pragma once
+
+// positions of an environment's rows in sweep order: 0..11 joint limits (leg K, joint j: 3 K + j), 12..17 payload rows, 18..29 normals
+// (leg K, contact point c, 0 = the foot: 18 + 3 K + c), 30..53 friction rows (30 + 6 K + 2 c + t).  `row`: index into the quad lane's
+// twelve rows (contact point c at 3 c, 3 c + 1, 3 c + 2; joint limits at 9 + j); `rec`: index of the row's record in LDS.
+struct RarePos {
+    static constexpr int N = 54, LIM0 = 0, PAY0 = 12, NRM0 = 18, FRI0 = 30, REC_FLOATS = 16, LAM_OFF = N * REC_FLOATS, SCRATCH_FLOATS = LAM_OFF + 64;
+    static constexpr int leg(int p) { return p < PAY0 ? p / 3 : p < NRM0 ? 4 : p < FRI0 ? (p - NRM0) / 3 : (p - FRI0) / 6; }   // 4: the payload block
+    static constexpr int row(int p) { return p < PAY0 ? 9 + p % 3 : p < NRM0 ? p - PAY0 : p < FRI0 ? 3 * ((p - NRM0) % 3) : 3 * (((p - FRI0) % 6) / 2) + 1 + (p - FRI0) % 2; }
+    static constexpr int rec(int p) { return p >= PAY0 && p < NRM0 ? 48 + (p - PAY0) : 12 * leg(p) + row(p); }
+    static constexpr int normal_of(int p) { return NRM0 + 3 * ((p - FRI0) / 6) + ((p - FRI0) % 6) / 2; }   // friction position -> its contact's normal
+    static constexpr int of_row(int K, int r) { return r >= 9 ? 3 * K + (r - 9) : (r % 3 == 0 ? NRM0 + 3 * K + r / 3 : FRI0 + 6 * K + 2 * (r / 3) + (r % 3 - 1)); }
+};
+
+template <class T, bool CONE> struct RareSolver;
+// M(0) .. M(n - 1) for the first `count` of them, as nested ifs: once j reaches the (wave-uniform) count ONE branch leaves the lot, and the
+// code stays structured (a goto per row, or a switch that falls through the rows, comes out of LLVM's CFG structurizer as flag variables
+// and four branches per row: measured 1.2 k cycles per sweep of ten rows)
+#define QS_NEST12(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) if (6 < (count)) { M(6) if (7 < (count)) { M(7) if (8 < (count)) { M(8) if (9 < (count)) { M(9) if (10 < (count)) { M(10) if (11 < (count)) { M(11) }}}}}}}}}}}}
+#define QS_NEST18(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) if (6 < (count)) { M(6) if (7 < (count)) { M(7) if (8 < (count)) { M(8) if (9 < (count)) { M(9) if (10 < (count)) { M(10) if (11 < (count)) { M(11) if (12 < (count)) { M(12) if (13 < (count)) { M(13) if (14 < (count)) { M(14) if (15 < (count)) { M(15) if (16 < (count)) { M(16) if (17 < (count)) { M(17) }}}}}}}}}}}}}}}}}}
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ the wave-wide solver (device)
+// Only rows that exist take a lane: the limit and payload rows go to lanes 0.. (region A, in sweep order), the normals to lanes 18..
+// (region B) and the friction pairs to lanes 30.. (region C; pair k belongs to the normal in lane 18 + k), each region packed to its
+// start.  The unrolled sweep code then walks a region up to its fill count and meets no empty row -- the first version kept every row
+// at its fixed position and skipped the empty ones with a scalar branch each: 44 taken branches per sweep of a typical fallen robot
+// (10 rows), 1.7 k cycles per sweep of which the rows themselves were 0.4 k (profiles/r04_b_rare_phases.md).
+template <bool CONE> struct RareSolver<LaneDev, CONE> {
+    using Ty = SimTypes<LaneDev>;
+    using Row = typename Ty::Row;
+    using PayRows = typename Ty::PayRows;
+    static QS_DEV float rl(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
+    static QS_DEV int rli(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+
+    // xr: the twelve rows of this lane's leg; pay: the block's rows (replicated over the quad) or nullptr; mine: this lane's environment has
+    // rare rows; warm: the foot's warm-start impulse (already x cfg.warmstart x act); scr: RarePos::SCRATCH_FLOATS floats of LDS shared by
+    // the wave.  Results (for the lanes with `mine`, zero elsewhere): lam12 = the impulses of the lane's twelve rows, plam = the payload rows'.
+    static QS_DEV void solve(const qs_config& cfg, float mu, const Row* xr, const PayRows* pay, bool mine, float warm, float* scr, float* lam12, float* plam) {
+        using P = RarePos;
+        constexpr int A0 = 0, B0 = P::NRM0, C0 = P::FRI0, NA = P::NRM0, NB = P::FRI0 - P::NRM0;
+        const int lane = (int)threadIdx.x, slot = lane >> 2, K = lane & 3;
+        int* const map = reinterpret_cast<int*>(scr + P::LAM_OFF);    // (the impulse buffer doubles as the lane map while the rows are dealt out)
+#pragma unroll
+        for (int r = 0; r < 12; r++) lam12[r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) plam[k] = 0.0f;
+        const bool track = cfg.solver_residual_threshold > 0.0f;
+        const float thr = sqrtf(cfg.solver_residual_threshold);
+        const float big = 1e10f, bound = 500.0f * (float)cfg.dt;
+        // canonical position `lane` (RarePos): the record it would read, the region it belongs to
+        const int p_rec = lane < P::PAY0 ? 12 * (lane / 3) + 9 + lane % 3 : lane < P::NRM0 ? 48 + (lane - P::PAY0)
+                        : lane < P::FRI0 ? 12 * ((lane - P::NRM0) / 3) + 3 * ((lane - P::NRM0) % 3)
+                        : 12 * ((lane - P::FRI0) / 6) + 3 * (((lane - P::FRI0) % 6) / 2) + 1 + (lane - P::FRI0) % 2;
+        const unsigned long long below = (1ull << lane) - 1ull, maskA = (1ull << P::NRM0) - 1ull, maskB = ((1ull << P::FRI0) - 1ull) & ~maskA,
+                                 maskC = ((1ull << P::N) - 1ull) & ~(maskA | maskB);
+        unsigned long long todo = __ballot(mine);
+        while (todo) {
+            const int e = (__ffsll((long long)todo) - 1) >> 2;     // wave-uniform: the quad this pass works for
+            todo &= ~(0xFull << (4 * e));
+            const float mu_e = rl(mu, 4 * e);
+            // ---- the quad's rows -> LDS (16 floats a row: w 6, a 3, b 3, rhs, dinv, diag, act)
+            map[lane] = -1;
+            if (slot == e) {
+#pragma unroll
+                for (int r = 0; r < 12; r++) {
+                    float4* d = reinterpret_cast<float4*>(scr + (12 * K + r) * P::REC_FLOATS);
+                    d[0] = make_float4(xr[r].w[0], xr[r].w[1], xr[r].w[2], xr[r].w[3]);
+                    d[1] = make_float4(xr[r].w[4], xr[r].w[5], xr[r].jq[0], xr[r].jq[1]);
+                    d[2] = make_float4(xr[r].jq[2], xr[r].u[0], xr[r].u[1], xr[r].u[2]);
+                    d[3] = make_float4(xr[r].rhs, xr[r].dinv, xr[r].diag, xr[r].act);
+                }
+                // (payload rows: a = -(rB x e_k) resp. -e_k, the block's angular Jacobian; b = a / inertia.  The linear part only meets itself.)
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if ((k & 3) != K) continue;           // lane K of the quad writes rows K and K + 4
+                    float4* d = reinterpret_cast<float4*>(scr + (48 + k) * P::REC_FLOATS);
+                    if (pay) {
+                        const PayRows& q = *pay;
+                        const float ax = k == 0 ? 0.0f : k == 1 ? q.rB.z : k == 2 ? -q.rB.y : k == 3 ? -1.0f : 0.0f;
+                        const float ay = k == 0 ? -q.rB.z : k == 1 ? 0.0f : k == 2 ? q.rB.x : k == 4 ? -1.0f : 0.0f;
+                        const float az = k == 0 ? q.rB.y : k == 1 ? -q.rB.x : k == 5 ? -1.0f : 0.0f;
+                        d[0] = make_float4(q.w[k][0], q.w[k][1], q.w[k][2], q.w[k][3]);
+                        d[1] = make_float4(q.w[k][4], q.w[k][5], ax, ay);
+                        d[2] = make_float4(az, ax * q.mI, ay * q.mI, az * q.mI);
+                        d[3] = make_float4(q.rhs[k], q.dinv[k], q.diag[k], q.act);
+                    } else {
+                        d[0] = d[1] = d[2] = d[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                }
+            }
+            LaneDev::sync();
+            // ---- which rows exist; every one of them gets the next free lane of its region
+            const bool exists = lane < P::N && scr[p_rec * P::REC_FLOATS + 15] > 0.5f;
+            const unsigned long long live = __ballot(exists);
+            const int mA = __popcll(live & maskA), mB = __popcll(live & maskB);      // (wave-uniform; region C holds mB pairs)
+            if (exists) {
+                const unsigned long long reg = lane < P::NRM0 ? maskA : lane < P::FRI0 ? maskB : maskC;
+                map[(lane < P::NRM0 ? A0 : lane < P::FRI0 ? B0 : C0) + __popcll(live & reg & below)] = lane;
+            }
+            LaneDev::sync();
+            const int cp = map[lane];                 // the canonical position of this lane's row, -1: none
+            const bool alive = cp >= 0;
+            LaneDev::sync();
+            scr[P::LAM_OFF + lane] = 0.0f;            // the buffer turns into the impulses by canonical position; the feet's warm start goes in
+            LaneDev::sync();
+            if (slot == e) scr[P::LAM_OFF + P::NRM0 + 3 * K] = warm;
+            LaneDev::sync();
+            // ---- this lane's row
+            float w[6], a[3], b[3], rhs, dinv, diag, lam, lo, hi;
+            int grp;
+            {
+                const int c = alive ? cp : 0;
+                grp = c < P::PAY0 ? c / 3 : c < P::NRM0 ? 4 : c < P::FRI0 ? (c - P::NRM0) / 3 : (c - P::FRI0) / 6;
+                const int rec = c < P::PAY0 ? 12 * grp + 9 + c % 3 : c < P::NRM0 ? 48 + (c - P::PAY0)
+                              : c < P::FRI0 ? 12 * grp + 3 * ((c - P::NRM0) % 3) : 12 * grp + 3 * (((c - P::FRI0) % 6) / 2) + 1 + (c - P::FRI0) % 2;
+                const float4* s4 = reinterpret_cast<const float4*>(scr + rec * P::REC_FLOATS);
+                const float4 r0 = s4[0], r1 = s4[1], r2 = s4[2], r3 = s4[3];
+                w[0] = r0.x; w[1] = r0.y; w[2] = r0.z; w[3] = r0.w; w[4] = r1.x; w[5] = r1.y;
+                a[0] = r1.z; a[1] = r1.w; a[2] = r2.x;
+                b[0] = r2.y; b[1] = r2.z; b[2] = r2.w;
+                rhs = r3.x; dinv = r3.y; diag = r3.z;
+                lam = alive ? scr[P::LAM_OFF + c] : 0.0f;
+                const bool payrow = c >= P::PAY0 && c < P::NRM0;
+                lo = payrow ? -bound : 0.0f; hi = payrow ? bound : big;
+                if (!alive) { grp = -1; rhs = 0.0f; diag = 0.0f; }
+            }
+            QS_PHASE_G(41)
+            // ---- this lane's column of the Delassus matrix, x (-1 / A_pp): Ap[J] = what a unit impulse of the row in lane J does to this
+            // lane's candidate.  The row data of lane J come over by v_readlane (SGPRs); the self entry is zero.
+            float Ap[P::N], ApR[NA];
+            {
+                const float nd = -dinv;
+                float ws[6], bs[3];
+#pragma unroll
+                for (int i = 0; i < 6; i++) ws[i] = w[i] * nd;
+#pragma unroll
+                for (int i = 0; i < 3; i++) bs[i] = b[i] * nd;
+#define QS_W_COL(DST, J)                                                                                               \
+    {                                                                                                                  \
+        const int l_ = (J);                                                                                            \
+        float t_ = rl(w[0], l_) * ws[0];                                                                               \
+        t_ = fmaf(rl(w[1], l_), ws[1], t_); t_ = fmaf(rl(w[2], l_), ws[2], t_); t_ = fmaf(rl(w[3], l_), ws[3], t_);     \
+        t_ = fmaf(rl(w[4], l_), ws[4], t_); t_ = fmaf(rl(w[5], l_), ws[5], t_);                                         \
+        float u_ = rl(a[0], l_) * bs[0];                                                                               \
+        u_ = fmaf(rl(a[1], l_), bs[1], u_); u_ = fmaf(rl(a[2], l_), bs[2], u_);                                         \
+        t_ = grp == rli(grp, l_) ? t_ + u_ : t_;                                                                       \
+        DST = lane == l_ ? 0.0f : t_;                                                                                  \
+    }
+                // the rows of region A are swept forwards and backwards in turn: ApR[j] is the entry of the row that the BACKWARD sweep meets
+                // j-th (lane mA - 1 - j), so that both directions index their coefficients with constants
+#define QS_W_COL_A(j) QS_W_COL(Ap[A0 + (j)], A0 + (j))
+#define QS_W_COL_R(j) QS_W_COL(ApR[(j)], mA - 1 - (j))
+#define QS_W_COL_B(j) QS_W_COL(Ap[B0 + (j)], B0 + (j)) QS_W_COL(Ap[C0 + 2 * (j)], C0 + 2 * (j)) QS_W_COL(Ap[C0 + 2 * (j) + 1], C0 + 2 * (j) + 1)
+                QS_NEST18(mA, QS_W_COL_A)
+                QS_NEST18(mA, QS_W_COL_R)
+                QS_NEST12(mB, QS_W_COL_B)
+#undef QS_W_COL_A
+#undef QS_W_COL_R
+#undef QS_W_COL_B
+#undef QS_W_COL
+            }
+            QS_PHASE_G(42)
+            // ---- candidates: rhs - dinv sum_{j != p} A_pj lambda_j; the warm start of the feet's normal rows is in already
+            float res = rhs;
+#define QS_W_WARM(j) res = fmaf(Ap[B0 + (j)], rl(lam, B0 + (j)), res);
+            QS_NEST12(mB, QS_W_WARM)
+#undef QS_W_WARM
+            // one row: every lane clamps its own candidate, the owner's change goes round
+#define QS_W_ROW(COEF, J)                                                                                              \
+    {                                                                                                                  \
+        const int l_ = (J);                                                                                            \
+        const float cand = qmed3(res, lo, hi);                                                                         \
+        const float d_ = rl(cand - lam, l_);                                                                           \
+        lam = lane == l_ ? cand : lam;                                                                                 \
+        res = fmaf((COEF), d_, res);                                                                                   \
+    }
+            // the friction rows of contact point KK (lanes C0 + 2 KK, + 1; its normal sits in lane B0 + KK): implicit cone -- both from the
+            // same candidates, their sum scaled back onto the disc of radius mu x the normal impulse --, or the pyramid: one by one, each
+            // bounded by mu x the normal impulse and left alone while that is not positive (Bullet's rule)
+#define QS_W_FRICTION(KK)                                                                                              \
+    {                                                                                                                  \
+        constexpr int FP = C0 + 2 * (KK);                                                                              \
+        const float ln_ = rl(lam, B0 + (KK)), lim_ = mu_e * ln_;                                                       \
+        if (CONE) {                                                                                                    \
+            const float ca_ = rl(res, FP), cb_ = rl(res, FP + 1);                                                      \
+            const float r2_ = fmaf(cb_, cb_, ca_ * ca_);                                                               \
+            const float sc_ = qmin(lim_ * qrsqrt(qmax(r2_, 1e-30f)), 1.0f);                                            \
+            const float cand = res * sc_;                                                                              \
+            const float dl_ = cand - lam;                                                                              \
+            const float da_ = rl(dl_, FP), db_ = rl(dl_, FP + 1);                                                      \
+            lam = (lane >> 1) == (FP >> 1) ? cand : lam;                                                               \
+            res = fmaf(Ap[FP], da_, res); res = fmaf(Ap[FP + 1], db_, res);                                            \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; t_++) {                                                         \
+                const float cl_ = qmed3(res, -lim_, lim_);                                                             \
+                const float d_ = ln_ > 0.0f ? rl(cl_ - lam, FP + t_) : 0.0f;                                           \
+                lam = lane == FP + t_ && ln_ > 0.0f ? cl_ : lam;                                                       \
+                res = fmaf(Ap[FP + t_], d_, res);                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+            int n_sweeps = 0;
+            const int mA_fix = mA, mB_fix = mB;
+            for (int it = 0; it < cfg.solver_iters; it++) {
+                n_sweeps++;
+                const float lam_in = lam;
+                // (opaque copies: otherwise the compiler hoists the ~100 loop-invariant comparisons `j < count` and `lane == j` out of the
+                // sweep loop as lane masks, spills them into VGPR lanes and fetches each back with two v_readlane per row)
+                int mA = mA_fix, mB = mB_fix, lane = (int)threadIdx.x;
+                asm volatile("" : "+s"(mA), "+s"(mB), "+v"(lane));
+#define QS_W_FWD_A(j) QS_W_ROW(Ap[A0 + (j)], A0 + (j))
+#define QS_W_BWD_A(j) QS_W_ROW(ApR[(j)], mA - 1 - (j))
+#define QS_W_FWD_B(j) QS_W_ROW(Ap[B0 + (j)], B0 + (j))
+#define QS_W_FWD_C(j) QS_W_FRICTION(j)
+                if (it & 1) { QS_NEST18(mA, QS_W_FWD_A) }   // limit rows, then the payload rows, forwards; on even sweeps the same backwards
+                else { QS_NEST18(mA, QS_W_BWD_A) }
+                QS_NEST12(mB, QS_W_FWD_B)
+                QS_NEST12(mB, QS_W_FWD_C)
+#undef QS_W_FWD_A
+#undef QS_W_BWD_A
+#undef QS_W_FWD_B
+#undef QS_W_FWD_C
+                // PyBullet's solverResidualThreshold: every row moved once in this sweep, by lam - lam_in
+                if (track && !__any(fabsf((lam - lam_in) * diag) > thr)) break;
+            }
+#undef QS_W_FRICTION
+#undef QS_W_ROW
+            QS_PHASE_G(43)
+#if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+            if (threadIdx.x == 0) {   // all workgroups: solves, sweeps, live rows, live contact points (normals)
+                atomicAdd(&qs_phase_cycles[0], 1ull); atomicAdd(&qs_phase_cycles[46], (unsigned long long)n_sweeps);
+                atomicAdd(&qs_phase_cycles[47], (unsigned long long)__popcll(live));
+                atomicAdd(&qs_phase_cycles[30], (unsigned long long)mB);
+            }
+#endif
+            (void)n_sweeps;
+            // ---- the impulses back to the quad (by canonical position; rows that do not exist keep their zero)
+            if (alive) scr[P::LAM_OFF + cp] = lam;
+            LaneDev::sync();
+            if (slot == e) {
+#pragma unroll
+                for (int r = 0; r < 12; r++) lam12[r] = scr[P::LAM_OFF + (r >= 9 ? 3 * K + (r - 9) : (r % 3 == 0 ? P::NRM0 + 3 * K + r / 3 : P::FRI0 + 6 * K + 2 * (r / 3) + (r % 3 - 1)))];
+#pragma unroll
+                for (int k = 0; k < 6; k++) plam[k] = scr[P::LAM_OFF + P::PAY0 + k];
+            }
+            LaneDev::sync();
+            QS_PHASE_G(44)
+        }
+    }
+};
+#endif
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// ------------------------------------------------------------------ the same solve for the 4-wide host emulation (tests only): one
+// environment, plain loops over its rows in the same order
+template <bool CONE> struct RareSolver<LaneEmu, CONE> {
+    using Ty = SimTypes<LaneEmu>;
+    using Row = typename Ty::Row;
+    using PayRows = typename Ty::PayRows;
+    static void solve(const qs_config& cfg, V4 mu, const Row* xr, const PayRows* pay, M4 mine, V4 warm, float*, V4* lam12, V4* plam) {
+        using P = RarePos;
+        for (int r = 0; r < 12; r++) lam12[r] = V4(0.0f);
+        for (int k = 0; k < 6; k++) plam[k] = V4(0.0f);
+        if (!mine.v[0]) return;
+        float w[P::N][6], a[P::N][3], b[P::N][3], rhs[P::N], dinv[P::N], diag[P::N], lam[P::N], res[P::N];
+        bool live[P::N];
+        for (int p = 0; p < P::N; p++) {
+            const int r = P::row(p);
+            if (p >= P::PAY0 && p < P::NRM0) {
+                const int k = p - P::PAY0;
+                live[p] = pay != nullptr && pay->act.v[0] > 0.5f;
+                for (int i = 0; i < 6; i++) w[p][i] = pay ? pay->w[k][i].v[0] : 0.0f;
+                const float rx = pay ? pay->rB.x.v[0] : 0.0f, ry = pay ? pay->rB.y.v[0] : 0.0f, rz = pay ? pay->rB.z.v[0] : 0.0f, mI = pay ? pay->mI.v[0] : 0.0f;
+                const float ja[6][3] = {{0, -rz, ry}, {rz, 0, -rx}, {-ry, rx, 0}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}};
+                for (int i = 0; i < 3; i++) { a[p][i] = ja[k][i]; b[p][i] = ja[k][i] * mI; }
+                rhs[p] = pay ? pay->rhs[k].v[0] : 0.0f; dinv[p] = pay ? pay->dinv[k].v[0] : 0.0f; diag[p] = pay ? pay->diag[k].v[0] : 0.0f;
+            } else {
+                const int L = P::leg(p);
+                const Row& q = xr[r];
+                live[p] = q.act.v[L] > 0.5f;
+                for (int i = 0; i < 6; i++) w[p][i] = q.w[i].v[L];
+                for (int i = 0; i < 3; i++) { a[p][i] = q.jq[i].v[L]; b[p][i] = q.u[i].v[L]; }
+                rhs[p] = q.rhs.v[L]; dinv[p] = q.dinv.v[L]; diag[p] = q.diag.v[L];
+            }
+            lam[p] = 0.0f;
+        }
+        for (int L = 0; L < 4; L++) if (live[P::NRM0 + 3 * L]) lam[P::NRM0 + 3 * L] = warm.v[L];
+        static float A[P::N][P::N];   // A[j][p] x (-1 / A_pp), self entries zero
+        for (int p = 0; p < P::N; p++)
+            for (int j = 0; j < P::N; j++) {
+                float t = 0.0f;
+                if (live[p] && live[j] && j != p) {
+                    const float nd = -dinv[p];
+                    t = w[j][0] * (w[p][0] * nd);
+                    for (int i = 1; i < 6; i++) t = fmaf(w[j][i], w[p][i] * nd, t);
+                    if (P::leg(j) == P::leg(p)) {
+                        float u = a[j][0] * (b[p][0] * nd);
+                        for (int i = 1; i < 3; i++) u = fmaf(a[j][i], b[p][i] * nd, u);
+                        t = t + u;
+                    }
+                }
+                A[j][p] = t;
+            }
+        for (int p = 0; p < P::N; p++) {
+            res[p] = rhs[p];
+            for (int L = 0; L < 4; L++) if (live[P::NRM0 + 3 * L]) res[p] = fmaf(A[P::NRM0 + 3 * L][p], lam[P::NRM0 + 3 * L], res[p]);
+        }
+        const float mu_e = mu.v[0], big = 1e10f, bound = 500.0f * (float)cfg.dt;
+        const bool track = cfg.solver_residual_threshold > 0.0f;
+        const float thr = sqrtf(cfg.solver_residual_threshold);
+        auto apply = [&](int p, float cand) {
+            const float d = cand - lam[p];
+            lam[p] = cand;
+            for (int q = 0; q < P::N; q++) res[q] = fmaf(A[p][q], d, res[q]);
+        };
+        auto row = [&](int p, float lo, float hi) { if (live[p]) apply(p, fminf(fmaxf(res[p], lo), hi)); };
+        for (int it = 0; it < cfg.solver_iters; it++) {
+            float lam_in[P::N];
+            for (int p = 0; p < P::N; p++) lam_in[p] = lam[p];
+            if (it & 1) { for (int p = 0; p < P::PAY0; p++) row(p, 0.0f, big); for (int p = P::PAY0; p < P::NRM0; p++) row(p, -bound, bound); }
+            else { for (int p = P::NRM0 - 1; p >= P::PAY0; p--) row(p, -bound, bound); for (int p = P::PAY0 - 1; p >= 0; p--) row(p, 0.0f, big); }
+            for (int p = P::NRM0; p < P::FRI0; p++) row(p, 0.0f, big);
+            for (int f = P::FRI0; f < P::N; f += 2) {
+                if (!live[f]) continue;
+                const float ln = lam[P::normal_of(f)], lim = mu_e * ln;
+                if (CONE) {
+                    const float ca = res[f], cb = res[f + 1];
+                    const float r2 = fmaf(cb, cb, ca * ca);
+                    const float sc = fminf(lim * (1.0f / sqrtf(fmaxf(r2, 1e-30f))), 1.0f);
+                    const float na = ca * sc, nb = cb * sc, da = na - lam[f], db = nb - lam[f + 1];
+                    lam[f] = na; lam[f + 1] = nb;
+                    for (int q = 0; q < P::N; q++) { res[q] = fmaf(A[f][q], da, res[q]); res[q] = fmaf(A[f + 1][q], db, res[q]); }
+                } else {
+                    for (int t = 0; t < 2; t++) apply(f + t, ln > 0.0f ? fminf(fmaxf(res[f + t], -lim), lim) : lam[f + t]);
+                }
+            }
+            if (track) {
+                bool moving = false;
+                for (int p = 0; p < P::N; p++) moving = moving || (live[p] && fabsf((lam[p] - lam_in[p]) * diag[p]) > thr);
+                if (!moving) break;
+            }
+        }
+        for (int L = 0; L < 4; L++)
+            for (int r = 0; r < 12; r++) lam12[r].v[L] = lam[P::of_row(L, r)];
+        for (int k = 0; k < 6; k++) plam[k] = V4(lam[P::PAY0 + k]);
+    }
+};
+#endif

@@ -291,9 +291,19 @@ def build_config(
     mass_inertia_rule="collision_shape",
     info_fields=True,
     payload="weld",
-    **_ignored,
+    on_rack=False,
+    render=False,
+    camera_mode="CLASSIC",
+    curriculum_level=0.0,
+    verbose=0,
 ):
-    """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config)."""
+    """Returns (QsConfig, meta). `meta` keeps the python-side view (names, limits, robot config).
+
+    The keywords are the reference constructor's (quadruped_gym_env.py:52-70) plus this build's own; anything else is a TypeError, as it
+    is there (a misspelt `enable_spring=True` must not silently simulate without springs).  Of the reference's, `camera_mode`,
+    `curriculum_level` and `verbose` are accepted and unused (rendering / dead curriculum code), `on_rack` and `render` must be False."""
+    if on_rack or render:
+        raise NotImplementedError("on_rack / render need the PyBullet GUI path, which this build does not provide")
     if motor_control_mode == "TORQUE" and isRLGymInterface:
         # gym_env.py:167-168
         raise ValueError(f"the motor control mode {motor_control_mode} not" "implemented yet for RL Gym interface.")

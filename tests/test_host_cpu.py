@@ -96,3 +96,18 @@ def test_symmetric_action_kat_from_survey():
     cfg, _ = build_config(enable_springs=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC")
     cmd = Oracle(cfg).action_to_command([0.3, -0.5, 0.9, -1, 1, 0.1])
     np.testing.assert_allclose(cmd, [0.06, 0.535398, -1.0275, -0.06, 0.535398, -1.0275, -0.2, 1.285398, -1.6475, 0.2, 1.285398, -1.6475], atol=1e-6)
+
+
+def test_unknown_keywords_are_refused():
+    """The reference's constructor raises TypeError for a keyword it does not know (quadruped_gym_env.py:52-70); so does build_config --
+    a typo must not silently run another simulation.  Its rendering / curriculum keywords are accepted and unused."""
+    import pytest
+    from qs_amd.config import build_config
+    with pytest.raises(TypeError):
+        build_config(n_envs=1, enable_spring=True)          # (enable_springs)
+    with pytest.raises(TypeError):
+        build_config(n_envs=1, reset_lookahead=4)           # (a QuadrupedVecEnv keyword, not a configuration field)
+    cfg, _ = build_config(n_envs=1, camera_mode="CLASSIC", curriculum_level=0.3, verbose=1, on_rack=False, render=False)
+    assert cfg.n_envs == 1
+    with pytest.raises(NotImplementedError):
+        build_config(n_envs=1, render=True)
