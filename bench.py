@@ -139,6 +139,12 @@ def parse_args(argv=None):
                     help="PyBullet's implicit cone (its default, and this build's) or the friction pyramid with Bullet's skip rule")
     ap.add_argument("--solver-residual-threshold", type=float, default=1e-7,
                     help="PyBullet solverResidualThreshold (its default 1e-7 is this build's default); 0 = always int(300/action_repeat) sweeps")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the benchmark.  gloo is the TEST MODE of this file's multi-rank code (tests/test_bench_launch.py): CPU "
+                         "ranks run the same launcher, barrier, MAX / MIN reduction and JSON path around a stand-in environment named by "
+                         "--standin; what it prints is not a measurement")
+    ap.add_argument("--standin", default="", help=argparse.SUPPRESS)   # module:factory of the gloo test mode's environment (lives under tests/)
+    ap.add_argument("--spread-steps", type=int, default=1000, help=argparse.SUPPRESS)   # steps of the episode-phase spreading in the preparation
     ap.add_argument("--env-kw", nargs="*", action="extend", default=[], metavar="KEY=VALUE",
                     help="extra QuadrupedVecEnv keywords for experiments (python literals, anything else is taken as a string), "
                          "e.g. self_collision=False payload=soft env_randomizer_mode=MASS_RANDOMIZER")
@@ -191,7 +197,7 @@ def launch_ranks(args, argv):
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks
         envs.append(e)
-    visible = visible_gpus()
+    visible = args.gpus if args.backend == "gloo" else visible_gpus()      # (the gloo test mode runs its ranks on the CPU)
     if visible < args.gpus and not args.dry_launch:
         print(f"bench.py: --gpus {args.gpus} but {visible} GPU(s) visible on this box; refusing to report a {args.gpus}-GPU line from fewer devices",
               file=sys.stderr)
@@ -250,23 +256,35 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus
-    if rank != 0:
-        # only rank 0 reports: whatever the other ranks (or the RCCL they load) write to stdout goes to stderr, so that the JSON line
-        # stays the last thing on the job's stdout whichever rank exits last
-        sys.stdout.flush()
-        os.dup2(2, 1)
+    # Only rank 0 reports, and only its JSON line: whatever else any rank -- or the RCCL / gloo it loads, which print banners through C stdio --
+    # writes to stdout goes to stderr.  Rank 0 keeps a duplicate of the real stdout for the line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1) if rank == 0 else None
+    os.dup2(2, 1)
     sharded = args.workload == "config4_sharded"
-    if not torch.cuda.is_available():
+    gloo = args.backend == "gloo"
+    if gloo and not args.standin:
+        raise SystemExit("bench.py --backend gloo is the test mode of the multi-rank code and needs --standin module:factory (see tests/test_bench_launch.py); "
+                         "the simulation step has no CPU path")
+    if not gloo and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the simulation step has no CPU path")
     if world > 1 or sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from qs_amd.vec_env import QuadrupedVecEnv
+        if gloo:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+    if gloo:
+        dev = torch.device("cpu")
+        import importlib
+        mod, _, fac = args.standin.partition(":")
+        QuadrupedVecEnv = getattr(importlib.import_module(mod), fac)
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        from qs_amd.vec_env import QuadrupedVecEnv
     n_default, kw = workload(args.workload)
     kw["solver_residual_threshold"] = args.solver_residual_threshold
     kw["friction_model"] = args.friction_model
@@ -292,7 +310,8 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not gloo:
+            torch.cuda.synchronize()
 
     def run(env_kw, with_exchange):
         """Preparation + the timed region for one handle; returns the measurements of this rank."""
@@ -333,9 +352,10 @@ def main():
         ids = torch.arange(n, device=dev)
         for gidx in range(groups):
             env.reset_tensor((ids % groups == gidx).to(torch.uint8))
-            for i in range(1000 // groups):
+            for i in range(args.spread_steps // groups):
                 local_step(acts[i % n_act])
-            torch.cuda.current_stream().synchronize()
+            if not gloo:
+                torch.cuda.current_stream().synchronize()
         # ... and let the reset rate and with it the settle lanes reach their steady state (episodes of random actions last ~600 steps, a
         # settle takes 250 launches, a cohort of lanes starts every 50)
         for i in range(args.preroll):
@@ -411,7 +431,7 @@ def main():
                                                                             float(args.solver_residual_threshold)):
                     pmc, pmc_file = p, os.path.relpath(f, REPO)
                     break
-            if pmc is not None:
+            if pmc is not None and not gloo:
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
                 if "sq_insts_valu" in pmc:
                     # the roof that does bound this kernel: one wave64 fp32 VALU instruction per SIMD every 4 cycles (one wave's issue rate)
@@ -440,7 +460,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
+            "config": {"backend": args.backend, "workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
                        "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True, "preroll_steps": args.preroll,
                        "reset_lookahead": K,
@@ -484,12 +504,12 @@ def main():
     if world > 1 or sharded:
         torch.distributed.destroy_process_group()
     if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which (piped) would otherwise
-        # be flushed at process exit, after anything printed here
+        # the JSON line is the ONLY thing on the job's stdout (C stdio buffers of RCCL's banner are flushed towards stderr first)
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -99,7 +99,7 @@ typedef struct qs_config {
                                   * whose state is not ready (K consecutive episodes shorter than one settle) settles in place and is
                                   * counted (QS_COUNTER_RESET_STALLS).  Ignored under QS_RAND_KEEP.  N x K x 1152 bytes. */
     int32_t env_id_offset;       /* global id of environment 0 (sharded runs): RNG streams are keyed by the global id */
-    int32_t wrapper_mode;        /* 0 none, 1 LandingWrapper, 2 GoToRestWrapper as a per-environment mode machine */
+    int32_t wrapper_mode;        /* QS_WRAP_*: none, or one of the reference's six landing / go-to-rest wrappers as a per-environment phase machine */
     uint64_t seed;
     double dt;
     double filt_b[3], filt_a[3]; /* scipy.signal.butter(2, 3 Hz) at 1/env_dt, action_filter.py:191-213 */
@@ -116,8 +116,8 @@ typedef struct qs_config {
     float task_p[16];
     float contact_slop;        /* btContactSolverInfo::m_linearSlop (PhysicsServerCommandProcessor sets 1e-5): added to a contact's distance
                                 * before the positional / speculative error terms of its normal row */
-    int32_t body_contacts;     /* 1: trunk / hip / thigh / calf primitives that touch the plane push back (normal + friction rows on the
-                                * rare path, at most two support points per leg); 0: they only count as invalid contacts (quadruped.py:243-249) */
+    int32_t body_contacts;     /* 1: trunk / hip / thigh / calf primitives that touch the plane push back (normal + friction rows in the
+                                * many-rows solve, at most two support points per leg); 0: they only count as invalid contacts (quadruped.py:243-249) */
     int32_t self_collision;    /* 1: link-link contacts that involve a calf are detected and counted as invalid contacts
                                 * (URDF_USE_SELF_COLLISION quadruped.py:533-539, rule :237-241); 0: no link-link test */
     int32_t info_fields;       /* 1: every step also writes the info block of the records (foot forces and flags, motor and spring torque, the
@@ -126,8 +126,9 @@ typedef struct qs_config {
                                 * and the getters fail */
     int32_t payload_soft;      /* 0: the payload block of the mass randomizer is welded to the trunk (the default: same motion to micrometres,
                                 * tests/test_body_contacts.py, and the common-path kernel); 1: a second body held by a six-row fixed constraint
-                                * in the same PGS, as the reference builds it (quadruped.py:796-819) -- every substep then takes the many-rows
-                                * solver (about 6x the step time); its state: QS_INFO_PAYLOAD_BLOCK */
+                                * in the same PGS, as the reference builds it (quadruped.py:796-819): under the implicit cone its rows ride
+                                * with the foot rows in the common-path solver (about 3x the step time: the constraint's rows need all the
+                                * sweeps), under the friction pyramid every substep takes the many-rows solve; its state: QS_INFO_PAYLOAD_BLOCK */
     float reserved_f[3];
     /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
@@ -226,10 +227,10 @@ enum { QS_COUNTER_SETTLE_SUBSTEPS = 0,      /* settle substeps executed (k_reset
        QS_COUNTER_LOOKAHEAD_SERVED = 2,     /* resets that took a look-ahead state */
        QS_COUNTER_LOOKAHEAD_SETTLED = 3,    /* look-ahead states the settle lanes have delivered */
        QS_COUNTER_LIMIT_PATH_SUBSTEPS = 4,  /* wave-substeps in which some joint of the wave's 16 environments sat at a stop or (body_contacts)
-                                               a non-foot link touched the plane: those run the slow many-rows-per-leg solver (per
-                                               process, not per handle) */
-       QS_COUNTER_SELF_NARROW_SUBSTEPS = 5, /* wave-substeps whose self-collision broad phase found a calf close enough to another leg or
-                                               the trunk to run the link-link tests (per process) */
+                                               a non-foot link touched the plane: those run the many-rows solve (of this handle; per
+                                               process before round 4) */
+       QS_COUNTER_SELF_NARROW_SUBSTEPS = 5, /* wave-substeps (the last of an env step) whose self-collision broad phase found a calf close
+                                               enough to another leg or the trunk to run the link-link tests (of this handle) */
        QS_COUNTER_RESET_STALLS = 6,         /* resets of a handle with reset_lookahead > 0 whose state was not ready: settled in place */
        QS_COUNTER_LOOKAHEAD_BACKLOG = 7     /* reset states the environments' look-ahead windows lack and no settle lane has taken yet */ };
 int qs_counter(qs_handle* h, int which, uint64_t* value);

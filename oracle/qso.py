@@ -16,7 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build(force=False):
     targets = [os.path.join(_HERE, n) for n in ("libqso_f64.so", "libqso_f32.so")]
-    if force or not all(os.path.exists(t) for t in targets):
+    stale = force or not all(os.path.exists(t) for t in targets)
+    if not stale:   # (the sources may be newer than libraries that travelled with the tree)
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
+        stale = max(os.path.getmtime(f) for f in srcs) > min(os.path.getmtime(t) for t in targets)
+    if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return targets
 
@@ -83,6 +87,10 @@ class Oracle:
     def set_state(self, s):
         s = np.ascontiguousarray(s, self.real).reshape(self.n, 37)
         self._check(self.lib.qso_set_state(self.h, self._p(s)))
+
+    def set_warm(self, w):
+        w = np.ascontiguousarray(w, self.real).reshape(self.n, 4)
+        self._check(self.lib.qso_set_warm(self.h, self._p(w)))
 
     _INFO_DIM = {0: 4, 1: 4, 2: 12, 3: 12, 4: 48, 5: 1, 6: 24, 7: 4, 8: 12, 10: 4}
 

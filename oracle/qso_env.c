@@ -868,6 +868,14 @@ int qso_set_state(qso_handle* h, const real* st) {
     return 0;
 }
 
+/* contact warm start of the feet (the normal impulses of the last substep): what qso_set_state zeroes; lets a test re-seat the oracle in a
+ * device state that carries its warm start (tests/test_gpu_parity.py::test_full_size_oracle_sampled) */
+int qso_set_warm(qso_handle* h, const real* w) {
+    for (int i = 0; i < h->cfg.n_envs; i++)
+        for (int L = 0; L < 4; L++) h->env[i].warm[L] = w[(size_t)i * 4 + L];
+    return 0;
+}
+
 static void pack_params(const qso_env* e, real* o) {
     o[0] = e->mu;
     for (int k = 0; k < 3; k++) { o[1 + k] = e->k[k]; o[4 + k] = e->b[k]; o[7 + k] = e->rest[k]; o[10 + k] = e->kp[k]; o[13 + k] = e->kd[k]; o[17 + k] = e->m_leg[k]; o[21 + k] = e->r_pay[k]; }

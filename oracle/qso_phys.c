@@ -8,9 +8,13 @@
  *   1. forward dynamics: Featherstone articulated-body algorithm, floating base, link coordinates
  *      (R. Featherstone, Rigid Body Dynamics Algorithms, 2008, Table 9.4), gravity (0,0,-g)
  *   2. v* = v + dt*a, every generalized velocity clamped to +-vel_cap (maxJointVelocity, quadruped.py:678-683)
- *   3. collision: foot sphere r=0.02 against the plane z=0; other link primitives only flag invalid contacts
- *   4. constraint rows: per active foot 1 normal + 2 friction rows (pyramid, |f_t| <= mu*f_n), violated joint
- *      limits as unilateral rows; projected Gauss-Seidel, `solver_iters` sweeps (gym_env.py:113,302), velocity space
+ *   3. collision: foot sphere r=0.02 against the plane z=0; the other link primitives (trunk box, hip cylinders, thigh and calf boxes,
+ *      payload block) flag invalid contacts and, under cfg.body_contacts, push back at up to two support points per leg; link-link
+ *      contacts that involve a calf (self-collision rule) are counted
+ *   4. constraint rows: per contact point 1 normal + 2 friction rows -- implicit cone (cfg.friction_cone, PyBullet's default: both friction
+ *      rows from the same velocities, projected onto the disc of radius mu*f_n) or pyramid (|f_t| <= mu*f_n per direction) --, violated
+ *      joint limits as unilateral rows, the six rows of the payload block's fixed constraint (cfg.payload_soft); projected Gauss-Seidel in
+ *      Bullet's row order, at most `solver_iters` sweeps (gym_env.py:113,302) with PyBullet's residual early exit, velocity space
  *   5. semi-implicit Euler on positions (quaternion by exponential map)
  */
 #include "qso_internal.h"
@@ -605,8 +609,8 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             real resid = dl / r->dinv;
             if (resid * resid > maxres2) maxres2 = resid * resid;
         }
-        /* solverResidualThreshold (PyBullet default 1e-7; this build's default 0: only an exactly stationary sweep ends early,
-           which cannot change the result) */
+        /* solverResidualThreshold (PyBullet's default 1e-7 is this build's default too; 0: only an exactly stationary sweep ends
+           early, which cannot change the result) */
         if (maxres2 <= (real)cfg->solver_residual_threshold) break;
     }
     for (int i = 0; i < nn; i++) {

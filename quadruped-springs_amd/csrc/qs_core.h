@@ -1091,7 +1091,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             M ctr = qand(qand(qlt(mc, V(TRUNK_HALF[1] + MARGIN)), qgt(qmax(p3.z, rf.z) + 0.02f, V(-TRUNK_HALF[2] - MARGIN))), qlt(nc, V(TRUNK_HALF[0] + MARGIN)));
             if (__builtin_expect(T::any(qor(qor(cy1, cx2), qor(c3, ctr))), 0)) {
                 if (HOT) return true;
-                T::count_self_narrow();
+                T::count_self_narrow(cfg);
                 LegGeom lg;
                 lg.p1 = p1; lg.ct = p2 + Z2 * V(LINK_BOX_Z); lg.X2 = X2; lg.Y = Y; lg.Z2 = Z2; lg.cc = p3 + Z3 * V(LINK_BOX_Z); lg.X3 = X3; lg.Z3 = Z3; lg.rf = rf;
                 o.n_invalid = o.n_invalid + T::quad_sum(self_contacts(lg, qflag(cy1), qflag(cx2), qflag(c3), qflag(ctr)));
@@ -1202,34 +1202,16 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         V rel = lim_sgn[j] * s.qd[j];                                                                                  \
         r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;                                  \
     }
-        // The full build's wave on a rare path: the environments that have NO rare row of their own (no joint at a stop, no link on the
-        // floor) still get the result of the common-path solver -- bit for bit what the common-path build gives them in a wave without
-        // such a neighbour --, computed on a copy next to the many-rows solve; only the environments with rare rows take that one's.
-        // (Both solvers run for the whole wave: their MFMAs and wave votes must not sit under a divergent branch.)
-        State s_c = s; Out o_c = o;
-        PayRows pay_c;      // cfg.payload_soft: the block's six rows (built once: payload_rows also applies gravity to the block), then the
-                            // common-path solver's results for them
-        if (HOT && SOFT) {      // (a handle without the block does not launch this build)
-            payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);
-            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R, &pay_c);
-            else solve_and_integrate<3, false, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R, &pay_c);
-            payload_integrate(cfg, blk, pay_c);
-        } else if (HOT) {
-            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
-            else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
-        } else if (!soft) {
-            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R);
-            else solve_and_integrate<3, false>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R);
-        } else {
-            payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);
-            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R, &pay_c);
-            else solve_and_integrate<3, false, true>(cfg, Pr.mu, s_c, o_c, rows, Sm, Ld, BK, R, &pay_c);
-        }
         // this environment has rare rows of its own and takes the many-rows solver's result
         const M rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, any_extra))), V(0.5f));
+        // The many-rows solve comes FIRST in the full build (on a copy; only its few results stay live while the common-path solver runs:
+        // the other way round, that one's copies of the state sat on the registers the many-rows part is short of).
+        State s_r = s; Out o_r = o;
+        PayRows pay_c, pay_r;   // cfg.payload_soft: the block's six rows (built once: payload_rows also applies gravity to the block) and the two solvers' results for them
+        if (!HOT && soft) payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);
         QS_PHASE_G(39)
         if (!HOT && T::any(rare_mine)) {
-            T::count_rare_path();
+            T::count_rare_path(cfg);
             Row xr[12];   // this leg's rows: contact point c at 3c .. 3c + 2 (0 = the foot), joint limits at 9 + j
 #pragma unroll
             for (int r = 0; r < 3; r++) xr[r] = rows[r];
@@ -1287,22 +1269,32 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             if (T::any(any_lim)) { QS_LIMIT_ROWS(xr + 9) }
             QS_PHASE_G(40)
             V lam12[12], plam[6];
-            PayRows pay_r;
             if (soft) pay_r = pay_c;   // (the rows; the results in it are overwritten)
             RareSolver<T, CONE>::solve(cfg, Pr.mu, xr, soft ? &pay_r : nullptr, rare_mine, s.warm * cfg.warmstart * rows[0].act, T::wave_scratch(scratch_row), lam12, plam);
-            integrate_rare(cfg, s, o, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam);
-            if (soft) keep_rare_payload(pay_c, pay_r, rare_mine);
+            integrate_rare(cfg, s_r, o_r, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam);
             QS_PHASE_G(45)
+        }
+        // The common-path solve.  In the full build's wave on a rare path the environments that have NO rare row of their own (no joint at a
+        // stop, no link on the floor) keep ITS result -- bit for bit what the common-path build gives them in a wave without such a
+        // neighbour; only the environments with rare rows take the many-rows solver's.  (Both solvers run for the whole wave: wave votes
+        // must not sit under a divergent branch.)
+        if (SOFT || (!HOT && soft)) {
+            if (HOT) payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);      // (a handle without the block does not launch this build)
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R, &pay_c);
+            else solve_and_integrate<3, false, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R, &pay_c);
+            if (HOT) payload_integrate(cfg, blk, pay_c);
+        } else {
+            if (cfg.solver_residual_threshold > 0.0f) solve_and_integrate<3, true>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
+            else solve_and_integrate<3, false>(cfg, Pr.mu, s, o, rows, Sm, Ld, BK, R);
         }
         if (!HOT) {   // (in a wave without any rare row: the common-path result for everybody)
 #pragma unroll
-            for (int j = 0; j < 3; j++) s.qd[j] = qsel(rare_mine, s.qd[j], s_c.qd[j]);
-            s.vang = mk3<V>(qsel(rare_mine, s.vang.x, s_c.vang.x), qsel(rare_mine, s.vang.y, s_c.vang.y), qsel(rare_mine, s.vang.z, s_c.vang.z));
-            s.vlin = mk3<V>(qsel(rare_mine, s.vlin.x, s_c.vlin.x), qsel(rare_mine, s.vlin.y, s_c.vlin.y), qsel(rare_mine, s.vlin.z, s_c.vlin.z));
-            s.warm = qsel(rare_mine, s.warm, s_c.warm); o.foot_force = qsel(rare_mine, o.foot_force, o_c.foot_force);
-            if (soft) payload_integrate(cfg, blk, pay_c);
+            for (int j = 0; j < 3; j++) s.qd[j] = qsel(rare_mine, s_r.qd[j], s.qd[j]);
+            s.vang = mk3<V>(qsel(rare_mine, s_r.vang.x, s.vang.x), qsel(rare_mine, s_r.vang.y, s.vang.y), qsel(rare_mine, s_r.vang.z, s.vang.z));
+            s.vlin = mk3<V>(qsel(rare_mine, s_r.vlin.x, s.vlin.x), qsel(rare_mine, s_r.vlin.y, s.vlin.y), qsel(rare_mine, s_r.vlin.z, s.vlin.z));
+            s.warm = qsel(rare_mine, s_r.warm, s.warm); o.foot_force = qsel(rare_mine, o_r.foot_force, o.foot_force);
+            if (soft) { keep_rare_payload(pay_c, pay_r, rare_mine); payload_integrate(cfg, blk, pay_c); }
         }
-#undef QS_RARE_COMMON
 #undef QS_LIMIT_ROWS
 #undef QS_CONTACT_ROW_AT
         } else {

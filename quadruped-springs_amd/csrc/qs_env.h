@@ -509,19 +509,20 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         //             d  < 12 -> the d values are replicated over the quad in act[0..d)
         // (every loop over these arrays runs to a constant bound under `#pragma unroll` with the runtime d as a guard: a runtime trip count
         // would put the arrays into scratch memory -- ~120 dword stores per environment and step, measured as WRITE_SIZE)
+        // (a RESUMED step fetches what only its epilogue needs -- the action as given, _last_action, the previous torque, the counters --
+        // behind the substep loop: the full build's loop is short of registers as it is)
         V act[15], act_in[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) act[k] = V(0.0f);
-        if (d == 12) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) act[12 + j] = T::ld_leg(act_row, j, 3);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 12; k++)
-                if (k < d) act[k] = T::ld(act_row, k);
-        }
-#pragma unroll
-        for (int k = 0; k < 15; k++) act_in[k] = act[k];
+#define QS_LOAD_ACTION_ROW                                                                                             \
+        if (d == 12) {                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 3; j++) act[12 + j] = T::ld_leg(act_row, j, 3);                      \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < 12; k++)                                                             \
+                if (k < d) act[k] = T::ld(act_row, k);                                                                 \
+        }                                                                                                              \
+        _Pragma("unroll") for (int k = 0; k < 15; k++) act_in[k] = act[k];
+        if (!RESUME) { QS_LOAD_ACTION_ROW }
         // scripted phases of the landing / go-to-rest wrappers (one inner env.step per call)
         V w_phase = V(0.0f), w_timer = V(0.0f), w_end = V(0.0f), w_tstart = V(0.0f);
         if (!RESUME && cfg.wrapper_mode != QS_WRAP_NONE && settle_n == 0) {
@@ -572,17 +573,7 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         V act_last[15];   // what env.step was given (after the scripted phases): _last_action, gym_env.py:230
 #pragma unroll
         for (int k = 0; k < 15; k++) act_last[k] = act[k];
-        if (RESUME) {   // what env.step was given is in the record already (R_LAST_ACTION), the filter has run
-#pragma unroll
-            for (int k = 0; k < 15; k++) act_last[k] = V(0.0f);
-            if (d == 12) {
-#pragma unroll
-                for (int j = 0; j < 3; j++) act_last[12 + j] = T::ld_leg(rec, R_LAST_ACTION + j, 3);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 12; k++)
-                    if (k < d) act_last[k] = T::ld(rec, R_LAST_ACTION + k);
-            }
+        if (RESUME) {   // what env.step was given is in the record already (R_LAST_ACTION), the filter has run: fetched behind the loop
         } else if (d == 12) {  // DEFAULT space / raw commands: every lane filters the 3 entries of its own leg
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -639,10 +630,12 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             for (int k = 0; k < 5; k++) cpg_p[k] = V(0.0f);
             action_to_command(cfg, act, cmd);
         }
-        int sim_step = f2i(rec[R_SIM_STEP]), env_step = f2i(rec[R_ENV_STEP]), total = f2i(rec[R_TOTAL_STEPS]);
+        int sim_step = 0, env_step = 0, total = 0;
         V old_tau[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) old_tau[j] = T::ld_leg(rec, R_NEW_TAU + j, 3);
+#define QS_LOAD_COUNTERS                                                                                               \
+        sim_step = f2i(rec[R_SIM_STEP]); env_step = f2i(rec[R_ENV_STEP]); total = f2i(rec[R_TOTAL_STEPS]);             \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) old_tau[j] = T::ld_leg(rec, R_NEW_TAU + j, 3);
+        if (!RESUME) { QS_LOAD_COUNTERS }
         const int n_sub = settle_n > 0 ? settle_n : cfg.action_repeat;
         float* const blk = cfg.payload_soft ? rec + R_BLOCK : nullptr;
         if (HOT) {
@@ -675,6 +668,23 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             return z;
         }
         if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.resume = -1; return z; }
+        if (RESUME) {
+            T::sync();
+            QS_LOAD_ACTION_ROW
+            QS_LOAD_COUNTERS
+#pragma unroll
+            for (int k = 0; k < 15; k++) act_last[k] = V(0.0f);
+            if (d == 12) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) act_last[12 + j] = T::ld_leg(rec, R_LAST_ACTION + j, 3);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    if (k < d) act_last[k] = T::ld(rec, R_LAST_ACTION + k);
+            }
+        }
+#undef QS_LOAD_ACTION_ROW
+#undef QS_LOAD_COUNTERS
         QS_PHASE(32)
         if (cpg) { T::st_leg(rec, R_CPG, 1, cpg_r); T::st_leg(rec, R_CPG + 4, 1, cpg_th); }
         sim_step += cfg.action_repeat; env_step += 1; total += 1;

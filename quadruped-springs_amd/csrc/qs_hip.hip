@@ -165,7 +165,8 @@ struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonst
 // fill count alternates between two counters: a step counts in cnt[parity] and clears the other one for the next step.
 struct TermTail { float* rows; int cap, parity; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
-       CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_N = 10 + QS_COHORTS };
+       CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_DEV = 10 + QS_COHORTS /* QS_DEVCTR_*: the rare paths' telemetry */,
+       CTL_N = 12 + QS_COHORTS };
 
 // settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines), and the slot's tag.
 // Every load is issued before the first value is used: as four rolled loops (`rec[i] = src[i]`) the copy was a load, a wait and an LDS write
@@ -435,6 +436,7 @@ __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const 
         if (job.y <= la.cur[job.x]) continue;
         float* dst = la.slots + ((size_t)job.x * la.K + (size_t)(job.y % la.K)) * QS_REC;
         dst[f] = f == R_EPISODE ? qs::i2f(job.y) : src[(size_t)e * QS_REC + f];
+        if (f == 0) atomicAdd(&ctl[CTL_SETTLED], 1ull);      // states DELIVERED (a stale one, dropped above, does not count)
     }
 }
 // ... then the cohort takes what the environments' windows lack: environment e in episode X wants the states of X + 1 .. X + K; those up to
@@ -452,7 +454,7 @@ __global__ void k_lookahead_publish(unsigned long long* __restrict__ ctl, const 
 __global__ __launch_bounds__(1024) void k_lookahead_plan(unsigned long long* __restrict__ ctl, LookAhead la, int n_envs, int2* __restrict__ stage_jobs, int cohort,
                                                           int slice, int base_cap, int take, int offset) {
     __shared__ int s_count, s_want, s_urgent;
-    if (threadIdx.x == 0) { s_count = 0; s_want = 0; s_urgent = 0; if (take) ctl[CTL_SETTLED] += ctl[CTL_R + cohort]; }
+    if (threadIdx.x == 0) { s_count = 0; s_want = 0; s_urgent = 0; }
     __syncthreads();
     int2* dst = stage_jobs + (size_t)cohort * slice;
     for (int pass = 0; pass < 2; pass++) {
@@ -716,12 +718,16 @@ static int create_impl(const qs_config* cfg, int device, qs_handle* h) {
         h->step_variant = v ? atoi(v) : 0;
     }
     const size_t n = (size_t)cfg->n_envs;
-    QS_HIP(hipMalloc(&h->d_cfg, sizeof(qs_config)));
+    QS_HIP(hipMalloc(&h->d_cfg, sizeof(QsDevCfg)));   // the configuration, and behind it the address of the rare paths' counters (qs_lane.h)
     QS_HIP(hipMalloc(&h->d_rec, n * QS_REC * sizeof(float)));
     QS_HIP(hipMalloc(&h->d_obs, n * cfg->obs_dim * sizeof(float)));
     QS_HIP(hipMalloc(&h->d_term_obs, n * cfg->obs_dim * sizeof(float)));
     QS_HIP(hipMalloc(&h->d_stats, CTL_N * sizeof(unsigned long long)));
-    QS_HIP(hipMemcpy(h->d_cfg, &h->cfg, sizeof(qs_config), hipMemcpyHostToDevice));
+    {
+        QsDevCfg dc;
+        dc.cfg = h->cfg; dc.counters = h->d_stats + CTL_DEV;
+        QS_HIP(hipMemcpy(h->d_cfg, &dc, sizeof(dc), hipMemcpyHostToDevice));
+    }
     QS_HIP(hipMemset(h->d_obs, 0, n * cfg->obs_dim * sizeof(float)));
     QS_HIP(hipMemset(h->d_term_obs, 0, n * cfg->obs_dim * sizeof(float)));
     QS_HIP(hipMemset(h->d_stats, 0, CTL_N * sizeof(unsigned long long)));
@@ -847,9 +853,9 @@ static int launch_step(qs_handle* h, const float* actions, float* obs, float* re
     lanes.n_env_waves = n_waves(h->cfg.n_envs); lanes.slice = 0;
     TraceTap tap; tap.rows = h->trace_rows; tap.env = h->trace_env;
     DemoTab demo; demo.rows = h->d_demo; demo.length = h->demo_len;
+    if (E::demo_task(h->cfg.task) && !h->d_demo) QS_FAIL(-1, "the DEMO tasks need a demonstration: qs_set_demo first");
     TermTail tail = h->tail;
     memset(&h->tail, 0, sizeof(h->tail));       // (set by qs_host_step_begin for its own launch only)
-    if (E::demo_task(h->cfg.task) && !h->d_demo) QS_FAIL(-1, "the DEMO tasks need a demonstration: qs_set_demo first");
     int grid = lanes.n_env_waves;
     bool lanes_fit = true;      // the environments' waves and the lanes' usual share fit the SIMDs
     if (h->la.K > 0 && h->lanes_on) {
@@ -917,25 +923,32 @@ struct HostPath {
     uint8_t* hd_block[2];    // (zero-copy mode) device addresses of the host blocks
     float* h_act; float* d_act; float* hd_act;
     int cur, parity, pending;
+    int registered;          // bits 0, 1: h_block[k], bit 2: h_act are page-locked (hipHostRegister succeeded)
     hipEvent_t ev;
 };
-static void host_path_free(qs_handle* h) {
-    HostPath* p = h->host;
+// (`registered`: which of the page-locked buffers hipHostRegister accepted -- only those are unregistered)
+static void host_path_release(HostPath* p) {
     if (!p) return;
-    for (int k = 0; k < 2; k++) if (p->h_block[k]) { hipHostUnregister(p->h_block[k]); free(p->h_block[k]); }
-    if (p->h_act) { hipHostUnregister(p->h_act); free(p->h_act); }
+    for (int k = 0; k < 2; k++) if (p->h_block[k]) { if (p->registered & (1 << k)) hipHostUnregister(p->h_block[k]); free(p->h_block[k]); }
+    if (p->h_act) { if (p->registered & 4) hipHostUnregister(p->h_act); free(p->h_act); }
     if (p->d_block) hipFree(p->d_block);
     if (p->d_act) hipFree(p->d_act);
     if (p->ev) hipEventDestroy(p->ev);
     delete p;
-    h->host = nullptr;
 }
+static void host_path_free(qs_handle* h) { host_path_release(h->host); h->host = nullptr; }
+static int host_path_build(qs_handle* h, HostPath* p);
 static int host_path_init(qs_handle* h) {
     if (h->host) return 0;
     HostPath* p = new (std::nothrow) HostPath();
     if (!p) QS_FAIL(-4, "out of host memory");
     memset(p, 0, sizeof(*p));
+    // the handle gets the path only once every buffer stands: a failed allocation / registration leaves no half-built one behind
+    if (int rc = host_path_build(h, p)) { host_path_release(p); return rc; }
     h->host = p;
+    return 0;
+}
+static int host_path_build(qs_handle* h, HostPath* p) {
     const size_t n = (size_t)h->cfg.n_envs, o = (size_t)h->cfg.obs_dim, d = (size_t)h->cfg.action_dim;
     p->cap = (int)(n < 256 ? n : 256);
     p->off_rew = n * o * 4; p->off_done = p->off_rew + n * 4; p->off_trunc = p->off_done + n;
@@ -954,6 +967,7 @@ static int host_path_init(qs_handle* h) {
         memset(m, 0, hb);
         p->h_block[k] = (uint8_t*)m;
         QS_HIP(hipHostRegister(m, hb, flags));
+        p->registered |= 1 << k;
         if (p->zero_copy) QS_HIP(hipHostGetDevicePointer((void**)&p->hd_block[k], m, 0));
     }
     void* m = nullptr;
@@ -961,6 +975,7 @@ static int host_path_init(qs_handle* h) {
     memset(m, 0, ab);
     p->h_act = (float*)m;
     QS_HIP(hipHostRegister(m, ab, flags));
+    p->registered |= 4;
     if (p->zero_copy) QS_HIP(hipHostGetDevicePointer((void**)&p->hd_act, m, 0));
     else {
         QS_HIP(hipMalloc(&p->d_block, p->bytes));
@@ -979,12 +994,15 @@ int qs_host_step_begin(qs_handle* h, const float* actions_host) {
     if (p->pending) QS_FAIL(-1, "qs_host_step_begin: the previous step has not been collected (qs_host_step_end)");
     const size_t n = (size_t)h->cfg.n_envs, d = (size_t)h->cfg.action_dim;
     memcpy(p->h_act, actions_host, n * d * 4);
-    p->cur ^= 1; p->parity ^= 1;
-    uint8_t* blk = p->zero_copy ? p->hd_block[p->cur] : p->d_block;
+    // the block and the terminal-list counter this step uses are the OTHER ones; the switch is made once the step is on the stream (a
+    // launch that fails -- a DEMO task without its demonstration -- must not leave a counter behind that no step has cleared)
+    const int cur = p->cur ^ 1, parity = p->parity ^ 1;
+    uint8_t* blk = p->zero_copy ? p->hd_block[cur] : p->d_block;
     const float* act = p->zero_copy ? p->hd_act : p->d_act;
     if (!p->zero_copy) QS_HIP(hipMemcpyAsync(p->d_act, p->h_act, n * d * 4, hipMemcpyHostToDevice, h->stream));
-    h->tail.rows = (float*)(blk + p->off_tail); h->tail.cap = p->cap; h->tail.parity = p->parity;
-    if (int rc = launch_step(h, act, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, blk + p->off_trunc)) return rc;
+    h->tail.rows = (float*)(blk + p->off_tail); h->tail.cap = p->cap; h->tail.parity = parity;
+    if (int rc = launch_step(h, act, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, blk + p->off_trunc)) { memset(&h->tail, 0, sizeof(h->tail)); return rc; }
+    p->cur = cur; p->parity = parity;
     if (!p->zero_copy) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
     QS_HIP(hipEventRecord(p->ev, h->stream));
     p->pending = 1;
@@ -1053,8 +1071,8 @@ int qs_counters_async(qs_handle* h, uint64_t* dev_out) {
     unsigned long long* out = reinterpret_cast<unsigned long long*>(dev_out);
     QS_HIP(hipMemcpyAsync(out, h->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
     QS_HIP(hipMemcpyAsync(out + QS_COUNTER_RESET_STALLS, h->d_stats + CTL_STALLS, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
-    QS_HIP(hipMemcpyFromSymbolAsync(out + QS_COUNTER_LIMIT_PATH_SUBSTEPS, HIP_SYMBOL(qs_rare_path_substeps), sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice, h->stream));
-    QS_HIP(hipMemcpyFromSymbolAsync(out + QS_COUNTER_SELF_NARROW_SUBSTEPS, HIP_SYMBOL(qs_self_narrow_substeps), sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice, h->stream));
+    QS_HIP(hipMemcpyAsync(out + QS_COUNTER_LIMIT_PATH_SUBSTEPS, h->d_stats + CTL_DEV + QS_DEVCTR_RARE_PATH, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+    QS_HIP(hipMemcpyAsync(out + QS_COUNTER_SELF_NARROW_SUBSTEPS, h->d_stats + CTL_DEV + QS_DEVCTR_SELF_NARROW, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
@@ -1077,8 +1095,8 @@ int qs_counter(qs_handle* h, int which, uint64_t* value) {
             QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_BACKLOG], sizeof(v), hipMemcpyDeviceToHost));
         }
         break;
-    case QS_COUNTER_LIMIT_PATH_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_rare_path_substeps), sizeof(v))); break;
-    case QS_COUNTER_SELF_NARROW_SUBSTEPS: QS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(qs_self_narrow_substeps), sizeof(v))); break;
+    case QS_COUNTER_LIMIT_PATH_SUBSTEPS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_DEV + QS_DEVCTR_RARE_PATH], sizeof(v), hipMemcpyDeviceToHost)); break;
+    case QS_COUNTER_SELF_NARROW_SUBSTEPS: QS_HIP(hipMemcpy(&v, &h->d_stats[CTL_DEV + QS_DEVCTR_SELF_NARROW], sizeof(v), hipMemcpyDeviceToHost)); break;
     default: QS_FAIL(-1, "unknown counter %d", which);
     }
     *value = v;

@@ -89,10 +89,10 @@ QS_FN bool qnot(bool a) { return !a; }
 QS_FN float qflag(bool m) { return m ? 1.0f : 0.0f; }
 
 #if defined(__HIPCC__)
-// telemetry: wave-substeps that took the joint-limit solver path (all handles of the process; read through qs_counter)
-__device__ unsigned long long qs_rare_path_substeps;
-// ... and wave-substeps whose self-collision broad phase asked for the link-link tests
-__device__ unsigned long long qs_self_narrow_substeps;
+// The configuration as the kernels see it: the public struct, and behind it the handle's counter block -- telemetry of the rare paths
+// (per HANDLE since round 4; a process-wide pair of __device__ variables before: two handles on one GPU mixed their counts).
+struct QsDevCfg { qs_config cfg; unsigned long long* counters; };
+enum { QS_DEVCTR_RARE_PATH = 0, QS_DEVCTR_SELF_NARROW = 1 };   // wave-substeps through the many-rows solve / whose broad phase asked for the link-link tests
 struct LaneDev {
     using V = float;
     using M = bool;
@@ -158,8 +158,9 @@ struct LaneDev {
     static QS_DEV void opaque(float& x) { asm volatile("" : "+v"(x)); }
     // the wave's sixteen observation rows (LDS) from the row of this lane's environment
     static QS_DEV float* wave_scratch(float* row) { return row - (size_t)(threadIdx.x >> 2) * QS_MAX_OBS; }
-    static QS_DEV void count_rare_path() { if (threadIdx.x == 0) atomicAdd(&qs_rare_path_substeps, 1ull); }
-    static QS_DEV void count_self_narrow() { if (threadIdx.x == 0) atomicAdd(&qs_self_narrow_substeps, 1ull); }
+    // (every qs_config the device code gets is the first member of a QsDevCfg in device memory: qs_hip.hip, create_impl)
+    static QS_DEV void count_rare_path(const qs_config& cfg) { if (threadIdx.x == 0) atomicAdd(&reinterpret_cast<const QsDevCfg&>(cfg).counters[QS_DEVCTR_RARE_PATH], 1ull); }
+    static QS_DEV void count_self_narrow(const qs_config& cfg) { if (threadIdx.x == 0) atomicAdd(&reinterpret_cast<const QsDevCfg&>(cfg).counters[QS_DEVCTR_SELF_NARROW], 1ull); }
     // orders LDS traffic between the lanes of a wave (in-order LDS queue per wave; this only pins the compiler)
     static QS_DEV void sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -226,8 +227,8 @@ struct LaneEmu {
     }
     static void fma2(V4 a0, V4 a1, V4 b, V4& c0, V4& c1) { for (int l = 0; l < 4; l++) { c0.v[l] = fmaf(a0.v[l], b.v[l], c0.v[l]); c1.v[l] = fmaf(a1.v[l], b.v[l], c1.v[l]); } }
     static float* wave_scratch(float* row) { return row; }
-    static void count_rare_path() {}
-    static void count_self_narrow() {}
+    static void count_rare_path(const qs_config&) {}
+    static void count_self_narrow(const qs_config&) {}
     struct Acc4 { V4 k[4]; };
     static Acc4 acc4_zero() { Acc4 z; for (int i = 0; i < 4; i++) z.k[i] = V4(0.0f); return z; }
     static void outer_fma(V4 a, V4 b, Acc4& acc) { for (int K = 0; K < 4; K++) for (int l = 0; l < 4; l++) acc.k[K].v[l] = fmaf(a.v[K], b.v[l], acc.k[K].v[l]); }

@@ -64,7 +64,6 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
         using P = RarePos;
         constexpr int A0 = 0, B0 = P::NRM0, C0 = P::FRI0, NA = P::NRM0, NB = P::FRI0 - P::NRM0;
         const int lane = (int)threadIdx.x, slot = lane >> 2, K = lane & 3;
-        int* const map = reinterpret_cast<int*>(scr + P::LAM_OFF);    // (the impulse buffer doubles as the lane map while the rows are dealt out)
 #pragma unroll
         for (int r = 0; r < 12; r++) lam12[r] = 0.0f;
 #pragma unroll
@@ -72,22 +71,32 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
         const bool track = cfg.solver_residual_threshold > 0.0f;
         const float thr = sqrtf(cfg.solver_residual_threshold);
         const float big = 1e10f, bound = 500.0f * (float)cfg.dt;
-        // canonical position `lane` (RarePos): the record it would read, the region it belongs to
-        const int p_rec = lane < P::PAY0 ? 12 * (lane / 3) + 9 + lane % 3 : lane < P::NRM0 ? 48 + (lane - P::PAY0)
-                        : lane < P::FRI0 ? 12 * ((lane - P::NRM0) / 3) + 3 * ((lane - P::NRM0) % 3)
-                        : 12 * ((lane - P::FRI0) / 6) + 3 * (((lane - P::FRI0) % 6) / 2) + 1 + (lane - P::FRI0) % 2;
-        const unsigned long long below = (1ull << lane) - 1ull, maskA = (1ull << P::NRM0) - 1ull, maskB = ((1ull << P::FRI0) - 1ull) & ~maskA,
-                                 maskC = ((1ull << P::N) - 1ull) & ~(maskA | maskB);
+        const unsigned long long maskA = (1ull << P::NRM0) - 1ull, maskB = ((1ull << P::FRI0) - 1ull) & ~maskA, maskC = ((1ull << P::N) - 1ull) & ~(maskA | maskB);
         unsigned long long todo = __ballot(mine);
         while (todo) {
             const int e = (__ffsll((long long)todo) - 1) >> 2;     // wave-uniform: the quad this pass works for
             todo &= ~(0xFull << (4 * e));
             const float mu_e = rl(mu, 4 * e);
-            // ---- the quad's rows -> LDS (16 floats a row: w 6, a 3, b 3, rhs, dinv, diag, act)
-            map[lane] = -1;
+            // ---- which rows exist (wave-uniform, from the quad's registers): bit p of `live` <=> the row of canonical position p
+            unsigned long long live = 0ull;
+            unsigned rows_used = 0u;     // bit r: row r exists in some leg
+#pragma unroll
+            for (int r = 0; r < 12; r++) {
+                const unsigned q = (unsigned)(__ballot(slot == e && xr[r].act > 0.5f) >> (4 * e)) & 0xFu;     // bit K: leg K has the row
+                if (q) rows_used |= 1u << r;
+                // leg K's row r sits at position of_row(K, r): 3 K apart for limits and normals, 6 K apart for friction rows
+                const unsigned long long s3 = (q & 1u) | ((q & 2u) << 2) | ((q & 4u) << 4) | ((q & 8u) << 6);
+                const unsigned long long s6 = (q & 1u) | ((q & 2u) << 5) | ((q & 4u) << 10) | ((q & 8u) << 15);
+                live |= r >= 9 ? s3 << (r - 9) : (r % 3 == 0 ? s3 << (P::NRM0 + r / 3) : s6 << (P::FRI0 + 2 * (r / 3) + (r % 3 - 1)));
+            }
+            const bool pay_live = pay != nullptr && rl(pay->act, 4 * e) > 0.5f;
+            if (pay_live) live |= 0x3Full << P::PAY0;
+            const int mA = __popcll(live & maskA), mB = __popcll(live & maskB);      // (region C holds mB pairs)
+            // ---- the quad's rows that exist -> LDS (16 floats a row: w 6, a 3, b 3, rhs, dinv, diag, act)
             if (slot == e) {
 #pragma unroll
                 for (int r = 0; r < 12; r++) {
+                    if (!((rows_used >> r) & 1u)) continue;
                     float4* d = reinterpret_cast<float4*>(scr + (12 * K + r) * P::REC_FLOATS);
                     d[0] = make_float4(xr[r].w[0], xr[r].w[1], xr[r].w[2], xr[r].w[3]);
                     d[1] = make_float4(xr[r].w[4], xr[r].w[5], xr[r].jq[0], xr[r].jq[1]);
@@ -95,11 +104,11 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
                     d[3] = make_float4(xr[r].rhs, xr[r].dinv, xr[r].diag, xr[r].act);
                 }
                 // (payload rows: a = -(rB x e_k) resp. -e_k, the block's angular Jacobian; b = a / inertia.  The linear part only meets itself.)
+                if (pay_live) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    if ((k & 3) != K) continue;           // lane K of the quad writes rows K and K + 4
-                    float4* d = reinterpret_cast<float4*>(scr + (48 + k) * P::REC_FLOATS);
-                    if (pay) {
+                    for (int k = 0; k < 6; k++) {
+                        if ((k & 3) != K) continue;           // lane K of the quad writes rows K and K + 4
+                        float4* d = reinterpret_cast<float4*>(scr + (48 + k) * P::REC_FLOATS);
                         const PayRows& q = *pay;
                         const float ax = k == 0 ? 0.0f : k == 1 ? q.rB.z : k == 2 ? -q.rB.y : k == 3 ? -1.0f : 0.0f;
                         const float ay = k == 0 ? -q.rB.z : k == 1 ? 0.0f : k == 2 ? q.rB.x : k == 4 ? -1.0f : 0.0f;
@@ -108,29 +117,22 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
                         d[1] = make_float4(q.w[k][4], q.w[k][5], ax, ay);
                         d[2] = make_float4(az, ax * q.mI, ay * q.mI, az * q.mI);
                         d[3] = make_float4(q.rhs[k], q.dinv[k], q.diag[k], q.act);
-                    } else {
-                        d[0] = d[1] = d[2] = d[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
                 }
             }
-            LaneDev::sync();
-            // ---- which rows exist; every one of them gets the next free lane of its region
-            const bool exists = lane < P::N && scr[p_rec * P::REC_FLOATS + 15] > 0.5f;
-            const unsigned long long live = __ballot(exists);
-            const int mA = __popcll(live & maskA), mB = __popcll(live & maskB);      // (wave-uniform; region C holds mB pairs)
-            if (exists) {
-                const unsigned long long reg = lane < P::NRM0 ? maskA : lane < P::FRI0 ? maskB : maskC;
-                map[(lane < P::NRM0 ? A0 : lane < P::FRI0 ? B0 : C0) + __popcll(live & reg & below)] = lane;
+            // ---- every row that exists gets the next free lane of its region (the regions' bits in ascending order = sweep order)
+            int cp = -1;                 // the canonical position of this lane's row, -1: none
+            {
+                int at = A0;
+                for (unsigned long long m = live & maskA; m; m &= m - 1ull, at++) cp = lane == at ? __ffsll((long long)m) - 1 : cp;
+                at = B0;
+                for (unsigned long long m = live & maskB; m; m &= m - 1ull, at++) cp = lane == at ? __ffsll((long long)m) - 1 : cp;
+                at = C0;
+                for (unsigned long long m = live & maskC; m; m &= m - 1ull, at++) cp = lane == at ? __ffsll((long long)m) - 1 : cp;
             }
-            LaneDev::sync();
-            const int cp = map[lane];                 // the canonical position of this lane's row, -1: none
             const bool alive = cp >= 0;
             LaneDev::sync();
-            scr[P::LAM_OFF + lane] = 0.0f;            // the buffer turns into the impulses by canonical position; the feet's warm start goes in
-            LaneDev::sync();
-            if (slot == e) scr[P::LAM_OFF + P::NRM0 + 3 * K] = warm;
-            LaneDev::sync();
-            // ---- this lane's row
+            // ---- this lane's row; the feet's warm start
             float w[6], a[3], b[3], rhs, dinv, diag, lam, lo, hi;
             int grp;
             {
@@ -144,10 +146,12 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
                 a[0] = r1.z; a[1] = r1.w; a[2] = r2.x;
                 b[0] = r2.y; b[1] = r2.z; b[2] = r2.w;
                 rhs = r3.x; dinv = r3.y; diag = r3.z;
-                lam = alive ? scr[P::LAM_OFF + c] : 0.0f;
+                lam = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const float wk = rl(warm, 4 * e + k); lam = cp == P::NRM0 + 3 * k ? wk : lam; }
                 const bool payrow = c >= P::PAY0 && c < P::NRM0;
                 lo = payrow ? -bound : 0.0f; hi = payrow ? bound : big;
-                if (!alive) { grp = -1; rhs = 0.0f; diag = 0.0f; }
+                if (!alive) { grp = -1; rhs = 0.0f; diag = 0.0f; lam = 0.0f; }
             }
             QS_PHASE_G(41)
             // ---- this lane's column of the Delassus matrix, x (-1 / A_pp): Ap[J] = what a unit impulse of the row in lane J does to this
@@ -205,17 +209,18 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
 #define QS_W_FRICTION(KK)                                                                                              \
     {                                                                                                                  \
         constexpr int FP = C0 + 2 * (KK);                                                                              \
-        const float ln_ = rl(lam, B0 + (KK)), lim_ = mu_e * ln_;                                                       \
         if (CONE) {                                                                                                    \
+            const float lim_ = rl(lam * mu_e, B0 + (KK));          /* (every lane's product; the normal's counts) */   \
             const float ca_ = rl(res, FP), cb_ = rl(res, FP + 1);                                                      \
-            const float r2_ = fmaf(cb_, cb_, ca_ * ca_);                                                               \
-            const float sc_ = qmin(lim_ * qrsqrt(qmax(r2_, 1e-30f)), 1.0f);                                            \
+            const float r2_ = fmaf(cb_, cb_, fmaf(ca_, ca_, 1e-30f));   /* (+ 1e-30: no candidate, no division by zero) */ \
+            const float sc_ = qmin(lim_ * qrsqrt(r2_), 1.0f);                                                          \
             const float cand = res * sc_;                                                                              \
             const float dl_ = cand - lam;                                                                              \
             const float da_ = rl(dl_, FP), db_ = rl(dl_, FP + 1);                                                      \
             lam = (lane >> 1) == (FP >> 1) ? cand : lam;                                                               \
             res = fmaf(Ap[FP], da_, res); res = fmaf(Ap[FP + 1], db_, res);                                            \
         } else {                                                                                                       \
+            const float ln_ = rl(lam, B0 + (KK)), lim_ = mu_e * ln_;                                                   \
             _Pragma("unroll") for (int t_ = 0; t_ < 2; t_++) {                                                         \
                 const float cl_ = qmed3(res, -lim_, lim_);                                                             \
                 const float d_ = ln_ > 0.0f ? rl(cl_ - lam, FP + t_) : 0.0f;                                           \
@@ -259,7 +264,9 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
             }
 #endif
             (void)n_sweeps;
-            // ---- the impulses back to the quad (by canonical position; rows that do not exist keep their zero)
+            // ---- the impulses back to the quad (by canonical position; rows that do not exist read zero)
+            scr[P::LAM_OFF + lane] = 0.0f;
+            LaneDev::sync();
             if (alive) scr[P::LAM_OFF + cp] = lam;
             LaneDev::sync();
             if (slot == e) {
@@ -350,8 +357,8 @@ template <bool CONE> struct RareSolver<LaneEmu, CONE> {
                 const float ln = lam[P::normal_of(f)], lim = mu_e * ln;
                 if (CONE) {
                     const float ca = res[f], cb = res[f + 1];
-                    const float r2 = fmaf(cb, cb, ca * ca);
-                    const float sc = fminf(lim * (1.0f / sqrtf(fmaxf(r2, 1e-30f))), 1.0f);
+                    const float r2 = fmaf(cb, cb, fmaf(ca, ca, 1e-30f));
+                    const float sc = fminf(lim * (1.0f / sqrtf(r2)), 1.0f);
                     const float na = ca * sc, nb = cb * sc, da = na - lam[f], db = nb - lam[f + 1];
                     lam[f] = na; lam[f + 1] = nb;
                     for (int q = 0; q < P::N; q++) { res[q] = fmaf(A[f][q], da, res[q]); res[q] = fmaf(A[f + 1][q], db, res[q]); }

@@ -300,37 +300,51 @@ class QuadrupedVecEnv(SB3VecEnv):
             self._views[key] = views
         return views
 
+    def _entry(self, old, truncated, terminal_observation):
+        """the info dict of an environment whose episode ended in this step: a new one under copy_outputs, the old one refilled otherwise"""
+        if self.copy_outputs:
+            return {"TimeLimit.truncated": truncated, "terminal_observation": terminal_observation}
+        old["TimeLimit.truncated"] = truncated; old["terminal_observation"] = terminal_observation
+        return old
+
     def step_wait(self):
         """VecEnv.step_wait: (obs [N, o] float32, rewards [N] float32, dones [N] bool, infos) -- the SB3 convention of load_model.py:113-133:
         finished environments are already reset, their last observation is infos[i]["terminal_observation"], infos[i]["TimeLimit.truncated"]
         says whether the time limit ended the episode (gym_env.py:246).  One H2D copy, the step, ONE D2H copy into page-locked host memory;
         the arrays returned are copies of it (copy_outputs=False: views, valid until the end of the NEXT step).  `infos` is ONE list
-        of N dicts kept by the environment: per step only the dicts of environments that had something to say are emptied and refilled."""
+        of N dicts kept by the environment, of which a step touches only the entries of environments that have (or had) something to
+        say.  With copy_outputs=True (the default) such an entry gets a NEW dict: a dict handed out by an earlier step is never changed,
+        so a consumer may keep the ones it cares about (a replay buffer that stores terminal observations); the LIST is the same object
+        every step -- copy it (list(infos)) to keep a whole step's worth.  copy_outputs=False reuses the dicts in place as well."""
         res = _lib.HostResult()
         _lib.check(self.lib.qs_host_step_end(self.h, C.byref(res)))
         obs, rew, done, trunc, term = self._host_views(res)
         if self.copy_outputs:
             obs, rew, done = obs.copy(), rew.copy(), done.copy()
         infos = self._infos
-        for i in self._dirty:
-            infos[i].clear()
+        if self.copy_outputs:
+            for i in self._dirty:
+                infos[i] = {}
+        else:
+            for i in self._dirty:
+                infos[i].clear()
         dirty = self._dirty = []
         idx = np.flatnonzero(done)
         if idx.size:
             if not self.cfg.auto_reset:
                 for i in idx.tolist():
-                    infos[i]["TimeLimit.truncated"] = bool(trunc[i]); infos[i]["terminal_observation"] = obs[i].copy()
+                    infos[i] = self._entry(infos[i], bool(trunc[i]), obs[i].copy())
             else:
                 rows = term[: idx.size] if idx.size <= term.shape[0] else None
                 if rows is None:    # more episode ends than the compact list holds: the per-environment array
                     full = self.get_info("terminal_obs").cpu().numpy()
                     for i in idx.tolist():
-                        infos[i]["TimeLimit.truncated"] = bool(trunc[i]); infos[i]["terminal_observation"] = full[i]
+                        infos[i] = self._entry(infos[i], bool(trunc[i]), full[i])
                 else:
                     rows = rows.copy()
                     envs = rows[:, 0].view(np.int32)
                     for k, i in enumerate(envs.tolist()):
-                        infos[i]["TimeLimit.truncated"] = bool(trunc[i]); infos[i]["terminal_observation"] = rows[k, 1:]
+                        infos[i] = self._entry(infos[i], bool(trunc[i]), rows[k, 1:])
             dirty.extend(idx.tolist())
         if self.cfg.wrapper_mode:
             # the reference's LandingWrapper / GoToRestWrapper loop over env.step inside one wrapper.step; here every inner
@@ -338,6 +352,8 @@ class QuadrupedVecEnv(SB3VecEnv):
             # environments in a scripted phase get the keys (read them with infos[i].get("scripted", False)).
             w = self.get_info("wrapper").cpu().numpy()
             for i in np.nonzero((w[:, 0] > 0.5) | (w[:, 1] > 0.5))[0].tolist():
+                if self.copy_outputs and not infos[i]:
+                    infos[i] = {}            # (an empty dict may have been handed out by an earlier step: it stays empty)
                 infos[i]["scripted"] = bool(w[i, 1])
                 infos[i]["phase"] = PHASE[int(w[i, 0])]
                 dirty.append(i)

@@ -556,6 +556,9 @@ def gen_traces():
              enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="TORQUE", steps=400, jump_at=60, raw_torque=True),
         dict(name="interp_f0", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", enable_springs=False, enable_action_interpolation=True,
              enable_action_filter=False, action_space_mode="DEFAULT", motor_control_mode="PD", steps=120, jump_at=60),
+        # BASELINE.json configs[0] as SURVEY.md 8d spells it: one environment, no springs, PD, jump in place, SYMMETRIC actions, the PPO_BASIC bundle
+        dict(name="cfg0_s0", task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=False,
+             enable_action_filter=False, action_space_mode="SYMMETRIC", motor_control_mode="PD", steps=240, jump_at=70),
     ]
     out = {}
     for case in cases:

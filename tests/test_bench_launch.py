@@ -110,3 +110,30 @@ def test_usable_cores_follow_the_cgroup_quota(monkeypatch):
     assert bench.usable_cores()[0] == 256
     fake.content = "50000 100000\n"           # half a CPU: still one thread
     assert bench.usable_cores()[0] == 1
+
+
+def test_bench_multi_rank_code_on_two_gloo_ranks():
+    """bench.py's own multi-rank path -- the launcher's children, the process group, the barrier around the timed region, the MAX and MIN
+    of the elapsed time over the ranks, rank 0's JSON line as the only thing on stdout -- executed with two CPU ranks over gloo around
+    a stand-in environment (tests/bench_standin.py): `--backend gloo` is that test mode.  The numbers mean nothing; the path is the
+    one `--gpus N` takes with RCCL."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "quadruped-springs_amd")]))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--standin", "bench_standin:StandInVecEnv",
+                          "--envs-per-gpu", "16", "--steps", "3", "--warmup", "1", "--preroll", "2", "--spread-steps", "125", "--no-info-line"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must hold the JSON line only: {out.stdout[:500]!r}"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["backend"] == "gloo" and cfg["rccl_ranks"] == 2 and cfg["envs_per_gpu"] == 16
+    lo, hi = cfg["rank_ms_per_step_min_max"]
+    assert 0 < lo <= hi and abs(hi - line["ms_per_step"]) < 1e-9          # the line's time is the MAX over the ranks
+    assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]   # whole-job aggregate over both ranks
+    assert "cpu_baseline" not in line                                     # (reported with the single-GPU line only)
+    # without a stand-in the mode refuses: the step has no CPU path
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--backend", "gloo", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "no CPU path" in out.stderr

@@ -127,7 +127,7 @@ def test_env_step_parity_resynced(torch_cuda, kw):
             o.reset(do.astype(np.uint8)); v.reset_tensor(do.astype(np.uint8))
 
 
-@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1", "interp_f1", "interp_f0", "raw_tau", "raw_tau_s0", "jipppohp_s1", "jfppohp_s0", "dt2_s1"])
+@pytest.mark.parametrize("name", ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1", "interp_f1", "interp_f0", "raw_tau", "raw_tau_s0", "jipppohp_s1", "jfppohp_s0", "dt2_s1", "cfg0_s0"])
 def test_reference_traces(torch_cuda, golden, name):
     """Traces recorded from the REFERENCE's QuadrupedGymEnv (tests/golden/traces.npz).  Trajectories are chaotic, so the
     device state is re-synchronised to the recorded state before every step; what is compared is one full env.step."""
@@ -149,6 +149,8 @@ def test_reference_traces(torch_cuda, golden, name):
         sv = v.get_state().cpu().numpy()[0]
         np.testing.assert_allclose(sv[13:25], state_ref[t][13:25], atol=1e-4, err_msg=f"q step {t}")
         np.testing.assert_allclose(sv[25:], state_ref[t][25:], atol=2e-2, err_msg=f"qd step {t}")
+        # the reference's reward of the step (incl. the end-of-episode bonus); tolerance of the CPU twin (tests/test_oracle_traces.py)
+        np.testing.assert_allclose(r[0], rew_ref[t], atol=5e-4, rtol=1e-3, err_msg=f"reward step {t}")
         if t == 0 or (t - 1) not in [x - 1 for x in reset_at[1:]]:
             np.testing.assert_allclose(ob[0], obs_ref[t], atol=2e-2, rtol=1e-3, err_msg=f"obs step {t}")
         if dn[0]:
@@ -239,6 +241,61 @@ def test_full_size_properties(torch_cuda, name):
     assert torch.isfinite(s).all()
     np.testing.assert_allclose(torch.linalg.norm(s[:, 3:7], dim=1).cpu().numpy(), 1.0, atol=1e-5)
     assert float(s[:, 25:].abs().max()) <= cfg.vel_cap + 1e-4   # K10
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+def test_full_size_oracle_sampled(torch_cuda, name):
+    """BASELINE.json sizes under the bench's settings (auto-reset, 16 look-ahead reset states, the configuration's randomizer): 256 of
+    the launch's environments -- four blocks of 64 at random places -- are shadowed by the oracle.  Before every step the oracle is
+    re-seated in the DEVICE's state of those environments (rigid-body state and contact warm start; the device itself runs free), and
+    its step is held against theirs with this file's tolerances: pose, velocities, joint state, observation, reward, done / truncation
+    flags, and the reset observations of the environments that finish."""
+    torch = torch_cuda
+    from oracle.qso import Oracle
+    from qs_amd.config import build_config
+    from qs_amd.vec_env import QuadrupedVecEnv
+    n, kw = FULL_SIZE[name]
+    kw = dict(dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True), **kw, seed=7, noise=False)
+    v = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_lookahead=16, **kw)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    blocks = [int(b) * 64 for b in sorted(rng.choice(n // 64, size=4, replace=False))]
+    oracles = [Oracle(build_config(n_envs=64, auto_reset=True, env_id_offset=b, **kw)[0]) for b in blocks]
+    d, dt = v.action_dim, float(v.cfg.dt)
+    ov = v.reset_tensor().cpu().numpy()
+    for o, b in zip(oracles, blocks):
+        np.testing.assert_allclose(ov[b:b + 64], o.reset(), atol=5e-4, err_msg=f"reset observation, block {b}")
+    finished = 0
+    for i in range(100):
+        a = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+        if i % 20 > 8:   # explosive extension in half of every block: flight, bad landings, terminations inside the run
+            rough = [1.0, 1.0, 1.0, 1.0, -1.0] if d == 5 else (np.tile([0.0, -1.0, 1.0], 4)[:d] if d != 4 else np.tile([-1.0, 1.0], 2))
+            for b in blocks:
+                a[b:b + 32] = rough
+        s = v.get_state().cpu().numpy()
+        warm = v.get_info("foot_force").cpu().numpy() * dt
+        for o, b in zip(oracles, blocks):
+            o.set_state(s[b:b + 64]); o.set_warm(warm[b:b + 64])
+        vo, rv, dv, tv = (x.cpu().numpy() for x in v.step_tensor(torch.from_numpy(a).to(v.device)))
+        sv = v.get_state().cpu().numpy()
+        for o, b in zip(oracles, blocks):
+            oo, ro, do, to = o.step(a[b:b + 64])
+            so, sl = o.get_state(), slice(b, b + 64)
+            np.testing.assert_array_equal(dv[sl].astype(bool), do, err_msg=f"done, step {i} block {b}")
+            np.testing.assert_array_equal(tv[sl].astype(bool), to, err_msg=f"truncated, step {i} block {b}")
+            run = ~do                                   # (a finished environment holds its NEXT episode's settled state: looser, as every reset)
+            np.testing.assert_allclose(sv[sl][run, :7], so[run, :7], atol=TOL_POS, err_msg=f"pose, step {i} block {b}")
+            np.testing.assert_allclose(sv[sl][run, 7:13], so[run, 7:13], atol=TOL_BASE_V, err_msg=f"base velocity, step {i} block {b}")
+            np.testing.assert_allclose(sv[sl][run, 13:25], so[run, 13:25], atol=TOL_Q, err_msg=f"q, step {i} block {b}")
+            np.testing.assert_allclose(sv[sl][run, 25:], so[run, 25:], atol=TOL_QD, err_msg=f"qd, step {i} block {b}")
+            np.testing.assert_allclose(sv[sl][do], so[do], atol=1e-3, err_msg=f"settled state of the next episode, step {i} block {b}")
+            np.testing.assert_allclose(rv[sl], ro, atol=2e-4, rtol=1e-3, err_msg=f"reward, step {i} block {b}")
+            np.testing.assert_allclose(vo[sl], oo, atol=TOL_QD, err_msg=f"observation, step {i} block {b}")
+            finished += int(do.sum())
+    assert finished > 0, "no episode of the shadowed environments ended: the run did not cover a reset"
+    assert v.counter("reset_stalls") == 0
+    for o in oracles:
+        o.close()
+    v.close()
 
 
 def test_auto_reset_and_terminal_observation(torch_cuda):

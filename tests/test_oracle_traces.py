@@ -11,7 +11,7 @@ import pytest
 from oracle.qso import Oracle
 from qs_amd.config import build_config
 
-CASES = ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1", "interp_f1", "interp_f0", "raw_tau", "raw_tau_s0", "jipppohp_s1", "jfppohp_s0", "dt2_s1"]
+CASES = ["jip_s1", "jip_s0", "jf_s1", "cjf_s1", "cjf2_s1", "jipppo_s1", "jfppo_s1", "bf_s1", "bfppo_s1", "cjf3_s1", "cjfppo_s1", "cart_s1", "interp_f1", "interp_f0", "raw_tau", "raw_tau_s0", "jipppohp_s1", "jfppohp_s0", "dt2_s1", "cfg0_s0"]
 
 
 @pytest.mark.parametrize("name", CASES)

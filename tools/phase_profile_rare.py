@@ -16,9 +16,9 @@ from scipy.spatial.transform import Rotation as Rot
 from qs_amd.vec_env import QuadrupedVecEnv
 
 NAMES = {1: "base rotation, velocities", 2: "leg kinematics", 3: "link inertias", 4: "RNEA bias", 5: "CRBA (B, D, K)", 6: "Schur + Cholesky",
-         7: "accelerations, v*", 8: "collision (+ link-link tests)", 9: "foot rows + Delassus (common-path solve)", 10: "its sweeps", 39: "its delta v",
+         7: "accelerations", 8: "collision (+ link-link tests), v*, foot rows", 39: "payload rows",
          40: "support-point and limit rows", 41: "rows -> LDS -> lanes", 42: "Delassus columns", 43: "wave-wide sweeps", 44: "impulses -> quad",
-         45: "delta v (many rows)", 11: "select", 12: "integrate positions"}
+         45: "delta v (many rows)", 9: "Delassus block (common-path solve)", 10: "its sweeps", 11: "its delta v, select", 12: "integrate positions"}
 n = 8192
 if len(sys.argv) > 1 and sys.argv[1] == "--headline":
     # the benchmark's workload with the links' contact response on: how many many-rows solves a step holds, and how long they are

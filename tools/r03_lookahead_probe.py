@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Round-3 design probe (written for the round-2 library, commit 5c69ebe: reset_pool / pool_streaming are its API; result: profiles/r03_lookahead_probe.json): what a per-environment look-ahead of reset states has to cope with.
+"""Round-3 design probe.  RUNS ONLY AGAINST THE ROUND-2 LIBRARY (commit 5c69ebe, QS_LIB_PATH=<that libqs_hip.so>): reset_pool / pool_streaming are its API and are gone since; result: profiles/r03_lookahead_probe.json.
+: what a per-environment look-ahead of reset states has to cope with.
 
 1. episode lengths under the benchmark's U(-1,1) actions at N = 8192: how often do K consecutive episodes of one environment together
    last fewer steps than one settle takes (250 launches + the wait for a cohort, ~300) -- the stall rate of a K-deep look-ahead;

@@ -25,13 +25,14 @@ for name, every in (("all standing", 0), ("one robot in 64 on its side", 64), ("
         s[idx, 3:7] = torch.tensor(Rot.from_euler("x", 1.45).as_quat(), dtype=torch.float32, device=s.device)
         s[idx, 13:25] = torch.tensor(np.tile([0.0, 1.2, -2.4], 4), dtype=torch.float32, device=s.device)
     env.set_state(s)
+    ring = [(torch.rand((n, 12), generator=g, device="cuda") - 0.5) * 4 for _ in range(16)]     # (the actions are made outside the timed loop)
+    for k in range(20):
+        env.step_tensor(ring[k % 16])
     c0 = env.counter("limit_path_substeps")
-    for _ in range(20):
-        env.step_tensor((torch.rand((n, 12), generator=g, device="cuda") - 0.5) * 4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(50):
-        env.step_tensor((torch.rand((n, 12), generator=g, device="cuda") - 0.5) * 4)
+    for k in range(50):
+        env.step_tensor(ring[k % 16])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 50
-    print(f"{name:32s} {1e3 * dt:8.3f} ms per step  ({n / dt / 1e6:6.1f} M env-steps/s), many-rows wave-substeps per step: {(env.counter('limit_path_substeps') - c0) / 70:.0f}")
+    print(f"{name:32s} {1e3 * dt:8.3f} ms per step  ({n / dt / 1e6:6.1f} M env-steps/s), many-rows wave-substeps per step: {(env.counter('limit_path_substeps') - c0) / 50:.0f}")
