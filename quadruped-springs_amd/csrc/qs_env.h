@@ -496,7 +496,26 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
         for (int j = 0; j < 3; j++) { T::st_leg(rec, R_Q + j, 3, s.q[j]); T::st_leg(rec, R_QD + j, 3, s.qd[j]); }
         T::st_leg(rec, R_WARM, 1, s.warm);
     }
-    template <bool RESUME = false>
+    // LEAN (HOT builds under a 256-register budget: k_step_dense): the substep loop keeps the per-environment parameters in LDS instead
+    // of 36 registers and fetches them at the top of every substep -- the raw parameters from the record, the scripted gains from the
+    // stash, the base's inertia (what build_base derives from the masses) from 11 more floats of the observation row.  Same values, same
+    // results; nine ds_read_b128 per substep against ~65 scratch instructions in the loop.
+    enum { ST_I0 = 40 };
+    static QS_FN void load_par_lean(const float* rec, const float* obs, typename S::Par& P) {
+        const float* p = rec + R_PARAMS;
+        P.mu = T::ld(p, P_MU);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            P.k[j] = T::ld(p, P_K + j); P.b[j] = T::ld(p, P_B + j); P.rest[j] = T::ld(p, P_REST + j);
+            P.kp[j] = T::ld(obs, ST_KP + j); P.kd[j] = T::ld(obs, ST_KD + j); P.m_leg[j] = T::ld(p, P_M_LEG + j);
+        }
+        P.m_pay = T::ld(p, P_M_PAY); P.r_pay = mk3<V>(T::ld(p, P_R_PAY), T::ld(p, P_R_PAY + 1), T::ld(p, P_R_PAY + 2));
+        P.I0.m = T::ld(obs, ST_I0); P.I0.h = mk3<V>(T::ld(obs, ST_I0 + 1), T::ld(obs, ST_I0 + 2), T::ld(obs, ST_I0 + 3));
+        P.I0.I.xx = T::ld(obs, ST_I0 + 4); P.I0.I.xy = T::ld(obs, ST_I0 + 5); P.I0.I.xz = T::ld(obs, ST_I0 + 6);
+        P.I0.I.yy = T::ld(obs, ST_I0 + 7); P.I0.I.yz = T::ld(obs, ST_I0 + 8); P.I0.I.zz = T::ld(obs, ST_I0 + 9);
+        P.mtot = T::ld(obs, ST_I0 + 10);
+    }
+    template <bool RESUME = false, bool LEAN = false>
     static QS_FN StepOut step(const qs_config& cfg, float* rec, const float* act_row, float* obs, uint32_t env_id, int settle_n = 0,
                               float* trace = nullptr, bool any_trace = false, const float* demo_rows = nullptr, int demo_len = 0, int resume_k = 0) {
         static_assert(!(RESUME && HOT), "an env step resumes in the full build");
@@ -647,13 +666,21 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
             T::st(obs, ST_W, w_phase); T::st(obs, ST_W + 1, w_timer); T::st(obs, ST_W + 2, w_end); T::st(obs, ST_W + 3, w_tstart);
 #pragma unroll
             for (int i = 0; i < 5; i++) T::st(obs, ST_CPGP + i, cpg_p[i]);
+            if (LEAN) {
+                T::st(obs, ST_I0, P.I0.m); T::st(obs, ST_I0 + 1, P.I0.h.x); T::st(obs, ST_I0 + 2, P.I0.h.y); T::st(obs, ST_I0 + 3, P.I0.h.z);
+                T::st(obs, ST_I0 + 4, P.I0.I.xx); T::st(obs, ST_I0 + 5, P.I0.I.xy); T::st(obs, ST_I0 + 6, P.I0.I.xz);
+                T::st(obs, ST_I0 + 7, P.I0.I.yy); T::st(obs, ST_I0 + 8, P.I0.I.yz); T::st(obs, ST_I0 + 9, P.I0.I.zz); T::st(obs, ST_I0 + 10, P.mtot);
+                T::sync();
+            }
         }
+        static_assert(!LEAN || HOT, "the lean loop keeps its parameters in the observation row, which the full build's many-rows solve borrows");
         int k = RESUME ? resume_k : 0;
         bool gave_up = false;   // (HOT builds, wave-uniform) substep k needs a rare path; `s` is as that substep found it
         for (; k < n_sub; k++) {  // gym_env.py:236-237, 207-216
             V tau[3];
             if (cpg && !(RESUME && k == resume_k)) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate (a resumed substep's tick has happened)
             QS_PHASE_SUB_BEGIN
+            if (LEAN) load_par_lean(rec, obs, P);
             S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
             if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts, blk, obs, k == n_sub - 1), 0)) { gave_up = true; break; }
             QS_PHASE_SUB(k)
@@ -661,6 +688,8 @@ template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
             }
         }
+        // (Tried instead, round 4: the state checkpointed into the LDS record after every substep -- eleven LDS stores -- so that the hand-over
+        // needs nothing kept: ~70 register moves fewer per substep in the ISA and 0.9 % SLOWER on the GPU, 109.5 against 110.5 M.)
         if (HOT && __builtin_expect(gave_up, 0)) {   // hand over to the full build: the state of this moment (the rest of the stash is in place)
             stash_state(rec, s);
             if (cpg) { T::st_leg(obs, ST_CMD, 3, cmd[0]); T::st_leg(obs, ST_CMD + 1, 3, cmd[1]); T::st_leg(obs, ST_CMD + 2, 3, cmd[2]); T::st_leg(obs, ST_CPGR, 1, cpg_r); T::st_leg(obs, ST_CPGTH, 1, cpg_th); }

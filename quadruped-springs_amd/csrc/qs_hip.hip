@@ -18,6 +18,9 @@ using qs::Env;
 using E = Env<LaneDev>;
 
 #define QS_TILE_FLOATS (QS_ENVS_PER_WAVE * QS_REC_END)
+#ifndef QS_LEAN_WAVES
+#define QS_LEAN_WAVES(W) ((W) == 2)     // which step kernels keep the per-environment parameters in LDS (Env::step, LEAN): the two-waves-per-SIMD one
+#endif
 
 // ------------------------------------------------------------------ tile movement (coalesced, 16 B per lane)
 // Range of a record that a step moves (qs_layout.h).  Loads [0, end): the parameters, the read-write block; the wrapper / CPG / DEMO
@@ -329,7 +332,7 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
     // A payload_soft handle under the friction pyramid has its block's rows in no common-path build: its first substep already hands over.
     typename E::StepOut r;
     {
-        const typename EH::StepOut rh = EH::step(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
+        const typename EH::StepOut rh = EH::template step<false, QS_LEAN_WAVES(WAVES)>(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length);
         r.reward = rh.reward; r.done = rh.done; r.trunc = rh.trunc; r.resume = rh.resume;
     }
     if (__builtin_expect(r.resume >= 0, 0)) r = E::template step<true>(cfg, rec, s_act + slot * 12, ob, gid, settle_n, trow, any_trace, demo.rows, demo.length, r.resume);
@@ -412,12 +415,17 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
                      float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep, \
                      float* __restrict__ term_obs, LookAhead la, unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo, TermTail tail
 #define QS_STEP_PASS cfgp, recs, actions, obs_out, rew_out, done_out, trunc_out, obs_keep, term_obs, la, stats, lanes, tap, demo, tail
-// One wave per SIMD: the whole 512-entry register file (256 VGPR + AGPR) for one wave, no spills.  The launch time is one
-// wave's instruction stream, so this is the variant while the grid does not oversubscribe the chip's SIMDs.
+// One wave per SIMD: the whole 512-entry register file (256 VGPR + 256 AGPR) for one wave.  The common-path substep loop holds no scratch
+// instruction (tools/isa_headline.py); the cold code behind it -- the full build's substeps of a handed-over step, the in-step settle --
+// spills (~110 values, ~470 B of scratch per lane).  The launch time is one wave's instruction stream, so this is the variant while the
+// grid does not oversubscribe the chip's SIMDs.
 template <bool CONE, bool SOFT> __global__ __launch_bounds__(QS_WAVE, 1) void k_step(QS_STEP_ARGS) { step_body<CONE, 1, SOFT>(QS_STEP_PASS); }
-// Two waves per SIMD: 256 registers per wave, ~140 values spilled to scratch outside the solver loop, but a second wave to
-// issue from while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued
-// (measured on MI355X: N = 32768: 155 vs 137 M env-steps/s, N = 65536: 169 vs 141 M; N = 16384: 124 vs 134 M).
+// Two waves per SIMD: 256 registers per wave (all of them VGPRs: the compiler takes no AGPRs under this budget), a second wave to issue from
+// while the first waits on a dependent result.  Slower per wave, faster per chip once every SIMD has work queued (N = 16384: 146 M
+// env-steps/s against 110 M at 8192; 65536: 222 M).  Its common-path loop keeps the per-environment parameters in LDS (Env::step, LEAN):
+// 23 scratch instructions per substep where round 3 had 65 (~1900 values of the whole kernel are spilled, nearly all of them in the cold
+// code) -- which measured as NO change of throughput (146.3 against 146.5 M at 16384, round 4): with two waves per SIMD the loop is bound by
+// VALU issue, and the scratch traffic hides behind the other wave.
 template <bool CONE, bool SOFT> __global__ __launch_bounds__(QS_WAVE, 2) void k_step_dense(QS_STEP_ARGS) { step_body<CONE, 2, SOFT>(QS_STEP_PASS); }
 
 // Settle lanes, between two settles of a cohort (an epoch = the launches one settle takes): the staging records that finished settling go

@@ -37,7 +37,9 @@ for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=Tru
             print(f"| {n[:50]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {r['Percentage']} |")
 # per-dispatch durations of the kernel trace: the same average restricted to the last N launches (the timed region of the profiled command)
 trace_avg_us = None
-for f in glob.glob(os.path.join(root, "**", "*_kernel_trace.csv"), recursive=True):
+# (the trace of the pass WITHOUT counters -- profile_round.sh's trace/ directory -- if it is there: under --pmc the launches run ~6 % slower)
+traces = sorted(glob.glob(os.path.join(root, "**", "*_kernel_trace.csv"), recursive=True), key=lambda f: (os.sep + "trace" + os.sep not in f, f))
+for f in traces:
     rows = [r for r in csv.DictReader(open(f)) if wanted(r.get("Kernel_Name", ""))]
     if rows and "Start_Timestamp" in rows[0]:
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
