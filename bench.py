@@ -350,10 +350,15 @@ def main():
         # (they would otherwise all hit the 1000-step limit of gym_env.py:35 in the same step: one burst of N resets).
         groups = 125    # (16 groups left a burst of several hundred time-limit resets every 62 steps: a 20-step timed region either held one or did not)
         ids = torch.arange(n, device=dev)
+        # (the robots stand still while their episode ages are spread: under the random actions some fall every ~20 steps from the very first
+        # launch on and use up their 16 look-ahead states before the settle lanes -- whose first states arrive 300 launches after
+        # qs_create -- deliver: ~155 in-step settles of 14.5 ms each in rounds 3-4's preparation, 2 s of the run and most of rocprofv3's
+        # all-launches average.  The pre-roll below is where the random actions' steady state builds up.)
+        still = torch.zeros((n, d), device=dev)
         for gidx in range(groups):
             env.reset_tensor((ids % groups == gidx).to(torch.uint8))
             for i in range(args.spread_steps // groups):
-                local_step(acts[i % n_act])
+                local_step(still)
             if not gloo:
                 torch.cuda.current_stream().synchronize()
         # ... and let the reset rate and with it the settle lanes reach their steady state (episodes of random actions last ~600 steps, a
@@ -428,7 +433,7 @@ def main():
                 p = json.load(open(f))
                 if (p["workload"], p["envs_per_gpu"], p.get("reset_lookahead"), p.get("friction_model", "pyramid"),
                         float(p.get("solver_residual_threshold", 0.0))) == (args.workload, n, args.reset_lookahead, args.friction_model,
-                                                                            float(args.solver_residual_threshold)):
+                                                                            float(args.solver_residual_threshold)) and not extra_kw:   # (a run with extra keywords is another configuration)
                     pmc, pmc_file = p, os.path.relpath(f, REPO)
                     break
             if pmc is not None and not gloo:

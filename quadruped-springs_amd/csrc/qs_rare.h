@@ -49,7 +49,7 @@ template <class T, bool CONE> struct RareSolver;
 // (region B) and the friction pairs to lanes 30.. (region C; pair k belongs to the normal in lane 18 + k), each region packed to its
 // start.  The unrolled sweep code then walks a region up to its fill count and meets no empty row -- the first version kept every row
 // at its fixed position and skipped the empty ones with a scalar branch each: 44 taken branches per sweep of a typical fallen robot
-// (10 rows), 1.7 k cycles per sweep of which the rows themselves were 0.4 k (profiles/r04_b_rare_phases.md).
+// (10 rows), 1.7 k cycles per sweep of which the rows themselves were 0.4 k (profiles/r04_d_rare_phases.md).
 template <bool CONE> struct RareSolver<LaneDev, CONE> {
     using Ty = SimTypes<LaneDev>;
     using Row = typename Ty::Row;

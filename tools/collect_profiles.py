@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy what a GPU call of tools/r03_gpu_profiles.sh (r02_gpu_profiles.sh) left under gpurun_out/ into profiles/ (tracked), named per round and tag.
+"""Copy what a GPU call of tools/r04_gpu_profiles.sh (r03_gpu_profiles.sh) left under gpurun_out/ into profiles/ (tracked), named per round and tag.
 usage: python tools/collect_profiles.py gpurun_out/r03p gpurun_out/prof_r03a r03_a"""
 import os
 import shutil
@@ -10,7 +10,7 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 rnd = tag.split("_")[0]
 for f in sorted(os.listdir(run)):
     if f.endswith(".json") and os.path.getsize(os.path.join(run, f)) > 10:
-        shutil.copy(os.path.join(run, f), os.path.join(dst, f"{tag}_{f[:-5]}_bench.json"))
+        shutil.copy(os.path.join(run, f), os.path.join(dst, f"{tag}_{f[:-5]}" + (".json" if f == "numpy_path.json" else "_bench.json")))
 for src, name in (("summary.md", "kernel_trace_pmc.md"), ("pmc.json", "pmc.json"), ("kernel_stats.csv", "kernel_stats.csv"), ("bench.json", "profiled_command_bench.json")):
     if os.path.exists(os.path.join(prof, src)):
         shutil.copy(os.path.join(prof, src), os.path.join(dst, f"{tag}_{name}"))
