@@ -271,7 +271,6 @@ template <> struct Rng<LaneEmu> {
 // returns true: the env step of that wave then goes on FROM THAT SUBSTEP in the full build (HOT = false; Env::step), whose rare code thus
 // sits behind the hot loop and costs it neither registers nor schedule (measured: inlined into the loop the rare code took 20 % off the
 // headline).  (Rounds 2-3 repeated the whole env step with the full build: a rare-path wave paid up to two steps' time.)
-// CALLS: unused since round 4 (rounds 2-3: the many-rows solvers as real functions in the one-wave-per-SIMD kernel).
 // SOFT (HOT builds): the common-path build ALSO holds the payload block's six rows (cfg.payload_soft), next to the twelve foot rows in
 // solve_and_integrate<.., PAY>; without it a common-path build gives up on every substep of such a handle and the full build does the work.
 // the values a substep works on: one set of types for every build of Sim (an env step may start in the common-path build and go on in
@@ -311,7 +310,7 @@ template <class T> struct SimTypes {
 
 #include "qs_rare.h"
 
-template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool SOFT = false> struct Sim : SimTypes<T> {
+template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struct Sim : SimTypes<T> {
     using V = typename T::V;
     using M = typename T::M;
     using V3v = V3<V>;

@@ -8,10 +8,10 @@ namespace qs {
 QS_FN float i2f(int v) { union { int i; float f; } u; u.i = v; return u.f; }
 QS_FN int f2i(float v) { union { int i; float f; } u; u.f = v; return u.i; }
 
-template <class T, bool CONE = false, bool HOT = false, bool CALLS = false, bool SOFT = false> struct Env {
+template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struct Env {
     using V = typename T::V;
     using M = typename T::M;
-    using S = Sim<T, CONE, HOT, CALLS, SOFT>;
+    using S = Sim<T, CONE, HOT, SOFT>;
     using V3v = V3<V>;
     static constexpr float PI = 3.14159265358979323846f;
 

@@ -258,13 +258,12 @@ template <bool CONE, int WAVES, bool SOFT> static __device__ __forceinline__ voi
                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ obs_keep,
                                                  float* __restrict__ term_obs, LookAhead la,
                                                  unsigned long long* __restrict__ stats, SettleLanes lanes, TraceTap tap, DemoTab demo, TermTail tail) {
-    // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch).  The full build's many-rows solver is inlined
-    // (CALLS = false) in both kernels: as a real function (round 2's one-wave-per-SIMD build) it takes State / Out by reference, which
-    // keeps them in memory around the call, and expressions that then span a store and a load are no longer contracted into the FMAs
-    // the common-path build forms -- a wave on a rare path gave its other 15 environments different last bits than the common-path build
-    // (tests/test_gpu_round2.py::test_results_do_not_depend_on_wave_mates); it also measured 4 % slower on the headline.
-    using E = Env<LaneDev, CONE, false, false>;         // the full build: resets, in-step settle
-    using EH = Env<LaneDev, CONE, true, false, SOFT>;   // the env step: common-path substeps, then (rare) the full build's (qs_env.h, Env::step)
+    // the friction model is compiled in (qs_config::friction_cone picks the kernel at launch).  Everything of the full build is inlined in
+    // both kernels: as real functions (round 2) the many-rows solvers took State / Out by reference, which kept them in memory around the
+    // call, and expressions that then span a store and a load are no longer contracted into the FMAs the common-path build forms -- a wave
+    // on a rare path gave its other 15 environments different last bits (tests/test_gpu_round2.py::test_results_do_not_depend_on_wave_mates).
+    using E = Env<LaneDev, CONE, false>;                // the full build: resets, in-step settle, the rest of a handed-over step
+    using EH = Env<LaneDev, CONE, true, SOFT>;          // the env step: common-path substeps, then (rare) the full build's (qs_env.h, Env::step)
     // LDS (sized at launch, step_lds_bytes): the 16 records at stride `ls`, the observation rows, the action rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const qs_config& cfg = *cfgp;

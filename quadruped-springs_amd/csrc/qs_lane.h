@@ -17,12 +17,8 @@
 #if defined(__HIPCC__)
 #define QS_FN __host__ __device__ __forceinline__
 #define QS_DEV __device__ __forceinline__
-#define QS_RARE_FN __host__ __device__ __attribute__((noinline))   // the joint-limit solver: a real call keeps its registers out of the common path's allocation
-#define QS_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define QS_FN inline
-#define QS_RARE_FN inline
-#define QS_NOINLINE inline
 #endif
 
 // ------------------------------------------------------------------ scalar (device) flavour
