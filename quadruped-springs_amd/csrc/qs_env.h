@@ -689,7 +689,8 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
             }
         }
         // (Tried instead, round 4: the state checkpointed into the LDS record after every substep -- eleven LDS stores -- so that the hand-over
-        // needs nothing kept: ~70 register moves fewer per substep in the ISA and 0.9 % SLOWER on the GPU, 109.5 against 110.5 M.)
+        // needs nothing kept: ~70 register moves fewer per substep in the ISA and 0.9 % SLOWER on the GPU, 109.5 against 110.5 M; the state
+        // stored inside the substep, at each of the three votes that give up: 109.9 against 110.7 M.)
         if (HOT && __builtin_expect(gave_up, 0)) {   // hand over to the full build: the state of this moment (the rest of the stash is in place)
             stash_state(rec, s);
             if (cpg) { T::st_leg(obs, ST_CMD, 3, cmd[0]); T::st_leg(obs, ST_CMD + 1, 3, cmd[1]); T::st_leg(obs, ST_CMD + 2, 3, cmd[2]); T::st_leg(obs, ST_CPGR, 1, cpg_r); T::st_leg(obs, ST_CPGTH, 1, cpg_th); }

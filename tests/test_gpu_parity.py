@@ -80,6 +80,12 @@ CASES = [
     dict(env_randomizer_mode="MASS_RANDOMIZER", seed=6),                                                      # Bullet's collision-shape rule
     dict(body_contacts=True, self_collision=False),               # a task that ends on the contact, with the links' response forced on
     dict(info_fields=False),
+    # the hand-over to the full build inside an env step (round 4) under the layers whose prologue it has to carry across: the Hopf CPG
+    # (oscillator state, per-substep commands), a landing wrapper (phase, timers, scripted gains), a 12-value action space
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="GROUND_RANDOMIZER", seed=4,
+         body_contacts=True, self_collision=False),
+    dict(wrapper="LANDING", body_contacts=True),
+    dict(action_space_mode="DEFAULT", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT", body_contacts=True, friction_model="pyramid"),
 ]
 
 
@@ -476,6 +482,37 @@ def test_trace_tap(torch_cuda):
     assert d["joint_angles"].shape == (10, 12) and d["time"].shape == (10,)
     v.set_trace(None)
     v.step(a)
+
+
+def test_trace_tap_across_the_hand_over(torch_cuda):
+    """The traced environment's wave hands over to the full build in the middle of an env step (a neighbour comes down on a thigh in
+    some substep, `body_contacts=True`): the rows of the substeps before it are the common-path build's, the rows after it the full
+    build's -- one row per substep, each equal to the oracle's, the last one the state after the step."""
+    n = 16
+    o, v, cfg = make_pair(n, torch_cuda, task_env="NO_TASK", observation_space_mode="ENCODER", body_contacts=True, self_collision=False)
+    o.reset(); v.reset()
+    to = o.set_trace(5)
+    v.set_trace(5)
+    from scipy.spatial.transform import Rotation as Rot
+    s = o.get_state()
+    s[3, 2] = 0.17; s[3, 3:7] = Rot.from_euler("x", 1.45).as_quat(); s[3, 13:25] = np.tile([0.0, 1.2, -2.4], 4)    # environment 3: on its side, 5 cm above where it will lie
+    o.set_state(s); v.set_state(s.astype(np.float32))
+    rng = np.random.default_rng(4)
+    c0, handed = v.counter("limit_path_substeps"), []
+    for i in range(16):
+        s = o.get_state()
+        o.set_state(s); v.set_state(s.astype(np.float32))
+        a = rng.uniform(-1, 1, size=(n, cfg.action_dim)).astype(np.float32)
+        o.step(a); v.step(a)
+        c1 = v.counter("limit_path_substeps"); handed.append(c1 - c0); c0 = c1
+        tv = v.get_trace(as_dict=False)
+        np.testing.assert_allclose(tv[:, 0], to[:, 0], atol=1e-6)
+        np.testing.assert_allclose(tv[-1, 1:38], v.get_state().cpu().numpy()[5], atol=0)
+        np.testing.assert_allclose(tv[:, 1:8], to[:, 1:8], atol=2e-5, err_msg=f"pose rows, step {i}")
+        np.testing.assert_allclose(tv[:, 14:26], to[:, 14:26], atol=5e-5, err_msg=f"joint rows, step {i}")
+        np.testing.assert_allclose(tv[:, 26:38], to[:, 26:38], atol=2e-2, err_msg=f"joint velocity rows, step {i}")
+        np.testing.assert_array_equal(tv[:, 66:70], to[:, 66:70])
+    assert any(0 < h < cfg.action_repeat for h in handed), f"no env step was handed over in its middle: many-rows substeps per step {handed}"
 
 
 def test_lookahead_resets_are_bitwise_the_exact_resets(torch_cuda):
