@@ -281,6 +281,17 @@ int qs_norm_reset(qs_norm* h, float* obs /* [N,o] */, int training, int norm_obs
 int qs_norm_step(qs_norm* h, float* obs /* [N,o] */, float* rew /* [N] */, const uint8_t* done /* [N] */, float* term_obs /* [N,o] or NULL */,
                  int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
 
+/* qs_norm_step with the host path's compact list of terminal observations (qs_host_result::terminal_rows while still on the device:
+ * [tail_cap][1 + obs_dim]) normalised like term_obs; tail_rows may be NULL. */
+int qs_norm_step_rows(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward,
+                      float* raw_obs, float* raw_rew, float* tail_rows, int tail_cap);
+/* VecNormalize around the HOST path (load_model.py:109-137: VecNormalize.load(stats, env), then env.step(numpy actions)): from the next
+ * qs_host_step_begin on, the step's results pass through `norm` (qs_norm_step_rows: statistics update if training, observations, rewards
+ * and the terminal observations of the compact list normalised) before they reach the host block, so that qs_host_step_end hands out
+ * what VecNormalize.step_wait returns.  raw_obs [N,o] / raw_rew [N] (device memory, may be NULL): the values before normalisation
+ * (get_original_obs / get_original_reward).  norm == NULL switches it off.  Not between a begin and its end. */
+int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
+
 const char* qs_last_error(void);
 const char* qs_version(void);
 

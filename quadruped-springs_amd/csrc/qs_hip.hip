@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <new>
 #include "qs_env.h"
 #include "qs_host.h"
@@ -932,6 +933,9 @@ struct HostPath {
     int cur, parity, pending;
     int registered;          // bits 0, 1: h_block[k], bit 2: h_act are page-locked (hipHostRegister succeeded)
     hipEvent_t ev;
+    // qs_host_set_norm: VecNormalize.step_wait between the step and the results' way to the host (the step then writes the DEVICE block,
+    // qs_norm_step_rows works on it in place, one copy brings it over)
+    qs_norm* norm; int norm_training, norm_obs, norm_rew; float* raw_obs; float* raw_rew;
 };
 // (`registered`: which of the page-locked buffers hipHostRegister accepted -- only those are unregistered)
 static void host_path_release(HostPath* p) {
@@ -1004,15 +1008,35 @@ int qs_host_step_begin(qs_handle* h, const float* actions_host) {
     // the block and the terminal-list counter this step uses are the OTHER ones; the switch is made once the step is on the stream (a
     // launch that fails -- a DEMO task without its demonstration -- must not leave a counter behind that no step has cleared)
     const int cur = p->cur ^ 1, parity = p->parity ^ 1;
-    uint8_t* blk = p->zero_copy ? p->hd_block[cur] : p->d_block;
+    const bool via_device = !p->zero_copy || p->norm != nullptr;     // the results pass through the device block
+    if (via_device && !p->d_block) {
+        QS_HIP(hipMalloc(&p->d_block, p->bytes));
+        QS_HIP(hipMemsetAsync(p->d_block, 0, p->bytes, h->stream));
+    }
+    uint8_t* blk = via_device ? p->d_block : p->hd_block[cur];
     const float* act = p->zero_copy ? p->hd_act : p->d_act;
     if (!p->zero_copy) QS_HIP(hipMemcpyAsync(p->d_act, p->h_act, n * d * 4, hipMemcpyHostToDevice, h->stream));
     h->tail.rows = (float*)(blk + p->off_tail); h->tail.cap = p->cap; h->tail.parity = parity;
     if (int rc = launch_step(h, act, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, blk + p->off_trunc)) { memset(&h->tail, 0, sizeof(h->tail)); return rc; }
     p->cur = cur; p->parity = parity;
-    if (!p->zero_copy) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
+    if (p->norm) {
+        if (int rc = qs_norm_set_stream(p->norm, (void*)h->stream)) return rc;
+        if (int rc = qs_norm_step_rows(p->norm, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, nullptr, p->norm_training, p->norm_obs, p->norm_rew,
+                                       p->raw_obs, p->raw_rew, (float*)(blk + p->off_tail), p->cap)) return rc;
+    }
+    if (via_device) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
     QS_HIP(hipEventRecord(p->ev, h->stream));
     p->pending = 1;
+    return 0;
+}
+
+int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew) {
+    if (!h) QS_FAIL(-1, "null handle");
+    QS_ON_DEVICE(h);
+    if (int rc = host_path_init(h)) return rc;
+    HostPath* p = h->host;
+    if (p->pending) QS_FAIL(-1, "qs_host_set_norm between qs_host_step_begin and qs_host_step_end");
+    p->norm = norm; p->norm_training = training; p->norm_obs = norm_obs; p->norm_rew = norm_reward; p->raw_obs = raw_obs; p->raw_rew = raw_rew;
     return 0;
 }
 
@@ -1021,7 +1045,24 @@ int qs_host_step_end(qs_handle* h, qs_host_result* out) {
     HostPath* p = h->host;
     if (!p || !p->pending) QS_FAIL(-1, "qs_host_step_end without qs_host_step_begin");
     QS_ON_DEVICE(h);
-    QS_HIP(hipEventSynchronize(p->ev));
+    // Poll the event for a while before blocking on it: hipEventSynchronize sleeps on the completion interrupt, and waking up costs the
+    // caller tens of microseconds -- of a step that takes ~100.  (QS_HOST_SPIN_US: how long to poll, default 2000; 0 = block at once.)
+    {
+        static const long spin_us = getenv("QS_HOST_SPIN_US") ? atol(getenv("QS_HOST_SPIN_US")) : 2000;
+        hipError_t q = hipErrorNotReady;
+        if (spin_us > 0) {
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (;;) {
+                q = hipEventQuery(p->ev);
+                if (q != hipErrorNotReady) break;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L > spin_us) break;
+            }
+            if (q != hipErrorNotReady && q != hipSuccess) QS_FAIL(-2, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
+        if (q != hipSuccess) QS_HIP(hipEventSynchronize(p->ev));
+    }
     p->pending = 0;
     const uint8_t* b = p->h_block[p->cur];
     out->obs = (const float*)b; out->rew = (const float*)(b + p->off_rew); out->done = b + p->off_done; out->truncated = b + p->off_trunc;

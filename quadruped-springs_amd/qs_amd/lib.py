@@ -14,6 +14,7 @@ EXPORTS = (
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
     "qs_settle_lanes", "qs_host_step_begin", "qs_host_step_end", "qs_set_trace", "qs_counter", "qs_counters_async", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
     "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
+    "qs_norm_step_rows", "qs_host_set_norm",
 )
 
 
@@ -75,6 +76,8 @@ def load():
     lib.qs_norm_get_stats.argtypes = [vp, vp, vp, pd, pd, pd, pd]
     lib.qs_norm_reset.argtypes = [vp, vp, i32, i32]
     lib.qs_norm_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.qs_norm_step_rows.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32]
+    lib.qs_host_set_norm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.qs_last_error.restype = C.c_char_p
     lib.qs_version.restype = C.c_char_p
     _lib = lib

@@ -67,6 +67,7 @@ class QuadrupedVecEnv(SB3VecEnv):
             self._trunc = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self._act = torch.zeros((n, d), dtype=torch.float32, device=self.device)
         self._views, self._infos, self._dirty = {}, [{} for _ in range(self.num_envs)], []
+        self._terminal_hook = None     # DeviceVecNormalize.step_async: normalises the per-environment terminal observations (overflow of the compact list)
         self.copy_outputs = bool(copy_outputs)
         self._trace = None
         self.render_mode = None
@@ -342,6 +343,8 @@ class QuadrupedVecEnv(SB3VecEnv):
                 rows = term[: idx.size] if idx.size <= term.shape[0] else None
                 if rows is None:    # more episode ends than the compact list holds: the per-environment array
                     full = self.get_info("terminal_obs").cpu().numpy()
+                    if self._terminal_hook is not None:      # DeviceVecNormalize: the per-environment array holds raw observations
+                        full = self._terminal_hook(full)
                     for i in idx.tolist():
                         infos[i] = self._entry(infos[i], bool(trunc[i]), full[i])
                 else:

@@ -65,24 +65,42 @@ class DeviceVecNormalize:
     def get_original_reward(self):
         return self.old_reward.cpu().numpy().copy()
 
-    # ---- SB3 VecEnv surface (numpy)
+    # ---- SB3 VecEnv surface (numpy): load_model.py:109-137 -- env = VecNormalize.load(stats, env); env.step(numpy actions)
     def reset(self):
         return self.reset_tensor().cpu().numpy().copy()
 
-    def step(self, actions):
+    def step_async(self, actions):
+        """The wrapped environment's host path with this normalisation attached (qs_host_set_norm): the step writes its result block on the
+        device, VecNormalize.step_wait's work runs on it in place (one more launch), ONE copy brings observations, rewards, flags and the
+        step's terminal observations -- normalised -- to page-locked host memory."""
         v = self.venv
-        v._act.copy_(self.torch.from_numpy(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.action_dim)))
-        obs, rew, done, trunc = self.step_tensor(v._act)
-        obs, rew = obs.cpu().numpy().copy(), rew.cpu().numpy().copy()
-        done, trunc = done.cpu().numpy().astype(bool), trunc.cpu().numpy().astype(bool)
-        infos = [{} for _ in range(self.num_envs)]
-        if done.any():
-            term = v.get_info("terminal_obs").cpu().numpy() if v.cfg.auto_reset else self.get_original_obs()
-            term = self.normalize_obs(term)
-            for i in np.nonzero(done)[0]:
-                infos[i]["TimeLimit.truncated"] = bool(trunc[i])
-                infos[i]["terminal_observation"] = term[i].copy()
-        return obs, rew, done, infos
+        v._stream()
+        _lib.check(self.lib.qs_host_set_norm(v.h, self.h, int(self.training), int(self.norm_obs), int(self.norm_reward), self._p(self.old_obs),
+                                             self._p(self.old_reward)))
+        v._terminal_hook = self.normalize_obs      # (only used when more episodes end in one step than the compact list holds)
+        try:
+            v.step_async(actions)
+        except Exception:
+            self._detach()
+            raise
+
+    def step_wait(self):
+        """-> (obs, rewards, dones, infos) as VecNormalize.step_wait returns them: normalised observations / rewards, and
+        infos[i]["terminal_observation"] normalised with the statistics of this step (vec_normalize.py step_wait)."""
+        try:
+            return self.venv.step_wait()
+        finally:
+            self._detach()
+
+    def _detach(self):
+        v = self.venv
+        v._terminal_hook = None
+        if v.h:
+            self.lib.qs_host_set_norm(v.h, None, 0, 0, 0, None, None)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
 
     # ---- statistics
     def get_stats(self):

@@ -632,6 +632,56 @@ def test_device_vec_normalize(torch_cuda, training, norm_reward):
     env.close()
 
 
+def test_vec_normalize_one_launch_equals_three_launches(torch_cuda, monkeypatch):
+    """qs_norm_step's one-launch kernel (k_norm_fused: the blocks hand their moments to the last one to arrive and wait for its statistics)
+    against the three-launch path (QS_NORM_FUSED=0) on the same arrays: the statistics agree to the rounding of the merge order, the
+    normalised arrays to float32 rounding; evaluation mode, terminal observations and the host path's compact list included."""
+    import ctypes as C
+    from qs_amd import lib as L
+    torch = torch_cuda
+    lib = L.load()
+    n, o, cap = 8192 + 37, 28, 40
+    def make(fused):
+        monkeypatch.setenv("QS_NORM_FUSED", "1" if fused else "0")
+        h = C.c_void_p()
+        L.check(lib.qs_norm_create(n, o, 10.0, 10.0, 0.99, 1e-8, 0, C.byref(h)))
+        return h
+    ha, hb = make(True), make(False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    scale = torch.linspace(0.01, 30.0, o, device="cuda"); shift = torch.linspace(-5.0, 5.0, o, device="cuda")
+    def stats(h):
+        mean, var = np.zeros(o), np.zeros(o)
+        c = [C.c_double() for _ in range(4)]
+        L.check(lib.qs_norm_get_stats(h, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), *[C.byref(x) for x in c]))
+        return mean, var, np.array([x.value for x in c])
+    obs0 = torch.randn((n, o), generator=g, device="cuda") * scale + shift
+    oa, ob = obs0.clone(), obs0.clone()
+    L.check(lib.qs_norm_reset(ha, p(oa), 1, 1)); L.check(lib.qs_norm_reset(hb, p(ob), 1, 1))
+    torch.testing.assert_close(oa, ob, atol=1e-5, rtol=1e-6)
+    for step in range(30):
+        training = 0 if step >= 25 else 1
+        obs = torch.randn((n, o), generator=g, device="cuda") * scale * (1 + 0.1 * step) + shift
+        rew = torch.randn(n, generator=g, device="cuda") * 3 + 1
+        done = (torch.rand(n, generator=g, device="cuda") < 0.02).to(torch.uint8)
+        term = torch.randn((n, o), generator=g, device="cuda") * scale + shift
+        tail = torch.randn((cap, o + 1), generator=g, device="cuda") * 5
+        outs = []
+        for h in (ha, hb):
+            a = [obs.clone(), rew.clone(), term.clone(), tail.clone(), torch.zeros_like(obs), torch.zeros_like(rew)]
+            L.check(lib.qs_norm_step_rows(h, p(a[0]), p(a[1]), p(done), p(a[2]), training, 1, 1, p(a[4]), p(a[5]), p(a[3]), cap))
+            outs.append(a)
+        torch.cuda.synchronize()
+        for x, y in zip(*outs):
+            torch.testing.assert_close(x, y, atol=2e-5, rtol=2e-6)
+        assert torch.equal(outs[0][4], obs) and torch.equal(outs[0][5], rew)                 # the raw copies
+        assert torch.equal(outs[0][3][:, 0], tail[:, 0]) and outs[0][0].abs().max() <= 10.0   # the list's index column is left alone
+        ma, va, ca = stats(ha); mb, vb, cb = stats(hb)
+        np.testing.assert_allclose(ma, mb, rtol=1e-12, atol=1e-13); np.testing.assert_allclose(va, vb, rtol=1e-11); np.testing.assert_allclose(ca, cb, rtol=1e-11)
+    assert abs(ca[0] - (1e-4 + 26 * n)) < 1e-6     # reset + 25 training steps; the five evaluation steps left the statistics alone
+    lib.qs_norm_destroy(ha); lib.qs_norm_destroy(hb)
+
+
 def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
     """The N = 1 QuadrupedGymEnv view with the getters the reference's wrappers use (get_sim_time, get_landing_action,
     task.is_switched_controller, task.compute_time_for_peak_heihgt, robot._motor_model._kp/_kd).  A host-side loop with the control
