@@ -266,7 +266,7 @@ int qs_set_trace(qs_handle* h, int env, float* rows);
  * as applied by the reference at load_model.py:109-137 and get_demonstrations.py:71.  Operates in place on the device arrays
  * a step / reset produced; statistics are float64.  norm handles are independent of simulation handles. */
 typedef struct qs_norm qs_norm;
-int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, float gamma, float epsilon, int device, qs_norm** out);
+int qs_norm_create(int n_envs, int obs_dim, double clip_obs, double clip_reward, double gamma, double epsilon, int device, qs_norm** out);
 void qs_norm_destroy(qs_norm* h);
 int qs_norm_set_stream(qs_norm* h, void* hip_stream);
 /* host arrays [obs_dim]; RunningMeanStd.mean / .var / .count of obs_rms and ret_rms (VecNormalize.load / save) */
@@ -281,12 +281,19 @@ int qs_norm_reset(qs_norm* h, float* obs /* [N,o] */, int training, int norm_obs
 int qs_norm_step(qs_norm* h, float* obs /* [N,o] */, float* rew /* [N] */, const uint8_t* done /* [N] */, float* term_obs /* [N,o] or NULL */,
                  int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
 
-/* qs_norm_step with the host path's compact list of terminal observations (qs_host_result::terminal_rows while still on the device:
- * [tail_cap][1 + obs_dim]) normalised like term_obs; tail_rows may be NULL. */
-int qs_norm_step_rows(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward,
-                      float* raw_obs, float* raw_rew, float* tail_rows, int tail_cap);
+/* qs_norm_step with everything a host-path step carries.  The arrays of the step (device memory): obs [N,o], rew [N], done [N], trunc [N]
+ * (may be NULL), term_obs [N,o] (may be NULL), tail_rows = the compact list of the step's terminal observations, [tail_cap][1 + o] (may
+ * be NULL; qs_host_result::terminal_rows while still on the device).  out_* all NULL: normalised in place.  Otherwise out_obs / out_rew
+ * receive the normalised arrays, out_done / out_trunc / out_tail copies of the flags and the (normalised) list -- e.g. mapped host memory,
+ * which the kernel then writes itself; the inputs stay raw.  raw_obs / raw_rew as in qs_norm_step. */
+typedef struct qs_norm_io {
+    float* obs; float* rew; const uint8_t* done; const uint8_t* trunc; float* term_obs; float* tail_rows; int32_t tail_cap;
+    float* out_obs; float* out_rew; uint8_t* out_done; uint8_t* out_trunc; float* out_tail;
+    float* raw_obs; float* raw_rew;
+} qs_norm_io;
+int qs_norm_step_io(qs_norm* h, const qs_norm_io* io, int training, int norm_obs, int norm_reward);
 /* VecNormalize around the HOST path (load_model.py:109-137: VecNormalize.load(stats, env), then env.step(numpy actions)): from the next
- * qs_host_step_begin on, the step's results pass through `norm` (qs_norm_step_rows: statistics update if training, observations, rewards
+ * qs_host_step_begin on, the step's results pass through `norm` (qs_norm_step_io: statistics update if training, observations, rewards
  * and the terminal observations of the compact list normalised) before they reach the host block, so that qs_host_step_end hands out
  * what VecNormalize.step_wait returns.  raw_obs [N,o] / raw_rew [N] (device memory, may be NULL): the values before normalisation
  * (get_original_obs / get_original_reward).  norm == NULL switches it off.  Not between a begin and its end. */

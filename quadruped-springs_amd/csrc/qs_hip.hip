@@ -10,7 +10,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <time.h>
 #include <new>
 #include "qs_env.h"
 #include "qs_host.h"
@@ -934,7 +933,8 @@ struct HostPath {
     int registered;          // bits 0, 1: h_block[k], bit 2: h_act are page-locked (hipHostRegister succeeded)
     hipEvent_t ev;
     // qs_host_set_norm: VecNormalize.step_wait between the step and the results' way to the host (the step then writes the DEVICE block,
-    // qs_norm_step_rows works on it in place, one copy brings it over)
+    // qs_norm_step_io reads it and writes the normalised arrays, the flags and the list into the mapped host block -- or, under
+    // QS_HOST_PATH=copy, works in place and one copy brings the block over)
     qs_norm* norm; int norm_training, norm_obs, norm_rew; float* raw_obs; float* raw_rew;
 };
 // (`registered`: which of the page-locked buffers hipHostRegister accepted -- only those are unregistered)
@@ -1021,10 +1021,18 @@ int qs_host_step_begin(qs_handle* h, const float* actions_host) {
     p->cur = cur; p->parity = parity;
     if (p->norm) {
         if (int rc = qs_norm_set_stream(p->norm, (void*)h->stream)) return rc;
-        if (int rc = qs_norm_step_rows(p->norm, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, nullptr, p->norm_training, p->norm_obs, p->norm_rew,
-                                       p->raw_obs, p->raw_rew, (float*)(blk + p->off_tail), p->cap)) return rc;
+        qs_norm_io io;
+        memset(&io, 0, sizeof(io));
+        io.obs = (float*)blk; io.rew = (float*)(blk + p->off_rew); io.done = blk + p->off_done; io.trunc = blk + p->off_trunc;
+        io.tail_rows = (float*)(blk + p->off_tail); io.tail_cap = p->cap; io.raw_obs = p->raw_obs; io.raw_rew = p->raw_rew;
+        if (p->zero_copy) {     // the normalising kernel writes the host block itself
+            uint8_t* to = p->hd_block[p->cur];
+            io.out_obs = (float*)to; io.out_rew = (float*)(to + p->off_rew); io.out_done = to + p->off_done; io.out_trunc = to + p->off_trunc;
+            io.out_tail = (float*)(to + p->off_tail);
+        }
+        if (int rc = qs_norm_step_io(p->norm, &io, p->norm_training, p->norm_obs, p->norm_rew)) return rc;
     }
-    if (via_device) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
+    if (via_device && !(p->norm && p->zero_copy)) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
     QS_HIP(hipEventRecord(p->ev, h->stream));
     p->pending = 1;
     return 0;
@@ -1045,24 +1053,9 @@ int qs_host_step_end(qs_handle* h, qs_host_result* out) {
     HostPath* p = h->host;
     if (!p || !p->pending) QS_FAIL(-1, "qs_host_step_end without qs_host_step_begin");
     QS_ON_DEVICE(h);
-    // Poll the event for a while before blocking on it: hipEventSynchronize sleeps on the completion interrupt, and waking up costs the
-    // caller tens of microseconds -- of a step that takes ~100.  (QS_HOST_SPIN_US: how long to poll, default 2000; 0 = block at once.)
-    {
-        static const long spin_us = getenv("QS_HOST_SPIN_US") ? atol(getenv("QS_HOST_SPIN_US")) : 2000;
-        hipError_t q = hipErrorNotReady;
-        if (spin_us > 0) {
-            struct timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
-            for (;;) {
-                q = hipEventQuery(p->ev);
-                if (q != hipErrorNotReady) break;
-                clock_gettime(CLOCK_MONOTONIC, &t1);
-                if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L > spin_us) break;
-            }
-            if (q != hipErrorNotReady && q != hipSuccess) QS_FAIL(-2, "hipEventQuery failed: %s", hipGetErrorString(q));
-        }
-        if (q != hipSuccess) QS_HIP(hipEventSynchronize(p->ev));
-    }
+    // (polling the event with hipEventQuery before blocking on it was measured in round 4: the wait is 99.7 us instead of 100.7, for a host
+    // core that spins -- not kept)
+    QS_HIP(hipEventSynchronize(p->ev));
     p->pending = 0;
     const uint8_t* b = p->h_block[p->cur];
     out->obs = (const float*)b; out->rew = (const float*)(b + p->off_rew); out->done = b + p->off_done; out->truncated = b + p->off_trunc;

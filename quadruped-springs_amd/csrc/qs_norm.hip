@@ -21,248 +21,197 @@ extern thread_local char qs_g_err[512];
 
 struct qs_norm {
     int n, o, device;
-    float clip_obs, clip_rew, gamma, eps;
+    double clip_obs, clip_rew, gamma, eps;      // (double like SB3's Python floats: gamma = 0.99 as a float32 moved the returns' statistics by 7e-9)
     hipStream_t stream;
-    // [0, C) mean, [C, 2C) var, [2C, 2C+2) count (obs, returns), [2C+2, 3C+2) batch mean, [3C+2, 4C+2) batch var,
-    // [4C+2, 5C+2) 1 / sqrt(var + eps); C = o + 1, column o = returns
+    // two copies of [0, C) mean, [C, 2C) var, [2C, 2C+2) count (obs, returns), [2C+2, 3C+2) batch mean, [3C+2, 4C+2) batch var,
+    // [4C+2, 5C+2) 1 / sqrt(var + eps); C = o + 1, column o = returns.  A training step reads copy `cur` and writes the other one (every
+    // block of k_norm_finish works out the new statistics from the old ones; block 0 stores them where no block reads), then `cur` flips.
     double* d_stat;
-    void* d_part;    // per-block moments of the batch [n_parts][C] (k_norm_partial -> k_norm_update)
+    int cur;
+    void* d_part;    // per-block moments of the batch [n_parts][C] (k_norm_moments -> k_norm_finish)
     int n_parts, rows_per_block;
     double* d_ret;   // discounted return of every environment (VecNormalize.returns)
-    unsigned* d_sync;   // k_norm_fused: [0] blocks that have delivered their moments (ever), [1] launches whose statistics are ready
-    unsigned gen;       // training launches of k_norm_fused so far
-    int fused;          // all n_parts blocks of k_norm_fused are resident at once (checked at create): one launch per step
 };
+#define QN_STAT(h, which) ((h)->d_stat + (size_t)(which) * (5 * ((h)->o + 1) + 2))
 
 namespace {
 struct Moments { double n, mean, m2; };
-__device__ inline Moments merge(Moments a, Moments b) {   // Chan et al. pairwise merge, the same formula RunningMeanStd uses
-    if (b.n == 0.0) return a;
-    if (a.n == 0.0) return b;
-    double tot = a.n + b.n, delta = b.mean - a.mean;
-    Moments r; r.n = tot; r.mean = a.mean + delta * b.n / tot; r.m2 = a.m2 + b.m2 + delta * delta * a.n * b.n / tot;
-    return r;
-}
 
-// Batch moments, stage 1: a block reduces `rows_per_block` consecutive rows, every column at once -- thread (cx, ry) takes column
-// c0 + cx of rows ry, ry + 8, ...: a wavefront reads two whole rows (coalesced), not one column with a stride of a row.  The
-// returns column (index o) also advances VecNormalize.returns (vec_normalize.py:_update_reward).
-#define QN_MAX_PARTS 1024
-__global__ __launch_bounds__(256) void k_norm_partial(const float* __restrict__ obs, const float* __restrict__ rew, double* __restrict__ ret, int n, int o,
+// Both kernels are chains of memory round trips, not of arithmetic (written with one load per loop trip the three kernels of rounds 2-3
+// took +55 us per step at N = 8192, `tools/time_vecnormalize.py`; a single kernel whose blocks wait for each other's moments was built and
+// measured in round 4: the device-scope fences of the hand-over write back and invalidate a whole L2 per XCD -- 120 us).  Every phase
+// issues all of a thread's loads before the first use (QN_CH at a time); a block's moments are plain sums about one of its own values (the
+// first row's: no cancellation, and adding needs no division); the blocks' moments are added up as sums about block 0's mean -- Chan's
+// pairwise merge (RunningMeanStd's own formula) written without its two divisions per pair.
+#define QN_MAX_PARTS 512
+#ifndef QN_CH
+#define QN_CH 4
+#endif
+#ifndef QN_MCH
+#define QN_MCH 8
+#endif
+
+// Batch moments: block b reduces rows [b * rows_per_block, ...), every column at once -- thread (cx, ry) takes column c0 + cx of rows ry,
+// ry + 8, ...: a wavefront reads two whole rows (coalesced).  The returns column (index o) also advances VecNormalize.returns
+// (vec_normalize.py:_update_reward).
+__global__ __launch_bounds__(256) void k_norm_moments(const float* __restrict__ obs, const float* __restrict__ rew, double* __restrict__ ret, int n, int o,
                                                       double gamma, int with_obs, int with_ret, int rows_per_block, Moments* __restrict__ part) {
     const int C = o + 1, cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
-    __shared__ Moments sh[8][32];
+    __shared__ double sh[3][8][33];
+    __shared__ double piv[32];
     for (int c0 = 0; c0 < C; c0 += 32) {
         const int c = c0 + cx;
         const bool act = c < C && ((c < o && with_obs) || (c == o && with_ret));
-        double pivot = 0.0, s1 = 0.0, s2 = 0.0, cnt = 0.0;       // sums about the first value: no cancellation in s2 - s1^2 / cnt
-        if (act)
-            for (int i = r0 + ry; i < r1; i += 8) {
-                double x;
-                if (c < o) x = (double)obs[(size_t)i * o + c];
-                else { x = ret[i] * gamma + (double)rew[i]; ret[i] = x; }
-                if (cnt == 0.0) pivot = x;
-                const double d = x - pivot;
-                s1 += d; s2 += d * d; cnt += 1.0;
+        double s1 = 0.0, s2 = 0.0, cnt = 0.0, p = 0.0;
+        for (int k0 = 0; k0 * 8 < rows_per_block; k0 += QN_CH) {
+            double x[QN_CH];
+#pragma unroll
+            for (int k = 0; k < QN_CH; k++) x[k] = 0.0;
+            if (act && c < o) {
+                float v[QN_CH];
+#pragma unroll
+                for (int k = 0; k < QN_CH; k++) { const int i = r0 + ry + 8 * (k0 + k); v[k] = obs[(size_t)(i < r1 ? i : r0) * o + c]; }
+#pragma unroll
+                for (int k = 0; k < QN_CH; k++) x[k] = (double)v[k];
+            } else if (act) {
+                double q[QN_CH]; float v[QN_CH];
+#pragma unroll
+                for (int k = 0; k < QN_CH; k++) { const int i = r0 + ry + 8 * (k0 + k); q[k] = i < r1 ? ret[i] : 0.0; v[k] = i < r1 ? rew[i] : 0.0f; }
+#pragma unroll
+                for (int k = 0; k < QN_CH; k++) { x[k] = q[k] * gamma + (double)v[k]; if (r0 + ry + 8 * (k0 + k) < r1) ret[r0 + ry + 8 * (k0 + k)] = x[k]; }
             }
-        Moments m; m.n = cnt; m.mean = cnt > 0.0 ? pivot + s1 / cnt : 0.0; m.m2 = cnt > 0.0 ? s2 - s1 * s1 / cnt : 0.0;
-        sh[ry][cx] = m;
+            if (k0 == 0) {   // the pivot: row r0 of the column (thread ry = 0 holds it in x[0])
+                if (ry == 0) piv[cx] = x[0];
+                __syncthreads();
+                p = piv[cx];
+            }
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < QN_CH; k++)
+                    if (r0 + ry + 8 * (k0 + k) < r1) { const double d = x[k] - p; s1 += d; s2 += d * d; cnt += 1.0; }
+            }
+        }
+        sh[0][ry][cx] = cnt; sh[1][ry][cx] = s1; sh[2][ry][cx] = s2;
         __syncthreads();
         if (ry == 0 && c < C) {
-            for (int k = 1; k < 8; k++) m = merge(m, sh[k][cx]);
+#pragma unroll
+            for (int k = 1; k < 8; k++) { cnt += sh[0][k][cx]; s1 += sh[1][k][cx]; s2 += sh[2][k][cx]; }
+            Moments m; m.n = cnt; m.mean = cnt > 0.0 ? p + s1 / cnt : 0.0; m.m2 = cnt > 0.0 ? s2 - s1 * s1 / cnt : 0.0;
             part[(size_t)blockIdx.x * C + c] = m;
         }
         __syncthreads();
     }
 }
 
-// Stage 2 + running_mean_std.py update_from_moments: one block merges the per-block moments of every column (Chan's pairwise
-// merge, the formula RunningMeanStd itself uses), folds the batch into the running statistics and refreshes 1 / sqrt(var + eps).
-__global__ __launch_bounds__(1024) void k_norm_update(double* __restrict__ stat, int o, double batch_count, int with_obs, int with_ret,
-                                                      const Moments* __restrict__ part, int n_parts, double eps) {
-    const int C = o + 1, cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
-    __shared__ Moments sh[32][33];
-    __shared__ double old_count[2];
-    if (threadIdx.x < 2) old_count[threadIdx.x] = stat[2 * C + threadIdx.x];
-    __syncthreads();
-    for (int c0 = 0; c0 < C; c0 += 32) {
-        const int c = c0 + cx;
-        Moments m; m.n = 0.0; m.mean = 0.0; m.m2 = 0.0;
-        if (c < C)
-            for (int g = gy; g < n_parts; g += 32) m = merge(m, part[(size_t)g * C + c]);
-        sh[gy][cx] = m;
-        __syncthreads();
-        for (int s = 16; s > 0; s >>= 1) {
-            if (gy < s) sh[gy][cx] = merge(sh[gy][cx], sh[gy + s][cx]);
-            __syncthreads();
-        }
-        if (gy == 0 && c < C && ((c < o && with_obs) || (c == o && with_ret))) {
-            const Moments b = sh[0][cx];
-            const double bm = b.mean, bv = b.m2 / b.n;
-            const double count = old_count[c == o ? 1 : 0], mean = stat[c], var = stat[C + c];
-            const double delta = bm - mean, tot = count + batch_count;
-            const double new_var = (var * count + bv * batch_count + delta * delta * count * batch_count / (count + batch_count)) / (count + batch_count);
-            stat[c] = mean + delta * batch_count / tot;
-            stat[C + c] = new_var;
-            stat[2 * C + 2 + c] = bm; stat[3 * C + 2 + c] = bv;
-            stat[4 * C + 2 + c] = 1.0 / sqrt(new_var + eps);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && with_obs) stat[2 * C] = old_count[0] + batch_count;
-    if (threadIdx.x == 0 && with_ret) stat[2 * C + 1] = old_count[1] + batch_count;
-}
-
-// vec_normalize.py: normalize_obs (incl. terminal observations), normalize_reward, returns[dones] = 0
-__global__ void k_norm_apply(float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ rew, const uint8_t* __restrict__ done,
-                             double* __restrict__ ret, int n, int o, const double* __restrict__ stat, double eps, double clip_obs, double clip_rew,
-                             int norm_obs, int norm_rew, float* __restrict__ raw_obs, float* __restrict__ raw_rew) {
-    const int C = o + 1;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (raw_obs && i < (size_t)n * o) raw_obs[i] = obs[i];
-    if (raw_rew && i < (size_t)n) raw_rew[i] = rew[i];
-    if (i < (size_t)n * o && norm_obs) {
-        const int c = (int)(i % o);
-        const double mean = stat[c], inv = stat[4 * C + 2 + c];   // 1 / sqrt(var + eps), refreshed by k_norm_update / qs_norm_set_stats
-        obs[i] = (float)fmin(fmax(((double)obs[i] - mean) * inv, -clip_obs), clip_obs);
-        if (term_obs) term_obs[i] = (float)fmin(fmax(((double)term_obs[i] - mean) * inv, -clip_obs), clip_obs);
-    }
-    if (i < (size_t)n && rew) {
-        if (norm_rew) rew[i] = (float)fmin(fmax((double)rew[i] / sqrt(stat[C + o] + eps), -clip_rew), clip_rew);
-        if (done && done[i]) ret[i] = 0.0;
-    }
-}
-// (the three-launch path's share of the host path's compact terminal list, see k_norm_fused)
-__global__ void k_norm_tail(float* __restrict__ tail_rows, int tail_cap, int o, const double* __restrict__ stat, double clip_obs) {
-    const int C = o + 1, e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= tail_cap * o) return;
-    const int r = e / o, c = e - r * o;
-    float* p = tail_rows + (size_t)r * (o + 1) + 1 + c;
-    *p = (float)fmin(fmax(((double)*p - stat[c]) * stat[4 * C + 2 + c], -clip_obs), clip_obs);
-}
-
-// The three kernels above as ONE launch (training mode: a step of a learner pays one launch latency instead of three).
-// Block b owns rows [b * rows_per_block, ...): it delivers their moments, waits until the LAST block to deliver has folded all of them
-// into the running statistics (the code of k_norm_update on 8 x 32 threads), then normalises its own rows.  Two device-wide
-// hand-overs: a counter that every block bumps behind its moments (`sync[0]`: launch g is complete at (g + 1) * gridDim.x) and a word
-// the folding block sets behind the statistics (`sync[1]` = g + 1).  Waiting inside a kernel needs every block resident: qs_norm_create
-// checks that (occupancy x CUs >= n_parts) and keeps the three launches otherwise.  training = 0: no hand-over, k_norm_apply's work only.
-__global__ __launch_bounds__(256) void k_norm_fused(float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ rew, const uint8_t* __restrict__ done,
-                                                    double* __restrict__ ret, int n, int o, double gamma, double* __restrict__ stat, Moments* __restrict__ part,
-                                                    int rows_per_block, unsigned* __restrict__ sync, unsigned gen, double batch_count, double eps,
-                                                    double clip_obs, double clip_rew, int training, int with_obs, int with_ret, int norm_obs, int norm_rew,
-                                                    float* __restrict__ raw_obs, float* __restrict__ raw_rew, float* __restrict__ tail_rows, int tail_cap) {
+// running_mean_std.py update_from_moments + vec_normalize.py normalize_obs (incl. terminal observations), normalize_reward,
+// returns[dones] = 0.  training: EVERY block adds up the blocks' moments (the same sums in the same order: the same bits) and folds the
+// batch into the statistics it reads from `stat`; block 0 stores the result in `stat_next`.  Then each block normalises its own rows.
+__global__ __launch_bounds__(256) void k_norm_finish(qs_norm_io io, double* __restrict__ ret, int n, int o, const double* __restrict__ stat, double* __restrict__ stat_next,
+                                                     const Moments* __restrict__ part, int n_parts, int rows_per_block, double batch_count, double eps,
+                                                     double clip_obs, double clip_rew, int training, int with_obs, int with_ret, int norm_obs, int norm_rew) {
+    float* const obs = io.obs; float* const term_obs = io.term_obs; float* const rew = io.rew; const uint8_t* const done = io.done;
+    float* const raw_obs = io.raw_obs; float* const raw_rew = io.raw_rew;
+    float* const obs_to = io.out_obs ? io.out_obs : io.obs; float* const rew_to = io.out_rew ? io.out_rew : io.rew;     // (in place unless told otherwise)
     const int C = o + 1, cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
-    __shared__ Moments sh[8][33];
-    __shared__ double old_count[2];
-    __shared__ int s_last;
-    if (training) {
-        // ---- this block's moments (k_norm_partial)
-        for (int c0 = 0; c0 < C; c0 += 32) {
-            const int c = c0 + cx;
-            const bool act = c < C && ((c < o && with_obs) || (c == o && with_ret));
-            double pivot = 0.0, s1 = 0.0, s2 = 0.0, cnt = 0.0;
-            if (act)
-                for (int i = r0 + ry; i < r1; i += 8) {
-                    double x;
-                    if (c < o) x = (double)obs[(size_t)i * o + c];
-                    else { x = ret[i] * gamma + (double)rew[i]; ret[i] = x; }
-                    if (cnt == 0.0) pivot = x;
-                    const double d = x - pivot;
-                    s1 += d; s2 += d * d; cnt += 1.0;
-                }
-            Moments m; m.n = cnt; m.mean = cnt > 0.0 ? pivot + s1 / cnt : 0.0; m.m2 = cnt > 0.0 ? s2 - s1 * s1 / cnt : 0.0;
-            sh[ry][cx] = m;
+    __shared__ double sh[3][8][33];
+    __shared__ double s_mean[256], s_inv[256];
+    __shared__ double s_rvar;      // variance of the returns (column o) after this step's update
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int c = c0 + cx, cc = c < C ? c : 0;
+        const bool upd = training && c < C && ((c < o && with_obs) || (c == o && with_ret));
+        if (training) {
+            const double P = part[cc].mean;        // sums about block 0's mean
+            double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+            for (int g0 = ry; g0 < n_parts; g0 += 8 * QN_MCH) {
+                Moments m[QN_MCH];
+#pragma unroll
+                for (int k = 0; k < QN_MCH; k++) { const int g = g0 + 8 * k; m[k] = part[(size_t)(g < n_parts ? g : 0) * C + cc]; }
+#pragma unroll
+                for (int k = 0; k < QN_MCH; k++)
+                    if (g0 + 8 * k < n_parts) { const double d = m[k].mean - P; S0 += m[k].n; S1 += m[k].n * d; S2 += m[k].m2 + m[k].n * d * d; }
+            }
+            sh[0][ry][cx] = S0; sh[1][ry][cx] = S1; sh[2][ry][cx] = S2;
             __syncthreads();
             if (ry == 0 && c < C) {
-                for (int k = 1; k < 8; k++) m = merge(m, sh[k][cx]);
-                part[(size_t)blockIdx.x * C + c] = m;
-            }
-            __syncthreads();
-        }
-        // ---- delivered: the last block to say so folds the batch into the running statistics (k_norm_update)
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(&sync[0], 1u) + 1u == (gen + 1u) * gridDim.x;
-        __syncthreads();
-        if (s_last) {
-            __threadfence();
-            if (threadIdx.x < 2) old_count[threadIdx.x] = stat[2 * C + threadIdx.x];
-            __syncthreads();
-            for (int c0 = 0; c0 < C; c0 += 32) {
-                const int c = c0 + cx;
-                Moments m; m.n = 0.0; m.mean = 0.0; m.m2 = 0.0;
-                if (c < C)
-                    for (int g = ry; g < (int)gridDim.x; g += 8) m = merge(m, part[(size_t)g * C + c]);
-                sh[ry][cx] = m;
-                __syncthreads();
-                for (int s = 4; s > 0; s >>= 1) {
-                    if (ry < s) sh[ry][cx] = merge(sh[ry][cx], sh[ry + s][cx]);
-                    __syncthreads();
-                }
-                if (ry == 0 && c < C && ((c < o && with_obs) || (c == o && with_ret))) {
-                    const Moments b = sh[0][cx];
-                    const double bm = b.mean, bv = b.m2 / b.n;
-                    const double count = old_count[c == o ? 1 : 0], mean = stat[c], var = stat[C + c];
+#pragma unroll
+                for (int k = 1; k < 8; k++) { S0 += sh[0][k][cx]; S1 += sh[1][k][cx]; S2 += sh[2][k][cx]; }
+                double mean = stat[c], var = stat[C + c], bm = stat[2 * C + 2 + c], bv = stat[3 * C + 2 + c], inv = stat[4 * C + 2 + c];
+                if (upd) {
+                    bm = P + S1 / S0; bv = (S2 - S1 * S1 / S0) / S0;
+                    const double count = stat[2 * C + (c == o ? 1 : 0)];
                     const double delta = bm - mean, tot = count + batch_count;
                     const double new_var = (var * count + bv * batch_count + delta * delta * count * batch_count / (count + batch_count)) / (count + batch_count);
-                    stat[c] = mean + delta * batch_count / tot;
-                    stat[C + c] = new_var;
-                    stat[2 * C + 2 + c] = bm; stat[3 * C + 2 + c] = bv;
-                    stat[4 * C + 2 + c] = 1.0 / sqrt(new_var + eps);
+                    mean = mean + delta * batch_count / tot;
+                    var = new_var;
+                    inv = 1.0 / sqrt(new_var + eps);
                 }
-                __syncthreads();
+                s_mean[c] = mean; s_inv[c] = inv;
+                if (c == o) s_rvar = var;
+                if (blockIdx.x == 0) { stat_next[c] = mean; stat_next[C + c] = var; stat_next[2 * C + 2 + c] = bm; stat_next[3 * C + 2 + c] = bv; stat_next[4 * C + 2 + c] = inv; }
             }
-            if (threadIdx.x == 0 && with_obs) stat[2 * C] = old_count[0] + batch_count;
-            if (threadIdx.x == 0 && with_ret) stat[2 * C + 1] = old_count[1] + batch_count;
-            __threadfence();
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(&sync[1], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (threadIdx.x == 0)
-                while (__hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen + 1u) __builtin_amdgcn_s_sleep(2);
-            __syncthreads();
-            __threadfence();
-        }
+        } else if (ry == 0 && c < C) { s_mean[c] = stat[c]; s_inv[c] = stat[4 * C + 2 + c]; if (c == o) s_rvar = stat[C + c]; }
     }
-    // ---- normalise this block's rows (k_norm_apply); the statistics were written by another block of this launch: no cached copy
-    const volatile double* vstat = stat;
+    if (training && blockIdx.x == 0 && threadIdx.x < 2)
+        stat_next[2 * C + threadIdx.x] = stat[2 * C + threadIdx.x] + ((threadIdx.x == 0 ? with_obs : with_ret) ? batch_count : 0.0);
+    __syncthreads();
     const int rows = r1 - r0;
     if (rows <= 0) return;
     // the host path's compact list of terminal observations [tail_cap][1 + o] (environment index, observation): the last block's share
-    if (tail_rows && norm_obs && blockIdx.x == gridDim.x - 1)
-        for (int e = threadIdx.x; e < tail_cap * o; e += 256) {
-            const int r = e / o, c = e - r * o;
-            float* p = tail_rows + (size_t)r * (o + 1) + 1 + c;
-            *p = (float)fmin(fmax(((double)*p - vstat[c]) * vstat[4 * C + 2 + c], -clip_obs), clip_obs);
-        }
-    for (int e = threadIdx.x; e < rows * o; e += 256) {
-        const size_t i = (size_t)r0 * o + e;
-        const int c = (int)(i % o);
-        const float x = obs[i];
-        if (raw_obs) raw_obs[i] = x;
-        if (norm_obs) {
-            const double mean = vstat[c], inv = vstat[4 * C + 2 + c];
-            obs[i] = (float)fmin(fmax(((double)x - mean) * inv, -clip_obs), clip_obs);
-            if (term_obs) term_obs[i] = (float)fmin(fmax(((double)term_obs[i] - mean) * inv, -clip_obs), clip_obs);
+    if (io.tail_rows && blockIdx.x == gridDim.x - 1) {
+        float* const tail_to = io.out_tail ? io.out_tail : io.tail_rows;
+        for (int e = threadIdx.x; e < io.tail_cap * (o + 1); e += 256) {
+            const int r = e / (o + 1), c = e - r * (o + 1) - 1;
+            const float x = io.tail_rows[e];
+            if (c >= 0 && norm_obs) tail_to[e] = (float)fmin(fmax(((double)x - s_mean[c]) * s_inv[c], -clip_obs), clip_obs);
+            else if (io.out_tail) tail_to[e] = x;
         }
     }
-    if (rew)
+    // the flags travel with the arrays (io.out_done: the host block of qs_host_step_*)
+    if (io.out_done)
+        for (int e = threadIdx.x; e < rows; e += 256) { io.out_done[r0 + e] = done[r0 + e]; if (io.trunc) io.out_trunc[r0 + e] = io.trunc[r0 + e]; }
+    const int total = rows * o;
+    const size_t base = (size_t)r0 * o;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * QN_CH) {
+        float x[QN_CH], t[QN_CH];
+#pragma unroll
+        for (int k = 0; k < QN_CH; k++) {
+            const int e = e0 + 256 * k, ee = e < total ? e : 0;
+            x[k] = obs[base + ee];
+            t[k] = term_obs && norm_obs ? term_obs[base + ee] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < QN_CH; k++) {
+            const int e = e0 + 256 * k;
+            if (e >= total) continue;
+            if (raw_obs) raw_obs[base + e] = x[k];
+            if (norm_obs) {
+                const int c = (int)((base + e) % o);
+                const double mean = s_mean[c], inv = s_inv[c];
+                obs_to[base + e] = (float)fmin(fmax(((double)x[k] - mean) * inv, -clip_obs), clip_obs);
+                if (term_obs) term_obs[base + e] = (float)fmin(fmax(((double)t[k] - mean) * inv, -clip_obs), clip_obs);
+            } else if (io.out_obs) obs_to[base + e] = x[k];
+        }
+    }
+    if (rew) {
+        const double rstd = sqrt(s_rvar + eps);
         for (int e = threadIdx.x; e < rows; e += 256) {
             const int i = r0 + e;
             const float x = rew[i];
             if (raw_rew) raw_rew[i] = x;
-            if (norm_rew) rew[i] = (float)fmin(fmax((double)x / sqrt(vstat[C + o] + eps), -clip_rew), clip_rew);
+            if (norm_rew) rew_to[i] = (float)fmin(fmax((double)x / rstd, -clip_rew), clip_rew);
+            else if (io.out_rew) rew_to[i] = x;
             if (done && done[i]) ret[i] = 0.0;
         }
+    }
 }
 }  // namespace
 
 extern "C" {
 
-int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, float gamma, float epsilon, int device, qs_norm** out) {
+int qs_norm_create(int n_envs, int obs_dim, double clip_obs, double clip_reward, double gamma, double epsilon, int device, qs_norm** out) {
     if (!out || n_envs <= 0 || obs_dim <= 0 || obs_dim > 255) QN_FAIL(-1, "bad argument (n_envs %d, obs_dim %d)", n_envs, obs_dim);
     int ndev = 0;
     hipError_t derr = hipGetDeviceCount(&ndev);
@@ -273,31 +222,21 @@ int qs_norm_create(int n_envs, int obs_dim, float clip_obs, float clip_reward, f
     if (!h) QN_FAIL(-4, "out of host memory");
     memset(h, 0, sizeof(*h));
     h->n = n_envs; h->o = obs_dim; h->device = device; h->clip_obs = clip_obs; h->clip_rew = clip_reward; h->gamma = gamma; h->eps = epsilon;
-    const int C = obs_dim + 1;
+    const int C = obs_dim + 1, S = 5 * C + 2;
 #define QN_HIP_H(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(qs_g_err, sizeof(qs_g_err), "%s failed: %s", #call, hipGetErrorString(e_)); qs_norm_destroy(h); return -2; } } while (0)
-    QN_HIP_H(hipMalloc(&h->d_stat, (size_t)(5 * C + 2) * sizeof(double)));
-    // rows per block: 128 from N = 8192 on (64 blocks there: the folding block of k_norm_fused merges 8 partial moments per thread), 64 below,
+    QN_HIP_H(hipMalloc(&h->d_stat, (size_t)2 * S * sizeof(double)));
+    // rows per block: 64 (128 blocks at N = 8192: eight rows per thread and column, sixteen blocks' moments per thread in k_norm_finish),
     // never more than QN_MAX_PARTS blocks
     h->rows_per_block = ((n_envs + QN_MAX_PARTS - 1) / QN_MAX_PARTS + 7) / 8 * 8;
-    const int want = n_envs >= 8192 ? 128 : 64;
-    if (h->rows_per_block < want) h->rows_per_block = want;
+    if (h->rows_per_block < 64) h->rows_per_block = 64;
     h->n_parts = (n_envs + h->rows_per_block - 1) / h->rows_per_block;
-    QN_HIP_H(hipMalloc(&h->d_sync, 2 * sizeof(unsigned)));
-    QN_HIP_H(hipMemset(h->d_sync, 0, 2 * sizeof(unsigned)));
-    {   // k_norm_fused waits inside the kernel for its other blocks: only if all of them fit the device at once (QS_NORM_FUSED=0: never)
-        int per_cu = 0; hipDeviceProp_t prop;
-        const char* sw = getenv("QS_NORM_FUSED");
-        if (!(sw && sw[0] == '0') && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_norm_fused, 256, 0) == hipSuccess &&
-            hipGetDeviceProperties(&prop, device) == hipSuccess)
-            h->fused = (long long)per_cu * prop.multiProcessorCount >= 2LL * h->n_parts;   // (twice: room for whatever else runs on the device)
-    }
     QN_HIP_H(hipMalloc(&h->d_part, (size_t)h->n_parts * C * 3 * sizeof(double)));
     QN_HIP_H(hipMalloc(&h->d_ret, (size_t)n_envs * sizeof(double)));
     QN_HIP_H(hipMemset(h->d_ret, 0, (size_t)n_envs * sizeof(double)));
     double init[5 * 256 + 2];
     for (int c = 0; c < C; c++) { init[c] = 0.0; init[C + c] = 1.0; init[2 * C + 2 + c] = 0.0; init[3 * C + 2 + c] = 0.0; init[4 * C + 2 + c] = 1.0 / sqrt(1.0 + (double)epsilon); }
     init[2 * C] = init[2 * C + 1] = 1e-4;   // RunningMeanStd(epsilon=1e-4)
-    QN_HIP_H(hipMemcpy(h->d_stat, init, (size_t)(5 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; k++) QN_HIP_H(hipMemcpy(QN_STAT(h, k), init, (size_t)S * sizeof(double), hipMemcpyHostToDevice));
 #undef QN_HIP_H
     *out = h;
     return 0;
@@ -307,7 +246,7 @@ void qs_norm_destroy(qs_norm* h) {
     if (!h) return;
     QS_ON_DEVICE(h);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d_stat); hipFree(h->d_ret); hipFree(h->d_part); hipFree(h->d_sync);
+    hipFree(h->d_stat); hipFree(h->d_ret); hipFree(h->d_part);
     delete h;
 }
 
@@ -321,10 +260,10 @@ int qs_norm_set_stats(qs_norm* h, const double* obs_mean, const double* obs_var,
     for (int c = 0; c < h->o; c++) { buf[c] = obs_mean[c]; buf[C + c] = obs_var[c]; }
     buf[h->o] = ret_mean; buf[C + h->o] = ret_var; buf[2 * C] = obs_count; buf[2 * C + 1] = ret_count;
     QN_HIP(hipStreamSynchronize(h->stream));
-    QN_HIP(hipMemcpy(h->d_stat, buf, (size_t)(2 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
+    QN_HIP(hipMemcpy(QN_STAT(h, h->cur), buf, (size_t)(2 * C + 2) * sizeof(double), hipMemcpyHostToDevice));
     double inv[256];
     for (int c = 0; c < C; c++) inv[c] = 1.0 / sqrt(buf[C + c] + (double)h->eps);
-    QN_HIP(hipMemcpy(h->d_stat + 4 * C + 2, inv, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
+    QN_HIP(hipMemcpy(QN_STAT(h, h->cur) + 4 * C + 2, inv, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -334,7 +273,7 @@ int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs
     const int C = h->o + 1;
     double buf[2 * 256 + 2];
     QN_HIP(hipStreamSynchronize(h->stream));
-    QN_HIP(hipMemcpy(buf, h->d_stat, (size_t)(2 * C + 2) * sizeof(double), hipMemcpyDeviceToHost));
+    QN_HIP(hipMemcpy(buf, QN_STAT(h, h->cur), (size_t)(2 * C + 2) * sizeof(double), hipMemcpyDeviceToHost));
     for (int c = 0; c < h->o; c++) { if (obs_mean) obs_mean[c] = buf[c]; if (obs_var) obs_var[c] = buf[C + c]; }
     if (ret_mean) *ret_mean = buf[h->o];
     if (ret_var) *ret_var = buf[C + h->o];
@@ -343,63 +282,45 @@ int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs
     return 0;
 }
 
+// the two launches of a step / reset: batch moments (training only), then fold + normalise
+static int norm_launch(qs_norm* h, const qs_norm_io& io, int training, int with_obs, int with_ret, int norm_obs, int norm_reward) {
+    if (training)
+        hipLaunchKernelGGL(k_norm_moments, dim3(h->n_parts), dim3(256), 0, h->stream, io.obs, io.rew, h->d_ret, h->n, h->o, h->gamma, with_obs, with_ret,
+                           h->rows_per_block, (Moments*)h->d_part);
+    hipLaunchKernelGGL(k_norm_finish, dim3(h->n_parts), dim3(256), 0, h->stream, io, h->d_ret, h->n, h->o, QN_STAT(h, h->cur), QN_STAT(h, h->cur ^ 1),
+                       (const Moments*)h->d_part, h->n_parts, h->rows_per_block, (double)h->n, h->eps, h->clip_obs, h->clip_rew,
+                       training, with_obs, with_ret, norm_obs, norm_reward);
+    QN_HIP(hipGetLastError());
+    if (training) h->cur ^= 1;
+    return 0;
+}
+
 // VecNormalize.reset (vec_normalize.py): returns = 0; obs_rms.update(obs) when training; normalize
 int qs_norm_reset(qs_norm* h, float* obs, int training, int norm_obs) {
     if (!h || !obs) QN_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);
     QN_HIP(hipMemsetAsync(h->d_ret, 0, (size_t)h->n * sizeof(double), h->stream));
-    const int upd = training && norm_obs;
-    if (h->fused) {
-        hipLaunchKernelGGL(k_norm_fused, dim3(h->n_parts), dim3(256), 0, h->stream, obs, (float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr, h->d_ret, h->n, h->o,
-                           (double)h->gamma, h->d_stat, (Moments*)h->d_part, h->rows_per_block, h->d_sync, h->gen, (double)h->n, (double)h->eps, (double)h->clip_obs,
-                           (double)h->clip_rew, upd, 1, 0, norm_obs, 0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
-        QN_HIP(hipGetLastError());
-        if (upd) h->gen++;
-        return 0;
-    }
-    if (upd) {
-        hipLaunchKernelGGL(k_norm_partial, dim3(h->n_parts), dim3(256), 0, h->stream, obs, (const float*)nullptr, h->d_ret, h->n, h->o, (double)h->gamma, 1, 0,
-                           h->rows_per_block, (Moments*)h->d_part);
-        hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(1024), 0, h->stream, h->d_stat, h->o, (double)h->n, 1, 0, (const Moments*)h->d_part, h->n_parts, (double)h->eps);
-    }
-    const size_t total = (size_t)h->n * h->o;
-    hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, obs, (float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr,
-                       h->d_ret, h->n, h->o, h->d_stat, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew, norm_obs, 0, (float*)nullptr, (float*)nullptr);
-    QN_HIP(hipGetLastError());
-    return 0;
+    qs_norm_io io;
+    memset(&io, 0, sizeof(io));
+    io.obs = obs;
+    return norm_launch(h, io, training && norm_obs, 1, 0, norm_obs, 0);
 }
 
-// VecNormalize.step_wait on the arrays a step produced (all in place, device memory; term_obs may be NULL).  tail_rows (may be NULL): the host
-// path's compact list of the step's terminal observations, [tail_cap][1 + obs_dim], normalised like term_obs
-int qs_norm_step_rows(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward,
-                      float* raw_obs, float* raw_rew, float* tail_rows, int tail_cap) {
-    if (!h || !obs || !rew || !done) QN_FAIL(-1, "null argument");
+// VecNormalize.step_wait on the arrays a step produced (device memory; in place unless io->out_* say where the results go)
+int qs_norm_step_io(qs_norm* h, const qs_norm_io* io, int training, int norm_obs, int norm_reward) {
+    if (!h || !io || !io->obs || !io->rew || !io->done) QN_FAIL(-1, "null argument");
+    if (io->out_done && (!io->out_obs || !io->out_rew || (io->trunc && !io->out_trunc) || (io->tail_rows && !io->out_tail)))
+        QN_FAIL(-1, "qs_norm_io: out_done set, but not every array that is given has its out_ counterpart");
     QS_ON_DEVICE(h);
-    if (h->fused) {
-        hipLaunchKernelGGL(k_norm_fused, dim3(h->n_parts), dim3(256), 0, h->stream, obs, term_obs, rew, done, h->d_ret, h->n, h->o, (double)h->gamma, h->d_stat,
-                           (Moments*)h->d_part, h->rows_per_block, h->d_sync, h->gen, (double)h->n, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew,
-                           training ? 1 : 0, norm_obs, 1, norm_obs, norm_reward, raw_obs, raw_rew, tail_rows, tail_cap);
-        QN_HIP(hipGetLastError());
-        if (training) h->gen++;
-        return 0;
-    }
-    if (training) {
-        hipLaunchKernelGGL(k_norm_partial, dim3(h->n_parts), dim3(256), 0, h->stream, obs, rew, h->d_ret, h->n, h->o, (double)h->gamma, norm_obs, 1,
-                           h->rows_per_block, (Moments*)h->d_part);
-        hipLaunchKernelGGL(k_norm_update, dim3(1), dim3(1024), 0, h->stream, h->d_stat, h->o, (double)h->n, norm_obs, 1, (const Moments*)h->d_part, h->n_parts, (double)h->eps);
-    }
-    const size_t total = (size_t)h->n * h->o;
-    hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, obs, term_obs, rew, done, h->d_ret, h->n, h->o,
-                       h->d_stat, (double)h->eps, (double)h->clip_obs, (double)h->clip_rew, norm_obs, norm_reward, raw_obs, raw_rew);
-    if (tail_rows && norm_obs && tail_cap > 0)
-        hipLaunchKernelGGL(k_norm_tail, dim3((unsigned)((tail_cap * h->o + 255) / 256)), dim3(256), 0, h->stream, tail_rows, tail_cap, h->o, h->d_stat, (double)h->clip_obs);
-    QN_HIP(hipGetLastError());
-    return 0;
+    return norm_launch(h, *io, training ? 1 : 0, norm_obs, 1, norm_obs, norm_reward);
 }
 
 int qs_norm_step(qs_norm* h, float* obs, float* rew, const uint8_t* done, float* term_obs, int training, int norm_obs, int norm_reward,
                  float* raw_obs, float* raw_rew) {
-    return qs_norm_step_rows(h, obs, rew, done, term_obs, training, norm_obs, norm_reward, raw_obs, raw_rew, nullptr, 0);
+    qs_norm_io io;
+    memset(&io, 0, sizeof(io));
+    io.obs = obs; io.rew = rew; io.done = done; io.term_obs = term_obs; io.raw_obs = raw_obs; io.raw_rew = raw_rew;
+    return qs_norm_step_io(h, &io, training, norm_obs, norm_reward);
 }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ EXPORTS = (
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
     "qs_settle_lanes", "qs_host_step_begin", "qs_host_step_end", "qs_set_trace", "qs_counter", "qs_counters_async", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
     "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
-    "qs_norm_step_rows", "qs_host_set_norm",
+    "qs_norm_step_io", "qs_host_set_norm",
 )
 
 
@@ -23,6 +23,14 @@ class HostResult(C.Structure):
     """qs_host_result (include/qs_amd.h): where the results of a host-path step lie in the handle's page-locked host memory."""
     _fields_ = [("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p), ("terminal_rows", C.c_void_p),
                 ("terminal_cap", C.c_int32)]
+
+
+class NormIO(C.Structure):
+    """qs_norm_io (include/qs_amd.h): the arrays of a step for qs_norm_step_io and, optionally, where the normalised ones go."""
+    _fields_ = [("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("trunc", C.c_void_p), ("term_obs", C.c_void_p), ("tail_rows", C.c_void_p),
+                ("tail_cap", C.c_int32),
+                ("out_obs", C.c_void_p), ("out_rew", C.c_void_p), ("out_done", C.c_void_p), ("out_trunc", C.c_void_p), ("out_tail", C.c_void_p),
+                ("raw_obs", C.c_void_p), ("raw_rew", C.c_void_p)]
 
 
 _lib = None
@@ -68,7 +76,7 @@ def load():
     lib.qs_counter.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
     lib.qs_counters_async.argtypes = [vp, vp]
     f32, f64, pd = C.c_float, C.c_double, C.POINTER(C.c_double)
-    lib.qs_norm_create.argtypes = [i32, i32, f32, f32, f32, f32, i32, C.POINTER(vp)]
+    lib.qs_norm_create.argtypes = [i32, i32, f64, f64, f64, f64, i32, C.POINTER(vp)]
     lib.qs_norm_destroy.argtypes = [vp]
     lib.qs_norm_destroy.restype = None
     lib.qs_norm_set_stream.argtypes = [vp, vp]
@@ -76,7 +84,7 @@ def load():
     lib.qs_norm_get_stats.argtypes = [vp, vp, vp, pd, pd, pd, pd]
     lib.qs_norm_reset.argtypes = [vp, vp, i32, i32]
     lib.qs_norm_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
-    lib.qs_norm_step_rows.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32]
+    lib.qs_norm_step_io.argtypes = [vp, C.POINTER(NormIO), i32, i32, i32]
     lib.qs_host_set_norm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.qs_last_error.restype = C.c_char_p
     lib.qs_version.restype = C.c_char_p

@@ -632,33 +632,49 @@ def test_device_vec_normalize(torch_cuda, training, norm_reward):
     env.close()
 
 
-def test_vec_normalize_one_launch_equals_three_launches(torch_cuda, monkeypatch):
-    """qs_norm_step's one-launch kernel (k_norm_fused: the blocks hand their moments to the last one to arrive and wait for its statistics)
-    against the three-launch path (QS_NORM_FUSED=0) on the same arrays: the statistics agree to the rounding of the merge order, the
-    normalised arrays to float32 rounding; evaluation mode, terminal observations and the host path's compact list included."""
+@pytest.mark.parametrize("n", [8192 + 37, 65536, 50])
+def test_vec_normalize_kernels_against_torch_float64(torch_cuda, n):
+    """qs_norm_reset / qs_norm_step_io (k_norm_moments -> k_norm_finish) against SB3's formulas written out in plain torch float64
+    (running_mean_std.py update_from_moments, vec_normalize.py step_wait) on the same random arrays: training and evaluation steps,
+    terminal observations, the host path's compact list, the raw copies, returns reset at episode ends; sizes that end in a partial
+    block, that need the most blocks, and that fit one."""
     import ctypes as C
     from qs_amd import lib as L
     torch = torch_cuda
     lib = L.load()
-    n, o, cap = 8192 + 37, 28, 40
-    def make(fused):
-        monkeypatch.setenv("QS_NORM_FUSED", "1" if fused else "0")
-        h = C.c_void_p()
-        L.check(lib.qs_norm_create(n, o, 10.0, 10.0, 0.99, 1e-8, 0, C.byref(h)))
-        return h
-    ha, hb = make(True), make(False)
+    o, cap, gamma, eps, clip = 28, 40, 0.99, 1e-8, 10.0
+    h = C.c_void_p()
+    L.check(lib.qs_norm_create(n, o, clip, clip, gamma, eps, 0, C.byref(h)))
     g = torch.Generator(device="cuda").manual_seed(3)
     p = lambda t: C.c_void_p(t.data_ptr())
+    f64 = torch.float64
     scale = torch.linspace(0.01, 30.0, o, device="cuda"); shift = torch.linspace(-5.0, 5.0, o, device="cuda")
-    def stats(h):
+
+    class Rms:     # RunningMeanStd(epsilon=1e-4)
+        def __init__(self, shape):
+            self.mean, self.var, self.count = torch.zeros(shape, dtype=f64, device="cuda"), torch.ones(shape, dtype=f64, device="cuda"), 1e-4
+
+        def update(self, x):
+            x = x.to(f64)
+            bm, bv, bc = x.mean(0), x.var(0, unbiased=False), x.shape[0]
+            delta, tot = bm - self.mean, self.count + bc
+            m2 = self.var * self.count + bv * bc + delta ** 2 * self.count * bc / tot
+            self.mean, self.var, self.count = self.mean + delta * bc / tot, m2 / tot, tot
+
+    obs_rms, ret_rms, returns = Rms((o,)), Rms(()), torch.zeros(n, dtype=f64, device="cuda")
+    norm = lambda x: torch.clamp((x.to(f64) - obs_rms.mean) / torch.sqrt(obs_rms.var + eps), -clip, clip).to(torch.float32)
+
+    def stats():
         mean, var = np.zeros(o), np.zeros(o)
         c = [C.c_double() for _ in range(4)]
         L.check(lib.qs_norm_get_stats(h, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), *[C.byref(x) for x in c]))
         return mean, var, np.array([x.value for x in c])
-    obs0 = torch.randn((n, o), generator=g, device="cuda") * scale + shift
-    oa, ob = obs0.clone(), obs0.clone()
-    L.check(lib.qs_norm_reset(ha, p(oa), 1, 1)); L.check(lib.qs_norm_reset(hb, p(ob), 1, 1))
-    torch.testing.assert_close(oa, ob, atol=1e-5, rtol=1e-6)
+
+    obs = torch.randn((n, o), generator=g, device="cuda") * scale + shift
+    dev = obs.clone()
+    L.check(lib.qs_norm_reset(h, p(dev), 1, 1))
+    obs_rms.update(obs)
+    torch.testing.assert_close(dev, norm(obs), atol=2e-6, rtol=2e-6)
     for step in range(30):
         training = 0 if step >= 25 else 1
         obs = torch.randn((n, o), generator=g, device="cuda") * scale * (1 + 0.1 * step) + shift
@@ -666,20 +682,36 @@ def test_vec_normalize_one_launch_equals_three_launches(torch_cuda, monkeypatch)
         done = (torch.rand(n, generator=g, device="cuda") < 0.02).to(torch.uint8)
         term = torch.randn((n, o), generator=g, device="cuda") * scale + shift
         tail = torch.randn((cap, o + 1), generator=g, device="cuda") * 5
-        outs = []
-        for h in (ha, hb):
-            a = [obs.clone(), rew.clone(), term.clone(), tail.clone(), torch.zeros_like(obs), torch.zeros_like(rew)]
-            L.check(lib.qs_norm_step_rows(h, p(a[0]), p(a[1]), p(done), p(a[2]), training, 1, 1, p(a[4]), p(a[5]), p(a[3]), cap))
-            outs.append(a)
-        torch.cuda.synchronize()
-        for x, y in zip(*outs):
-            torch.testing.assert_close(x, y, atol=2e-5, rtol=2e-6)
-        assert torch.equal(outs[0][4], obs) and torch.equal(outs[0][5], rew)                 # the raw copies
-        assert torch.equal(outs[0][3][:, 0], tail[:, 0]) and outs[0][0].abs().max() <= 10.0   # the list's index column is left alone
-        ma, va, ca = stats(ha); mb, vb, cb = stats(hb)
-        np.testing.assert_allclose(ma, mb, rtol=1e-12, atol=1e-13); np.testing.assert_allclose(va, vb, rtol=1e-11); np.testing.assert_allclose(ca, cb, rtol=1e-11)
-    assert abs(ca[0] - (1e-4 + 26 * n)) < 1e-6     # reset + 25 training steps; the five evaluation steps left the statistics alone
-    lib.qs_norm_destroy(ha); lib.qs_norm_destroy(hb)
+        a = [obs.clone(), rew.clone(), term.clone(), tail.clone(), torch.zeros_like(obs), torch.zeros_like(rew)]
+        v = lambda t: t.data_ptr()
+        if step % 2 == 0:     # in place
+            io = L.NormIO(obs=v(a[0]), rew=v(a[1]), done=v(done), term_obs=v(a[2]), tail_rows=v(a[3]), tail_cap=cap, raw_obs=v(a[4]), raw_rew=v(a[5]))
+            L.check(lib.qs_norm_step_io(h, C.byref(io), training, 1, 1))
+        else:                 # into other arrays (the host path's mapped block), the flags and the list copied along; the inputs stay raw
+            trunc = (torch.rand(n, generator=g, device="cuda") < 0.5).to(torch.uint8)
+            out = [torch.zeros_like(obs), torch.zeros_like(rew), torch.zeros_like(done), torch.zeros_like(trunc), torch.zeros_like(tail)]
+            io = L.NormIO(obs=v(a[0]), rew=v(a[1]), done=v(done), trunc=v(trunc), term_obs=v(a[2]), tail_rows=v(a[3]), tail_cap=cap, raw_obs=v(a[4]), raw_rew=v(a[5]),
+                          out_obs=v(out[0]), out_rew=v(out[1]), out_done=v(out[2]), out_trunc=v(out[3]), out_tail=v(out[4]))
+            L.check(lib.qs_norm_step_io(h, C.byref(io), training, 1, 1))
+            assert torch.equal(a[0], obs) and torch.equal(a[1], rew) and torch.equal(a[3], tail) and torch.equal(out[2], done) and torch.equal(out[3], trunc)
+            a[0], a[1], a[3] = out[0], out[1], out[4]
+        if training:                                   # vec_normalize.py step_wait: the statistics and the returns move only in training
+            obs_rms.update(obs)
+            returns = returns * gamma + rew.to(f64)
+            ret_rms.update(returns)
+        r_ref = torch.clamp(rew.to(f64) / torch.sqrt(ret_rms.var + eps), -clip, clip).to(torch.float32)
+        torch.testing.assert_close(a[0], norm(obs), atol=2e-6, rtol=2e-6)
+        torch.testing.assert_close(a[2], norm(term), atol=2e-6, rtol=2e-6)
+        torch.testing.assert_close(a[3][:, 1:], norm(tail[:, 1:]), atol=2e-6, rtol=2e-6)
+        torch.testing.assert_close(a[1], r_ref, atol=2e-6, rtol=2e-6)
+        assert torch.equal(a[4], obs) and torch.equal(a[5], rew) and torch.equal(a[3][:, 0], tail[:, 0])   # raw copies; the list's index column
+        returns = torch.where(done.bool(), torch.zeros_like(returns), returns)
+        mean, var, cnt = stats()
+        np.testing.assert_allclose(mean, obs_rms.mean.cpu().numpy(), rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(var, obs_rms.var.cpu().numpy(), rtol=1e-9)
+        np.testing.assert_allclose(cnt, [obs_rms.count, float(ret_rms.mean), float(ret_rms.var), ret_rms.count], rtol=1e-9, atol=1e-10)
+    assert abs(cnt[0] - (1e-4 + 26 * n)) < 1e-6     # reset + 25 training steps; the five evaluation steps left the statistics alone
+    lib.qs_norm_destroy(h)
 
 
 def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):

@@ -73,7 +73,6 @@ out["normalised_numpy_training_ms"] = timeit(lambda: np_step(env), n=100, warm=1
 env.training = False; env.norm_reward = False      # load_model.py:113-116
 out["normalised_numpy_eval_ms"] = timeit(lambda: np_step(env), n=100, warm=10)
 out["legacy_normalised_numpy_eval_ms"] = timeit(lambda: legacy_np_step(env), n=100, warm=10)
-out["one_launch"] = os.environ.get("QS_NORM_FUSED", "1") != "0"
 for key, v in out.items():
     if key.endswith("_ms"):
         print(f"{key:36s} {v:.4f} ms  ({N / v / 1e3:.1f} M env-steps/s)")
