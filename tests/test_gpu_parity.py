@@ -714,6 +714,48 @@ def test_vec_normalize_kernels_against_torch_float64(torch_cuda, n):
     lib.qs_norm_destroy(h)
 
 
+@pytest.mark.parametrize("n", [1, 50, 600])
+def test_device_vec_normalize_numpy_path_edges(torch_cuda, n):
+    """DeviceVecNormalize.step (the wrapped environment's host path with qs_host_set_norm) where the batch is one environment, ends in a
+    partial wave, and where MORE episodes end in one step than the compact list of terminal observations holds (600 robots reach the time
+    limit together: the per-environment array is fetched and normalised through the hook): every array against the numpy restatement of
+    SB3's VecNormalize on the raw values, evaluation mode with loaded statistics as in load_model.py:109-137, then a training step."""
+    from oracle.vecnorm import VecNormalizeRef
+    from qs_amd.vec_env import QuadrupedVecEnv
+    from qs_amd.vec_normalize import DeviceVecNormalize
+    venv = QuadrupedVecEnv(num_envs=n, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                           enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=11)
+    env = DeviceVecNormalize(venv, training=False, norm_reward=False)
+    ref = VecNormalizeRef(n, venv.obs_dim, training=False, norm_reward=False, moments_dtype=np.float64)
+    rng0 = np.random.default_rng(0)
+    mean, var = rng0.normal(size=venv.obs_dim), rng0.uniform(0.5, 4.0, size=venv.obs_dim)
+    env.set_stats(mean, var, 12345.0, 0.3, 2.0, 777.0)
+    ref.obs_rms.mean, ref.obs_rms.var, ref.obs_rms.count = mean, var, 12345.0
+    ref.ret_rms.mean, ref.ret_rms.var, ref.ret_rms.count = 0.3, 2.0, 777.0
+    obs = env.reset()
+    np.testing.assert_allclose(obs, ref.reset(env.get_original_obs()), atol=2e-5)
+    still = np.zeros((n, 6), np.float32)
+    ends = 0
+    for i in range(1003):      # standing robots run into the 1000-step limit of gym_env.py:35 in the same step
+        if i == 1001:
+            env.training = ref.training = True; env.norm_reward = ref.norm_reward = True
+        obs, rew, done, infos = env.step(still)
+        if i < 3 or i >= 995:
+            raw_obs, raw_rew = env.get_original_obs(), env.get_original_reward()
+            term_raw = venv.get_info("terminal_obs").cpu().numpy()
+            o_ref, r_ref, t_ref = ref.step(raw_obs, raw_rew, done, term_raw)
+            np.testing.assert_allclose(obs, o_ref, atol=2e-5, err_msg=f"obs step {i}")
+            np.testing.assert_allclose(rew, r_ref, atol=2e-5, rtol=1e-5, err_msg=f"reward step {i}")
+            for k in np.nonzero(done)[0]:
+                assert infos[k]["TimeLimit.truncated"] is True
+                np.testing.assert_allclose(infos[k]["terminal_observation"], t_ref[k], atol=2e-5)
+            ends += int(done.sum())
+        else:
+            assert not done.any()
+    assert ends == n, ends      # every robot's episode ended once, at the limit
+    env.close()
+
+
 def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
     """The N = 1 QuadrupedGymEnv view with the getters the reference's wrappers use (get_sim_time, get_landing_action,
     task.is_switched_controller, task.compute_time_for_peak_heihgt, robot._motor_model._kp/_kd).  A host-side loop with the control
