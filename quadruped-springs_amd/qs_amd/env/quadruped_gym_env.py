@@ -83,6 +83,65 @@ class _RobotView:
         c = self._robot_config
         return c.SPRINGS_STIFFNESS, c.SPRINGS_DAMPING, c.SPRINGS_REST_ANGLE
 
+    # ---- further getters of quadruped.py that evaluation / analysis code of the reference calls
+    def getHeight(self):                                   # quadruped.py:82-84
+        return self.GetBasePosition()[-1]
+
+    def GetBaseOrientationMatrix(self):                    # quadruped.py:172-175 (getMatrixFromQuaternion: base -> world, row major)
+        x, y, z, w = self.GetBaseOrientation()
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def TransformAngularVelocityToLocalFrame(self, angular_velocity, orientation):   # quadruped.py:151-170: R(orientation)^T w
+        x, y, z, w = orientation
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        return R.T @ np.asarray(angular_velocity, dtype=np.float64)
+
+    def GetTrueBaseRollPitchYawRate(self):                 # quadruped.py:141-149
+        return self.TransformAngularVelocityToLocalFrame(self.GetBaseAngularVelocity(), self.GetBaseOrientation())
+
+    def _params(self):
+        return self._env._vec.get_info("params")[0].cpu().numpy().astype(np.float64)
+
+    def get_spring_real_stiffness_and_damping(self):       # quadruped.py:727-730 -> springs.py:28-74: (k, b, rest angles), unilateral gating
+        p, q = self._params(), self.GetMotorAngles()
+        k, b, rest = np.tile(p[1:4], 4), np.tile(p[4:7], 4), np.tile(p[7:10], 4)
+        if not self._env._enable_springs:
+            return np.zeros(12), np.zeros(12), rest
+        for leg in range(4):
+            hip, thigh, calf = q[3 * leg:3 * leg + 3]
+            right = leg % 2 == 0                           # side_map = ["right", "left"] * 2
+            off = [hip > rest[0] if right else hip < rest[0], thigh < rest[1], calf > rest[2]]
+            for j in range(3):
+                if off[j]:
+                    k[3 * leg + j] = b[3 * leg + j] = 0.0
+        return k, b, rest
+
+    # masses as _RecordMassAndInertiaInfoFromURDF keeps them (quadruped.py:605-645; go1.urdf, PyBullet link order: SURVEY.md App. A)
+    def GetBaseMassFromURDF(self):
+        return [5.204]
+
+    def GetLegMassesFromURDF(self):
+        return [0.591, 0.92, 0.131] * 4
+
+    def GetFootMassesFromURDF(self):
+        return [0.06] * 4
+
+    def GetTotalMassFromURDF(self):
+        return [1e-5, 5.204, 0.001] + [0.591, 0.92, 0.131, 0.06] * 4
+
+    def get_offset_mass_value(self):                       # quadruped.py:701-707: the payload block of the mass randomizer (0 without one)
+        return float(self._params()[20])
+
+    def get_offset_mass_position(self):                    # quadruped.py:709-719: block centre - base position, world frame
+        if self._env._vec.cfg.payload_soft:                # the block is a body of its own: its own centre
+            blk = self._env._vec.get_info("payload_block")[0, :3].cpu().numpy().astype(np.float64)
+            return blk - np.asarray(self.GetBasePosition())
+        return self.GetBaseOrientationMatrix() @ self._params()[21:24]
+
     def set_spring_stiffness(self, k):
         self._env._vec.set_params("spring_k", np.asarray(k, np.float32)[None])
 

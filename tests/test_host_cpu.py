@@ -111,3 +111,48 @@ def test_unknown_keywords_are_refused():
     assert cfg.n_envs == 1
     with pytest.raises(NotImplementedError):
         build_config(n_envs=1, render=True)
+
+
+def test_robot_view_getters_follow_the_reference_formulas():
+    """The getters of quadruped.py that need no simulation step -- orientation matrix, body-frame angular velocity (quadruped.py:141-175),
+    the springs' real stiffness / damping under the unilateral gating (springs.py:28-74), URDF masses (go1.urdf: 12.01301 kg), the
+    payload block's offset -- on a stand-in for the device handle: plain formulas, checked against scipy's rotation and by hand."""
+    import math
+    from types import SimpleNamespace
+
+    import torch
+    from scipy.spatial.transform import Rotation
+
+    from qs_amd.env.quadruped_gym_env import _RobotView
+    from qs_amd.go1_config import make_config
+
+    rng = np.random.default_rng(0)
+    quat = Rotation.random(random_state=1).as_quat()          # xyzw, as PyBullet
+    state = np.zeros(37); state[0:3] = [0.1, -0.2, 0.31]; state[3:7] = quat; state[10:13] = [0.3, -1.1, 0.7]
+    q = np.tile([0.0, math.pi / 4, -math.pi / 2 + 0.3], 4) + np.array([0.1, 0.1, 0.1, 0.1, -0.1, -0.1, -0.1, 0.1, 0.1, -0.1, -0.1, -0.1])
+    state[13:25] = q
+    params = np.zeros(24); params[1:4] = [20, 20, 30]; params[4:7] = 0.3; params[7:10] = [0.0, math.pi / 4, -math.pi / 2 + 0.3]
+    params[20] = 1.5; params[21:24] = [0.05, -0.02, 0.1]
+
+    class Vec:
+        cfg = SimpleNamespace(payload_soft=0)
+        def get_state(self): return torch.tensor(state[None])
+        def get_info(self, which): assert which == "params"; return torch.tensor(params[None])
+
+    env = SimpleNamespace(_vec=Vec(), _replay_row=None, _robot_config=make_config(True), _enable_springs=True)
+    r = _RobotView(env)
+    R = Rotation.from_quat(quat).as_matrix()
+    np.testing.assert_allclose(r.GetBaseOrientationMatrix(), R, atol=1e-12)
+    np.testing.assert_allclose(r.GetTrueBaseRollPitchYawRate(), R.T @ state[10:13], atol=1e-12)
+    assert r.getHeight() == 0.31
+    k, b, rest = r.get_spring_real_stiffness_and_damping()
+    # FR (right): hip 0.1 > rest -> off, thigh above rest -> on, calf above rest -> off; FL (left): hip 0.1 > rest -> on, thigh below -> off, calf below -> on
+    np.testing.assert_allclose(k[:6], [0, 20, 0, 20, 0, 30]); np.testing.assert_allclose(b[:6], [0, 0.3, 0, 0.3, 0, 0.3])
+    # RR (right): hip -0.1 -> on, thigh above -> on, calf above -> off; RL (left): hip -0.1 < rest -> off, thigh below -> off, calf below -> on
+    np.testing.assert_allclose(k[6:], [20, 20, 0, 0, 0, 30]); np.testing.assert_allclose(rest, np.tile(params[7:10], 4))
+    assert abs(sum(r.GetTotalMassFromURDF()) - 12.01301) < 1e-9 and len(r.GetTotalMassFromURDF()) == 19     # base + 18 links
+    assert r.GetBaseMassFromURDF() == [5.204] and len(r.GetLegMassesFromURDF()) == 12 and r.GetFootMassesFromURDF() == [0.06] * 4
+    assert r.get_offset_mass_value() == 1.5
+    np.testing.assert_allclose(r.get_offset_mass_position(), R @ params[21:24], atol=1e-12)
+    env._enable_springs = False
+    assert not r.get_spring_real_stiffness_and_damping()[0].any()
