@@ -213,6 +213,15 @@ class _TaskView:
     def get_jumping(self):
         return bool(self._scalars()[2] > 0.5)
 
+    @property
+    def is_jumping(self):                     # what the "is jumping" sensor reads (robot_sensors.py:182)
+        return self.get_jumping()
+
+    def compute_jumping_distance(self):       # task_base.py:108-116 (evaluation_wrapper.py:38): forward distance in the take-off frame
+        sc = self._scalars()                  # [4:7] pose at take-off, [7] yaw at take-off, [32:35] task._pos_abs (the info block's pose cache)
+        dx, dy, yaw = float(sc[32] - sc[4]), float(sc[33] - sc[5]), float(sc[7])
+        return max(np.cos(yaw) * dx - np.sin(yaw) * dy, 0.0)
+
     def enable_rest_mode(self):   # robot_tasks.py:346-347: sets a flag the reference never reads
         pass
 

@@ -756,6 +756,43 @@ def test_device_vec_normalize_numpy_path_edges(torch_cuda, n):
     env.close()
 
 
+def test_gym_env_view_task_and_robot_getters(torch_cuda):
+    """QuadrupedGymEnv's task / robot getters that analysis code of the reference reads (evaluation_wrapper.py:38
+    task.compute_jumping_distance; quadruped.py:141-175 orientation matrix and body rates): the jumping distance is the quantity whose
+    running maximum the device keeps as _max_forward_distance (task_base.py:108-121), the matrix agrees with the device's roll / pitch /
+    yaw, the body-frame rate with the PitchRate sensor's formula."""
+    from qs_amd.env.quadruped_gym_env import QuadrupedGymEnv
+    env = QuadrupedGymEnv(task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC", action_space_mode="SYMMETRIC", motor_control_mode="PD",
+                          enable_springs=True, enable_action_filter=True, seed=4, noise=False)
+    env.reset()
+    rng = np.random.default_rng(2)
+    prev, rises = 0.0, 0
+    for i in range(400):
+        a = rng.uniform(-1, 1, 6)
+        a[[1, 4]] = 1.0 if (i // 12) % 2 else -1.0        # pump the thighs: hops
+        a[[2, 5]] = -a[[1, 4]]
+        _, _, done, _ = env.step(a)
+        m, d = env.task._max_forward_distance, env.task.compute_jumping_distance()
+        assert d >= 0.0 and isinstance(env.task.is_jumping, bool)
+        if done:
+            env.reset(); prev = 0.0
+            continue
+        if m > prev + 1e-7:                               # the maximum moved in this step: by this step's distance
+            assert abs(m - d) < 2e-6, (i, m, d)
+            rises += 1
+        prev = m
+        R = env.robot.GetBaseOrientationMatrix()
+        roll, pitch, yaw = env.robot.GetBaseOrientationRollPitchYaw()
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+        np.testing.assert_allclose([np.arctan2(R[2, 1], R[2, 2]), -np.arcsin(R[2, 0]), np.arctan2(R[1, 0], R[0, 0])], [roll, pitch, yaw], atol=2e-6)
+        np.testing.assert_allclose(env.robot.GetTrueBaseRollPitchYawRate(), R.T @ env.robot.GetBaseAngularVelocity(), atol=1e-9)
+        assert abs(env.robot.getHeight() - env.robot.GetBasePosition()[2]) == 0
+    assert rises > 3, rises
+    k, b, rest = env.robot.get_spring_real_stiffness_and_damping()
+    assert k.shape == (12,) and set(np.unique(k)) <= {0.0, 20.0, 30.0} and abs(sum(env.robot.GetTotalMassFromURDF()) - 12.01301) < 1e-9
+    env.close()
+
+
 def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
     """The N = 1 QuadrupedGymEnv view with the getters the reference's wrappers use (get_sim_time, get_landing_action,
     task.is_switched_controller, task.compute_time_for_peak_heihgt, robot._motor_model._kp/_kd).  A host-side loop with the control
