@@ -59,6 +59,37 @@ class DeviceVecNormalize:
         s = self.get_stats()
         return np.clip((obs - s["obs_mean"]) / np.sqrt(s["obs_var"] + self.epsilon), -self.clip_obs, self.clip_obs).astype(np.float32)
 
+    def normalize_reward(self, reward):
+        """normalize_reward on a host array with the current statistics (vec_normalize.py:normalize_reward)."""
+        if not self.norm_reward:
+            return reward
+        s = self.get_stats()
+        return np.clip(reward / np.sqrt(s["ret_var"] + self.epsilon), -self.clip_reward, self.clip_reward)
+
+    def unnormalize_obs(self, obs):
+        if not self.norm_obs:
+            return obs
+        s = self.get_stats()
+        return obs * np.sqrt(s["obs_var"] + self.epsilon) + s["obs_mean"]
+
+    def unnormalize_reward(self, reward):
+        if not self.norm_reward:
+            return reward
+        return reward * np.sqrt(self.get_stats()["ret_var"] + self.epsilon)
+
+    @property
+    def obs_rms(self):
+        """a snapshot of the running statistics under the names SB3 uses (RunningMeanStd.mean / .var / .count); set_stats writes them"""
+        from types import SimpleNamespace
+        s = self.get_stats()
+        return SimpleNamespace(mean=s["obs_mean"], var=s["obs_var"], count=s["obs_count"])
+
+    @property
+    def ret_rms(self):
+        from types import SimpleNamespace
+        s = self.get_stats()
+        return SimpleNamespace(mean=s["ret_mean"], var=s["ret_var"], count=s["ret_count"])
+
     def get_original_obs(self):
         return self.old_obs.cpu().numpy().copy()
 

@@ -753,6 +753,15 @@ def test_device_vec_normalize_numpy_path_edges(torch_cuda, n):
         else:
             assert not done.any()
     assert ends == n, ends      # every robot's episode ended once, at the limit
+    if n == 50:     # the host-side helpers of VecNormalize's surface, on the statistics the device holds now
+        st = env.get_stats()
+        np.testing.assert_allclose(env.obs_rms.mean, st["obs_mean"]); assert env.ret_rms.count == st["ret_count"]
+        x = rng0.normal(size=(7, venv.obs_dim))
+        back = env.unnormalize_obs(env.normalize_obs(x).astype(np.float64))
+        inside = np.abs((x - st["obs_mean"]) / np.sqrt(st["obs_var"] + 1e-8)) < 10        # (not clipped)
+        np.testing.assert_allclose(back[inside], x[inside], rtol=2e-5, atol=2e-5)         # normalize_obs hands out float32
+        r = rng0.normal(size=9)
+        np.testing.assert_allclose(env.unnormalize_reward(env.normalize_reward(r)), np.clip(r, -10 * np.sqrt(st["ret_var"] + 1e-8), 10 * np.sqrt(st["ret_var"] + 1e-8)), rtol=1e-12)
     env.close()
 
 
