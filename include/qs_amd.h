@@ -296,7 +296,8 @@ int qs_norm_step_io(qs_norm* h, const qs_norm_io* io, int training, int norm_obs
  * qs_host_step_begin on, the step's results pass through `norm` (qs_norm_step_io: statistics update if training, observations, rewards
  * and the terminal observations of the compact list normalised) before they reach the host block, so that qs_host_step_end hands out
  * what VecNormalize.step_wait returns.  raw_obs [N,o] / raw_rew [N] (device memory, may be NULL): the values before normalisation
- * (get_original_obs / get_original_reward).  norm == NULL switches it off.  Not between a begin and its end. */
+ * (get_original_obs / get_original_reward).  norm == NULL switches it off.  Not between a begin and its end.  The handle keeps the
+ * pointer, not the object: switch it off (or destroy the simulation handle) before qs_norm_destroy(norm). */
 int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
 
 const char* qs_last_error(void);

@@ -1041,9 +1041,12 @@ int qs_host_step_begin(qs_handle* h, const float* actions_host) {
 int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew) {
     if (!h) QS_FAIL(-1, "null handle");
     QS_ON_DEVICE(h);
+    if (!norm && !h->host) return 0;     // nothing to switch off
     if (int rc = host_path_init(h)) return rc;
     HostPath* p = h->host;
-    if (p->pending) QS_FAIL(-1, "qs_host_set_norm between qs_host_step_begin and qs_host_step_end");
+    // (switching it off is always possible: a step already on the stream keeps using the statistics' buffers, and qs_norm_destroy waits
+    // for its stream before it frees them)
+    if (p->pending && norm) QS_FAIL(-1, "qs_host_set_norm between qs_host_step_begin and qs_host_step_end");
     p->norm = norm; p->norm_training = training; p->norm_obs = norm_obs; p->norm_rew = norm_reward; p->raw_obs = raw_obs; p->raw_rew = raw_rew;
     return 0;
 }

@@ -171,6 +171,7 @@ class DeviceVecNormalize:
 
     def close(self):
         if self.h:
+            self._detach()          # (the environment's host path must not keep a pointer to the statistics that go away now)
             self.lib.qs_norm_destroy(self.h)
             self.h = None
         self.venv.close()
