@@ -43,12 +43,18 @@ def build(force=False, verbose=False):
     # (round 4: ROCm 7.2's "AMDGPU Rewrite AGPR-Copy-MFMA" pass, which only has work under -amdgpu-mfma-vgpr-form, segfaults on some
     # register allocations of the step kernels -- eliminateSpillsOfReassignedVGPRs --: seen on k_step<false, false> for two harmless
     # variations of the many-rows solver's source.  The build retries without the flag, loudly; QS_MFMA_VGPR_FORM=0 leaves it out at once.)
+    # -greedy-regclass-priority-trumps-globalness=1 -split-spill-mode=size (end of round 4): two knobs of LLVM's greedy register allocator --
+    # which live ranges it colours first, and where it puts the spill code of a split range.  Same instructions' arithmetic, same results
+    # bit for bit (the front end has fixed every FMA); the substep loop keeps fewer copies in flight: +1.3 % at N = 8192 under the cone
+    # (112.2 against 110.8 M on one box), +0.7 % at N = 65536, +-0.3 % on the pyramid / body_contacts workloads (gpurun_out/r04zm, r04zn;
+    # twelve allocator / scheduler options were tried, the others lost or changed nothing).
     vgpr_form = os.environ.get("QS_MFMA_VGPR_FORM", "1") != "0"
 
     def command(with_form):
         c = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
              "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
-             "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
+             "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+             "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-split-spill-mode=size"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
             os.environ.get("QS_HIPCC_EXTRA", "").split() + ["-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
         if verbose:
             c.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -13,7 +13,7 @@ NAMES = {0: "base rotation, velocities", 1: "leg kinematics", 2: "link inertias"
          6: "accelerations, v*", 7: "collision", 8: "contact rows + Delassus", 9: "PGS (loop body x sweeps not expanded)", 10: "delta v", 11: "integrate positions"}
 with tempfile.TemporaryDirectory() as d:
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm",
-                           "-amdgpu-sched-strategy=iterative-ilp", "-DQS_COUNT_PHASES", "-I" + os.path.join(REPO, "include"), "-save-temps", "-o", "t.so",
+                           "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-split-spill-mode=size", "-DQS_COUNT_PHASES", "-I" + os.path.join(REPO, "include"), "-save-temps", "-o", "t.so",
                            os.path.join(REPO, "quadruped-springs_amd", "csrc", "qs_hip.hip")], cwd=d, stderr=subprocess.DEVNULL)
     lines = open(os.path.join(d, "qs_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
 start = [i for i, l in enumerate(lines) if l.startswith("_Z6k_step")][0]

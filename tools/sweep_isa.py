@@ -11,7 +11,8 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize", "-ffinite-math-only",
-         "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+         "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-split-spill-mode=size", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 with tempfile.TemporaryDirectory() as d:
     subprocess.check_call(["hipcc"] + FLAGS + ["-I" + os.path.join(REPO, "include"), "-save-temps", "-o", "t.so",
                                                os.path.join(REPO, "quadruped-springs_amd", "csrc", "qs_hip.hip")], cwd=d, stderr=subprocess.DEVNULL)
