@@ -714,8 +714,8 @@ def test_vec_normalize_kernels_against_torch_float64(torch_cuda, n):
     lib.qs_norm_destroy(h)
 
 
-@pytest.mark.parametrize("n", [1, 50, 600])
-def test_device_vec_normalize_numpy_path_edges(torch_cuda, n):
+@pytest.mark.parametrize("n,host_path", [(1, "zero"), (50, "zero"), (600, "zero"), (50, "copy"), (600, "copy")])
+def test_device_vec_normalize_numpy_path_edges(torch_cuda, monkeypatch, n, host_path):
     """DeviceVecNormalize.step (the wrapped environment's host path with qs_host_set_norm) where the batch is one environment, ends in a
     partial wave, and where MORE episodes end in one step than the compact list of terminal observations holds (600 robots reach the time
     limit together: the per-environment array is fetched and normalised through the hook): every array against the numpy restatement of
@@ -723,6 +723,9 @@ def test_device_vec_normalize_numpy_path_edges(torch_cuda, n):
     from oracle.vecnorm import VecNormalizeRef
     from qs_amd.vec_env import QuadrupedVecEnv
     from qs_amd.vec_normalize import DeviceVecNormalize
+    # QS_HOST_PATH=copy: the handle's other host path (H2D / D2H copies around the step instead of mapped host memory: the normalisation then
+    # works in place on the device block and one copy brings it over); read when the handle's host path is first used
+    monkeypatch.setenv("QS_HOST_PATH", "copy" if host_path == "copy" else "zero_copy")
     venv = QuadrupedVecEnv(num_envs=n, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
                            enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=11)
     env = DeviceVecNormalize(venv, training=False, norm_reward=False)
@@ -753,7 +756,7 @@ def test_device_vec_normalize_numpy_path_edges(torch_cuda, n):
         else:
             assert not done.any()
     assert ends == n, ends      # every robot's episode ended once, at the limit
-    if n == 50:     # the host-side helpers of VecNormalize's surface, on the statistics the device holds now
+    if n == 50 and host_path == "zero":     # the host-side helpers of VecNormalize's surface, on the statistics the device holds now
         st = env.get_stats()
         np.testing.assert_allclose(env.obs_rms.mean, st["obs_mean"]); assert env.ret_rms.count == st["ret_count"]
         x = rng0.normal(size=(7, venv.obs_dim))
