@@ -289,13 +289,18 @@ class QuadrupedGymEnv(GymEnv):
         seed=0,
         noise=True,   # extensions (not in the reference's signature): device, seed of the counter-based RNG, sensor noise on / off
         demo=None,    # DEMO tasks: the demonstration rows (array or .npy path) the reference would np.load (task_base.py:173)
-        **solver_settings,   # friction_model, contact_erp, joint_erp, warmstart, solver_residual_threshold (qs_amd.config.build_config)
+        **solver_settings,   # the engine settings of qs_amd.config.build_config (friction_model, contact_erp, body_contacts, payload, ...)
     ):
         if on_rack or render:
             raise NotImplementedError("on_rack / render need the PyBullet GUI path, which this build does not provide")
-        unknown = set(solver_settings) - {"friction_model", "contact_erp", "joint_erp", "warmstart", "solver_residual_threshold"}
+        unknown = set(solver_settings) - {"friction_model", "contact_erp", "contact_slop", "joint_erp", "warmstart", "solver_residual_threshold",
+                                          "body_contacts", "self_collision", "payload", "mass_inertia_rule"}
         if unknown:
             raise TypeError(f"unexpected keyword argument(s) {sorted(unknown)}")
+        # ONE environment, stepped by a caller who may go on after `done` (no auto-reset here): every collision primitive pushes back, as in
+        # the reference (quadruped.py:533-539).  The vectorised environment's "auto" leaves that response off under a task because a
+        # launch of thousands waits for the one wave whose robot has just fallen; with one environment nobody waits.
+        solver_settings.setdefault("body_contacts", True)
         self.verbose = verbose
         self._vec = QuadrupedVecEnv(
             num_envs=1, device=device, auto_reset=False, isRLGymInterface=isRLGymInterface, time_step=time_step,

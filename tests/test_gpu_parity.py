@@ -800,9 +800,26 @@ def test_gym_env_view_task_and_robot_getters(torch_cuda):
         np.testing.assert_allclose(env.robot.GetTrueBaseRollPitchYawRate(), R.T @ env.robot.GetBaseAngularVelocity(), atol=1e-9)
         assert abs(env.robot.getHeight() - env.robot.GetBasePosition()[2]) == 0
     assert rises > 3, rises
+    assert env._vec.cfg.body_contacts == 1      # the single-environment view: every link pushes back, as in the reference (a task notwithstanding)
     k, b, rest = env.robot.get_spring_real_stiffness_and_damping()
     assert k.shape == (12,) and set(np.unique(k)) <= {0.0, 20.0, 30.0} and abs(sum(env.robot.GetTotalMassFromURDF()) - 12.01301) < 1e-9
     env.close()
+    # ... and stepping on after the fall that ended an episode leaves the robot lying ON the floor
+    env = QuadrupedGymEnv(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, seed=4, noise=False)
+    env.reset()
+    st = env._vec.get_state().cpu().numpy()
+    st[0, 2] = 0.25; st[0, 3:7] = [np.sin(0.7), 0.0, 0.0, np.cos(0.7)]      # rolled onto its side, dropped from 25 cm
+    env._vec.set_state(st)
+    done_seen = False
+    for i in range(150):
+        _, _, done, _ = env.step(np.zeros(6))
+        done_seen = done_seen or done
+    z = env.robot.getHeight()
+    assert done_seen and 0.03 < z < 0.25 and np.abs(env.robot.GetBaseLinearVelocity()).max() < 0.5, z
+    env.close()
+    auto = QuadrupedGymEnv(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, body_contacts="auto")
+    assert auto._vec.cfg.body_contacts == 0
+    auto.close()
 
 
 def test_gym_env_view_runs_a_host_side_landing_wrapper(torch_cuda, golden):
