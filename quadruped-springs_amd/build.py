@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
     vgpr_form = os.environ.get("QS_MFMA_VGPR_FORM", "1") != "0"
 
     def command(with_form):
-        c = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
+        c = [hipcc(), "--offload-arch=" + os.environ.get("QS_OFFLOAD_ARCH", "gfx950"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
              "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
              "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
              "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-split-spill-mode=size"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
