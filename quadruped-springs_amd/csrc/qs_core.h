@@ -76,6 +76,7 @@ constexpr float TRUNK_HALF[3] = {0.1881f, 0.04675f, 0.057f};                    
 constexpr float HIP_CYL_HALF_LEN = 0.02f, HIP_CYL_R = 0.046f;                              // cylinder :128-131
 constexpr float LINK_BOX_Z = -0.1065f, THIGH_HALF[3] = {0.017f, 0.01225f, 0.1065f}, CALF_HALF[3] = {0.008f, 0.008f, 0.1065f};
 constexpr float PAYLOAD_I = 0.1f * 0.1f / 6.0f;                                            // cube of half extent 0.05, quadruped.py:793
+constexpr float SUPPORT_MARGIN = 0.5f;     // m/s: a support point's rows are built once its normal row comes this close to acting (substep)
 constexpr float PAYLOAD_HALF = 0.05f, THR_PAYLOAD = 0.00173f;                              // its box against the plane (0.02 x |half extents|)
 constexpr float HIP_SELF_R = 0.046f;   // link-link tests treat the hip's motor housing (cylinder r 0.046, half length 0.02) as a sphere
 }  // namespace go1
@@ -1201,16 +1202,16 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
         V rel = lim_sgn[j] * s.qd[j];                                                                                  \
         r_.rhs = ((-lim_pen[j]) * (cfg.joint_erp * inv_dt) - rel) * r_.dinv * r_.act;                                  \
     }
-        // this environment has rare rows of its own and takes the many-rows solver's result
-        const M rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, any_extra))), V(0.5f));
+        // this environment has rare rows of its own and takes the many-rows solver's result: a joint at its stop, or a support point whose
+        // rows are built (below)
+        M rare_mine = qgt(T::quad_sum(qflag(any_lim)), V(0.5f));
         // The many-rows solve comes FIRST in the full build (on a copy; only its few results stay live while the common-path solver runs:
         // the other way round, that one's copies of the state sat on the registers the many-rows part is short of).
         State s_r = s; Out o_r = o;
         PayRows pay_c, pay_r;   // cfg.payload_soft: the block's six rows (built once: payload_rows also applies gravity to the block) and the two solvers' results for them
         if (!HOT && soft) payload_rows(cfg, Pr, s, vs, Rx, Ry, Rz, Sm, Ld, blk, pay_c);
         QS_PHASE_G(39)
-        if (!HOT && T::any(rare_mine)) {
-            T::count_rare_path(cfg);
+        if (!HOT && T::any(qor(any_lim, any_extra))) {
             Row xr[12];   // this leg's rows: contact point c at 3c .. 3c + 2 (0 = the foot), joint limits at 9 + j
 #pragma unroll
             for (int r = 0; r < 3; r++) xr[r] = rows[r];
@@ -1223,6 +1224,15 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
 #pragma unroll
                 for (int i = 0; i < 3; i++) { e_.jq[i] = zero; e_.u[i] = zero; }
             }
+            M extra_live = qlt(one, zero);
+#if defined(QS_PROBE_LAZY) && defined(__HIP_DEVICE_COMPILE__)
+            M probe_rule[2][4];
+#pragma unroll
+            for (int a_ = 0; a_ < 2; a_++)
+#pragma unroll
+                for (int m_ = 0; m_ < 4; m_++) probe_rule[a_][m_] = qlt(one, zero);
+#endif
+            const M lim_env = qgt(T::quad_sum(qflag(any_lim)), V(0.5f));   // a joint of this environment sits at its stop
             if (T::any(any_extra)) {
                 // A non-foot primitive of some environment of the wave is within its contact range: up to two support points per leg
                 // besides the foot, the lowest of {own trunk corner, hip housing, the two ends of the thigh box, knee end of the calf box}.
@@ -1256,22 +1266,69 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                     }
 #pragma unroll
                     for (int i = 0; i < 5; i++) hh[i] = qsel(qand(qgt(bi, V(i - 0.5f)), qlt(bi, V(i + 0.5f))), bigh, hh[i]);   // taken
-                    V act_x = qflag(qlt(best, V(1e8f)));
                     V dist_x = qsel(qlt(best, V(1e8f)), best, zero);
                     V f1 = qflag(qgt(dep, V(0.5f))), f2 = qflag(qgt(dep, V(1.5f))), f3 = qflag(qgt(dep, V(2.5f)));
                     V3v e1 = cross(ax1, pt - p1) * f1, e2 = cross(Y, pt - p2) * f2, e3 = cross(Y, pt - p3) * f3;
+                    // The point's rows are built once its normal row can act in this substep.  A contact inside the range but still
+                    // APPROACHING is speculative (btMultiBodyConstraintSolver: a positive distance allows a closing speed of distance / dt):
+                    // its rows end every sweep at zero impulse and the environment has the common-path solver's result -- 81 % of the
+                    // environment-substeps that reach this code in the benchmark with body_contacts=True (4 mm range, robots falling at
+                    // ~1 m/s).  Left out: a point whose predicted closing speed (v* of this substep) stays SUPPORT_MARGIN short of what
+                    // the gap allows.  Measured with a counting build over 8868 such environment-substeps: at a margin of 0 m/s 0.76 % of
+                    // the rows left out would have ended with an impulse (the feet's impulses tilt the trunk), at 0.25 m/s none; the
+                    // rule's margin is twice that.  An environment with a joint AT ITS STOP keeps all its points: the
+                    // impact at the stop changes the leg's velocities by metres per second inside the solve, which no margin on v*
+                    // covers (tests/test_emu_vs_oracle.py::test_joint_limits_together_with_sliding_contacts found it).
+                    V3v jan = cross(pt, Rz);
+                    V reln = jan.x * vs.a.x + jan.y * vs.a.y + jan.z * vs.a.z + Rz.x * vs.l.x + Rz.y * vs.l.y + Rz.z * vs.l.z +
+                             dot(Rz, e1) * s.qd[0] + dot(Rz, e2) * s.qd[1] + dot(Rz, e3) * s.qd[2];
+                    V pen_x = dist_x + cfg.contact_slop;
+                    M live = qand(qlt(best, V(1e8f)), qor(qor(lim_env, qle(pen_x, zero)), qgt((-reln) - pen_x * inv_dt, V(-SUPPORT_MARGIN))));
+#if defined(QS_PROBE_LAZY) && defined(__HIP_DEVICE_COMPILE__)
+                    // counting build (tools/probe_lazy_rows.py): every point in range gets its rows, as before the rule; what the rule
+                    // would have said at four margins is kept next to it
+#pragma unroll
+                    for (int m_ = 0; m_ < 4; m_++) probe_rule[slot][m_] = qand(qlt(best, V(1e8f)), qor(qor(lim_env, qle(pen_x, zero)), qgt((-reln) - pen_x * inv_dt, V(-0.25f * (float)((1 << m_) >> 1)))));
+                    live = qlt(best, V(1e8f));
+#endif
+                    extra_live = qor(extra_live, live);
+                    if (!T::any(live)) continue;               // nobody's point in this slot can act: no rows
+                    V act_x = qflag(live);
                     QS_CONTACT_ROW_AT(xr[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
                     QS_CONTACT_ROW_AT(xr[4 + 3 * slot], (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
                     QS_CONTACT_ROW_AT(xr[5 + 3 * slot], Rx, false, pt, e1, e2, e3, dist_x, act_x)
                 }
             }
-            if (T::any(any_lim)) { QS_LIMIT_ROWS(xr + 9) }
-            QS_PHASE_G(40)
-            V lam12[12], plam[6];
-            if (soft) pay_r = pay_c;   // (the rows; the results in it are overwritten)
-            RareSolver<T, CONE>::solve(cfg, Pr.mu, xr, soft ? &pay_r : nullptr, rare_mine, s.warm * cfg.warmstart * rows[0].act, T::wave_scratch(scratch_row), lam12, plam);
-            integrate_rare(cfg, s_r, o_r, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam);
-            QS_PHASE_G(45)
+            rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, extra_live))), V(0.5f));
+            if (T::any(rare_mine)) {
+                T::count_rare_path(cfg);
+                if (T::any(any_lim)) { QS_LIMIT_ROWS(xr + 9) }
+                QS_PHASE_G(40)
+                V lam12[12], plam[6];
+                if (soft) pay_r = pay_c;   // (the rows; the results in it are overwritten)
+                RareSolver<T, CONE>::solve(cfg, Pr.mu, xr, soft ? &pay_r : nullptr, rare_mine, s.warm * cfg.warmstart * rows[0].act, T::wave_scratch(scratch_row), lam12, plam);
+                integrate_rare(cfg, s_r, o_r, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam);
+#if defined(QS_PROBE_LAZY) && defined(__HIP_DEVICE_COMPILE__)
+                {   // probe[0] environment-substeps with a support point in range, [1] of them with every such row at zero impulse and no joint
+                    // at its stop, [2 + 2 m] environments the rule at margin m would have sent to the many-rows solve, [3 + 2 m] environments in
+                    // which it would have left out a point whose normal row ended with an impulse; margins 0, 0.25, 0.5, 1.0 m/s
+                    unsigned long long* pc = reinterpret_cast<const QsDevCfg&>(cfg).counters + 2;
+                    const bool ext_q = T::quad_sum(qflag(any_extra)) > 0.5f;
+                    const bool zero_q = !lim_env && T::quad_sum(qabs(lam12[3]) + qabs(lam12[6])) == 0.0f;
+                    const unsigned long long b0 = __ballot(ext_q), b1 = __ballot(ext_q && zero_q);
+                    if (threadIdx.x == 0) { atomicAdd(&pc[0], (unsigned long long)(__popcll(b0) / 4)); atomicAdd(&pc[1], (unsigned long long)(__popcll(b1) / 4)); }
+#pragma unroll
+                    for (int m_ = 0; m_ < 4; m_++) {
+                        const bool keep_q = lim_env || T::quad_sum(qflag(probe_rule[0][m_]) + qflag(probe_rule[1][m_])) > 0.5f;
+                        const float w0 = !probe_rule[0][m_] && qabs(lam12[3]) > 0.0f ? 1.0f : 0.0f, w1 = !probe_rule[1][m_] && qabs(lam12[6]) > 0.0f ? 1.0f : 0.0f;
+                        const bool wrong_q = T::quad_sum(w0 + w1) > 0.5f;
+                        const unsigned long long bk = __ballot(ext_q && keep_q), bw = __ballot(ext_q && wrong_q);
+                        if (threadIdx.x == 0) { atomicAdd(&pc[2 + 2 * m_], (unsigned long long)(__popcll(bk) / 4)); atomicAdd(&pc[3 + 2 * m_], (unsigned long long)(__popcll(bw) / 4)); }
+                    }
+                }
+#endif
+                QS_PHASE_G(45)
+            }
         }
         // The common-path solve.  In the full build's wave on a rare path the environments that have NO rare row of their own (no joint at a
         // stop, no link on the floor) keep ITS result -- bit for bit what the common-path build gives them in a wave without such a

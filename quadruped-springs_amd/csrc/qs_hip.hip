@@ -169,7 +169,11 @@ struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonst
 struct TermTail { float* rows; int cap, parity; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
        CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_DEV = 10 + QS_COHORTS /* QS_DEVCTR_*: the rare paths' telemetry */,
+#ifdef QS_PROBE_LAZY
+       CTL_N = 12 + QS_COHORTS + 10 /* the counting build's counters (qs_core.h, tools/probe_lazy_rows.py) */ };
+#else
        CTL_N = 12 + QS_COHORTS };
+#endif
 
 // settled-state fields a look-ahead reset copies into the record (everything the 2500-substep settle determines), and the slot's tag.
 // Every load is issued before the first value is used: as four rolled loops (`rec[i] = src[i]`) the copy was a load, a wait and an LDS write
@@ -789,6 +793,14 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     delete h;
 }
 
+#ifdef QS_PROBE_LAZY
+extern "C" int qs_probe_counters(qs_handle* h, unsigned long long* out10) {   // counting build only (tools/probe_lazy_rows.py)
+    QS_ON_DEVICE(h);
+    QS_HIP(hipStreamSynchronize(h->stream));
+    QS_HIP(hipMemcpy(out10, h->d_stats + CTL_DEV + 2, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 int qs_set_stream(qs_handle* h, void* s) { if (!h) QS_FAIL(-1, "null handle"); h->stream = (hipStream_t)s; return 0; }
 int qs_enable_timing(qs_handle* h, int on) {
     if (!h) QS_FAIL(-1, "null handle");
