@@ -129,6 +129,53 @@ def test_fallen_robot_comes_to_rest_on_the_floor(torch_cuda):
     assert out[False][:, 2].max() < -0.05
 
 
+def test_support_points_get_their_rows_once_they_can_act(torch_cuda):
+    """The rule of DESIGN.md 4a on a known situation: a robot lying on its side under PD (no joint near a stop) is lifted 3 mm off its resting
+    place and released.  For the first env step its trunk, hip and leg links are inside their 4-mm contact range (invalid contacts are
+    reported) but 2.5 mm of gap cannot close at 0.1 m/s: no support point gets rows, the many-rows solve does not run, and the state is
+    the float32 oracle's all the same -- there the rows exist and end every sweep at zero impulse.  Two env steps later the links touch
+    down: the solve runs, the robot rests where it rested before."""
+    from oracle.qso import Oracle
+    from scipy.spatial.transform import Rotation as Rot
+    n = 16
+    PD = dict(task_env="NO_TASK", observation_space_mode="ENCODER", enable_action_filter=False, isRLGymInterface=False, motor_control_mode="PD")
+    v = vec_env(n, **PD)
+    o = Oracle(v.cfg, "f32")
+    v.reset(); o.reset()
+    hold = np.tile([0.0, 1.2, -2.4], (n, 4)).astype(np.float32)
+    s = v.get_state().cpu().numpy()
+    s[:, :3] = [0, 0, 0.16]; s[:, 3:7] = Rot.from_euler("x", 1.45).as_quat(); s[:, 7:] = 0; s[:, 13:25] = hold
+    v.set_state(s)
+    for _ in range(300):
+        v.step(hold)
+    rest = v.get_state().cpu().numpy()
+    assert np.abs(rest[:, 7:13]).max() < 2e-2 and np.abs(rest[:, 13:25] - hold).max() < 0.5      # at rest, the joints held well inside their ranges (the springs pull the calves 0.3 rad off their target)
+    lifted = rest.copy()
+    lifted[:, 2] += 0.003; lifted[:, 7:13] = 0; lifted[:, 25:] = 0
+    v.set_state(lifted); o.set_state(lifted.astype(np.float64))
+    c0 = v.counter("limit_path_substeps")
+    solves = []
+    for i in range(6):
+        st = o.get_state()
+        o.set_state(st); v.set_state(st.astype(np.float32))
+        o.step(hold); v.step(hold)
+        so, sv = o.get_state(), v.get_state().cpu().numpy()
+        np.testing.assert_allclose(sv[:, :7], so[:, :7], atol=5e-5, err_msg=f"pose step {i}")
+        np.testing.assert_allclose(sv[:, 7:13], so[:, 7:13], atol=2e-2, err_msg=f"base velocity step {i}")
+        np.testing.assert_allclose(sv[:, 13:25], so[:, 13:25], atol=2e-4, err_msg=f"q step {i}")
+        c1 = v.counter("limit_path_substeps")
+        solves.append(c1 - c0); c0 = c1
+        if i == 0:
+            assert (v.get_info("n_invalid").cpu().numpy()[:, 0] > 0).all() and (o.get_info(5)[:, 0] > 0).all()      # in range: reported as contacts ...
+    assert solves[0] == 0, solves              # ... whose rows cannot act yet: no many-rows solve in the first env step
+    assert sum(solves[2:]) > 0, solves         # touch-down: the solve runs
+    for _ in range(100):
+        v.step(hold)
+    end = v.get_state().cpu().numpy()
+    assert np.abs(end[:, 2] - rest[:, 2]).max() < 2e-3 and np.abs(end[:, 7:13]).max() < 5e-2
+    v.close()
+
+
 def crossed(s):
     s = s.copy()
     s[:, :3] = [0, 0, 0.6]; s[:, 3:7] = [0, 0, 0, 1]; s[:, 7:] = 0
