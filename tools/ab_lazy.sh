@@ -1,4 +1,7 @@
 #!/bin/bash
+# A/B of a second build of the library (quadruped-springs_amd/qs_amd/exp/lazy.so: QS_BUILD_OUT=... python quadruped-springs_amd/build.py --force) against the
+# one in place on what a change of the rare paths moves: the headline, the headline with body_contacts=True (twice each) and tools/time_rare_path.py.
+# The support points' rule of DESIGN.md 4a was measured with it (gpurun_out/r04zu).   bash tools/ab_lazy.sh   on the GPU box
 out=gpurun_out/r04zu; mkdir -p $out
 for rep in 1 2; do for lib in cur lazy; do
   if [ $lib = cur ]; then L=$PWD/quadruped-springs_amd/qs_amd/libqs_hip.so; else L=$PWD/quadruped-springs_amd/qs_amd/exp/lazy.so; fi
