@@ -55,6 +55,26 @@ def test_config_struct_layout_matches_header():
     assert out2 == out
 
 
+def test_host_result_and_norm_io_layouts_match_header():
+    """The two other structs that cross the C ABI by pointer (qs_host_result, qs_norm_io) against their ctypes mirrors in qs_amd/lib.py."""
+    import subprocess
+    import tempfile
+    from qs_amd.lib import HostResult, NormIO
+    for cname, mirror in (("qs_host_result", HostResult), ("qs_norm_io", NormIO)):
+        fields = [f[0] for f in mirror._fields_]
+        src = '#include <stdio.h>\n#include <stddef.h>\n#include "qs_amd.h"\nint main(){printf("%zu\\n", sizeof(' + cname + '));\n'
+        for f in fields:
+            src += f'printf("%zu\\n", offsetof({cname}, {f}));\n'
+        src += "return 0;}\n"
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "t.c"), "w").write(src)
+            subprocess.check_call(["gcc", "-I" + os.path.join(REPO, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+            out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+        assert int(out[0]) == C.sizeof(mirror), cname
+        for f, off in zip(fields, out[1:]):
+            assert getattr(mirror, f).offset == int(off), (cname, f)
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
