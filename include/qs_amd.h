@@ -285,7 +285,8 @@ int qs_norm_step(qs_norm* h, float* obs /* [N,o] */, float* rew /* [N] */, const
  * (may be NULL), term_obs [N,o] (may be NULL), tail_rows = the compact list of the step's terminal observations, [tail_cap][1 + o] (may
  * be NULL; qs_host_result::terminal_rows while still on the device).  out_* all NULL: normalised in place.  Otherwise out_obs / out_rew
  * receive the normalised arrays, out_done / out_trunc / out_tail copies of the flags and the (normalised) list -- e.g. mapped host memory,
- * which the kernel then writes itself; the inputs stay raw.  raw_obs / raw_rew as in qs_norm_step. */
+ * which the kernel then writes itself; the inputs stay raw (term_obs is normalised in place either way).  raw_obs / raw_rew as in
+ * qs_norm_step. */
 typedef struct qs_norm_io {
     float* obs; float* rew; const uint8_t* done; const uint8_t* trunc; float* term_obs; float* tail_rows; int32_t tail_cap;
     float* out_obs; float* out_rew; uint8_t* out_done; uint8_t* out_trunc; float* out_tail;
@@ -296,8 +297,9 @@ int qs_norm_step_io(qs_norm* h, const qs_norm_io* io, int training, int norm_obs
  * qs_host_step_begin on, the step's results pass through `norm` (qs_norm_step_io: statistics update if training, observations, rewards
  * and the terminal observations of the compact list normalised) before they reach the host block, so that qs_host_step_end hands out
  * what VecNormalize.step_wait returns.  raw_obs [N,o] / raw_rew [N] (device memory, may be NULL): the values before normalisation
- * (get_original_obs / get_original_reward).  norm == NULL switches it off.  Not between a begin and its end.  The handle keeps the
- * pointer, not the object: switch it off (or destroy the simulation handle) before qs_norm_destroy(norm). */
+ * (get_original_obs / get_original_reward).  norm == NULL switches it off (at any time); it is switched on between two steps, not between
+ * a begin and its end.  The handle keeps the pointer, not the object: switch it off (or destroy the simulation handle) before
+ * qs_norm_destroy(norm). */
 int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
 
 const char* qs_last_error(void);
