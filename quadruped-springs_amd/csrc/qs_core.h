@@ -508,7 +508,13 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
         // (the implicit cone's projection is not idempotent in floating point: once an environment is frozen its friction bound is lifted,
         // so that the sweeps the rest of the wave still needs leave it exactly alone and no result depends on the wave's other environments)
         V mu_c = mu;
+#if defined(QS_PROBE_SWEEPS) && defined(__HIP_DEVICE_COMPILE__)
+        float probe_wave = 0.0f, probe_own = 0.0f, probe_frozen = 0.0f;   // counting build (tools/probe_sweeps.py): sweeps the wave ran / this environment needed
+#endif
         for (int it = 0; it < cfg.solver_iters; it++) {
+#if defined(QS_PROBE_SWEEPS) && defined(__HIP_DEVICE_COMPILE__)
+            probe_wave += 1.0f; probe_own += 1.0f - probe_frozen;
+#endif
             V dvmax = zero;   // largest |row velocity change| of this sweep (replicated over the quad)
             // (PAY) the impulse changes of the lane's OWN foot rows in this sweep.  The payload rows read J^T lambda's base part (py) at the
             // start of a sweep only, the foot rows do not read it at all (their candidates move with Ap / Apc directly): so the foot rows'
@@ -597,9 +603,28 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                     V mine = qsel(T::is_leg(0), lam_all[NR * 0 + c], qsel(T::is_leg(1), lam_all[NR * 1 + c], qsel(T::is_leg(2), lam_all[NR * 2 + c], lam_all[NR * 3 + c])));
                     res[c] = qsel(conv, mine, res[c]);
                 }
+#if defined(QS_PROBE_SWEEPS) && defined(__HIP_DEVICE_COMPILE__)
+                probe_frozen = conv ? 1.0f : probe_frozen;
+#endif
                 if (!T::any(qnot(conv))) break;
             }
         }
+#if defined(QS_PROBE_SWEEPS) && defined(__HIP_DEVICE_COMPILE__)
+        {   // probe[0] solves (wave level), [1] sweeps the waves ran, [2] environment-solves, [3] sweeps the environments needed (until frozen),
+            // [4] solves in which the wave ran every sweep, [5] environment-solves that never froze
+            unsigned long long* pc = reinterpret_cast<const QsDevCfg&>(cfg).counters + 2;
+            const float own_sum = T::quad_sum(probe_own) * 0.25f;     // (replicated over the quad)
+            float tot = own_sum;                                       // sum over the wave's 16 environments: one lane per quad
+            const unsigned long long never = __ballot(probe_frozen < 0.5f);
+            for (int off = 4; off < 64; off <<= 1) tot += __shfl_xor(tot, off);
+            if (threadIdx.x == 0) {
+                atomicAdd(&pc[0], 1ull); atomicAdd(&pc[1], (unsigned long long)probe_wave);
+                atomicAdd(&pc[2], 16ull); atomicAdd(&pc[3], (unsigned long long)(tot + 0.5f));
+                if (probe_wave >= (float)cfg.solver_iters) atomicAdd(&pc[4], 1ull);
+                atomicAdd(&pc[5], (unsigned long long)(__popcll(never) / 4));
+            }
+        }
+#endif
 #pragma unroll
         for (int c = 0; c < NR; c++)
             lam_own[c] = qsel(T::is_leg(0), lam_all[NR * 0 + c], qsel(T::is_leg(1), lam_all[NR * 1 + c], qsel(T::is_leg(2), lam_all[NR * 2 + c], lam_all[NR * 3 + c])));

@@ -169,8 +169,8 @@ struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonst
 struct TermTail { float* rows; int cap, parity; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
        CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_DEV = 10 + QS_COHORTS /* QS_DEVCTR_*: the rare paths' telemetry */,
-#ifdef QS_PROBE_LAZY
-       CTL_N = 12 + QS_COHORTS + 10 /* the counting build's counters (qs_core.h, tools/probe_lazy_rows.py) */ };
+#if defined(QS_PROBE_LAZY) || defined(QS_PROBE_SWEEPS)
+       CTL_N = 12 + QS_COHORTS + 10 /* the counting builds' counters (qs_core.h, tools/probe_*.py) */ };
 #else
        CTL_N = 12 + QS_COHORTS };
 #endif
@@ -793,8 +793,8 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     delete h;
 }
 
-#ifdef QS_PROBE_LAZY
-extern "C" int qs_probe_counters(qs_handle* h, unsigned long long* out10) {   // counting build only (tools/probe_lazy_rows.py)
+#if defined(QS_PROBE_LAZY) || defined(QS_PROBE_SWEEPS)
+extern "C" int qs_probe_counters(qs_handle* h, unsigned long long* out10) {   // counting builds only (tools/probe_*.py)
     QS_ON_DEVICE(h);
     QS_HIP(hipStreamSynchronize(h->stream));
     QS_HIP(hipMemcpy(out10, h->d_stats + CTL_DEV + 2, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
