@@ -307,10 +307,18 @@ def main():
     d_gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     n_act = 64  # a ring of pre-generated U(-1,1) action batches, resident in HBM
 
+    spin = os.environ.get("QS_BENCH_SPIN", "1") != "0"
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         if not gloo:
+            if spin:   # poll an event behind the work first: the synchronize below then returns at once instead of waking up late
+                       # (measured over four 20-step regions each way on one box: 104.1 against 102.9 M on average, inside the +-2.5 % of such regions)
+                ev = torch.cuda.Event()
+                ev.record()
+                while not ev.query():
+                    pass
             torch.cuda.synchronize()
 
     def run(env_kw, with_exchange):
