@@ -383,16 +383,20 @@ def main():
         # the step kernel's launches of the timed region between two HIP events on the kernel's own stream (qs_enable_timing: one event in
         # front of the first launch, one behind the last): per-launch duration for the roofline, measured over the timed region itself
         env.enable_timing(True)
+        debug = bool(os.environ.get("QS_BENCH_DEBUG"))
         t0 = time.perf_counter()
+        t_first = t0
         for i in range(args.steps):
             step_fn(acts[i % n_act])
+            if debug and i == 0:
+                t_first = time.perf_counter()
         t_loop = time.perf_counter()
         env.enable_timing(2)                        # the closing event, in stream order behind the last launch; waited for after the region
         barrier()
         elapsed = time.perf_counter() - t0
         kernel_ms = env.last_step_kernel_ms()
-        if os.environ.get("QS_BENCH_DEBUG"):
-            print(f"[debug] launching {1e6 * (t_loop - t0):.0f} us, until the barrier returned {1e6 * elapsed:.0f} us, kernel_ms x K {1e3 * kernel_ms * args.steps:.0f} us", file=sys.stderr)
+        if debug:
+            print(f"[debug] first call {1e6 * (t_first - t0):.0f} us, launching {1e6 * (t_loop - t0):.0f} us, until the barrier returned {1e6 * elapsed:.0f} us, kernel_ms x K {1e3 * kernel_ms * args.steps:.0f} us", file=sys.stderr)
         env.enable_timing(False)
         c0 = {k: int(v) for k, v in zip(("settle_substeps", "resets", "lookahead_served", "lookahead_settled", "limit_path_substeps", "self_narrow_substeps",
                                          "reset_stalls"), snap0.cpu().tolist())}
