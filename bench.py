@@ -117,7 +117,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--preroll", type=int, default=1500,
+    ap.add_argument("--preroll", type=int, default=2048,
                     help="untimed steps before the warmup steps that bring episode ages, reset rate and the settle lanes "
                          "to their steady state (part of the preparation; 0 to skip)")
     ap.add_argument("--workload", default="jump_in_place_8192")
@@ -131,6 +131,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-settle-lanes", action="store_true",
                     help="experiments: leave the look-ahead states un-replenished (resets settle in place once an environment has used its K states)")
     ap.add_argument("--no-info-line", action="store_true", help="skip the second timed loop with info_fields=True (value_info_fields_true)")
+    ap.add_argument("--no-body-contacts-line", action="store_true",
+                    help="skip the timed loop of the OTHER setting of body_contacts (value_body_contacts_true / value_body_contacts_auto: the "
+                         "reference's all-links contact response on / left to the task, DESIGN.md 4a)")
+    ap.add_argument("--allow-short-preroll", action="store_true",
+                    help="experiments: accept a --preroll below two episode lengths for the headline workload (the reset rate is then not the steady state's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     ap.add_argument("--dry-launch", action="store_true",
@@ -224,6 +229,61 @@ def launch_ranks(args, argv):
     return 0
 
 
+def _build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("qs_build", os.path.join(REPO, "quadruped-springs_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def running_fingerprint():
+    """(source fingerprint, reason it cannot be trusted or None): the tree this process's libqs_hip.so was built from.  Another
+    library through QS_LIB_PATH, or a library older than its sources, belongs to no fingerprint."""
+    b = _build_module()
+    if os.environ.get("QS_LIB_PATH"):
+        return None, "QS_LIB_PATH names another library than the tree's"
+    if b.needs_build():
+        return None, "libqs_hip.so is older than its sources"
+    return b.source_fingerprint(), None
+
+
+def pmc_for_run(profiles_dir, key, fingerprint, why_no_fingerprint=None):
+    """The committed counter passes that belong to THIS run: the newest profiles/r*_pmc.json whose workload keys equal `key` AND whose
+    `source_sha256` equals the fingerprint of the tree the running library was built from.  Returns (pmc dict or None, file or None,
+    reason or None).  Counters of another binary are not reported (round 4 copied them unchecked)."""
+    import glob
+    stale = None
+    for f in sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc.json")), reverse=True):
+        try:
+            p = json.load(open(f))
+            k = (p["workload"], p["envs_per_gpu"], p.get("reset_lookahead"), p.get("friction_model", "pyramid"), float(p.get("solver_residual_threshold", 0.0)),
+                 p.get("body_contacts", "auto"))
+        except (OSError, KeyError, ValueError):
+            continue
+        if k != key:
+            continue
+        if fingerprint is not None and p.get("source_sha256") == fingerprint:
+            return p, f, None
+        if stale is None:
+            stale = (f, "carries no source fingerprint" if "source_sha256" not in p else "was taken on another source tree")
+    if stale:
+        return None, None, f"{os.path.basename(stale[0])} {stale[1]}" + (f" ({why_no_fingerprint})" if fingerprint is None and why_no_fingerprint else "") + ": counters not reported"
+    return None, None, "no committed counter pass of this configuration"
+
+
+def default_body_contacts(gloo=False):
+    """What QuadrupedVecEnv does when the caller says nothing (qs_amd.config.build_config's default)."""
+    if gloo:
+        return "auto"
+    import inspect
+    from qs_amd.config import build_config
+    return inspect.signature(build_config).parameters["body_contacts"].default
+
+
+EPISODE_STEPS = 1001   # gym_env.py:35, 245: an episode ends once sim_time exceeds 10 s = after 1001 env steps of 10 ms
+
+
 def metric_name(workload_name, kw, n, world, total_envs):
     if workload_name == "jump_in_place_8192" and n == 8192 and not total_envs:
         return "env-steps/sec (whole node), Go1+PEA jump-in-place, N=8192 envs"     # BASELINE.json's metric, verbatim
@@ -242,6 +302,10 @@ def main():
         return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    headline_cmd = args.workload == "jump_in_place_8192" and not args.env_kw and args.reset_lookahead == 16 and not args.no_settle_lanes
+    if headline_cmd and args.preroll < 2 * EPISODE_STEPS and not args.allow_short_preroll and not args.standin:
+        raise SystemExit(f"bench.py: --preroll {args.preroll} is below two episode lengths ({2 * EPISODE_STEPS} steps): the headline is quoted at the steady-state "
+                         "reset rate, which the pre-roll builds up (--allow-short-preroll for experiments)")
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if under_launcher and int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; they must agree")
@@ -415,12 +479,21 @@ def main():
         env.close()
         return res
 
+    # body_contacts: the reference's contact response of EVERY link (quadruped.py:533-539) is `True`; "auto" leaves the non-foot links'
+    # response off under a task that ends the episode on such a contact.  The line always says which one `value` was taken
+    # with (config.body_contacts) and carries the other one next to it, timed the same way by the same process.
+    main_bc = kw.get("body_contacts", default_body_contacts(gloo))
+    kw["body_contacts"] = main_bc
+    other_bc = "auto" if main_bc is True else True
     m = run(kw, sharded)
     m_info = None
     if not kw["info_fields"] and not args.no_info_line and not sharded:
         m_info = run(dict(kw, info_fields=True), False)
+    m_bc = None
+    if not args.no_body_contacts_line and not sharded and main_bc in (True, "auto"):
+        m_bc = run(dict(kw, body_contacts=other_bc), False)
     elapsed_local = m["elapsed"]
-    t = torch.tensor([m["elapsed"], m["local_elapsed"] or 0.0, m_info["elapsed"] if m_info else 0.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([m["elapsed"], m["local_elapsed"] or 0.0, m_info["elapsed"] if m_info else 0.0, m_bc["elapsed"] if m_bc else 0.0], dtype=torch.float64, device=dev)
     tmin = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
     rccl_ranks = 1
     if world > 1:
@@ -429,7 +502,7 @@ def main():
         torch.distributed.all_reduce(tmin, op=torch.distributed.ReduceOp.MIN)
     elif sharded:
         rccl_ranks = torch.distributed.get_world_size()
-    elapsed, local_elapsed, info_elapsed = float(t[0].item()), (float(t[1].item()) if sharded else None), float(t[2].item())
+    elapsed, local_elapsed, info_elapsed, bc_elapsed = float(t[0].item()), (float(t[1].item()) if sharded else None), float(t[2].item()), float(t[3].item())
     total_steps = n * world * args.steps
     if rank == 0:
         d = m["action_dim"]
@@ -438,19 +511,20 @@ def main():
         achieved = n * algo_bytes / kavg / 1e9
         # HBM bytes per launch: rocprofv3 cannot run inside this process, so the figure is the PMC byte count of the committed
         # passes of this very configuration (roofline.traffic_source names the file); null when the run differs from every profiled one
-        traffic = valu = pmc = pmc_file = None
+        traffic = valu = pmc = pmc_file = pmc_why = None
         try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")), reverse=True):
-                p = json.load(open(f))
-                if (p["workload"], p["envs_per_gpu"], p.get("reset_lookahead"), p.get("friction_model", "pyramid"),
-                        float(p.get("solver_residual_threshold", 0.0))) == (args.workload, n, args.reset_lookahead, args.friction_model,
-                                                                            float(args.solver_residual_threshold)) and not extra_kw:   # (a run with extra keywords is another configuration)
-                    pmc, pmc_file = p, os.path.relpath(f, REPO)
-                    break
-            if pmc is not None and not gloo:
+            key = (args.workload, n, args.reset_lookahead, args.friction_model, float(args.solver_residual_threshold), "true" if main_bc is True else str(main_bc).lower())
+            if extra_kw and set(extra_kw) - {"body_contacts"}:   # (a run with other extra keywords is another configuration)
+                pmc_why = "extra keywords: not a profiled configuration"
+            elif gloo:
+                pmc_why = "gloo test mode"
+            else:
+                fp, fp_why = running_fingerprint()
+                pmc, pmc_file, pmc_why = pmc_for_run(os.path.join(REPO, "profiles"), key, fp, fp_why)
+                pmc_file = os.path.relpath(pmc_file, REPO) if pmc_file else None
+            if pmc is not None:
                 traffic = (pmc["fetch_correction"] * pmc["fetch_size_kb"] + pmc["write_size_kb"]) * 1024 / kavg / 1e9
-                if "sq_insts_valu" in pmc:
+                if pmc.get("sq_insts_valu"):
                     # the roof that does bound this kernel: one wave64 fp32 VALU instruction per SIMD every 4 cycles (one wave's issue rate)
                     prop = torch.cuda.get_device_properties(dev)
                     peak = prop.multi_processor_count * 4 * getattr(prop, "clock_rate", 2.4e6) * 1e3 / 4 / 1e9
@@ -459,8 +533,8 @@ def main():
                             "note": "SQ_INSTS_VALU per launch (committed PMC passes, steady-state launches only) / live step-kernel duration, against SIMDs x clock / 4; " +
                                     (f"at N = {n} only {(n // 16) / (prop.multi_processor_count * 4):.0%} of the SIMDs hold a stepping wave"
                                      if n // 16 < prop.multi_processor_count * 4 else f"at N = {n} every SIMD holds {(n // 16) / (prop.multi_processor_count * 4):.0f} stepping waves")}
-        except (OSError, KeyError, ValueError):
-            pmc = None
+        except (OSError, KeyError, ValueError) as e:
+            pmc, pmc_why = None, f"{type(e).__name__}: {e}"
         dl = m["delta"]
         resets, settle_sub = int(dl["resets"]), int(dl["settle_substeps"])
         K = m["lookahead"]
@@ -480,6 +554,10 @@ def main():
             "config": {"backend": args.backend, "workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
                        "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
                        "auto_reset": True, "preroll_steps": args.preroll,
+                       "body_contacts": main_bc,
+                       # how the timed region is bracketed and how the preparation spreads the episode ages (both changed in round 4: lines of
+                       # earlier rounds polled nothing and spread the ages under random actions)
+                       "spin_barrier": bool(spin and not gloo), "spread_actions": "zero (robots stand still while episode ages are spread)", "spread_steps": args.spread_steps,
                        "reset_lookahead": K,
                        "reset": ((f"exact: every environment takes its own next reset state (randomizer draws of (seed, env, episode), spawn, {m['settle_steps']} settle "
                                   f"substeps), settled up to {K} episodes ahead by extra workgroups of the step kernel (settle lanes); bitwise the in-step settle")
@@ -501,13 +579,26 @@ def main():
                        "parallelism": (f"env-sharded x{world}, actions broadcast + one all-gather of [n, o+2] per step (both skipped on one rank), results land in rank 0's rollout buffer" if sharded
                                        else f"env-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": pmc_file, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
+                         "traffic": traffic, "traffic_source": pmc_file, "traffic_note": pmc_why, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
                          "algorithmic_bytes_per_env_step": algo_bytes,
                          "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / average k_step launch duration over the timed region (two HIP events on the kernel's stream around all its launches: includes the ~1 us between back-to-back launches, so it lies between rocprofv3's kernel average and ms_per_step); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~30 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
         }
+        ratio = out["config"]["settle_work_ratio"]
+        if ratio is not None and ratio < 0.9:
+            out["config"]["settle_work_note"] = (f"this timed region executed {ratio:.0%} of the settle work its {resets} resets are worth: a region of {args.steps} steps "
+                                                 "catches the settle lanes' cohorts at a phase, not on average (a 1000-step region reads 1.00); the lanes run on SIMDs "
+                                                 "the stepping waves leave idle, so the rate moves by less than the ratio suggests (DESIGN.md 5)")
         if m_info is not None:
             out["value_info_fields_true"] = total_steps / info_elapsed     # the default handle of QuadrupedVecEnv: every step also stores torques, foot forces, pose cache
             out["config"]["stalls_info_fields_true"] = int(m_info["delta"]["reset_stalls"])
+        bc_key = lambda v: "value_body_contacts_" + ("true" if v is True else str(v).lower())
+        out[bc_key(main_bc)] = out["value"]
+        out["roofline"]["kernel_ms_body_contacts_" + ("true" if main_bc is True else str(main_bc).lower())] = kavg * 1e3
+        if m_bc is not None:
+            out[bc_key(other_bc)] = total_steps / bc_elapsed
+            out["roofline"]["kernel_ms_body_contacts_" + ("true" if other_bc is True else str(other_bc).lower())] = m_bc["kernel_ms"]
+            out["config"]["stalls_body_contacts_other"] = int(m_bc["delta"]["reset_stalls"])
+            out["config"]["many_rows_wave_substeps_body_contacts_other"] = int(m_bc["delta"]["limit_path_substeps"])
         if sharded:
             out["config"]["local_ms_per_step"] = 1e3 * local_elapsed / args.steps
             out["config"]["exchange_us"] = 1e6 * (elapsed - local_elapsed) / args.steps

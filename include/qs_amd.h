@@ -129,7 +129,11 @@ typedef struct qs_config {
                                 * in the same PGS, as the reference builds it (quadruped.py:796-819): under the implicit cone its rows ride
                                 * with the foot rows in the common-path solver (about 3x the step time: the constraint's rows need all the
                                 * sweeps), under the friction pyramid every substep takes the many-rows solve; its state: QS_INFO_PAYLOAD_BLOCK */
-    float reserved_f[3];
+    float support_margin;      /* m/s.  body_contacts: a non-foot support point inside its contact range gets its rows once its normal row comes this
+                                * close to acting on the substep's predicted velocities (a point still approaching has speculative rows that end
+                                * every sweep at zero impulse: the same solve at the many-rows price); >= 1e30: EVERY point in range
+                                * gets its rows, as Bullet and the oracle build them (parity / debug runs).  Default 0.5. */
+    float reserved_f[2];
     /* Hopf-oscillator CPG action layer (hopf_network.py:26-173); BASELINE.json configs[4] */
     float cpg_phi[16];         /* coupling phase matrix PHI[i][j] of the gait (hopf_network.py:74-115) */
     float cpg_lo[5], cpg_hi[5];/* action -> (omega_swing, omega_stance, mu, des_step_len, robot_height) */
@@ -218,6 +222,10 @@ typedef struct qs_host_result {
     const float* terminal_rows;  /* [terminal_cap, 1 + obs_dim] */
     int32_t terminal_cap;
 } qs_host_result;
+/* Failures: one BEFORE the step's launch (bad arguments, a DEMO task without its demonstration, the previous step not collected) leaves the
+ * handle as it was.  One BEHIND the launch (the attached normalisation or the copy of the block failed) is returned by qs_host_step_begin
+ * and the step STAYS pending -- the simulation has advanced --: qs_host_step_end waits for it, reports the same failure once more and
+ * closes the step; the host block then does not hold that step's results. */
 int qs_host_step_begin(qs_handle* h, const float* actions);
 int qs_host_step_end(qs_handle* h, qs_host_result* out);
 
@@ -291,6 +299,8 @@ typedef struct qs_norm_io {
     float* obs; float* rew; const uint8_t* done; const uint8_t* trunc; float* term_obs; float* tail_rows; int32_t tail_cap;
     float* out_obs; float* out_rew; uint8_t* out_done; uint8_t* out_trunc; float* out_tail;
     float* raw_obs; float* raw_rew;
+    const uint64_t* tail_count;   /* device memory, may be NULL: how many rows of tail_rows this step filled (only those are normalised / copied;
+                                   * NULL: all tail_cap rows) */
 } qs_norm_io;
 int qs_norm_step_io(qs_norm* h, const qs_norm_io* io, int training, int norm_obs, int norm_reward);
 /* VecNormalize around the HOST path (load_model.py:109-137: VecNormalize.load(stats, env), then env.step(numpy actions)): from the next
@@ -304,6 +314,11 @@ int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, in
 
 const char* qs_last_error(void);
 const char* qs_version(void);
+/* Bumped whenever the meaning or type of an existing entry point's argument or of a struct field changes (a caller built against an older
+ * header would pass garbage without any loader error): 5 = round 5 (qs_norm_create takes its four float arguments as double since round 4;
+ * qs_config::reserved_f[0] became support_margin).  A binding compares it with the QS_ABI_VERSION of the header it was written against. */
+#define QS_ABI_VERSION 5
+int qs_abi_version(void);
 
 #ifdef __cplusplus
 }

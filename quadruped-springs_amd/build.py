@@ -12,9 +12,47 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "qs_hip.hip")
 SRC_NORM = os.path.join(HERE, "csrc", "qs_norm.hip")
-DEPS = [SRC, SRC_NORM] + [os.path.join(HERE, "csrc", f) for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h", "qs_host.h")] + \
-       [os.path.join(REPO, "include", "qs_amd.h")]
 OUT = os.path.join(HERE, "qs_amd", "libqs_hip.so")
+
+
+def deps():
+    """Everything the library is compiled from: every file under csrc/ and every public header (listed by directory, not by name: round 4's
+    qs_rare.h was missing from a hand-kept list, and an edit of the many-rows solver alone left a stale library behind)."""
+    import glob
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(HERE, "csrc", "*.hip")) +
+                  glob.glob(os.path.join(REPO, "include", "*.h")) + [os.path.abspath(__file__)])
+
+
+def needs_build(out=None):
+    out = out or OUT
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps())
+
+
+def source_fingerprint():
+    """sha256 over everything the library is compiled from (deps(): sources, public headers, this file with its flags) plus the
+    environment variables that change the build.  A profile (profiles/r*_pmc.json) carries the fingerprint of the tree it was taken
+    on; bench.py reports counter-derived figures only for a matching tree (a rebuilt library on another box still matches, an
+    edited kernel does not)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in deps():
+        h.update(os.path.relpath(d, REPO).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for var in ("QS_HIPCC_EXTRA", "QS_MFMA_VGPR_FORM", "QS_OFFLOAD_ARCH"):
+        h.update((var + "=" + os.environ.get(var, "")).encode() + b"\0")
+    return h.hexdigest()
+
+
+def fingerprint(path=None):
+    """sha256 of the built library: what bench.py and the profile tools use to say which binary a number belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path or OUT, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def hipcc():
@@ -25,7 +63,7 @@ def hipcc():
 
 
 def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
+    if not force and not needs_build():
         return OUT
     # -fno-slp-vectorize: packed fp32 (v_pk_*) costs more moves than it saves here.  iterative-ilp: with one wave per SIMD
     # there is no other wave to hide a dependent instruction's latency, so the scheduler should chase ILP, not occupancy

@@ -76,7 +76,6 @@ constexpr float TRUNK_HALF[3] = {0.1881f, 0.04675f, 0.057f};                    
 constexpr float HIP_CYL_HALF_LEN = 0.02f, HIP_CYL_R = 0.046f;                              // cylinder :128-131
 constexpr float LINK_BOX_Z = -0.1065f, THIGH_HALF[3] = {0.017f, 0.01225f, 0.1065f}, CALF_HALF[3] = {0.008f, 0.008f, 0.1065f};
 constexpr float PAYLOAD_I = 0.1f * 0.1f / 6.0f;                                            // cube of half extent 0.05, quadruped.py:793
-constexpr float SUPPORT_MARGIN = 0.5f;     // m/s: a support point's rows are built once its normal row comes this close to acting (substep)
 constexpr float PAYLOAD_HALF = 0.05f, THR_PAYLOAD = 0.00173f;                              // its box against the plane (0.02 x |half extents|)
 constexpr float HIP_SELF_R = 0.046f;   // link-link tests treat the hip's motor housing (cylinder r 0.046, half length 0.02) as a sphere
 }  // namespace go1
@@ -1298,7 +1297,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                     // APPROACHING is speculative (btMultiBodyConstraintSolver: a positive distance allows a closing speed of distance / dt):
                     // its rows end every sweep at zero impulse and the environment has the common-path solver's result -- 81 % of the
                     // environment-substeps that reach this code in the benchmark with body_contacts=True (4 mm range, robots falling at
-                    // ~1 m/s).  Left out: a point whose predicted closing speed (v* of this substep) stays SUPPORT_MARGIN short of what
+                    // ~1 m/s).  Left out: a point whose predicted closing speed (v* of this substep) stays cfg.support_margin (0.5 m/s) short of what
                     // the gap allows.  Measured with a counting build over 8868 such environment-substeps: at a margin of 0 m/s 0.76 % of
                     // the rows left out would have ended with an impulse (the feet's impulses tilt the trunk), at 0.25 m/s none; the
                     // rule's margin is twice that.  An environment with a joint AT ITS STOP keeps all its points: the
@@ -1308,7 +1307,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                     V reln = jan.x * vs.a.x + jan.y * vs.a.y + jan.z * vs.a.z + Rz.x * vs.l.x + Rz.y * vs.l.y + Rz.z * vs.l.z +
                              dot(Rz, e1) * s.qd[0] + dot(Rz, e2) * s.qd[1] + dot(Rz, e3) * s.qd[2];
                     V pen_x = dist_x + cfg.contact_slop;
-                    M live = qand(qlt(best, V(1e8f)), qor(qor(lim_env, qle(pen_x, zero)), qgt((-reln) - pen_x * inv_dt, V(-SUPPORT_MARGIN))));
+                    M live = qand(qlt(best, V(1e8f)), qor(qor(lim_env, qle(pen_x, zero)), qgt((-reln) - pen_x * inv_dt, V(-cfg.support_margin))));
 #if defined(QS_PROBE_LAZY) && defined(__HIP_DEVICE_COMPILE__)
                     // counting build (tools/probe_lazy_rows.py): every point in range gets its rows, as before the rule; what the rule
                     // would have said at four margins is kept next to it

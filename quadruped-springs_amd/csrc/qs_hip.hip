@@ -679,10 +679,14 @@ static int sensor_dim(int s) {
 }
 static int n_waves(int n) { return (n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE; }
 
+#define QS_STR2(x) #x
+#define QS_STR(x) QS_STR2(x)
+
 extern "C" {
 
 const char* qs_last_error(void) { return g_err; }
-const char* qs_version(void) { return "qs_amd 0.1 (gfx950, quad-per-env)"; }
+const char* qs_version(void) { return "qs_amd 0.5 (gfx950, quad-per-env; ABI " QS_STR(QS_ABI_VERSION) ")"; }
+int qs_abi_version(void) { return QS_ABI_VERSION; }
 
 static int create_impl(const qs_config* cfg, int device, qs_handle* h);
 
@@ -942,6 +946,7 @@ struct HostPath {
     uint8_t* hd_block[2];    // (zero-copy mode) device addresses of the host blocks
     float* h_act; float* d_act; float* hd_act;
     int cur, parity, pending;
+    int late_rc;            // a failure behind the launch of the pending step (qs_host_step_begin), reported again by qs_host_step_end
     int registered;          // bits 0, 1: h_block[k], bit 2: h_act are page-locked (hipHostRegister succeeded)
     hipEvent_t ev;
     // qs_host_set_norm: VecNormalize.step_wait between the step and the results' way to the host (the step then writes the DEVICE block,
@@ -1009,6 +1014,26 @@ static int host_path_build(qs_handle* h, HostPath* p) {
     return 0;
 }
 
+// what qs_host_step_begin enqueues behind the step's launch: the normalisation attached by qs_host_set_norm, the copy of the result block
+static int host_step_after_launch(qs_handle* h, HostPath* p, uint8_t* blk, bool via_device) {
+    if (p->norm) {
+        if (int rc = qs_norm_set_stream(p->norm, (void*)h->stream)) return rc;
+        qs_norm_io io;
+        memset(&io, 0, sizeof(io));
+        io.obs = (float*)blk; io.rew = (float*)(blk + p->off_rew); io.done = blk + p->off_done; io.trunc = blk + p->off_trunc;
+        io.tail_rows = (float*)(blk + p->off_tail); io.tail_cap = p->cap; io.raw_obs = p->raw_obs; io.raw_rew = p->raw_rew;
+        io.tail_count = (const uint64_t*)&h->d_stats[CTL_TERM_CNT + p->parity];      // the rows this step's launch claimed
+        if (p->zero_copy) {     // the normalising kernel writes the host block itself
+            uint8_t* to = p->hd_block[p->cur];
+            io.out_obs = (float*)to; io.out_rew = (float*)(to + p->off_rew); io.out_done = to + p->off_done; io.out_trunc = to + p->off_trunc;
+            io.out_tail = (float*)(to + p->off_tail);
+        }
+        if (int rc = qs_norm_step_io(p->norm, &io, p->norm_training, p->norm_obs, p->norm_rew)) return rc;
+    }
+    if (via_device && !(p->norm && p->zero_copy)) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
 int qs_host_step_begin(qs_handle* h, const float* actions_host) {
     if (!h || !actions_host) QS_FAIL(-1, "null argument");
     QS_ON_DEVICE(h);
@@ -1031,23 +1056,13 @@ int qs_host_step_begin(qs_handle* h, const float* actions_host) {
     h->tail.rows = (float*)(blk + p->off_tail); h->tail.cap = p->cap; h->tail.parity = parity;
     if (int rc = launch_step(h, act, (float*)blk, (float*)(blk + p->off_rew), blk + p->off_done, blk + p->off_trunc)) { memset(&h->tail, 0, sizeof(h->tail)); return rc; }
     p->cur = cur; p->parity = parity;
-    if (p->norm) {
-        if (int rc = qs_norm_set_stream(p->norm, (void*)h->stream)) return rc;
-        qs_norm_io io;
-        memset(&io, 0, sizeof(io));
-        io.obs = (float*)blk; io.rew = (float*)(blk + p->off_rew); io.done = blk + p->off_done; io.trunc = blk + p->off_trunc;
-        io.tail_rows = (float*)(blk + p->off_tail); io.tail_cap = p->cap; io.raw_obs = p->raw_obs; io.raw_rew = p->raw_rew;
-        if (p->zero_copy) {     // the normalising kernel writes the host block itself
-            uint8_t* to = p->hd_block[p->cur];
-            io.out_obs = (float*)to; io.out_rew = (float*)(to + p->off_rew); io.out_done = to + p->off_done; io.out_trunc = to + p->off_trunc;
-            io.out_tail = (float*)(to + p->off_tail);
-        }
-        if (int rc = qs_norm_step_io(p->norm, &io, p->norm_training, p->norm_obs, p->norm_rew)) return rc;
-    }
-    if (via_device && !(p->norm && p->zero_copy)) QS_HIP(hipMemcpyAsync(p->h_block[p->cur], p->d_block, p->bytes, hipMemcpyDeviceToHost, h->stream));
-    QS_HIP(hipEventRecord(p->ev, h->stream));
-    p->pending = 1;
-    return 0;
+    // From here on the simulation HAS advanced one step.  Whatever fails behind the launch -- the normalisation, the copy -- must not leave the
+    // handle looking as if no step were under way (round 4 returned with pending = 0: the step's results could not be collected and
+    // qs_host_step_end said "without begin"): the step stays pending, the failure is reported here AND by the qs_host_step_end that collects it.
+    const int late = host_step_after_launch(h, p, blk, via_device);
+    hipEventRecord(p->ev, h->stream);
+    p->pending = 1; p->late_rc = late;
+    return late;
 }
 
 int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew) {
@@ -1072,6 +1087,11 @@ int qs_host_step_end(qs_handle* h, qs_host_result* out) {
     // core that spins -- not kept)
     QS_HIP(hipEventSynchronize(p->ev));
     p->pending = 0;
+    if (p->late_rc) {
+        const int rc = p->late_rc;
+        p->late_rc = 0;
+        QS_FAIL(rc, "qs_host_step_end: the step ran, but what qs_host_step_begin enqueued behind it (normalisation / copy) had failed with %d: the host block does not hold its results", rc);
+    }
     const uint8_t* b = p->h_block[p->cur];
     out->obs = (const float*)b; out->rew = (const float*)(b + p->off_rew); out->done = b + p->off_done; out->truncated = b + p->off_trunc;
     out->terminal_rows = (const float*)(b + p->off_tail); out->terminal_cap = p->cap;

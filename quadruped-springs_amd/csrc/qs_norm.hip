@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void k_norm_finish(qs_norm_io io, double* __re
     // the host path's compact list of terminal observations [tail_cap][1 + o] (environment index, observation): the last block's share
     if (io.tail_rows && blockIdx.x == gridDim.x - 1) {
         float* const tail_to = io.out_tail ? io.out_tail : io.tail_rows;
-        for (int e = threadIdx.x; e < io.tail_cap * (o + 1); e += 256) {
+        // only the rows THIS step filled (io.tail_count; round 4 normalised all tail_cap rows, stale ones of earlier steps again and again)
+        int filled = io.tail_cap;
+        if (io.tail_count) { const unsigned long long c = *io.tail_count; filled = c < (unsigned long long)io.tail_cap ? (int)c : io.tail_cap; }
+        for (int e = threadIdx.x; e < filled * (o + 1); e += 256) {
             const int r = e / (o + 1), c = e - r * (o + 1) - 1;
             const float x = io.tail_rows[e];
             if (c >= 0 && norm_obs) tail_to[e] = (float)fmin(fmax(((double)x - s_mean[c]) * s_inv[c], -clip_obs), clip_obs);

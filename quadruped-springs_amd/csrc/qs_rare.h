@@ -317,7 +317,7 @@ template <bool CONE> struct RareSolver<LaneEmu, CONE> {
             lam[p] = 0.0f;
         }
         for (int L = 0; L < 4; L++) if (live[P::NRM0 + 3 * L]) lam[P::NRM0 + 3 * L] = warm.v[L];
-        static float A[P::N][P::N];   // A[j][p] x (-1 / A_pp), self entries zero
+        float A[P::N][P::N];          // A[j][p] x (-1 / A_pp), self entries zero (11.6 KB on the stack: the emulation must be re-entrant -- threaded tests)
         for (int p = 0; p < P::N; p++)
             for (int j = 0; j < P::N; j++) {
                 float t = 0.0f;

@@ -123,7 +123,7 @@ class QsConfig(C.Structure):
         ("spring_k", C.c_float * 3), ("spring_b", C.c_float * 3), ("spring_rest", C.c_float * 3),
         ("fallen_height", C.c_float), ("leg_len", C.c_float * 3),
         ("contact_erp", C.c_float), ("joint_erp", C.c_float), ("warmstart", C.c_float), ("vel_cap", C.c_float),
-        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("contact_slop", C.c_float), ("body_contacts", C.c_int32), ("self_collision", C.c_int32), ("info_fields", C.c_int32), ("payload_soft", C.c_int32), ("reserved_f", C.c_float * 3),
+        ("obs_noise_std", C.c_float * MAX_OBS), ("task_p", C.c_float * 16), ("contact_slop", C.c_float), ("body_contacts", C.c_int32), ("self_collision", C.c_int32), ("info_fields", C.c_int32), ("payload_soft", C.c_int32), ("support_margin", C.c_float), ("reserved_f", C.c_float * 2),
         ("cpg_phi", C.c_float * 16), ("cpg_lo", C.c_float * 5), ("cpg_hi", C.c_float * 5),
         ("cpg_clearance", C.c_float), ("cpg_penetration", C.c_float), ("cpg_coupling", C.c_float), ("cpg_alpha", C.c_float),
         ("solver_residual_threshold", C.c_float), ("friction_cone", C.c_int32),
@@ -287,6 +287,7 @@ def build_config(
     warmstart=0.1,
     friction_model="cone",
     body_contacts="auto",
+    support_margin=0.5,
     self_collision=True,
     mass_inertia_rule="collision_shape",
     info_fields=True,
@@ -408,6 +409,11 @@ def build_config(
     if body_contacts == "auto":
         body_contacts = task_env == "NO_TASK"
     cfg.body_contacts, cfg.self_collision = int(bool(body_contacts)), int(bool(self_collision))
+    # m/s: a support point's rows are built once its normal row comes this close to acting (include/qs_amd.h); inf = every point in range
+    # gets its rows, Bullet's (and the oracle's) row set
+    if not float(support_margin) >= 0.0:
+        raise ValueError(f"support_margin must be >= 0 (m/s) or inf, got {support_margin!r}")
+    cfg.support_margin = min(float(support_margin), 3.0e38)
     # changeDynamics(mass=...) is only ever called by the mass randomizer (env_randomizer.py:56-83 -> quadruped.py:761, 776), at every
     # reset and for every randomised link, also when the drawn mass equals the URDF's: without it the URDF tensors stay
     rule = mass_inertia_rule if (rand & RAND_MASSES) else "scale"

@@ -9,10 +9,12 @@ from .config import QsConfig
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QS_LIB_PATH") or os.path.join(_HERE, "libqs_hip.so")   # QS_LIB_PATH: kernel experiments (another build of the same ABI)
 
+ABI_VERSION = 5   # QS_ABI_VERSION of include/qs_amd.h this file was written against
+
 EXPORTS = (
     "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_reset_to", "qs_get_obs", "qs_step", "qs_step_fused", "qs_get_state", "qs_set_state",
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
-    "qs_settle_lanes", "qs_host_step_begin", "qs_host_step_end", "qs_set_trace", "qs_counter", "qs_counters_async", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version",
+    "qs_settle_lanes", "qs_host_step_begin", "qs_host_step_end", "qs_set_trace", "qs_counter", "qs_counters_async", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version", "qs_abi_version",
     "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
     "qs_norm_step_io", "qs_host_set_norm",
 )
@@ -30,7 +32,7 @@ class NormIO(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("trunc", C.c_void_p), ("term_obs", C.c_void_p), ("tail_rows", C.c_void_p),
                 ("tail_cap", C.c_int32),
                 ("out_obs", C.c_void_p), ("out_rew", C.c_void_p), ("out_done", C.c_void_p), ("out_trunc", C.c_void_p), ("out_tail", C.c_void_p),
-                ("raw_obs", C.c_void_p), ("raw_rew", C.c_void_p)]
+                ("raw_obs", C.c_void_p), ("raw_rew", C.c_void_p), ("tail_count", C.c_void_p)]
 
 
 _lib = None
@@ -88,6 +90,11 @@ def load():
     lib.qs_host_set_norm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.qs_last_error.restype = C.c_char_p
     lib.qs_version.restype = C.c_char_p
+    # (QS_ALLOW_ABI_MISMATCH=1: the A/B tools that time an older round's library through QS_LIB_PATH on entry points that did not change)
+    if os.environ.get("QS_ALLOW_ABI_MISMATCH") != "1" and (not hasattr(lib, "qs_abi_version") or lib.qs_abi_version() != ABI_VERSION):
+        have = lib.qs_abi_version() if hasattr(lib, "qs_abi_version") else "none (a library of round 4 or earlier)"
+        raise RuntimeError(f"{LIB_PATH} speaks ABI {have}, this binding was written against ABI {ABI_VERSION} of include/qs_amd.h: rebuild it "
+                           "(python quadruped-springs_amd/build.py --force)")
     _lib = lib
     return lib
 

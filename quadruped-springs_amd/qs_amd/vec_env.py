@@ -289,7 +289,12 @@ class QuadrupedVecEnv(SB3VecEnv):
         if a.size != self.num_envs * self.action_dim:
             raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {a.shape}")
         self._stream()
-        _lib.check(self.lib.qs_host_step_begin(self.h, a.ctypes.data_as(C.c_void_p)))
+        rc = self.lib.qs_host_step_begin(self.h, a.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            msg = self.lib.qs_last_error().decode()
+            # a failure BEHIND the step's launch leaves the step pending (include/qs_amd.h): close it, so that the next step_async starts clean
+            self.lib.qs_host_step_end(self.h, C.byref(_lib.HostResult()))
+            raise RuntimeError("qs_amd: " + msg)
 
     def _host_views(self, res):
         """numpy views of the result block qs_host_step_end points at (one set per host block: two alternate)."""

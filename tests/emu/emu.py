@@ -8,8 +8,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "libqs_emu.so")
-_SRC = [os.path.join(_HERE, "qs_emu.cpp")] + [os.path.join(_REPO, "quadruped-springs_amd", "csrc", f)
-                                             for f in ("qs_env.h", "qs_core.h", "qs_lane.h", "qs_layout.h")] + \
+import glob
+# every header under csrc/ counts (round 4's hand-kept list lacked qs_rare.h: an edit of the many-rows solver left a stale emulation behind)
+_SRC = [os.path.join(_HERE, "qs_emu.cpp")] + sorted(glob.glob(os.path.join(_REPO, "quadruped-springs_amd", "csrc", "*.h"))) + \
        [os.path.join(_REPO, "include", "qs_amd.h")]
 
 

@@ -137,3 +137,47 @@ def test_bench_multi_rank_code_on_two_gloo_ranks():
     # without a stand-in the mode refuses: the step has no CPU path
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--backend", "gloo", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0 and "no CPU path" in out.stderr
+
+
+def test_counters_of_another_binary_are_not_reported(tmp_path):
+    """bench.py copies roofline.traffic / valu_issue from a committed counter pass (rocprofv3 cannot run inside the benchmark).  It may do
+    so only when the pass was taken on the source tree the running library was built from: a mismatching fingerprint, a profile without
+    one, another configuration or an overridden library yield traffic = null and the reason."""
+    sys.path.insert(0, REPO)
+    import bench
+    key = ("jump_in_place_8192", 8192, 16, "cone", 1e-7, "auto")
+    base = {"kernel": "k_step<true, false>", "workload": key[0], "envs_per_gpu": key[1], "reset_lookahead": key[2], "friction_model": key[3],
+            "solver_residual_threshold": key[4], "fetch_size_kb": 4000.0, "write_size_kb": 7000.0, "fetch_correction": 2.0, "sq_insts_valu": 2e7}
+    (tmp_path / "r04_f_pmc.json").write_text(json.dumps(base))                                         # round 4's files: no fingerprint
+    p, f, why = bench.pmc_for_run(str(tmp_path), key, "a" * 64)
+    assert p is None and f is None and "no source fingerprint" in why
+    (tmp_path / "r05_a_pmc.json").write_text(json.dumps(dict(base, source_sha256="b" * 64, body_contacts="auto")))
+    p, f, why = bench.pmc_for_run(str(tmp_path), key, "a" * 64)
+    assert p is None and "another source tree" in why
+    p, f, why = bench.pmc_for_run(str(tmp_path), key, "b" * 64)
+    assert p is not None and f.endswith("r05_a_pmc.json") and why is None
+    p, f, why = bench.pmc_for_run(str(tmp_path), key, None, "QS_LIB_PATH names another library than the tree's")
+    assert p is None and "QS_LIB_PATH" in why
+    p, f, why = bench.pmc_for_run(str(tmp_path), key[:5] + ("true",), "b" * 64)                       # the other contact setting: another configuration
+    assert p is None and "no committed counter pass" in why
+    # the fingerprint itself: stable, and sensitive to the build's environment switches
+    b = bench._build_module()
+    fp = b.source_fingerprint()
+    assert fp == b.source_fingerprint() and len(fp) == 64
+    old = os.environ.get("QS_HIPCC_EXTRA")
+    os.environ["QS_HIPCC_EXTRA"] = "-DQS_PROBE_SWEEPS"
+    try:
+        assert b.source_fingerprint() != fp
+    finally:
+        if old is None:
+            del os.environ["QS_HIPCC_EXTRA"]
+        else:
+            os.environ["QS_HIPCC_EXTRA"] = old
+    # bench.py's own verdict on this checkout: either a fingerprint or the reason there is none
+    fp2, why2 = bench.running_fingerprint()
+    assert (fp2 is None) != (why2 is None)
+
+
+def test_headline_command_refuses_a_short_preroll():
+    r = run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--preroll", "100"])
+    assert r.returncode != 0 and "two episode lengths" in r.stderr

@@ -684,16 +684,24 @@ def test_vec_normalize_kernels_against_torch_float64(torch_cuda, n):
         tail = torch.randn((cap, o + 1), generator=g, device="cuda") * 5
         a = [obs.clone(), rew.clone(), term.clone(), tail.clone(), torch.zeros_like(obs), torch.zeros_like(rew)]
         v = lambda t: t.data_ptr()
+        filled = cap                                   # rows of the list this "step" filled (qs_norm_io::tail_count; NULL = all)
+        if step % 3 == 2:
+            filled = int(torch.randint(0, cap + 5, (1,), generator=torch.Generator().manual_seed(step)).item())
+            cnt_dev = torch.tensor([filled], dtype=torch.int64, device="cuda")
+        tail_count = v(cnt_dev) if step % 3 == 2 else None
+        filled = min(filled, cap)
         if step % 2 == 0:     # in place
-            io = L.NormIO(obs=v(a[0]), rew=v(a[1]), done=v(done), term_obs=v(a[2]), tail_rows=v(a[3]), tail_cap=cap, raw_obs=v(a[4]), raw_rew=v(a[5]))
+            io = L.NormIO(obs=v(a[0]), rew=v(a[1]), done=v(done), term_obs=v(a[2]), tail_rows=v(a[3]), tail_cap=cap, raw_obs=v(a[4]), raw_rew=v(a[5]), tail_count=tail_count)
             L.check(lib.qs_norm_step_io(h, C.byref(io), training, 1, 1))
         else:                 # into other arrays (the host path's mapped block), the flags and the list copied along; the inputs stay raw
             trunc = (torch.rand(n, generator=g, device="cuda") < 0.5).to(torch.uint8)
             out = [torch.zeros_like(obs), torch.zeros_like(rew), torch.zeros_like(done), torch.zeros_like(trunc), torch.zeros_like(tail)]
             io = L.NormIO(obs=v(a[0]), rew=v(a[1]), done=v(done), trunc=v(trunc), term_obs=v(a[2]), tail_rows=v(a[3]), tail_cap=cap, raw_obs=v(a[4]), raw_rew=v(a[5]),
-                          out_obs=v(out[0]), out_rew=v(out[1]), out_done=v(out[2]), out_trunc=v(out[3]), out_tail=v(out[4]))
+                          out_obs=v(out[0]), out_rew=v(out[1]), out_done=v(out[2]), out_trunc=v(out[3]), out_tail=v(out[4]), tail_count=tail_count)
             L.check(lib.qs_norm_step_io(h, C.byref(io), training, 1, 1))
             assert torch.equal(a[0], obs) and torch.equal(a[1], rew) and torch.equal(a[3], tail) and torch.equal(out[2], done) and torch.equal(out[3], trunc)
+            assert torch.equal(out[4][filled:], torch.zeros_like(tail)[filled:])      # rows beyond the step's count are not written
+            out[4][filled:] = tail[filled:]
             a[0], a[1], a[3] = out[0], out[1], out[4]
         if training:                                   # vec_normalize.py step_wait: the statistics and the returns move only in training
             obs_rms.update(obs)
@@ -702,7 +710,8 @@ def test_vec_normalize_kernels_against_torch_float64(torch_cuda, n):
         r_ref = torch.clamp(rew.to(f64) / torch.sqrt(ret_rms.var + eps), -clip, clip).to(torch.float32)
         torch.testing.assert_close(a[0], norm(obs), atol=2e-6, rtol=2e-6)
         torch.testing.assert_close(a[2], norm(term), atol=2e-6, rtol=2e-6)
-        torch.testing.assert_close(a[3][:, 1:], norm(tail[:, 1:]), atol=2e-6, rtol=2e-6)
+        torch.testing.assert_close(a[3][:filled, 1:], norm(tail[:filled, 1:]), atol=2e-6, rtol=2e-6)
+        assert torch.equal(a[3][filled:], tail[filled:])                                 # stale rows of earlier steps are left alone
         torch.testing.assert_close(a[1], r_ref, atol=2e-6, rtol=2e-6)
         assert torch.equal(a[4], obs) and torch.equal(a[5], rew) and torch.equal(a[3][:, 0], tail[:, 0])   # raw copies; the list's index column
         returns = torch.where(done.bool(), torch.zeros_like(returns), returns)

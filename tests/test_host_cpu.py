@@ -176,3 +176,40 @@ def test_robot_view_getters_follow_the_reference_formulas():
     np.testing.assert_allclose(r.get_offset_mass_position(), R @ params[21:24], atol=1e-12)
     env._enable_springs = False
     assert not r.get_spring_real_stiffness_and_damping()[0].any()
+
+
+def _load_build_module():
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("qs_build_under_test", os.path.join(repo, "quadruped-springs_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, repo
+
+
+def test_touching_any_source_makes_the_build_recompile(tmp_path):
+    """build.py decides by modification times whether libqs_hip.so is current.  Round 4 kept the list of sources by hand and qs_rare.h was
+    not on it: every file under csrc/, every public header and every quoted #include of the .hip files must count."""
+    b, repo = _load_build_module()
+    deps = b.deps()
+    csrc = os.path.join(repo, "quadruped-springs_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert os.path.join(csrc, f) in deps, f
+    for f in os.listdir(os.path.join(repo, "include")):
+        assert os.path.join(repo, "include", f) in deps, f
+    names = {os.path.basename(d) for d in deps}
+    for d in deps:
+        if d.endswith((".hip", ".h")):
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(d).read(), re.M):
+                assert os.path.basename(inc) in names, (d, inc)
+    out = tmp_path / "lib.so"
+    out.write_bytes(b"x")
+    newest = max(os.path.getmtime(d) for d in deps)
+    os.utime(out, (newest + 1, newest + 1))
+    assert not b.needs_build(str(out))
+    for d in deps:                      # a library older than ANY one of them is stale
+        t = os.path.getmtime(d) - 1
+        os.utime(out, (t, t))
+        assert b.needs_build(str(out)), d
+    assert b.needs_build(str(tmp_path / "missing.so"))
+    assert len(b.fingerprint(str(out))) == 64

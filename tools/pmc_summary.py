@@ -69,11 +69,16 @@ if meta:
     print(f"\n{kernel}: grid {meta['Grid_Size']}, workgroup {meta['Workgroup_Size']}, LDS {meta['LDS_Block_Size']} B, scratch {meta['Scratch_Size']} B/lane, "
           f"VGPR {meta['VGPR_Count']}, AGPR {meta['Accum_VGPR_Count']}, SGPR {meta['SGPR_Count']}")
 if out_json and avg:
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("qs_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quadruped-springs_amd", "build.py"))
+    build = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(build)
     b = json.load(open(bench_json))
     c = b["config"]
     j = {"kernel": names.most_common(1)[0][0], "workload": c["workload"], "envs_per_gpu": c["envs_per_gpu"],
          "reset_lookahead": c["reset_lookahead"],
          "friction_model": c["friction_model"], "solver_residual_threshold": c["solver_residual_threshold"],
+         "body_contacts": "true" if c.get("body_contacts") is True else str(c.get("body_contacts", "auto")).lower(),
+         "source_sha256": build.source_fingerprint(), "library_sha256": build.fingerprint(os.environ.get("QS_LIB_PATH") or None),
          "fetch_size_kb": avg["FETCH_SIZE"][0], "write_size_kb": avg["WRITE_SIZE"][0], "fetch_correction": 2.0,
          "sq_insts_valu": avg.get("SQ_INSTS_VALU", (None, 0))[0], "sq_waves": avg.get("SQ_WAVES", (None, 0))[0],
          "launches": avg["FETCH_SIZE"][1], "bench_value": b["value"], "bench_kernel_ms": b["roofline"]["kernel_ms"], "rocprof_kernel_us_timed_region": trace_avg_us,

@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1000 --warmup 50 --no-cpu-baseline --no-info-line $*"
+ARGS="--steps ${QS_PROF_LAST:-1000} --warmup 50 --no-cpu-baseline --no-info-line --no-body-contacts-line $*"
 python3 $REPO/bench.py $ARGS 2> "$OUT/bench.err" | tail -1 > "$OUT/bench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
 i=0
@@ -19,8 +19,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BU
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python3 $REPO/bench.py $ARGS > "$OUT/pmc$i.log" 2>&1
 done
 cd "$REPO"
-python3 tools/pmc_summary.py "$OUT" k_step "$OUT/bench.json" "$OUT/pmc.json" --last 1000 > "$OUT/summary.md" 2>&1
-{ echo; echo "(rocprofv3's VGPR / AGPR / scratch columns above come from its dispatch records: it reports the architected VGPR half only.  The code object itself -- tools/kernel_resources.py on the library that ran:)"; echo '```'; python3 tools/kernel_resources.py k_step; echo '```'; } >> "$OUT/summary.md" 2>&1
+python3 tools/pmc_summary.py "$OUT" ${QS_PROF_KERNEL:-k_step} "$OUT/bench.json" "$OUT/pmc.json" --last ${QS_PROF_LAST:-1000} > "$OUT/summary.md" 2>&1
+{ echo; echo "(rocprofv3's VGPR / AGPR / scratch columns above come from its dispatch records: it reports the architected VGPR half only.  The code object itself -- tools/kernel_resources.py on the library that ran:)"; echo '```'; python3 tools/kernel_resources.py ${QS_PROF_KERNEL:-k_step}; echo '```'; } >> "$OUT/summary.md" 2>&1
 cp $(find "$OUT/trace" -name "*_kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
 rm -rf "$OUT/trace" "$OUT"/pmc[0-9] "$OUT"/*.log
 du -sh "$OUT"; cat "$OUT/summary.md"; cut -c1-300 "$OUT/bench.json"

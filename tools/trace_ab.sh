@@ -2,7 +2,7 @@
 # kernel-trace average of the timed region's launches for two libraries on one box
 REPO=$(pwd); OUT=$REPO/gpurun_out/r04q; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for name in r03 new; do
-  if [ $name = r03 ]; then export QS_LIB_PATH=$REPO/quadruped-springs_amd/qs_amd/exp/r03.so; else unset QS_LIB_PATH; fi
+  if [ $name = r03 ]; then export QS_LIB_PATH=$REPO/tools/bin/r03.so; else unset QS_LIB_PATH; fi
   rm -rf $OUT/tr_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$name -- python3 $REPO/bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-info-line > $OUT/tr_$name.log 2>&1
   tail -1 $OUT/tr_$name.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name live under profiler: value', d['value'], 'kernel_ms', d['roofline']['kernel_ms'])"
