@@ -165,6 +165,10 @@ class Oracle:
     def set_gravity(self, g):
         self.lib.qso_phys_set_gravity(self.h, self._creal(g))
 
+    def set_manifold(self, mode):
+        """0: two support points per leg (default, what the kernels build); 1: up to four points per collision primitive (experiment)."""
+        self._check(self.lib.qso_phys_set_manifold(self.h, int(mode)))
+
     def crba_rnea(self, env):
         H = np.zeros((18, 18), self.real)
         Cb = np.zeros(18, self.real)

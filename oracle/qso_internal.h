@@ -58,6 +58,8 @@ typedef struct {
        link -1 base / plane, 0 trunk, 2/6/10/14 hips, 3/7/11/15 thighs, 4/8/12/16 calves, 5/9/13/17 feet) */
     struct { int body_a, body_b, link_a, link_b; real dist, force; } contacts[QSO_MAX_CONTACTS];
     int n_contacts;
+    int manifold_mode;   /* qso_phys_set_manifold: 0 = up to two support points per leg (what the kernels build); 1 = experiment: up to four
+                          * points per collision primitive, as Bullet's persistent manifolds can hold */
     real warm[4];
     /* payload block as its own body (cfg->payload_soft): position of its centre, orientation, velocities (world); constraint impulses of
        the last substep and the distance between the two pivots */

@@ -442,10 +442,12 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
     }
 
     /* ---- constraint rows ---- */
-    row rows[24 + 12 + 24]; int nlim = 0, nn = 0, nf = 0;
-    row* lim = rows; row* nor = rows + 24; row* fr = rows + 36;
-    int nor_foot[12];    /* foot index of a normal row, -1 for the other links' support points */
-    int nor_contact[12]; /* contact-list entry that receives the row's force */
+    /* (capacity: mode 0 has at most 4 feet + 8 support points; the four-points-per-primitive experiment 4 + 4 (trunk) + 4 x (2 + 4 + 4)) */
+    enum { MAXN = 48 };
+    static _Thread_local row rows[24 + MAXN + 2 * MAXN]; int nlim = 0, nn = 0, nf = 0;
+    row* lim = rows; row* nor = rows + 24; row* fr = rows + 24 + MAXN;
+    int nor_foot[MAXN];    /* foot index of a normal row, -1 for the other links' support points */
+    int nor_contact[MAXN]; /* contact-list entry that receives the row's force */
     e->n_contacts = 0;
     /* joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint) */
     for (int j = 0; j < NJ; j++) {
@@ -525,6 +527,53 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             nn++; nf += 2;
         }
         if (!cfg->body_contacts) continue;
+        if (e->manifold_mode == 1) {
+            /* experiment: up to four points per primitive -- the vertices (for the hip cylinder: the lowest point of each end's rim) inside the
+               primitive's contact range, lowest first */
+            for (int prim = (L == 0 ? 0 : 1); prim < 4; prim++) {
+                real pts[8][3]; int np = 0, body, link; real thr;
+                if (prim == 0) {   /* trunk box (once) */
+                    body = 0; link = 0; thr = THR_TRUNK;
+                    for (int a = 0; a < 8; a++) {
+                        real pb[3] = {(a & 1 ? 1 : -1) * TRUNK_HALF[0], (a & 2 ? 1 : -1) * TRUNK_HALF[1], (a & 4 ? 1 : -1) * TRUNK_HALF[2]}, pw[3];
+                        m3v(C.R0, pb, pw);
+                        for (int k = 0; k < 3; k++) pts[np][k] = s->pos[k] + pw[k];
+                        np++;
+                    }
+                } else if (prim == 1) {   /* hip cylinder: both ends */
+                    body = ih; link = 2 + 4 * L; thr = THR_HIP;
+                    real a[3] = {C.Rw[ih][0][1], C.Rw[ih][1][1], C.Rw[ih][2][1]};
+                    real az = a[2], s2 = 1 - az * az; if (s2 < (real)1e-12) s2 = (real)1e-12;
+                    real inv = HIP_CYL_R / sqrt(s2);
+                    for (int end = -1; end <= 1; end += 2) {
+                        for (int k = 0; k < 3; k++) pts[np][k] = C.ow[ih][k] + end * HIP_CYL_H * a[k] - ((k == 2 ? 1 : 0) - az * a[k]) * inv;
+                        np++;
+                    }
+                } else {   /* thigh / calf box */
+                    int b = prim == 2 ? it : ic;
+                    const real* half = prim == 2 ? THIGH_HALF : CALF_HALF;
+                    body = b; link = (prim == 2 ? 3 : 4) + 4 * L; thr = prim == 2 ? THR_THIGH : THR_CALF;
+                    for (int a = 0; a < 8; a++) {
+                        real pl[3] = {LINK_BOX_C[0] + (a & 1 ? 1 : -1) * half[0], LINK_BOX_C[1] + (a & 2 ? 1 : -1) * half[1], LINK_BOX_C[2] + (a & 4 ? 1 : -1) * half[2]}, pw[3];
+                        if (prim == 3 && (a & 4) == 0) continue;   /* the calf box's foot end belongs to the foot sphere, as in mode 0 */
+                        m3v(C.Rw[b], pl, pw);
+                        for (int k = 0; k < 3; k++) pts[np][k] = C.ow[b][k] + pw[k];
+                        np++;
+                    }
+                }
+                int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int slot = 0; slot < 4 && nn < MAXN; slot++) {
+                    int bi = -1;
+                    for (int i = 0; i < np; i++) if (!used[i] && pts[i][2] < thr && (bi < 0 || pts[i][2] < pts[bi][2])) bi = i;
+                    if (bi < 0) break;
+                    used[bi] = 1;
+                    contact_rows(cfg, M, &C, s, v, e->mu, body, pts[bi], pts[bi][2], 0, &nor[nn], &fr[nf], &fr[nf + 1], nn);
+                    nor_foot[nn] = -1; nor_contact[nn] = -1 - link;
+                    nn++; nf += 2;
+                }
+            }
+            continue;
+        }
         real fx = (L < 2) ? 1 : -1, sy = (L & 1) ? 1 : -1;
         real cand[5][3], ch[5]; int cbody[5] = {0, ih, it, it, ic}, clink[5] = {0, 2 + 4 * L, 3 + 4 * L, 3 + 4 * L, 4 + 4 * L};
         real cthr[5] = {THR_TRUNK, THR_HIP, THR_THIGH, THR_THIGH, THR_CALF};
@@ -733,6 +782,11 @@ int qso_phys_step(qso_handle* h, int env, const real* tau) {
     return 0;
 }
 int qso_phys_set_gravity(qso_handle* h, real g) { h->gravity = g; return 0; }
+int qso_phys_set_manifold(qso_handle* h, int mode) {
+    if (mode != 0 && mode != 1) return -1;
+    for (int i = 0; i < h->cfg.n_envs; i++) h->env[i].manifold_mode = mode;
+    return 0;
+}
 int qso_get_block(qso_handle* h, real* out /*[N,20]: pos3 quat4 v3 w3 lam6 gap*/) {
     for (int i = 0; i < h->cfg.n_envs; i++) {
         const qso_env* e = &h->env[i]; real* o = out + 20 * i;

@@ -1249,6 +1249,9 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                 for (int i = 0; i < 3; i++) { e_.jq[i] = zero; e_.u[i] = zero; }
             }
             M extra_live = qlt(one, zero);
+#if defined(QS_PROBE_WARM) && defined(__HIP_DEVICE_COMPILE__)
+            M probe_live[2] = {qlt(one, zero), qlt(one, zero)};
+#endif
 #if defined(QS_PROBE_LAZY) && defined(__HIP_DEVICE_COMPILE__)
             M probe_rule[2][4];
 #pragma unroll
@@ -1316,6 +1319,9 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                     live = qlt(best, V(1e8f));
 #endif
                     extra_live = qor(extra_live, live);
+#if defined(QS_PROBE_WARM) && defined(__HIP_DEVICE_COMPILE__)
+                    probe_live[slot] = live;
+#endif
                     if (!T::any(live)) continue;               // nobody's point in this slot can act: no rows
                     V act_x = qflag(live);
                     QS_CONTACT_ROW_AT(xr[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
@@ -1324,6 +1330,28 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                 }
             }
             rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, extra_live))), V(0.5f));
+#if defined(QS_PROBE_WARM) && defined(__HIP_DEVICE_COMPILE__)
+            {   // counting build (tools/probe_warm.py): what the environments that reach the many-rows solve look like.  [0] environment-substeps
+                // with rows of their own, [1] of them with a joint at its stop, [2] no stop but a leg with two live support points, [3..5] no stop,
+                // at most one point per leg: 1 / 2 / 3+ points in all; [6] wave-substeps in the full build, [7] of them with a many-rows solve,
+                // [8] of them in which every environment with rows of its own is "simple" (no stop, one point per leg at most)
+                unsigned long long* pc = reinterpret_cast<const QsDevCfg&>(cfg).counters + 2;
+                const float pts_leg = qflag(probe_live[0]) + qflag(probe_live[1]);
+                const float pts = T::quad_sum(pts_leg), two = T::quad_sum(pts_leg > 1.5f ? 1.0f : 0.0f);
+                const bool mine = rare_mine, lim = lim_env;
+                const bool simple = mine && !lim && two < 0.5f;
+                const unsigned long long b0 = __ballot(mine), b1 = __ballot(mine && lim), b2 = __ballot(mine && !lim && two > 0.5f),
+                                         b3 = __ballot(simple && pts < 1.5f), b4 = __ballot(simple && pts > 1.5f && pts < 2.5f), b5 = __ballot(simple && pts > 2.5f);
+                if (threadIdx.x == 0) {
+                    atomicAdd(&pc[0], (unsigned long long)(__popcll(b0) / 4)); atomicAdd(&pc[1], (unsigned long long)(__popcll(b1) / 4));
+                    atomicAdd(&pc[2], (unsigned long long)(__popcll(b2) / 4)); atomicAdd(&pc[3], (unsigned long long)(__popcll(b3) / 4));
+                    atomicAdd(&pc[4], (unsigned long long)(__popcll(b4) / 4)); atomicAdd(&pc[5], (unsigned long long)(__popcll(b5) / 4));
+                    atomicAdd(&pc[6], 1ull);
+                    if (b0) atomicAdd(&pc[7], 1ull);
+                    if (b0 && b0 == (b3 | b4 | b5)) atomicAdd(&pc[8], 1ull);
+                }
+            }
+#endif
             if (T::any(rare_mine)) {
                 T::count_rare_path(cfg);
                 if (T::any(any_lim)) { QS_LIMIT_ROWS(xr + 9) }

@@ -169,7 +169,7 @@ struct DemoTab { const float* rows; int length; };   // qs_set_demo: the demonst
 struct TermTail { float* rows; int cap, parity; };
 enum { CTL_SETTLE_SUBSTEPS = 0, CTL_RESETS = 1, CTL_SERVED = 2, CTL_SETTLED = 3, CTL_BACKLOG = 4, CTL_STALLS = 6,
        CTL_R = 8 /* one per cohort */, CTL_TERM_CNT = 8 + QS_COHORTS /* two */, CTL_DEV = 10 + QS_COHORTS /* QS_DEVCTR_*: the rare paths' telemetry */,
-#if defined(QS_PROBE_LAZY) || defined(QS_PROBE_SWEEPS)
+#if defined(QS_PROBE_LAZY) || defined(QS_PROBE_SWEEPS) || defined(QS_PROBE_WARM)
        CTL_N = 12 + QS_COHORTS + 10 /* the counting builds' counters (qs_core.h, tools/probe_*.py) */ };
 #else
        CTL_N = 12 + QS_COHORTS };
@@ -797,7 +797,7 @@ void qs_destroy(qs_handle* h) {   // also used on a partially built handle (null
     delete h;
 }
 
-#if defined(QS_PROBE_LAZY) || defined(QS_PROBE_SWEEPS)
+#if defined(QS_PROBE_LAZY) || defined(QS_PROBE_SWEEPS) || defined(QS_PROBE_WARM)
 extern "C" int qs_probe_counters(qs_handle* h, unsigned long long* out10) {   // counting builds only (tools/probe_*.py)
     QS_ON_DEVICE(h);
     QS_HIP(hipStreamSynchronize(h->stream));

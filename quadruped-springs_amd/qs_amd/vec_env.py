@@ -56,6 +56,7 @@ class QuadrupedVecEnv(SB3VecEnv):
         d = self.cfg.action_dim
         self.action_space = Box(-np.ones(d), np.ones(d), dtype=np.float32)                                       # gym_env.py:179-182
         self.action_dim, self.obs_dim = d, self.cfg.obs_dim
+        self._init_vec_env_base()
         self.h = C.c_void_p()
         self._closed = False
         _lib.check(self.lib.qs_create(C.byref(self.cfg), device, C.byref(self.h)))
@@ -78,6 +79,13 @@ class QuadrupedVecEnv(SB3VecEnv):
                 raise ValueError(f"task {self.meta['task_env']} imitates a demonstration: pass demo=<array [L, action_dim + 38] or path of the "
                                  f".npy> (the reference loads demonstrations/{DEMO_FILES[self.meta['task_env']]}, task_base.py:173)")
             self.set_demo(self.meta["demo"])
+
+    def _init_vec_env_base(self):
+        """stable_baselines3.common.vec_env.VecEnv.__init__(num_envs, observation_space, action_space) when SB3 is importable and this
+        class therefore IS a VecEnv (qs_amd/spaces.py): SB3's wrappers (VecNormalize.load(stats, env), load_model.py:120) read what the base
+        class sets up, and isinstance(env, VecEnv) holds.  Without SB3 the base is `object` and there is nothing to call."""
+        if SB3VecEnv is not object:
+            SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
     # ---- plumbing
     def _stream(self):
@@ -376,7 +384,28 @@ class QuadrupedVecEnv(SB3VecEnv):
         return self.step_wait()
 
     def seed(self, seed=None):
-        return [None] * self.num_envs  # randomness is counter based: fixed by the `seed` keyword at construction
+        """VecEnv.seed(seed) (SB3: each sub-environment gets seed + index; load_model.py's make_vec_env(seed=...) calls it right after the
+        constructor).  Randomness here is counter based -- Philox streams keyed by (seed, global environment id, episode / step), which
+        also key the reset states settled ahead of time -- so a new seed means a new device handle: the old one is destroyed and one
+        with cfg.seed = seed created in its place.  EVERY ENVIRONMENT IS UNRESET AFTERWARDS, as after the constructor: call reset()
+        next (what SB3's own flow does).  seed=None leaves everything as it is.  Returns SB3's list: seed + i for environment i (None s
+        when nothing was changed)."""
+        if seed is None:
+            return [None] * self.num_envs
+        seed = int(seed)
+        if seed < 0:
+            raise ValueError(f"seed must be a non-negative integer, got {seed}")
+        h, self.h = self.h, C.c_void_p()
+        if h:
+            self.lib.qs_destroy(h)
+        self.cfg.seed = seed
+        self._views, self._dirty = {}, []
+        self._infos = [{} for _ in range(self.num_envs)]
+        _lib.check(self.lib.qs_create(C.byref(self.cfg), self.device.index or 0, C.byref(self.h)))
+        if self.demo_list is not None:
+            self.set_demo(self.demo_list)
+        self._trace = None
+        return [seed + i for i in range(self.num_envs)]
 
     def get_attr(self, attr_name, indices=None):
         return [getattr(self, attr_name)] * len(self._indices(indices))

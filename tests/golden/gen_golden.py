@@ -932,8 +932,8 @@ def gen_demo():
                 setattr(mod, attr, np.zeros_like(np.asarray(saved[attr], float)))
 
         def factory(dt, iters, kw=kw):
-            # physics only (the task lives in the reference's env on top); body_contacts as the DEMO tasks' own configuration has it
-            cfg, _ = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", task_env="NO_TASK", body_contacts=False, **dict(kw, time_step=dt))
+            # physics only (the task lives in the reference's env on top); every link pushes back (the default)
+            cfg, _ = build_config(n_envs=1, noise=False, env_randomizer_mode="NONE", task_env="NO_TASK", **dict(kw, time_step=dt))
             cfg.solver_iters = iters
             cfg.randomizer_flags = 8
             return Oracle(cfg)

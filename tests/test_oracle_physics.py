@@ -243,3 +243,68 @@ def test_f32_build_tracks_f64():
         b.set_state(a.get_state())
         oa, ob = a.step(act)[0], b.step(act)[0]
         np.testing.assert_allclose(oa, ob, atol=5e-3, rtol=1e-3)
+
+
+def _normal_mode_period(step, get_state, set_state, H, s0, k, mode_index, dt, n_periods=6, eps=2e-3):
+    """Excite ONE small-oscillation mode of the robot whose joints are held by torsional springs of stiffness k about the pose s0 (zero
+    gravity, floating base) and measure its period from the zero crossings of the mode's largest joint."""
+    import scipy.linalg
+    K = np.diag([0.0] * 6 + [k] * 12)
+    w2, V = scipy.linalg.eigh(K, H)                 # K v = w^2 H v ; six rigid-body modes at w = 0, twelve elastic ones
+    assert np.abs(w2[:6]).max() < 1e-6 * w2[6] and w2[6] > 0
+    w, v = np.sqrt(w2[mode_index]), V[:, mode_index]
+    v = v / np.abs(v[6:]).max()
+    s = s0.copy()
+    q0 = s0[0, 13:25].copy()
+    s[0, 10:13] = eps * w * v[0:3]                  # H's coordinates: base angular 3, base linear 3 (H[3,3] = total mass), joints 12;
+    s[0, 7:10] = eps * w * v[3:6]                   # identity orientation: base frame = world frame
+    s[0, 25:37] = eps * w * v[6:]
+    set_state(s)
+    j = int(np.abs(v[6:]).argmax())
+    n = int(np.ceil(n_periods * 2 * np.pi / w / dt)) + 5
+    x = np.zeros(n + 1)
+    for i in range(n):
+        q = get_state()[0, 13:25].astype(np.float64)
+        step(-k * (q - q0))
+        x[i + 1] = get_state()[0, 13 + j] - q0[j]
+    up = [i + x[i] / (x[i] - x[i + 1]) for i in range(1, n) if x[i] < 0 <= x[i + 1]]      # upward zero crossings, linear interpolation
+    assert len(up) >= n_periods - 1
+    T = (up[-1] - up[0]) / (len(up) - 1) * dt
+    amp = np.abs(x).max()
+    return T, w, amp, eps * np.abs(v[6 + j])
+
+
+@pytest.mark.parametrize("which", ["oracle_f64", "kernel_arithmetic_f32"])
+def test_k4_small_oscillation_periods_match_the_analytic_modes(which):
+    """K4 of SURVEY 8c ("single-leg pendulum period vs analytic small-angle").  A floating base in free fall feels no gravity, so the
+    restoring force of the known answer is a torsional spring in every joint (zero gravity, tau = -k (q - q0), no damping) instead of
+    gravity; what sets the period is the same: the inertia the legs present to their joints, here with the coupling through the floating
+    base.  Analytic answer: the generalised eigenproblem K v = w^2 H v with H the 18 x 18 mass matrix at q0 (tests/test_urdf_model.py
+    holds the oracle's H to first principles, 2e-6).  Semi-implicit Euler is symplectic: a linear mode keeps its amplitude and runs at
+    the discrete frequency sin(w_d dt / 2) = w dt / 2.  The slowest and the fastest elastic mode are excited one at a time on the oracle
+    (float64) and on the kernels' own arithmetic (host lane emulation, float32); measured period against the analytic one."""
+    o, cfg = make(springs=False)
+    o.set_gravity(0.0)
+    o.reset()
+    s0 = o.get_state()
+    s0[0, :3] = [0.0, 0.0, 1.0]
+    s0[0, 3:7] = [0, 0, 0, 1]
+    s0[0, 7:13] = 0
+    s0[0, 25:] = 0
+    o.set_state(s0)
+    H, _ = o.crba_rnea(0)
+    k, dt = 40.0, cfg.dt
+    if which == "oracle_f64":
+        step, get, put, tol = (lambda tau: o.phys_step(0, tau)), o.get_state, o.set_state, 5e-5
+    else:
+        from emu.emu import Emu
+        cfg.gravity = 0.0
+        e = Emu(cfg)
+        e.reset()
+        step, get, put, tol = (lambda tau: e.phys_step(0, tau)), e.get_state, (lambda s: e.set_state(s.astype(np.float32))), 2e-4
+    for mode in (6, 17):
+        T, w, amp, amp0 = _normal_mode_period(step, get, put, H, s0, k, mode, dt)
+        w_d = 2.0 / dt * np.arcsin(w * dt / 2.0)
+        assert abs(T - 2 * np.pi / w_d) < tol * T, (mode, T, 2 * np.pi / w_d)
+        assert abs(amp / amp0 - 1.0) < 2e-2, (mode, amp, amp0)        # one pure mode: the joint swings at the amplitude it was given
+    assert 2 * np.pi / w < 0.2                                         # (the fastest mode: tens of hertz, ~60 steps per period)

@@ -298,3 +298,108 @@ def test_contact_step_balances_impulse_and_momentum(model, seed, friction, engin
     vz = (J @ nu).reshape(4, 3)[:, 2]
     # a contact row lets a foot that is still `gap` (+ Bullet's linear slop) above the plane close exactly that distance in this step
     assert np.all(vz[touching] >= -np.maximum(gap[touching] + slop, 0) / dt - 2e-3), "a touching foot still moves into the ground"
+
+
+def _foot_gaps(model, s, r_foot=0.02):
+    from scipy.spatial.transform import Rotation
+    fr = model.link_frames(s[:3], Rotation.from_quat(s[3:7]).as_matrix(), s[13:25])
+    return np.array([fr[f"{leg}_foot"][1][2] - r_foot for leg in ("FR", "FL", "RR", "RL")])
+
+
+def _engine(name, cfg, mu=0.8):
+    """(substep(tau), get_state() -> float64 [37], set_state, foot normal forces of the last substep)"""
+    if name == "kernel":
+        from emu.emu import Emu
+        k = Emu(cfg)
+        k.set_mu(mu)
+        return (lambda tau: k.phys_step(0, tau)), (lambda: k.get_state()[0].astype(np.float64)), (lambda s: k.set_state(s[None].astype(np.float32))), \
+               (lambda: k.get("R_FOOT_FORCE", 4)[0].astype(np.float64))
+    o = Oracle(cfg)
+    o.set_params(0, np.array([[mu]]))
+    return (lambda tau: o.phys_step(0, tau)), (lambda: o.get_state()[0]), (lambda s: o.set_state(s[None])), (lambda: o.get_info(0)[0])
+
+
+@pytest.mark.parametrize("engine", ["oracle", "kernel"])
+def test_penetration_recovers_at_the_erp_rate(model, engine):
+    """Bullet's multibody contact row (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint): a penetrating contact is pushed out at
+    erp2 x penetration / dt, penetration = distance + linearSlop -- a foot 2 mm inside the ground leaves at 0.08 x 1.99 mm per substep, and the
+    penetration decays geometrically at (1 - erp) per substep while the contact pushes.  Foot heights from the URDF tables, not from the
+    engine.  (physics pins that need no PyBullet.)"""
+    cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False, solver_residual_threshold=0.0)
+    o = Oracle(cfg)
+    o.reset()
+    hold, s = o.get_info(2)[0].copy(), o.get_state()[0].copy()
+    s[7:13], s[25:] = 0.0, 0.0
+    s[2] -= _foot_gaps(model, s).min() + 2e-3                      # lowest foot 2 mm inside
+    step, get, put, _ = _engine(engine, cfg)
+    put(s)
+    erp, slop, tol = cfg.contact_erp, cfg.contact_slop, (1e-3 if engine == "oracle" else 5e-3)
+    pen = -(_foot_gaps(model, s) + slop)
+    assert np.all(pen > 1.5e-3)                                    # the settled stance is level: all four feet are inside
+    for i in range(12):
+        step(hold)
+        pen1 = -(_foot_gaps(model, get()) + slop)
+        np.testing.assert_allclose(pen1 / pen, 1.0 - erp, atol=tol, err_msg=f"substep {i}")
+        pen = pen1
+    assert np.all(pen < 2e-3 * (1 - erp) ** 12 * 1.05)
+
+
+@pytest.mark.parametrize("engine", ["oracle", "kernel"])
+def test_inelastic_touchdown_after_a_five_centimetre_drop(model, engine):
+    """The robot is released at rest with its feet 5 cm above the ground, joints limp (no torque: in free fall it then moves as one rigid
+    body), and lands at 0.99 m/s.  Known answers, all from first principles and the URDF tables: (1) until the first foot comes within the 0.727 mm contact
+    range the centre of mass falls at g; (2) the contact is INELASTIC (Bullet's default restitution 0): in the substep in which a foot
+    touches down its normal velocity goes from -1 m/s to what the row allows -- closing the remaining gap, or leaving at erp x penetration
+    / dt -- and never to a rebound; (3) in every substep the vertical momentum of the whole robot changes by the feet's normal impulses
+    minus m g dt (momentum = sum of link masses x the velocities of their centres of mass, differentiated from the URDF tables; impulses = reported foot forces x dt); (4) no foot goes
+    deeper than the distance it covers in the one substep that carries it across the contact range."""
+    from scipy.spatial.transform import Rotation
+    cfg, _ = build_config(n_envs=1, isRLGymInterface=False, motor_control_mode="TORQUE", task_env="NO_TASK", observation_space_mode="ENCODER",
+                          enable_springs=False, env_randomizer_mode="NONE", enable_action_filter=False, solver_residual_threshold=0.0)
+    o = Oracle(cfg)
+    o.reset()
+    hold, s = np.zeros(12), o.get_state()[0].copy()
+    s[7:13], s[25:] = 0.0, 0.0
+    s[2] += 0.05 - _foot_gaps(model, s).min()
+    step, get, put, forces = _engine(engine, cfg)
+    put(s)
+    dt, slop, thr, g, mass = cfg.dt, cfg.contact_slop, 7.27e-4, 9.8, 12.01301
+    tol_p = 2e-6 if engine == "oracle" else 2e-4
+
+    def pz(st, at=None, eps=1e-6):
+        """vertical momentum of the whole robot from the URDF tables: sum of m_i x (vertical velocity of link i's centre of mass), the links'
+        velocities by moving the configuration `at` (default: st's own) along st's generalized velocity"""
+        at = st if at is None else at
+        R = Rotation.from_quat(at[3:7]).as_matrix()
+        nu = np.concatenate([R.T @ st[10:13], R.T @ st[7:10], st[25:]])
+        a, b = model.bodies(*model.displaced(at[:3], R, at[13:25], nu, eps)), model.bodies(*model.displaced(at[:3], R, at[13:25], nu, -eps))
+        return sum(m * (ca[2] - cb[2]) / (2 * eps) for (m, ca, _, _), (_, cb, _, _) in zip(a, b))
+
+    touched, deepest, v_land, landed_at = False, 0.0, None, None
+    s0 = get()
+    for i in range(140):
+        gap0 = _foot_gaps(model, s0)
+        step(hold)
+        s1, f = get(), forces()
+        gap1 = _foot_gaps(model, s1)
+        vz = (gap1 - gap0) / dt                                   # feet's vertical velocity over the substep (semi-implicit Euler: the NEW velocity)
+        if not touched and not (f > 0).any():
+            assert abs((s1[9] - s0[9]) / dt + g) < 1e-3 and np.abs(s1[25:]).max() < 1e-3   # (1) still one rigid body falling at g
+        if (f > 0).any() and not touched:
+            # (3) the touchdown substep: the robot comes in as one translating rigid body (no velocity-product forces), so the velocity step
+            # M(q0) (nu1 - nu0) = dt (tau - G) + J^T p holds without further terms: the jump of the vertical momentum is the feet's impulse
+            assert abs(pz(s1, at=s0) - pz(s0) - (f.sum() * dt - mass * g * dt)) < tol_p * max(1.0, f.sum() * dt), f"substep {i}"
+            assert f.sum() * dt > 0.2                              # (limp legs: the first impulse stops the feet and shanks, 0.5 of the 11.9 kg m/s; the rest follows)
+        elif (f > 0).any() and i % 4 == 0:
+            # later substeps, legs folding: momentum at the new configuration against the impulses, to the integrator's O(dt)
+            assert abs(pz(s1) - pz(s0) - (f.sum() * dt - mass * g * dt)) < 2e-2 * max(0.05, f.sum() * dt), f"substep {i}"
+        for k in np.flatnonzero(f > 0):                           # (2) a foot that the ground pushes neither rebounds nor keeps falling
+            allowed = -(gap0[k] + slop) / dt if gap0[k] + slop > 0 else cfg.contact_erp * -(gap0[k] + slop) / dt
+            assert abs(vz[k] - allowed) < (2e-3 if engine == "oracle" else 1e-2), (i, k, vz[k], allowed)
+        if (f > 0).any() and not touched:
+            touched, landed_at, v_land = True, i, -s0[9]
+        deepest = min(deepest, gap1.min())
+        s0 = s1
+    assert touched and 0.9 < v_land < 1.1 and 95 <= landed_at <= 105   # sqrt(2 g h) = 0.99 m/s after 0.101 s
+    assert deepest > -(v_land * dt - thr) - 1e-4                       # (4) 0.3 mm: one substep's travel minus the contact range
