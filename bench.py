@@ -121,6 +121,10 @@ def parse_args(argv=None):
                     help="untimed steps before the warmup steps that bring episode ages, reset rate and the settle lanes "
                          "to their steady state (part of the preparation; 0 to skip)")
     ap.add_argument("--workload", default="jump_in_place_8192")
+    ap.add_argument("--action-ring", type=int, default=64,
+                    help="number of pre-generated U(-1,1) action batches resident in HBM; step i uses batch i mod ring.  (With 64 an environment whose "
+                         "64-step pattern throws it down does so at the same ring phase episode after episode: the fall rate is periodic in the step "
+                         "count, and a 20-step region sees a fixed stretch of that period, DESIGN.md 6)")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--total-envs", type=int, default=0, help="strong scaling: this many environments split over the ranks (SURVEY 8e: 65536)")
     ap.add_argument("--reset-lookahead", type=int, default=16,
@@ -369,7 +373,7 @@ def main():
         assert args.total_envs % (16 * world) == 0, "--total-envs must split into whole waves (16 environments) per rank"
         n = args.total_envs // world
     d_gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act = 64  # a ring of pre-generated U(-1,1) action batches, resident in HBM
+    n_act = max(1, args.action_ring)  # a ring of pre-generated U(-1,1) action batches, resident in HBM
 
     spin = os.environ.get("QS_BENCH_SPIN", "1") != "0"
 
@@ -552,7 +556,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"backend": args.backend, "workload": args.workload, "envs_per_gpu": n, "substeps_per_env_step": kw["action_repeat"],
-                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM",
+                       "solver_sweeps": int(300 / kw["action_repeat"]), "solver_residual_threshold": args.solver_residual_threshold, "friction_model": args.friction_model, "info_fields": bool(kw["info_fields"]), "extra_keywords": extra_kw, "dt": kw["time_step"], "actions": "U(-1,1), resident in HBM", "action_ring": n_act,
                        "auto_reset": True, "preroll_steps": args.preroll,
                        "body_contacts": main_bc,
                        # how the timed region is bracketed and how the preparation spreads the episode ages (both changed in round 4: lines of

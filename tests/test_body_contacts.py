@@ -349,7 +349,9 @@ def test_payload_weld_against_the_soft_fixed_constraint():
         if done.any():
             ow.reset(done.astype(np.uint8)); osf.reset(done.astype(np.uint8))
             osf.set_state(ow.get_state())
-    assert gap < 5e-4 and lam < 0.1, (gap, lam)                     # impulse bound of the constraint: 500 N x dt = 0.5 N s
+    # impulse bound of the constraint: 500 N x dt = 0.5 N s.  (Jumps load it to 7 %; since round 5 every link pushes back by default, and a
+    # crash landing on the trunk -- the last env step of an episode that ends in a fall -- loads it to 23 %: 0.115.)
+    assert gap < 5e-4 and lam < 0.15, (gap, lam)
     assert worst_pose < 5e-5 and worst_vel < 2e-2, (worst_pose, worst_vel)
 
 
@@ -479,3 +481,28 @@ def test_support_margin_rule_leaves_out_only_rows_that_end_at_zero_impulse(kw):
         impacts += int(((sa[:, 9] - v_in) > 0.3).sum())
     assert loaded > 40 and impacts >= 4, (loaded, impacts)       # links did hit the floor and stop falling inside the run
     assert off_oracle <= 3, off_oracle                             # of 320 env steps
+
+
+@pytest.mark.parametrize("roll,pitch,pose_tol", [(1.45, 0.0, 1e-5), (0.0, 0.0, 1e-5), (3.0, 0.0, 5e-3)], ids=["side", "belly", "back"])
+def test_two_support_points_per_leg_against_four_points_per_primitive(roll, pitch, pose_tol):
+    """Sensitivity of the cap (VERDICT r04 item 4; DESIGN.md 7).  Oracle and kernels let a leg's non-foot links push back at two support points;
+    a btPersistentManifold can hold four per collision primitive.  The oracle's experiment mode (qso_phys_set_manifold(1): up to four vertices
+    / rim points per primitive) against the default on a robot dropped in a folded pose and left alone for 3 s: both come to rest carried
+    by m g; on its side and on its belly the resting poses agree to micrometres, on its BACK -- where the trunk box wants its four top
+    corners and the cap hands a leg its hip and thigh first -- they differ by a millimetre and the capped robot keeps creeping at mm/s.
+    Measured, stated in DESIGN.md, not removed: the one-row-per-lane solve has lanes for 15 contact points, and which four points a
+    manifold holds depends on its contact history, which nothing here can pin."""
+    res = []
+    for mode in (0, 1):
+        o = Oracle(make(solver_residual_threshold=0.0))
+        o.reset()
+        o.set_manifold(mode)
+        o.set_state(fallen_state(o, roll, pitch, z=0.16))
+        for _ in range(3000):
+            o.phys_step(0, np.zeros(12))
+        ground = [c for c in o.contacts() if c[1] == 0]
+        res.append((o.get_state()[0].copy(), sum(c[5] for c in ground), min(c[4] for c in ground)))
+    for s, force, depth in res:
+        assert force == pytest.approx(TOTAL_MASS * 9.8, rel=5e-3) and depth > -2e-3
+    assert np.abs(res[0][0][:3] - res[1][0][:3]).max() < pose_tol
+    assert np.abs(res[1][0][7:13]).max() < 2e-3                       # with the full manifolds the robot is at rest in every attitude
