@@ -112,19 +112,22 @@ def test_env_step_parity_resynced(torch_cuda, kw):
         so, sv = o.get_state(), v.get_state().cpu().numpy()
         # An env step in which a non-foot link touched the ground (the last one of its episode under a task) went through the many-rows
         # solve, with the links' contact response on by default since round 5: an impact of trunk / thigh / calf, held to the bounds of the
-        # fallen-robot tests (tests/test_body_contacts.py, tools/fuzz_parity.py `fallen`) instead of the strict ones -- 10 x on positions,
-        # the impact's own scale on velocities.  Everything else stays strict.
+        # fallen-robot tests (tests/test_body_contacts.py, tools/fuzz_parity.py `fallen`) instead of the strict ones -- 10 x on positions;
+        # on velocities the bounds of test_full_size_oracle_sampled's "switching" environments: an impact is a discontinuity of the step
+        # map (kw19, step 59, run down in round 5 on the host emulation: from states 1e-6 away the ORACLE's angular velocity after the
+        # step jumps between +0.06 and -0.56 rad/s, the kernel arithmetic jumping with it; the oracle's own float32 build parts from its
+        # float64 build by 0.16 m/s and 11 rad/s two steps later).  Everything else stays strict.
         hit = o.get_info(5)[:, 0] > 0
         fell += int(hit.sum())
         for rows_, f in ((~hit, 1.0), (hit, 10.0)):
             if not rows_.any():
                 continue
             np.testing.assert_allclose(sv[rows_, :7], so[rows_, :7], atol=TOL_POS * f, err_msg=f"pose step {i}")
-            np.testing.assert_allclose(sv[rows_, 7:13], so[rows_, 7:13], atol=TOL_BASE_V if f == 1.0 else 2e-2, err_msg=f"base velocity step {i}")
+            np.testing.assert_allclose(sv[rows_, 7:13], so[rows_, 7:13], atol=TOL_BASE_V if f == 1.0 else 0.5, err_msg=f"base velocity step {i}")
             np.testing.assert_allclose(sv[rows_, 13:25], so[rows_, 13:25], atol=TOL_Q * f, err_msg=f"q step {i}")
-            np.testing.assert_allclose(sv[rows_, 25:], so[rows_, 25:], atol=TOL_QD if f == 1.0 else 1e-1, err_msg=f"qd step {i}")
+            np.testing.assert_allclose(sv[rows_, 25:], so[rows_, 25:], atol=TOL_QD if f == 1.0 else 2.0, err_msg=f"qd step {i}")
             np.testing.assert_allclose(rv[rows_], ro[rows_], atol=2e-4 * f, rtol=1e-3, err_msg=f"reward step {i}")
-            np.testing.assert_allclose(vo[rows_], oo[rows_], atol=TOL_QD if f == 1.0 else 1e-1, err_msg=f"obs step {i}")
+            np.testing.assert_allclose(vo[rows_], oo[rows_], atol=TOL_QD if f == 1.0 else 2.0, err_msg=f"obs step {i}")
         np.testing.assert_array_equal(dv, do)
         tv = np.array([inf.get("TimeLimit.truncated", False) for inf in infos])
         np.testing.assert_array_equal(tv, to)
@@ -216,7 +219,7 @@ def test_reference_wrapper_traces(torch_cuda, golden, name):
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # share of the shadowed env-steps that test_full_size_oracle_sampled compares STRICTLY (no foot touching down or lifting off inside the step):
 # the round-5 measurement minus 0.03 (profiles/r05_*_full_size_oracle_sampled.jsonl)
-STRICT_SHARE_FLOOR = {}
+STRICT_SHARE_FLOOR = {"jump_in_place_8192": 0.88, "config2_4096": 0.88, "config3_8192": 0.88, "config4_8192": 0.87, "config5_8192": 0.65}   # measured 0.913, 0.910, 0.911, 0.907, 0.686
 
 FULL_SIZE = {   # BASELINE.json configs[0..4] at their full sizes (configs[3] = 8 x 8192: its per-GPU share)
     "jump_in_place_8192": (8192, dict(env_randomizer_mode="GROUND_RANDOMIZER")),

@@ -10,7 +10,7 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 rnd = tag.split("_")[0]
 for f in sorted(os.listdir(run)):
     if f.endswith(".json") and os.path.getsize(os.path.join(run, f)) > 10:
-        shutil.copy(os.path.join(run, f), os.path.join(dst, f"{tag}_{f[:-5]}" + (".json" if f == "numpy_path.json" else "_bench.json")))
+        shutil.copy(os.path.join(run, f), os.path.join(dst, f"{tag}_{f[:-5]}" + (".json" if f.startswith("numpy_path") else "_bench.json")))
 for src, name in (("summary.md", "kernel_trace_pmc.md"), ("pmc.json", "pmc.json"), ("kernel_stats.csv", "kernel_stats.csv"), ("bench.json", "profiled_command_bench.json")):
     if os.path.exists(os.path.join(prof, src)):
         shutil.copy(os.path.join(prof, src), os.path.join(dst, f"{tag}_{name}"))
@@ -21,7 +21,8 @@ for src, name in (("summary.md", "static_pool_kernel_trace_pmc.md"), ("pmc.json"
         shutil.copy(os.path.join(static, src), os.path.join(dst, f"{tag}_{name}"))
 for src, name, title in (("phase_cycles.txt", "phase_cycles.md", "Cycles per phase of one physics substep (tools/phase_profile.py, -DQS_PROFILE_PHASES build of the same source)"),
                          ("rare_path.txt", "rare_path.md", "Step time when waves take the many-rows solver (tools/time_rare_path.py: NO_TASK, raw torques, N = 8192)"),
-                         ("falling_policy.txt", "falling_policy.md", "Look-ahead resets under a policy that throws every robot down every ~38 steps (tools/falling_policy_rate.py, N = 8192)")):
+                         ("falling_policy.txt", "falling_policy.md", "Look-ahead resets under a policy that throws every robot down every ~38 steps (tools/falling_policy_rate.py, N = 8192)"),
+                         ("gym_env_rate.txt", "gym_env_rate.md", "One environment through QuadrupedGymEnv.step (tools/gym_env_rate.py): the latency of one launch")):
     if os.path.exists(os.path.join(run, src)):
         body = [l for l in open(os.path.join(run, src)).read().splitlines() if "amdgpu.ids" not in l]
         with open(os.path.join(dst, f"{tag}_{name}"), "w") as f:

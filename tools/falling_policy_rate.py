@@ -8,11 +8,12 @@ import time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "quadruped-springs_amd"))
 import torch
 from qs_amd.vec_env import QuadrupedVecEnv
+BC = {"true": True, "auto": "auto", "false": False}[__import__("os").environ.get("QS_BODY_CONTACTS", "true").lower()]   # the links' contact response: the default (True) or QS_BODY_CONTACTS=auto
 
 n = 8192
 for K in [int(x) for x in sys.argv[1:]] or [8, 16]:
     v = QuadrupedVecEnv(num_envs=n, auto_reset=True, reset_lookahead=K, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True,
-                        enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=3, info_fields=False)
+                        enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=3, info_fields=False, body_contacts=BC)
     v.reset_tensor()
     gen = torch.Generator(device=v.device).manual_seed(1)
     acts = torch.rand((64, n, v.action_dim), generator=gen, device=v.device) * 2 - 1

@@ -11,10 +11,11 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "q
 import numpy as np
 import torch
 from qs_amd import DeviceVecNormalize, QuadrupedVecEnv
+BC = {"true": True, "auto": "auto", "false": False}[__import__("os").environ.get("QS_BODY_CONTACTS", "true").lower()]   # the links' contact response: the default (True) or QS_BODY_CONTACTS=auto
 
 N = 8192
 venv = QuadrupedVecEnv(num_envs=N, device=0, auto_reset=True, reset_lookahead=16, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
-                       enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1)
+                       enable_springs=True, enable_action_filter=True, env_randomizer_mode="GROUND_RANDOMIZER", seed=1, body_contacts=BC)
 env = DeviceVecNormalize(venv)
 obs = env.reset_tensor()
 ring = torch.rand((64, N, 6), device="cuda") * 2 - 1
