@@ -279,6 +279,8 @@ void qs_norm_destroy(qs_norm* h);
 int qs_norm_set_stream(qs_norm* h, void* hip_stream);
 /* host arrays [obs_dim]; RunningMeanStd.mean / .var / .count of obs_rms and ret_rms (VecNormalize.load / save) */
 int qs_norm_set_stats(qs_norm* h, const double* obs_mean, const double* obs_var, double obs_count, double ret_mean, double ret_var, double ret_count);
+/* what the handle was created for (any pointer may be NULL) */
+int qs_norm_dims(const qs_norm* h, int* n_envs, int* obs_dim, int* device);
 int qs_norm_get_stats(qs_norm* h, double* obs_mean, double* obs_var, double* obs_count, double* ret_mean, double* ret_var, double* ret_count);
 /* VecNormalize.reset: returns <- 0, obs_rms.update(obs) if training && norm_obs, obs <- normalize_obs(obs) */
 int qs_norm_reset(qs_norm* h, float* obs /* [N,o] */, int training, int norm_obs);
@@ -309,7 +311,8 @@ int qs_norm_step_io(qs_norm* h, const qs_norm_io* io, int training, int norm_obs
  * what VecNormalize.step_wait returns.  raw_obs [N,o] / raw_rew [N] (device memory, may be NULL): the values before normalisation
  * (get_original_obs / get_original_reward).  norm == NULL switches it off (at any time); it is switched on between two steps, not between
  * a begin and its end.  The handle keeps the pointer, not the object: switch it off (or destroy the simulation handle) before
- * qs_norm_destroy(norm). */
+ * qs_norm_destroy(norm).  Fails -- before anything is launched -- if `norm` was created for another number of environments, another
+ * observation width or another device than `h`. */
 int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, int norm_reward, float* raw_obs, float* raw_rew);
 
 const char* qs_last_error(void);

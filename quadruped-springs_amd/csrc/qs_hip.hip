@@ -1074,6 +1074,13 @@ int qs_host_set_norm(qs_handle* h, qs_norm* norm, int training, int norm_obs, in
     // (switching it off is always possible: a step already on the stream keeps using the statistics' buffers, and qs_norm_destroy waits
     // for its stream before it frees them)
     if (p->pending && norm) QS_FAIL(-1, "qs_host_set_norm between qs_host_step_begin and qs_host_step_end");
+    if (norm) {   // everything that can be checked is checked HERE: a failure behind a step's launch costs that step's results (qs_host_step_begin)
+        int nn = 0, no = 0, nd = -1;
+        if (int rc = qs_norm_dims(norm, &nn, &no, &nd)) return rc;
+        if (nn != h->cfg.n_envs || no != h->cfg.obs_dim || nd != h->device)
+            QS_FAIL(-1, "qs_host_set_norm: the normalisation handle is for %d environments x %d observations on device %d, the simulation handle for %d x %d on device %d",
+                    nn, no, nd, h->cfg.n_envs, h->cfg.obs_dim, h->device);
+    }
     p->norm = norm; p->norm_training = training; p->norm_obs = norm_obs; p->norm_rew = norm_reward; p->raw_obs = raw_obs; p->raw_rew = raw_rew;
     return 0;
 }

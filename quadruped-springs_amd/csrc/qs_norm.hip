@@ -298,6 +298,14 @@ static int norm_launch(qs_norm* h, const qs_norm_io& io, int training, int with_
     return 0;
 }
 
+int qs_norm_dims(const qs_norm* h, int* n_envs, int* obs_dim, int* device) {
+    if (!h) QN_FAIL(-1, "null handle");
+    if (n_envs) *n_envs = h->n;
+    if (obs_dim) *obs_dim = h->o;
+    if (device) *device = h->device;
+    return 0;
+}
+
 // VecNormalize.reset (vec_normalize.py): returns = 0; obs_rms.update(obs) when training; normalize
 int qs_norm_reset(qs_norm* h, float* obs, int training, int norm_obs) {
     if (!h || !obs) QN_FAIL(-1, "null argument");

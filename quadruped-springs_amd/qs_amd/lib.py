@@ -15,7 +15,7 @@ EXPORTS = (
     "qs_create", "qs_destroy", "qs_set_stream", "qs_reset", "qs_reset_to", "qs_get_obs", "qs_step", "qs_step_fused", "qs_get_state", "qs_set_state",
     "qs_info_dim", "qs_get_info", "qs_set_params", "qs_stats", "qs_enable_timing", "qs_last_step_kernel_ms",
     "qs_settle_lanes", "qs_host_step_begin", "qs_host_step_end", "qs_set_trace", "qs_counter", "qs_counters_async", "qs_set_demo", "qs_set_demo_counter", "qs_last_error", "qs_version", "qs_abi_version",
-    "qs_norm_create", "qs_norm_destroy", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
+    "qs_norm_create", "qs_norm_destroy", "qs_norm_dims", "qs_norm_set_stream", "qs_norm_set_stats", "qs_norm_get_stats", "qs_norm_reset", "qs_norm_step",
     "qs_norm_step_io", "qs_host_set_norm",
 )
 
@@ -80,6 +80,7 @@ def load():
     f32, f64, pd = C.c_float, C.c_double, C.POINTER(C.c_double)
     lib.qs_norm_create.argtypes = [i32, i32, f64, f64, f64, f64, i32, C.POINTER(vp)]
     lib.qs_norm_destroy.argtypes = [vp]
+    lib.qs_norm_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.qs_norm_destroy.restype = None
     lib.qs_norm_set_stream.argtypes = [vp, vp]
     lib.qs_norm_set_stats.argtypes = [vp, vp, vp, f64, f64, f64, f64]

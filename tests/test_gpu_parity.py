@@ -138,9 +138,10 @@ def test_env_step_parity_resynced(torch_cuda, kw):
             same = flag_v == flag_o
             flag_flips += int((~same).sum())
             assert flag_flips <= 2, f"contact flags step {i}"
+            same &= ~hit[:, None]                          # (an impact step's forces and torques follow its velocities: held above, loosely)
             np.testing.assert_allclose(v.get_info("foot_force").cpu().numpy()[same], o.get_info(0)[same], rtol=2e-2, atol=0.5)
-            np.testing.assert_allclose(v.get_info("torque").cpu().numpy(), o.get_info(2), atol=5e-3)
-        np.testing.assert_allclose(v.get_info("reward_end").cpu().numpy()[:, 0], o.eval_reward(1), atol=2e-4, rtol=1e-3,
+            np.testing.assert_allclose(v.get_info("torque").cpu().numpy()[~hit], o.get_info(2)[~hit], atol=5e-3)
+        np.testing.assert_allclose(v.get_info("reward_end").cpu().numpy()[~hit, 0], o.eval_reward(1)[~hit], atol=2e-4, rtol=1e-3,
                                    err_msg=f"get_reward_end_episode step {i}")
         if do.any():
             o.reset(do.astype(np.uint8)); v.reset_tensor(do.astype(np.uint8))
@@ -751,6 +752,30 @@ def test_vec_normalize_kernels_against_torch_float64(torch_cuda, n):
         np.testing.assert_allclose(cnt, [obs_rms.count, float(ret_rms.mean), float(ret_rms.var), ret_rms.count], rtol=1e-9, atol=1e-10)
     assert abs(cnt[0] - (1e-4 + 26 * n)) < 1e-6     # reset + 25 training steps; the five evaluation steps left the statistics alone
     lib.qs_norm_destroy(h)
+
+
+def test_host_path_refuses_a_normalisation_handle_of_another_shape(torch_cuda):
+    """qs_host_set_norm checks what can be checked BEFORE any step is launched (a failure behind the launch of a host-path step costs
+    that step's results): a qs_norm created for another number of environments or another observation width is refused with the reason, the
+    simulation handle is left as it was and steps on."""
+    import ctypes as C
+    from qs_amd import lib as L
+    from qs_amd.vec_env import QuadrupedVecEnv
+    lib = L.load()
+    venv = QuadrupedVecEnv(num_envs=32, auto_reset=True, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, seed=2)
+    venv.reset()
+    for n_, o_ in ((16, venv.obs_dim), (32, venv.obs_dim + 1)):
+        h = C.c_void_p()
+        L.check(lib.qs_norm_create(n_, o_, 10.0, 10.0, 0.99, 1e-8, 0, C.byref(h)))
+        n, o, d = C.c_int(), C.c_int(), C.c_int()
+        L.check(lib.qs_norm_dims(h, C.byref(n), C.byref(o), C.byref(d)))
+        assert (n.value, o.value, d.value) == (n_, o_, 0)
+        assert lib.qs_host_set_norm(venv.h, h, 1, 1, 1, None, None) != 0
+        assert b"normalisation handle is for" in lib.qs_last_error()
+        lib.qs_norm_destroy(h)
+    obs, rew, done, infos = venv.step(np.zeros((32, 6), np.float32))     # nothing was attached
+    assert obs.shape == (32, venv.obs_dim) and np.isfinite(obs).all()
+    venv.close()
 
 
 @pytest.mark.parametrize("n,host_path", [(1, "zero"), (50, "zero"), (600, "zero"), (50, "copy"), (600, "copy")])
