@@ -585,7 +585,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_file, "traffic_note": pmc_why, "valu_issue": valu, "kernel": (pmc or {}).get("kernel", "k_step"), "kernel_ms": kavg * 1e3,
                          "algorithmic_bytes_per_env_step": algo_bytes,
-                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / average k_step launch duration over the timed region (two HIP events on the kernel's stream around all its launches: includes the ~1 us between back-to-back launches, so it lies between rocprofv3's kernel average and ms_per_step); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~30 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s"},
+                         "note": "achieved = N x algorithmic bytes per env-step (SURVEY 8d: 736 + 44 d + 4 o) / average k_step launch duration over the timed region (two HIP events on the kernel's stream around all its launches: includes the ~1 us between back-to-back launches, so it lies between rocprofv3's kernel average and ms_per_step); traffic = PMC bytes per launch of the committed profile named in traffic_source (2 x FETCH_SIZE + WRITE_SIZE) / the same duration, GB/s; the step is ~30 k dependent fp32 VALU instructions per wave per env-step: issue-bound, not HBM-bound -- 40 % of HBM peak would need 2.9 G env-steps/s; with body_contacts=True (the default: every link pushes back, as in PyBullet) a launch waits for the wave whose robot is going down -- kernel_ms_body_contacts_auto is the common path alone"},
         }
         ratio = out["config"]["settle_work_ratio"]
         if ratio is not None and ratio < 0.9:
