@@ -134,6 +134,15 @@ def test_bench_multi_rank_code_on_two_gloo_ranks():
     assert 0 < lo <= hi and abs(hi - line["ms_per_step"]) < 1e-9          # the line's time is the MAX over the ranks
     assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]   # whole-job aggregate over both ranks
     assert "cpu_baseline" not in line                                     # (reported with the single-GPU line only)
+    # strong scaling (--total-envs: SURVEY 8e's 65536 split over the ranks): the same path with the environments divided, "scaling": "strong"
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--standin", "bench_standin:StandInVecEnv",
+                          "--total-envs", "32", "--steps", "2", "--warmup", "1", "--preroll", "1", "--spread-steps", "125", "--no-info-line", "--no-body-contacts-line"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["envs_per_gpu"] == 16
+    assert abs(line["value"] - 32 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]          # the job's 32 environments, not 32 per rank
+    assert line["config"]["body_contacts"] == "auto" and line["value_body_contacts_auto"] == line["value"] and "value_body_contacts_true" not in line   # (the stand-in's default; the other loop was switched off)
     # without a stand-in the mode refuses: the step has no CPU path
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--backend", "gloo", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0 and "no CPU path" in out.stderr
