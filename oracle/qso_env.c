@@ -863,6 +863,7 @@ int qso_set_state(qso_handle* h, const real* st) {
         memcpy(s->pos, o, 3 * sizeof(real)); memcpy(s->quat, o + 3, 4 * sizeof(real)); memcpy(s->vlin, o + 7, 3 * sizeof(real));
         memcpy(s->vang, o + 10, 3 * sizeof(real)); memcpy(s->q, o + 13, 12 * sizeof(real)); memcpy(s->qd, o + 25, 12 * sizeof(real));
         memset(h->env[i].warm, 0, sizeof(h->env[i].warm));
+        memset(h->env[i].warm_sup, 0, sizeof(h->env[i].warm_sup));
         qso_block_place(&h->env[i]);
     }
     return 0;

@@ -59,7 +59,9 @@ typedef struct {
     struct { int body_a, body_b, link_a, link_b; real dist, force; } contacts[QSO_MAX_CONTACTS];
     int n_contacts;
     int manifold_mode;   /* qso_phys_set_manifold: 0 = up to two support points per leg (what the kernels build); 1 = experiment: up to four
-                          * points per collision primitive, as Bullet's persistent manifolds can hold */
+                          * points per collision primitive, as Bullet's persistent manifolds can hold; 2 = experiment: mode 0 with
+                          * the support points' normal rows warm-started like the feet's (x cfg.warmstart) while the same candidate stays selected */
+    real warm_sup[4][5]; /* mode 2: last normal impulse of leg L's candidate i (0 once it is not selected) */
     real warm[4];
     /* payload block as its own body (cfg->payload_soft): position of its centre, orientation, velocities (world); constraint impulses of
        the last substep and the distance between the two pivots */

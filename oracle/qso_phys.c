@@ -448,6 +448,8 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
     row* lim = rows; row* nor = rows + 24; row* fr = rows + 24 + MAXN;
     int nor_foot[MAXN];    /* foot index of a normal row, -1 for the other links' support points */
     int nor_contact[MAXN]; /* contact-list entry that receives the row's force */
+    int sup_of[MAXN];      /* mode 0 / 2: 8 x leg + candidate of a support point's normal row */
+    int sel[4][5]; memset(sel, 0, sizeof(sel)); memset(sup_of, 0xff, sizeof(sup_of));
     e->n_contacts = 0;
     /* joint limits: a row exists only while the limit is violated (btMultiBodyJointLimitConstraint) */
     for (int j = 0; j < NJ; j++) {
@@ -605,11 +607,13 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             int bi = 0;
             for (int i = 1; i < 5; i++) if (ch[i] < ch[bi]) bi = i;
             if (!(ch[bi] < (real)1e8)) break;
-            contact_rows(cfg, M, &C, s, v, e->mu, cbody[bi], cand[bi], ch[bi], 0, &nor[nn], &fr[nf], &fr[nf + 1], nn);
+            contact_rows(cfg, M, &C, s, v, e->mu, cbody[bi], cand[bi], ch[bi], e->manifold_mode == 2 ? e->warm_sup[L][bi] : 0, &nor[nn], &fr[nf], &fr[nf + 1], nn);
             nor_foot[nn] = -1; nor_contact[nn] = -1 - clink[bi];
+            sup_of[nn] = 8 * L + bi; sel[L][bi] = 1;
             ch[bi] = (real)1e9;
             nn++; nf += 2;
         }
+        for (int i = 0; i < 5; i++) if (!sel[L][i]) e->warm_sup[L][i] = 0;     /* (a candidate that is not selected has left the manifold) */
     }
     e->n_invalid = collect_invalid(cfg, e, &C, s);
     /* ---- projected Gauss-Seidel in velocity space (btMultiBodyConstraintSolver::solveSingleIteration order) ---- */
@@ -668,6 +672,7 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             e->warm[nor_foot[i]] = nor[i].lam;
             e->contacts[nor_contact[i]].force = nor[i].lam / dt;
         } else {   /* support point of another link: its force goes to that link's entry of the contact list */
+            if (sup_of[i] >= 0) e->warm_sup[sup_of[i] / 8][sup_of[i] % 8] = nor[i].lam;
             for (int c = 0; c < e->n_contacts; c++)
                 if (e->contacts[c].body_a == 1 && e->contacts[c].body_b == 0 && e->contacts[c].link_a == -1 - nor_contact[i]) { e->contacts[c].force += nor[i].lam / dt; break; }
         }
@@ -783,7 +788,7 @@ int qso_phys_step(qso_handle* h, int env, const real* tau) {
 }
 int qso_phys_set_gravity(qso_handle* h, real g) { h->gravity = g; return 0; }
 int qso_phys_set_manifold(qso_handle* h, int mode) {
-    if (mode != 0 && mode != 1) return -1;
+    if (mode < 0 || mode > 2) return -1;
     for (int i = 0; i < h->cfg.n_envs; i++) h->env[i].manifold_mode = mode;
     return 0;
 }

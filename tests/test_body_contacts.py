@@ -506,3 +506,21 @@ def test_two_support_points_per_leg_against_four_points_per_primitive(roll, pitc
         assert force == pytest.approx(TOTAL_MASS * 9.8, rel=5e-3) and depth > -2e-3
     assert np.abs(res[0][0][:3] - res[1][0][:3]).max() < pose_tol
     assert np.abs(res[1][0][7:13]).max() < 2e-3                       # with the full manifolds the robot is at rest in every attitude
+
+
+@pytest.mark.parametrize("roll,pitch", [(1.45, 0.0), (0.0, 0.0), (3.0, 0.0)], ids=["side", "belly", "back"])
+def test_warm_starting_the_support_points_is_a_small_effect(roll, pitch):
+    """Another stated deviation, measured: Bullet warm-starts the normal row of every manifold point that persists (0.1 x its last
+    impulse); oracle and kernels do so for the feet only.  The oracle's experiment mode 2 carries a support point's impulse over while the same
+    candidate stays selected: a robot dropped in a folded pose lands within 4e-5 m and 1.2e-3 rad of where it lands without, after 3 s."""
+    res = []
+    for mode in (0, 2):
+        o = Oracle(make())
+        o.reset()
+        o.set_manifold(mode)
+        o.set_state(fallen_state(o, roll, pitch, z=0.16))
+        for _ in range(3000):
+            o.phys_step(0, np.zeros(12))
+        res.append(o.get_state()[0].copy())
+    assert np.abs(res[0][:3] - res[1][:3]).max() < 1e-4 and np.abs(res[0][13:25] - res[1][13:25]).max() < 5e-3
+    assert 0.0 < np.abs(res[0] - res[1]).max()                 # (the switch does something)
