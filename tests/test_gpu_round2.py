@@ -656,3 +656,53 @@ def test_examples_run(torch_cuda, cmd):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(repo, cmd[0])] + cmd[1:], cwd=repo, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_body_contacts_auto_moves_no_done_step_and_no_reward():
+    """What INTEGRATION.md / DESIGN.md 4a say body_contacts="auto" (the non-foot links' contact response left off under a task) changes against
+    the default (on), in small: two handles, same seed, the e-th episode of an environment from the same reset state under the same actions
+    (a function of environment and step of the episode): every episode ends in the same step, the terminal rewards agree, the terminal
+    observations of some fall-ended episodes do not (tools/body_contacts_delta.py is the 10^5-episode version of this)."""
+    import torch
+    from qs_amd.vec_env import QuadrupedVecEnv
+    n, ring, steps, emax = 2048, 64, 1300, 48
+    kw = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", env_randomizer_mode="GROUND_RANDOMIZER", enable_springs=True,
+              enable_action_filter=True, noise=False, seed=1234, auto_reset=True, reset_lookahead=16)
+    dev = torch.device("cuda", 0)
+    acts = torch.rand((ring, n, 6), generator=torch.Generator(device=dev).manual_seed(5), device=dev) * 2 - 1
+    ids = torch.arange(n, device=dev)
+    out = []
+    for bc in (True, "auto"):
+        env = QuadrupedVecEnv(num_envs=n, body_contacts=bc, **kw)
+        env.reset_tensor()
+        ep_step, ep_idx = torch.zeros(n, dtype=torch.long, device=dev), torch.zeros(n, dtype=torch.long, device=dev)
+        length = torch.zeros((n, emax), dtype=torch.int32, device=dev)
+        rew_t = torch.zeros((n, emax), device=dev)
+        term = torch.zeros((n, emax, env.obs_dim), device=dev)
+        trunc_t = torch.zeros((n, emax), dtype=torch.uint8, device=dev)
+        for _ in range(steps):
+            obs, rew, done, trunc = env.step_tensor(acts[ep_step % ring, ids])
+            d = done.bool()
+            if bool(d.any()):
+                i = d.nonzero().squeeze(1)
+                e = ep_idx[i]
+                ok = e < emax
+                i, e = i[ok], e[ok]
+                length[i, e] = (ep_step[i] + 1).to(torch.int32); rew_t[i, e] = rew[i]; trunc_t[i, e] = trunc[i]
+                term[i, e] = env.get_info("terminal_obs")[i]
+            ep_step = torch.where(d, torch.zeros_like(ep_step), ep_step + 1)
+            ep_idx = ep_idx + d.long()
+        out.append((ep_idx.cpu().numpy(), length.cpu().numpy(), rew_t.cpu().numpy(), term.cpu().numpy(), trunc_t.cpu().numpy().astype(bool)))
+        env.close()
+    (na, la, ra, ta, ua), (nb, lb, rb, tb, ub) = out
+    both = np.arange(emax)[None, :] < np.minimum(np.minimum(na, nb), emax)[:, None]
+    assert both.sum() > 1500 and (~ua[both]).sum() > 500                      # thousands of episodes, hundreds of them ended by a fall
+    np.testing.assert_array_equal(la[both], lb[both])                          # the step every episode ends in
+    np.testing.assert_array_equal(ua[both], ub[both])
+    np.testing.assert_allclose(ra[both], rb[both], atol=1e-3)                  # the terminal step's reward (measured at scale: 5e-5)
+    fell = both & ~ua
+    delta = np.abs(ta[fell] - tb[fell]).max(axis=1)
+    assert (delta > 5e-3).mean() > 0.05                                        # ... and the switch is not a no-op: terminal observations do move
+    tl = both & ua
+    assert np.array_equal(ta[tl], tb[tl])                                      # episodes that ran to the time limit: bitwise the same
