@@ -1138,7 +1138,56 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
         // Nothing to solve when no foot of the wave's 16 environments is within contact range and no joint sits at a stop:
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
-        if (HOT && __builtin_expect(T::any(qor(any_lim, any_extra)), 0)) return true;
+        if (HOT && __builtin_expect(T::any(any_lim), 0)) return true;
+        if (HOT && __builtin_expect(T::any(any_extra), 0)) {
+            // A non-foot link is inside its contact range.  The full build gives a support point rows only once its normal row can act on the
+            // predicted velocities (cfg.support_margin, below); while every point in range is still approaching, its result IS the common-path
+            // result -- so the wave stays here.  Same predicate, same expressions, evaluated for all five candidates of the leg (the full
+            // build looks at the two lowest: a subset).  Cold code: it runs in the three or four substeps a falling link spends in the
+            // 4-mm range, which the full build took at 25 k cycles each instead of 16 k (round 5: ranges scaled to a quarter, as a
+            // diagnostic, read 67.7 against 63.6 M).
+            const V cap_ = V(cfg.vel_cap), inv_dt_ = V(qrcp(dt));
+            V3v wxv_ = cross(v0.a, v0.l);
+            V3v al_ = mk3<V>(ab[3] + wxv_.x, ab[4] + wxv_.y, ab[5] + wxv_.z);
+            V3v wa_, wl_;
+            wa_.x = clampv<V>(s.vang.x + dt * (R[0] * ab[0] + R[1] * ab[1] + R[2] * ab[2]), -cap_, cap_);
+            wa_.y = clampv<V>(s.vang.y + dt * (R[3] * ab[0] + R[4] * ab[1] + R[5] * ab[2]), -cap_, cap_);
+            wa_.z = clampv<V>(s.vang.z + dt * (R[6] * ab[0] + R[7] * ab[1] + R[8] * ab[2]), -cap_, cap_);
+            wl_.x = clampv<V>(s.vlin.x + dt * (R[0] * al_.x + R[1] * al_.y + R[2] * al_.z), -cap_, cap_);
+            wl_.y = clampv<V>(s.vlin.y + dt * (R[3] * al_.x + R[4] * al_.y + R[5] * al_.z), -cap_, cap_);
+            wl_.z = clampv<V>(s.vlin.z + dt * (R[6] * al_.x + R[7] * al_.y + R[8] * al_.z), -cap_, cap_);
+            V qp_[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) qp_[j] = clampv<V>(s.qd[j] + dt * qdd[j], -cap_, cap_);
+            Spv vp_;
+            vp_.a = mk3<V>(R[0] * wa_.x + R[3] * wa_.y + R[6] * wa_.z, R[1] * wa_.x + R[4] * wa_.y + R[7] * wa_.z, R[2] * wa_.x + R[5] * wa_.y + R[8] * wa_.z);
+            vp_.l = mk3<V>(R[0] * wl_.x + R[3] * wl_.y + R[6] * wl_.z, R[1] * wl_.x + R[4] * wl_.y + R[7] * wl_.z, R[2] * wl_.x + R[5] * wl_.y + R[8] * wl_.z);
+            V sgz_ = qsel(qlt(Rz.z, zero), -one, one), sga_ = qsel(qlt(az, zero), -one, one);
+            V sg2_ = qsel(qlt(gx2, zero), -one, one), sg3_ = qsel(qlt(gx3, zero), -one, one);
+            V rad_ = HIP_CYL_R * qrsqrt(qmax(one - az * az, V(1e-12f)));
+            V3v pc_[5];
+            pc_[0] = mk3<V>(fx * TRUNK_HALF[0], sy * TRUNK_HALF[1], sgz_ * (-TRUNK_HALF[2]));
+            pc_[1] = p1 - Y * (sga_ * HIP_CYL_HALF_LEN) - (Rz - Y * az) * rad_;
+            V3v toff_ = X2 * (sg2_ * THIGH_HALF[0]) + Y * (sga_ * THIGH_HALF[1]);
+            pc_[2] = p2 - toff_; pc_[3] = p3 - toff_;
+            pc_[4] = p3 - X3 * (sg3_ * CALF_HALF[0]) - Y * (sga_ * CALF_HALF[1]);
+            const V hc_[5] = {h_trunk, h_hip, h_th_hi, h_th_lo, h_cf_hi};
+            const float thr_[5] = {THR_TRUNK, THR_HIP, THR_THIGH, THR_THIGH, THR_CALF};
+            const int dep_[5] = {0, 1, 2, 2, 3};   // joints of the leg that move the point
+            M can_act = qlt(one, zero);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const V3v pt = pc_[i];
+                const V f1 = V(dep_[i] > 0 ? 1.0f : 0.0f), f2 = V(dep_[i] > 1 ? 1.0f : 0.0f), f3 = V(dep_[i] > 2 ? 1.0f : 0.0f);
+                V3v e1 = cross(ax1, pt - p1) * f1, e2 = cross(Y, pt - p2) * f2, e3 = cross(Y, pt - p3) * f3;
+                V3v jan = cross(pt, Rz);
+                V reln = jan.x * vp_.a.x + jan.y * vp_.a.y + jan.z * vp_.a.z + Rz.x * vp_.l.x + Rz.y * vp_.l.y + Rz.z * vp_.l.z +
+                         dot(Rz, e1) * qp_[0] + dot(Rz, e2) * qp_[1] + dot(Rz, e3) * qp_[2];
+                V pen_x = hc_[i] + cfg.contact_slop;
+                can_act = qor(can_act, qand(qlt(hc_[i], V(thr_[i])), qor(qle(pen_x, zero), qgt((-reln) - pen_x * inv_dt_, V(-cfg.support_margin)))));
+            }
+            if (T::any(can_act)) return true;
+        }
         // ---- v* = v + dt a (world frame for the base; classical acceleration of the origin = a_lin + w x v).  The first write to `s` of the
         // substep: a HOT build's wave that gives up (above) hands the state back as it came, and the env step goes on in the full build from
         // THIS substep (qs_env.h).  (The first version updated the velocities before the collision phase and kept the old ones for that
