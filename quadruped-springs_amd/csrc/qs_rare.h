@@ -8,8 +8,9 @@
 // a wave with ONE fallen robot (profiles/r03_g_rare_path.md), and the launch ends with its slowest wave.
 //
 // Here the wave turns to one environment with rare rows at a time (the others wait; they get the common-path solver's result anyway):
-//   * the environment's quad writes its rows to LDS; lane p of the wave takes the row of position p in Bullet's sweep order
-//     (limits, payload rows, normals, friction pairs -- RarePos below);
+//   * the environment's quad writes its rows to LDS, each at the record of the lane that is to take it: the rows are packed, in Bullet's
+//     sweep order, into three regions of the wave (limit + payload rows, normals, friction pairs -- RarePos below), and a row's lane is
+//     worked out by the quad lane that holds it (round 5: a prefix sum over the quad; round 4 had every lane search a 64-bit mask);
 //   * every lane builds ITS column of the Delassus matrix, A[j][p] = w_j . w_p + [same body part] a_j . b_p, pre-scaled by -1 / A_pp,
 //     into registers, the other rows' data fetched with v_readlane: up to 54 values;
 //   * projected Gauss-Seidel in impulse space on lane-private candidates, as in the common path: a row update is one v_med3 (every lane
@@ -20,7 +21,7 @@
 //   * the impulses go back to the quad through LDS, which turns them into velocities (Sim::substep).
 // Same rows, order, clamps and early exit as before (and as oracle/qso_phys.c); a result depends on the environment's own rows only.
 //
-// LDS: 54 rows x 16 floats + 64 impulses = 3.7 KB of the wave's observation rows, which nobody uses between two epilogues.
+// LDS: 54 rows x 16 floats + 64 impulses + a dummy record = 3.9 KB of the wave's observation rows, which nobody uses between two epilogues.
 // (included by qs_core.h inside namespace qs, after SimTypes)
 #pragma once
 
@@ -72,84 +73,104 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
         const float thr = sqrtf(cfg.solver_residual_threshold);
         const float big = 1e10f, bound = 500.0f * (float)cfg.dt;
         const unsigned long long maskA = (1ull << P::NRM0) - 1ull, maskB = ((1ull << P::FRI0) - 1ull) & ~maskA, maskC = ((1ull << P::N) - 1ull) & ~(maskA | maskB);
+        // Which lane a row goes to is worked out by the lanes that HOLD the rows (round 5; before: a 64-bit mask of the canonical positions from
+        // twelve ballots, and three loops over its set bits in which every lane looked for its rank): a leg's limit rows, normals and friction
+        // pairs sit leg by leg in their regions, so a row's lane is the region's start + the rows of the legs in front of it (an exclusive
+        // prefix over the quad: three DPP broadcasts) + the leg's own rows in front of it.
+        bool lrow[3], nrow[3];
+        int n_lim = 0, n_nrm = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { lrow[j] = xr[9 + j].act > 0.5f; n_lim += lrow[j] ? 1 : 0; nrow[j] = xr[3 * j].act > 0.5f; n_nrm += nrow[j] ? 1 : 0; }
+        const int packed = n_lim | (n_nrm << 8);     // (one value through the DPP moves)
+        auto qb = [](int x, int k) {
+            return k == 0 ? __builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true) : k == 1 ? __builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true)
+                 : k == 2 ? __builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+        };
+        const int q0 = qb(packed, 0), q1 = qb(packed, 1), q2 = qb(packed, 2), q3 = qb(packed, 3);
+        const int pre = (K > 0 ? q0 : 0) + (K > 1 ? q1 : 0) + (K > 2 ? q2 : 0), tot = q0 + q1 + q2 + q3;
+        const int preA = pre & 0xFF, preB = pre >> 8;
+        constexpr int DUMMY = 60;          // a record nobody reads: where the rows that do not exist are written (no EXEC juggling per row)
+        static_assert((DUMMY + 1) * P::REC_FLOATS <= P::LAM_OFF + 64 + 64 && DUMMY >= P::N, "the dummy record lies behind the rows'");
         unsigned long long todo = __ballot(mine);
         while (todo) {
             const int e = (__ffsll((long long)todo) - 1) >> 2;     // wave-uniform: the quad this pass works for
             todo &= ~(0xFull << (4 * e));
             const float mu_e = rl(mu, 4 * e);
-            // ---- which rows exist (wave-uniform, from the quad's registers): bit p of `live` <=> the row of canonical position p
-            unsigned long long live = 0ull;
-            unsigned rows_used = 0u;     // bit r: row r exists in some leg
-#pragma unroll
-            for (int r = 0; r < 12; r++) {
-                const unsigned q = (unsigned)(__ballot(slot == e && xr[r].act > 0.5f) >> (4 * e)) & 0xFu;     // bit K: leg K has the row
-                if (q) rows_used |= 1u << r;
-                // leg K's row r sits at position of_row(K, r): 3 K apart for limits and normals, 6 K apart for friction rows
-                const unsigned long long s3 = (q & 1u) | ((q & 2u) << 2) | ((q & 4u) << 4) | ((q & 8u) << 6);
-                const unsigned long long s6 = (q & 1u) | ((q & 2u) << 5) | ((q & 4u) << 10) | ((q & 8u) << 15);
-                live |= r >= 9 ? s3 << (r - 9) : (r % 3 == 0 ? s3 << (P::NRM0 + r / 3) : s6 << (P::FRI0 + 2 * (r / 3) + (r % 3 - 1)));
-            }
+            const int tot_e = rli(tot, 4 * e);
+            const int mLim = tot_e & 0xFF, mB = tot_e >> 8;        // limit rows and contact points of the environment
             const bool pay_live = pay != nullptr && rl(pay->act, 4 * e) > 0.5f;
-            if (pay_live) live |= 0x3Full << P::PAY0;
-            const int mA = __popcll(live & maskA), mB = __popcll(live & maskB);      // (region C holds mB pairs)
-            // ---- the quad's rows that exist -> LDS (16 floats a row: w 6, a 3, b 3, rhs, dinv, diag, act)
-            if (slot == e) {
+            const int mA = mLim + (pay_live ? 6 : 0);              // region A: the limit rows, then the payload rows
+            // ---- the quad's rows -> LDS, each at the record of ITS lane (16 floats: w 6, a 3, leg, b 3, rhs, dinv, diag); the normals' warm
+            // start goes where the impulses come back from
+            unsigned rows_used = 0u;     // bit r: row r exists in some leg (wave-uniform: a row slot nobody fills is not written at all)
 #pragma unroll
-                for (int r = 0; r < 12; r++) {
-                    if (!((rows_used >> r) & 1u)) continue;
-                    float4* d = reinterpret_cast<float4*>(scr + (12 * K + r) * P::REC_FLOATS);
-                    d[0] = make_float4(xr[r].w[0], xr[r].w[1], xr[r].w[2], xr[r].w[3]);
-                    d[1] = make_float4(xr[r].w[4], xr[r].w[5], xr[r].jq[0], xr[r].jq[1]);
-                    d[2] = make_float4(xr[r].jq[2], xr[r].u[0], xr[r].u[1], xr[r].u[2]);
-                    d[3] = make_float4(xr[r].rhs, xr[r].dinv, xr[r].diag, xr[r].act);
+            for (int r = 0; r < 12; r++) if (__ballot(slot == e && xr[r].act > 0.5f) != 0ull) rows_used |= 1u << r;
+            if (slot == e) {
+                const float legf = __builtin_bit_cast(float, K);
+                auto put = [&](const Row& q, int at, float grp_bits) {
+                    float4* d = reinterpret_cast<float4*>(scr + at * P::REC_FLOATS);
+                    d[0] = make_float4(q.w[0], q.w[1], q.w[2], q.w[3]);
+                    d[1] = make_float4(q.w[4], q.w[5], q.jq[0], q.jq[1]);
+                    d[2] = make_float4(q.jq[2], grp_bits, q.u[0], q.u[1]);
+                    d[3] = make_float4(q.u[2], q.rhs, q.dinv, q.diag);
+                };
+                int dl = A0 + preA, dn = B0 + preB;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (!((rows_used >> (9 + j)) & 1u)) continue;
+                    const int at = lrow[j] ? dl : DUMMY;
+                    put(xr[9 + j], at, legf);
+                    scr[P::LAM_OFF + at] = 0.0f;
+                    dl += lrow[j] ? 1 : 0;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (!((rows_used >> (3 * c)) & 1u)) continue;
+                    const int at = nrow[c] ? dn : DUMMY, af = nrow[c] ? C0 + 2 * (dn - B0) : DUMMY;
+                    put(xr[3 * c], at, legf);
+                    put(xr[3 * c + 1], af, legf);
+                    put(xr[3 * c + 2], nrow[c] ? af + 1 : DUMMY, legf);
+                    scr[P::LAM_OFF + at] = c == 0 ? warm : 0.0f;
+                    scr[P::LAM_OFF + af] = 0.0f; scr[P::LAM_OFF + (nrow[c] ? af + 1 : DUMMY)] = 0.0f;
+                    dn += nrow[c] ? 1 : 0;
                 }
                 // (payload rows: a = -(rB x e_k) resp. -e_k, the block's angular Jacobian; b = a / inertia.  The linear part only meets itself.)
                 if (pay_live) {
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
                         if ((k & 3) != K) continue;           // lane K of the quad writes rows K and K + 4
-                        float4* d = reinterpret_cast<float4*>(scr + (48 + k) * P::REC_FLOATS);
+                        const int at = A0 + mLim + k;
+                        float4* d = reinterpret_cast<float4*>(scr + at * P::REC_FLOATS);
                         const PayRows& q = *pay;
                         const float ax = k == 0 ? 0.0f : k == 1 ? q.rB.z : k == 2 ? -q.rB.y : k == 3 ? -1.0f : 0.0f;
                         const float ay = k == 0 ? -q.rB.z : k == 1 ? 0.0f : k == 2 ? q.rB.x : k == 4 ? -1.0f : 0.0f;
                         const float az = k == 0 ? q.rB.y : k == 1 ? -q.rB.x : k == 5 ? -1.0f : 0.0f;
                         d[0] = make_float4(q.w[k][0], q.w[k][1], q.w[k][2], q.w[k][3]);
                         d[1] = make_float4(q.w[k][4], q.w[k][5], ax, ay);
-                        d[2] = make_float4(az, ax * q.mI, ay * q.mI, az * q.mI);
-                        d[3] = make_float4(q.rhs[k], q.dinv[k], q.diag[k], q.act);
+                        d[2] = make_float4(az, __builtin_bit_cast(float, 4), ax * q.mI, ay * q.mI);
+                        d[3] = make_float4(az * q.mI, q.rhs[k], q.dinv[k], q.diag[k]);
+                        scr[P::LAM_OFF + at] = 0.0f;
                     }
                 }
             }
-            // ---- every row that exists gets the next free lane of its region (the regions' bits in ascending order = sweep order)
-            int cp = -1;                 // the canonical position of this lane's row, -1: none
-            {
-                int at = A0;
-                for (unsigned long long m = live & maskA; m; m &= m - 1ull, at++) cp = lane == at ? __ffsll((long long)m) - 1 : cp;
-                at = B0;
-                for (unsigned long long m = live & maskB; m; m &= m - 1ull, at++) cp = lane == at ? __ffsll((long long)m) - 1 : cp;
-                at = C0;
-                for (unsigned long long m = live & maskC; m; m &= m - 1ull, at++) cp = lane == at ? __ffsll((long long)m) - 1 : cp;
-            }
-            const bool alive = cp >= 0;
+            // ---- a lane inside the filled part of a region has a row; its position in Bullet's sweep order is the lane itself
+            const bool inA = lane < A0 + mA, inB = lane >= B0 && lane < B0 + mB, inC = lane >= C0 && lane < C0 + 2 * mB;
+            const bool alive = inA || inB || inC;
             LaneDev::sync();
             // ---- this lane's row; the feet's warm start
             float w[6], a[3], b[3], rhs, dinv, diag, lam, lo, hi;
             int grp;
             {
-                const int c = alive ? cp : 0;
-                grp = c < P::PAY0 ? c / 3 : c < P::NRM0 ? 4 : c < P::FRI0 ? (c - P::NRM0) / 3 : (c - P::FRI0) / 6;
-                const int rec = c < P::PAY0 ? 12 * grp + 9 + c % 3 : c < P::NRM0 ? 48 + (c - P::PAY0)
-                              : c < P::FRI0 ? 12 * grp + 3 * ((c - P::NRM0) % 3) : 12 * grp + 3 * (((c - P::FRI0) % 6) / 2) + 1 + (c - P::FRI0) % 2;
-                const float4* s4 = reinterpret_cast<const float4*>(scr + rec * P::REC_FLOATS);
+                const int me = alive ? lane : DUMMY;
+                const float4* s4 = reinterpret_cast<const float4*>(scr + me * P::REC_FLOATS);
                 const float4 r0 = s4[0], r1 = s4[1], r2 = s4[2], r3 = s4[3];
+                lam = scr[P::LAM_OFF + me];
                 w[0] = r0.x; w[1] = r0.y; w[2] = r0.z; w[3] = r0.w; w[4] = r1.x; w[5] = r1.y;
                 a[0] = r1.z; a[1] = r1.w; a[2] = r2.x;
-                b[0] = r2.y; b[1] = r2.z; b[2] = r2.w;
-                rhs = r3.x; dinv = r3.y; diag = r3.z;
-                lam = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const float wk = rl(warm, 4 * e + k); lam = cp == P::NRM0 + 3 * k ? wk : lam; }
-                const bool payrow = c >= P::PAY0 && c < P::NRM0;
+                grp = __builtin_bit_cast(int, r2.y);
+                b[0] = r2.z; b[1] = r2.w; b[2] = r3.x;
+                rhs = r3.y; dinv = r3.z; diag = r3.w;
+                const bool payrow = inA && lane >= A0 + mLim;
                 lo = payrow ? -bound : 0.0f; hi = payrow ? bound : big;
                 if (!alive) { grp = -1; rhs = 0.0f; diag = 0.0f; lam = 0.0f; }
             }
@@ -259,21 +280,28 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
 #if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
             if (threadIdx.x == 0) {   // all workgroups: solves, sweeps, live rows, live contact points (normals)
                 atomicAdd(&qs_phase_cycles[0], 1ull); atomicAdd(&qs_phase_cycles[46], (unsigned long long)n_sweeps);
-                atomicAdd(&qs_phase_cycles[47], (unsigned long long)__popcll(live));
+                atomicAdd(&qs_phase_cycles[47], (unsigned long long)(mA + 3 * mB));
                 atomicAdd(&qs_phase_cycles[30], (unsigned long long)mB);
             }
 #endif
             (void)n_sweeps;
-            // ---- the impulses back to the quad (by canonical position; rows that do not exist read zero)
-            scr[P::LAM_OFF + lane] = 0.0f;
-            LaneDev::sync();
-            if (alive) scr[P::LAM_OFF + cp] = lam;
+            // ---- the impulses back to the quad: every lane leaves its row's where the quad's lane -- which knows where it sent the row -- finds it
+            if (alive) scr[P::LAM_OFF + lane] = lam;
             LaneDev::sync();
             if (slot == e) {
+                int dl = A0 + preA, dn = B0 + preB;
 #pragma unroll
-                for (int r = 0; r < 12; r++) lam12[r] = scr[P::LAM_OFF + (r >= 9 ? 3 * K + (r - 9) : (r % 3 == 0 ? P::NRM0 + 3 * K + r / 3 : P::FRI0 + 6 * K + 2 * (r / 3) + (r % 3 - 1)))];
+                for (int j = 0; j < 3; j++) { lam12[9 + j] = lrow[j] ? scr[P::LAM_OFF + dl] : 0.0f; dl += lrow[j] ? 1 : 0; }
 #pragma unroll
-                for (int k = 0; k < 6; k++) plam[k] = scr[P::LAM_OFF + P::PAY0 + k];
+                for (int c = 0; c < 3; c++) {
+                    const int af = C0 + 2 * (dn - B0);
+                    lam12[3 * c] = nrow[c] ? scr[P::LAM_OFF + dn] : 0.0f;
+                    lam12[3 * c + 1] = nrow[c] ? scr[P::LAM_OFF + af] : 0.0f;
+                    lam12[3 * c + 2] = nrow[c] ? scr[P::LAM_OFF + af + 1] : 0.0f;
+                    dn += nrow[c] ? 1 : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) plam[k] = pay_live ? scr[P::LAM_OFF + A0 + mLim + k] : 0.0f;
             }
             LaneDev::sync();
             QS_PHASE_G(44)
