@@ -423,12 +423,15 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
             for (int r = 0; r < NR; r++)
 #pragma unroll
                 for (int c = 0; c < NR; c++) acc[r][c] = T::acc4_zero();
+            // (MFMA in the full build as well since round 5: round 4 ran these products on the vector ALU there -- bitwise the same -- because hipcc
+            // crashed on spilled MFMA accumulators; it does not on this source, and build.py still retries without -amdgpu-mfma-vgpr-form if it
+            // does: +1.5 % with the links' response on)
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
                 for (int r = 0; r < NR; r++)
 #pragma unroll
-                    for (int c = 0; c < NR; c++) { if (HOT) T::outer_fma(rows[r].w[i], wc[c][i], acc[r][c]); else T::outer_fma_valu(rows[r].w[i], wc[c][i], acc[r][c]); }
+                    for (int c = 0; c < NR; c++) { T::outer_fma(rows[r].w[i], wc[c][i], acc[r][c]); }
 #define QS_SCATTER(K)                                                                                                  \
     {                                                                                                                  \
         M own = T::is_leg(K);                                                                                          \

@@ -42,6 +42,7 @@ template <class T, bool CONE> struct RareSolver;
 // code stays structured (a goto per row, or a switch that falls through the rows, comes out of LLVM's CFG structurizer as flag variables
 // and four branches per row: measured 1.2 k cycles per sweep of ten rows)
 #define QS_NEST12(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) if (6 < (count)) { M(6) if (7 < (count)) { M(7) if (8 < (count)) { M(8) if (9 < (count)) { M(9) if (10 < (count)) { M(10) if (11 < (count)) { M(11) }}}}}}}}}}}}
+#define QS_NEST6(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) }}}}}}
 #define QS_NEST18(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) if (6 < (count)) { M(6) if (7 < (count)) { M(7) if (8 < (count)) { M(8) if (9 < (count)) { M(9) if (10 < (count)) { M(10) if (11 < (count)) { M(11) if (12 < (count)) { M(12) if (13 < (count)) { M(13) if (14 < (count)) { M(14) if (15 < (count)) { M(15) if (16 < (count)) { M(16) if (17 < (count)) { M(17) }}}}}}}}}}}}}}}}}}
 
 #if defined(__HIPCC__)
@@ -57,6 +58,117 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
     using PayRows = typename Ty::PayRows;
     static QS_DEV float rl(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
     static QS_DEV int rli(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+
+    // Delassus column, candidates and sweeps of one environment's solve (the lanes hold their rows: w, a, b, rhs, dinv, diag, lam, lo, hi, grp).
+    // NAX / NBX: how many rows of region A / contact points the coefficient arrays hold -- <18, 12> takes everything, <0, 6> what the benchmark's
+    // falling robots need (no joint at its stop, six contact points at most) with a quarter of the registers.
+    template <int NAX, int NBX>
+    static QS_DEV void core(const qs_config& cfg, const float (&w)[6], const float (&a)[3], const float (&b)[3], float rhs, float dinv, float diag, float& lam,
+                            float lo, float hi, int grp, int mA, int mB, float mu_e, bool track, float thr, int& n_sweeps) {
+        using P = RarePos;
+        constexpr int A0 = 0, B0 = P::NRM0, C0 = P::FRI0, IB = NAX, IC = NAX + NBX;
+        const int lane = (int)threadIdx.x;
+            // ---- this lane's column of the Delassus matrix, x (-1 / A_pp): Ap[J] = what a unit impulse of the row in lane J does to this
+        // lane's candidate.  The row data of lane J come over by v_readlane (SGPRs); the self entry is zero.
+        float Ap[NAX + 3 * NBX], ApR[NAX > 0 ? NAX : 1];
+        {
+            const float nd = -dinv;
+            float ws[6], bs[3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) ws[i] = w[i] * nd;
+#pragma unroll
+            for (int i = 0; i < 3; i++) bs[i] = b[i] * nd;
+#define QS_W_COL(DST, J)                                                                                               \
+    {                                                                                                                  \
+        const int l_ = (J);                                                                                            \
+        float t_ = rl(w[0], l_) * ws[0];                                                                               \
+        t_ = fmaf(rl(w[1], l_), ws[1], t_); t_ = fmaf(rl(w[2], l_), ws[2], t_); t_ = fmaf(rl(w[3], l_), ws[3], t_);     \
+        t_ = fmaf(rl(w[4], l_), ws[4], t_); t_ = fmaf(rl(w[5], l_), ws[5], t_);                                         \
+        float u_ = rl(a[0], l_) * bs[0];                                                                               \
+        u_ = fmaf(rl(a[1], l_), bs[1], u_); u_ = fmaf(rl(a[2], l_), bs[2], u_);                                         \
+        t_ = grp == rli(grp, l_) ? t_ + u_ : t_;                                                                       \
+        DST = lane == l_ ? 0.0f : t_;                                                                                  \
+    }
+            // the rows of region A are swept forwards and backwards in turn: ApR[j] is the entry of the row that the BACKWARD sweep meets
+            // j-th (lane mA - 1 - j), so that both directions index their coefficients with constants
+#define QS_W_COL_A(j) QS_W_COL(Ap[(j)], A0 + (j))
+#define QS_W_COL_R(j) QS_W_COL(ApR[(j)], mA - 1 - (j))
+#define QS_W_COL_B(j) QS_W_COL(Ap[IB + (j)], B0 + (j)) QS_W_COL(Ap[IC + 2 * (j)], C0 + 2 * (j)) QS_W_COL(Ap[IC + 2 * (j) + 1], C0 + 2 * (j) + 1)
+            if constexpr (NAX > 0) { QS_NEST18(mA, QS_W_COL_A) QS_NEST18(mA, QS_W_COL_R) }
+            if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_COL_B) } else { QS_NEST6(mB, QS_W_COL_B) }
+#undef QS_W_COL_A
+#undef QS_W_COL_R
+#undef QS_W_COL_B
+#undef QS_W_COL
+        }
+        QS_PHASE_G(42)
+        // ---- candidates: rhs - dinv sum_{j != p} A_pj lambda_j; the warm start of the feet's normal rows is in already
+        float res = rhs;
+#define QS_W_WARM(j) res = fmaf(Ap[IB + (j)], rl(lam, B0 + (j)), res);
+        if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_WARM) } else { QS_NEST6(mB, QS_W_WARM) }
+#undef QS_W_WARM
+        // one row: every lane clamps its own candidate, the owner's change goes round
+#define QS_W_ROW(COEF, J)                                                                                              \
+    {                                                                                                                  \
+        const int l_ = (J);                                                                                            \
+        const float cand = qmed3(res, lo, hi);                                                                         \
+        const float d_ = rl(cand - lam, l_);                                                                           \
+        lam = lane == l_ ? cand : lam;                                                                                 \
+        res = fmaf((COEF), d_, res);                                                                                   \
+    }
+        // the friction rows of contact point KK (lanes C0 + 2 KK, + 1; its normal sits in lane B0 + KK): implicit cone -- both from the
+        // same candidates, their sum scaled back onto the disc of radius mu x the normal impulse --, or the pyramid: one by one, each
+        // bounded by mu x the normal impulse and left alone while that is not positive (Bullet's rule)
+#define QS_W_FRICTION(KK)                                                                                              \
+    {                                                                                                                  \
+        constexpr int FP = C0 + 2 * (KK);                                                                              \
+        if (CONE) {                                                                                                    \
+        const float lim_ = rl(lam * mu_e, B0 + (KK));          /* (every lane's product; the normal's counts) */   \
+        const float ca_ = rl(res, FP), cb_ = rl(res, FP + 1);                                                      \
+        const float r2_ = fmaf(cb_, cb_, fmaf(ca_, ca_, 1e-30f));   /* (+ 1e-30: no candidate, no division by zero) */ \
+        const float sc_ = qmin(lim_ * qrsqrt(r2_), 1.0f);                                                          \
+        const float cand = res * sc_;                                                                              \
+        const float dl_ = cand - lam;                                                                              \
+        const float da_ = rl(dl_, FP), db_ = rl(dl_, FP + 1);                                                      \
+        lam = (lane >> 1) == (FP >> 1) ? cand : lam;                                                               \
+        res = fmaf(Ap[IC + 2 * (KK)], da_, res); res = fmaf(Ap[IC + 2 * (KK) + 1], db_, res);                                            \
+        } else {                                                                                                       \
+        const float ln_ = rl(lam, B0 + (KK)), lim_ = mu_e * ln_;                                                   \
+        _Pragma("unroll") for (int t_ = 0; t_ < 2; t_++) {                                                         \
+            const float cl_ = qmed3(res, -lim_, lim_);                                                             \
+            const float d_ = ln_ > 0.0f ? rl(cl_ - lam, FP + t_) : 0.0f;                                           \
+            lam = lane == FP + t_ && ln_ > 0.0f ? cl_ : lam;                                                       \
+            res = fmaf(Ap[IC + 2 * (KK) + t_], d_, res);                                                                      \
+        }                                                                                                          \
+        }                                                                                                              \
+    }
+        const int mA_fix = mA, mB_fix = mB;
+        for (int it = 0; it < cfg.solver_iters; it++) {
+            n_sweeps++;
+            const float lam_in = lam;
+            // (opaque copies: otherwise the compiler hoists the ~100 loop-invariant comparisons `j < count` and `lane == j` out of the
+            // sweep loop as lane masks, spills them into VGPR lanes and fetches each back with two v_readlane per row)
+            int mA = mA_fix, mB = mB_fix, lane = (int)threadIdx.x;
+            asm volatile("" : "+s"(mA), "+s"(mB), "+v"(lane));
+#define QS_W_FWD_A(j) QS_W_ROW(Ap[(j)], A0 + (j))
+#define QS_W_BWD_A(j) QS_W_ROW(ApR[(j)], mA - 1 - (j))
+#define QS_W_FWD_B(j) QS_W_ROW(Ap[IB + (j)], B0 + (j))
+#define QS_W_FWD_C(j) QS_W_FRICTION(j)
+            if constexpr (NAX > 0) {
+                if (it & 1) { QS_NEST18(mA, QS_W_FWD_A) }   // limit rows, then the payload rows, forwards; on even sweeps the same backwards
+                else { QS_NEST18(mA, QS_W_BWD_A) }
+            }
+            if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_FWD_B) QS_NEST12(mB, QS_W_FWD_C) } else { QS_NEST6(mB, QS_W_FWD_B) QS_NEST6(mB, QS_W_FWD_C) }
+#undef QS_W_FWD_A
+#undef QS_W_BWD_A
+#undef QS_W_FWD_B
+#undef QS_W_FWD_C
+            // PyBullet's solverResidualThreshold: every row moved once in this sweep, by lam - lam_in
+            if (track && !__any(fabsf((lam - lam_in) * diag) > thr)) break;
+        }
+#undef QS_W_FRICTION
+#undef QS_W_ROW
+    }
 
     // xr: the twelve rows of this lane's leg; pay: the block's rows (replicated over the quad) or nullptr; mine: this lane's environment has
     // rare rows; warm: the foot's warm-start impulse (already x cfg.warmstart x act); scr: RarePos::SCRATCH_FLOATS floats of LDS shared by
@@ -175,107 +287,12 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
                 if (!alive) { grp = -1; rhs = 0.0f; diag = 0.0f; lam = 0.0f; }
             }
             QS_PHASE_G(41)
-            // ---- this lane's column of the Delassus matrix, x (-1 / A_pp): Ap[J] = what a unit impulse of the row in lane J does to this
-            // lane's candidate.  The row data of lane J come over by v_readlane (SGPRs); the self entry is zero.
-            float Ap[P::N], ApR[NA];
-            {
-                const float nd = -dinv;
-                float ws[6], bs[3];
-#pragma unroll
-                for (int i = 0; i < 6; i++) ws[i] = w[i] * nd;
-#pragma unroll
-                for (int i = 0; i < 3; i++) bs[i] = b[i] * nd;
-#define QS_W_COL(DST, J)                                                                                               \
-    {                                                                                                                  \
-        const int l_ = (J);                                                                                            \
-        float t_ = rl(w[0], l_) * ws[0];                                                                               \
-        t_ = fmaf(rl(w[1], l_), ws[1], t_); t_ = fmaf(rl(w[2], l_), ws[2], t_); t_ = fmaf(rl(w[3], l_), ws[3], t_);     \
-        t_ = fmaf(rl(w[4], l_), ws[4], t_); t_ = fmaf(rl(w[5], l_), ws[5], t_);                                         \
-        float u_ = rl(a[0], l_) * bs[0];                                                                               \
-        u_ = fmaf(rl(a[1], l_), bs[1], u_); u_ = fmaf(rl(a[2], l_), bs[2], u_);                                         \
-        t_ = grp == rli(grp, l_) ? t_ + u_ : t_;                                                                       \
-        DST = lane == l_ ? 0.0f : t_;                                                                                  \
-    }
-                // the rows of region A are swept forwards and backwards in turn: ApR[j] is the entry of the row that the BACKWARD sweep meets
-                // j-th (lane mA - 1 - j), so that both directions index their coefficients with constants
-#define QS_W_COL_A(j) QS_W_COL(Ap[A0 + (j)], A0 + (j))
-#define QS_W_COL_R(j) QS_W_COL(ApR[(j)], mA - 1 - (j))
-#define QS_W_COL_B(j) QS_W_COL(Ap[B0 + (j)], B0 + (j)) QS_W_COL(Ap[C0 + 2 * (j)], C0 + 2 * (j)) QS_W_COL(Ap[C0 + 2 * (j) + 1], C0 + 2 * (j) + 1)
-                QS_NEST18(mA, QS_W_COL_A)
-                QS_NEST18(mA, QS_W_COL_R)
-                QS_NEST12(mB, QS_W_COL_B)
-#undef QS_W_COL_A
-#undef QS_W_COL_R
-#undef QS_W_COL_B
-#undef QS_W_COL
-            }
-            QS_PHASE_G(42)
-            // ---- candidates: rhs - dinv sum_{j != p} A_pj lambda_j; the warm start of the feet's normal rows is in already
-            float res = rhs;
-#define QS_W_WARM(j) res = fmaf(Ap[B0 + (j)], rl(lam, B0 + (j)), res);
-            QS_NEST12(mB, QS_W_WARM)
-#undef QS_W_WARM
-            // one row: every lane clamps its own candidate, the owner's change goes round
-#define QS_W_ROW(COEF, J)                                                                                              \
-    {                                                                                                                  \
-        const int l_ = (J);                                                                                            \
-        const float cand = qmed3(res, lo, hi);                                                                         \
-        const float d_ = rl(cand - lam, l_);                                                                           \
-        lam = lane == l_ ? cand : lam;                                                                                 \
-        res = fmaf((COEF), d_, res);                                                                                   \
-    }
-            // the friction rows of contact point KK (lanes C0 + 2 KK, + 1; its normal sits in lane B0 + KK): implicit cone -- both from the
-            // same candidates, their sum scaled back onto the disc of radius mu x the normal impulse --, or the pyramid: one by one, each
-            // bounded by mu x the normal impulse and left alone while that is not positive (Bullet's rule)
-#define QS_W_FRICTION(KK)                                                                                              \
-    {                                                                                                                  \
-        constexpr int FP = C0 + 2 * (KK);                                                                              \
-        if (CONE) {                                                                                                    \
-            const float lim_ = rl(lam * mu_e, B0 + (KK));          /* (every lane's product; the normal's counts) */   \
-            const float ca_ = rl(res, FP), cb_ = rl(res, FP + 1);                                                      \
-            const float r2_ = fmaf(cb_, cb_, fmaf(ca_, ca_, 1e-30f));   /* (+ 1e-30: no candidate, no division by zero) */ \
-            const float sc_ = qmin(lim_ * qrsqrt(r2_), 1.0f);                                                          \
-            const float cand = res * sc_;                                                                              \
-            const float dl_ = cand - lam;                                                                              \
-            const float da_ = rl(dl_, FP), db_ = rl(dl_, FP + 1);                                                      \
-            lam = (lane >> 1) == (FP >> 1) ? cand : lam;                                                               \
-            res = fmaf(Ap[FP], da_, res); res = fmaf(Ap[FP + 1], db_, res);                                            \
-        } else {                                                                                                       \
-            const float ln_ = rl(lam, B0 + (KK)), lim_ = mu_e * ln_;                                                   \
-            _Pragma("unroll") for (int t_ = 0; t_ < 2; t_++) {                                                         \
-                const float cl_ = qmed3(res, -lim_, lim_);                                                             \
-                const float d_ = ln_ > 0.0f ? rl(cl_ - lam, FP + t_) : 0.0f;                                           \
-                lam = lane == FP + t_ && ln_ > 0.0f ? cl_ : lam;                                                       \
-                res = fmaf(Ap[FP + t_], d_, res);                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
+            // ---- Delassus column, candidates, sweeps (core<>, above).  A solve without limit / payload rows and with six contact points at most --
+            // every one of the benchmark's -- takes the instantiation with 18 coefficient registers instead of 72: the sweep loop of the large
+            // one re-read ~ 30 coefficients from AGPRs and SGPR-spill lanes at the head of every sweep
             int n_sweeps = 0;
-            const int mA_fix = mA, mB_fix = mB;
-            for (int it = 0; it < cfg.solver_iters; it++) {
-                n_sweeps++;
-                const float lam_in = lam;
-                // (opaque copies: otherwise the compiler hoists the ~100 loop-invariant comparisons `j < count` and `lane == j` out of the
-                // sweep loop as lane masks, spills them into VGPR lanes and fetches each back with two v_readlane per row)
-                int mA = mA_fix, mB = mB_fix, lane = (int)threadIdx.x;
-                asm volatile("" : "+s"(mA), "+s"(mB), "+v"(lane));
-#define QS_W_FWD_A(j) QS_W_ROW(Ap[A0 + (j)], A0 + (j))
-#define QS_W_BWD_A(j) QS_W_ROW(ApR[(j)], mA - 1 - (j))
-#define QS_W_FWD_B(j) QS_W_ROW(Ap[B0 + (j)], B0 + (j))
-#define QS_W_FWD_C(j) QS_W_FRICTION(j)
-                if (it & 1) { QS_NEST18(mA, QS_W_FWD_A) }   // limit rows, then the payload rows, forwards; on even sweeps the same backwards
-                else { QS_NEST18(mA, QS_W_BWD_A) }
-                QS_NEST12(mB, QS_W_FWD_B)
-                QS_NEST12(mB, QS_W_FWD_C)
-#undef QS_W_FWD_A
-#undef QS_W_BWD_A
-#undef QS_W_FWD_B
-#undef QS_W_FWD_C
-                // PyBullet's solverResidualThreshold: every row moved once in this sweep, by lam - lam_in
-                if (track && !__any(fabsf((lam - lam_in) * diag) > thr)) break;
-            }
-#undef QS_W_FRICTION
-#undef QS_W_ROW
+            if (mA == 0 && mB <= 6) core<0, 6>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+            else core<NA, NB>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
             QS_PHASE_G(43)
 #if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
             if (threadIdx.x == 0) {   // all workgroups: solves, sweeps, live rows, live contact points (normals)
