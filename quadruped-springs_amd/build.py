@@ -81,18 +81,23 @@ def build(force=False, verbose=False):
     # (round 4: ROCm 7.2's "AMDGPU Rewrite AGPR-Copy-MFMA" pass, which only has work under -amdgpu-mfma-vgpr-form, segfaults on some
     # register allocations of the step kernels -- eliminateSpillsOfReassignedVGPRs --: seen on k_step<false, false> for two harmless
     # variations of the many-rows solver's source.  The build retries without the flag, loudly; QS_MFMA_VGPR_FORM=0 leaves it out at once.)
-    # -greedy-regclass-priority-trumps-globalness=1 -split-spill-mode=size (end of round 4): two knobs of LLVM's greedy register allocator --
-    # which live ranges it colours first, and where it puts the spill code of a split range.  Same instructions' arithmetic, same results
-    # bit for bit (the front end has fixed every FMA); the substep loop keeps fewer copies in flight: +1.3 % at N = 8192 under the cone
-    # (112.2 against 110.8 M on one box), +0.7 % at N = 65536, +-0.3 % on the pyramid / body_contacts workloads (gpurun_out/r04zm, r04zn;
-    # twelve allocator / scheduler options were tried, the others lost or changed nothing).
+    # -greedy-regclass-priority-trumps-globalness=1 (end of round 4): which live ranges LLVM's greedy register allocator colours first.  Same
+    # instructions' arithmetic, same results bit for bit (the front end has fixed every FMA); the substep loop keeps fewer copies in flight:
+    # about +1 % at N = 8192 under the cone (gpurun_out/r04zm, r04zn; twelve allocator / scheduler options were tried, the others lost or
+    # changed nothing).
+    # NOT -split-spill-mode=size any more (round 4 had it next to the knob above, +0.3 %): round 5's source with the <0, 4> instantiation of the
+    # many-rows solver's core came out of it MISCOMPILED -- 17 of 120 fallen-robot fuzz configurations off by 1e-2, the kernel depending on
+    # its wave-mates -- while the same source without that option, without the knob above, or with two more instantiations passed, and a
+    # build that ran <0, 4> and <0, 6> side by side on the same rows (-DQS_DBG_CORE4, tools/diag/core4_differential.py) found them equal bit
+    # for bit: the damage is in the spill code around the solve, not in it.  Without the option the library is as fast (70.5 / 111.5 M
+    # against 70.4 / 111.0 M, gpurun_out/ab_tmp2) and every parity gate is green again.
     vgpr_form = os.environ.get("QS_MFMA_VGPR_FORM", "1") != "0"
 
     def command(with_form):
         c = [hipcc(), "--offload-arch=" + os.environ.get("QS_OFFLOAD_ARCH", "gfx950"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
              "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
              "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-             "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-split-spill-mode=size"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
+             "-mllvm", "-greedy-regclass-priority-trumps-globalness=1"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
             os.environ.get("QS_HIPCC_EXTRA", "").split() + ["-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
         if verbose:
             c.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -42,6 +42,7 @@ template <class T, bool CONE> struct RareSolver;
 // code stays structured (a goto per row, or a switch that falls through the rows, comes out of LLVM's CFG structurizer as flag variables
 // and four branches per row: measured 1.2 k cycles per sweep of ten rows)
 #define QS_NEST12(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) if (6 < (count)) { M(6) if (7 < (count)) { M(7) if (8 < (count)) { M(8) if (9 < (count)) { M(9) if (10 < (count)) { M(10) if (11 < (count)) { M(11) }}}}}}}}}}}}
+#define QS_NEST4(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) }}}}
 #define QS_NEST6(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) }}}}}}
 #define QS_NEST18(count, M) if (0 < (count)) { M(0) if (1 < (count)) { M(1) if (2 < (count)) { M(2) if (3 < (count)) { M(3) if (4 < (count)) { M(4) if (5 < (count)) { M(5) if (6 < (count)) { M(6) if (7 < (count)) { M(7) if (8 < (count)) { M(8) if (9 < (count)) { M(9) if (10 < (count)) { M(10) if (11 < (count)) { M(11) if (12 < (count)) { M(12) if (13 < (count)) { M(13) if (14 < (count)) { M(14) if (15 < (count)) { M(15) if (16 < (count)) { M(16) if (17 < (count)) { M(17) }}}}}}}}}}}}}}}}}}
 
@@ -61,7 +62,8 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
 
     // Delassus column, candidates and sweeps of one environment's solve (the lanes hold their rows: w, a, b, rhs, dinv, diag, lam, lo, hi, grp).
     // NAX / NBX: how many rows of region A / contact points the coefficient arrays hold -- <18, 12> takes everything, <0, 6> what the benchmark's
-    // falling robots need (no joint at its stop, six contact points at most) with a quarter of the registers.
+    // falling robots need (no joint at its stop, six contact points at most) with a quarter of the registers, <0, 4> the four-point solves among
+    // them with a sixth (round 5: 66.2 -> 68.1 -> 70.3 M on the benchmark; a finer ladder -- <0, 2>, <0, 3> -- added nothing).
     template <int NAX, int NBX>
     static QS_DEV void core(const qs_config& cfg, const float (&w)[6], const float (&a)[3], const float (&b)[3], float rhs, float dinv, float diag, float& lam,
                             float lo, float hi, int grp, int mA, int mB, float mu_e, bool track, float thr, int& n_sweeps) {
@@ -95,7 +97,7 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
 #define QS_W_COL_R(j) QS_W_COL(ApR[(j)], mA - 1 - (j))
 #define QS_W_COL_B(j) QS_W_COL(Ap[IB + (j)], B0 + (j)) QS_W_COL(Ap[IC + 2 * (j)], C0 + 2 * (j)) QS_W_COL(Ap[IC + 2 * (j) + 1], C0 + 2 * (j) + 1)
             if constexpr (NAX > 0) { QS_NEST18(mA, QS_W_COL_A) QS_NEST18(mA, QS_W_COL_R) }
-            if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_COL_B) } else { QS_NEST6(mB, QS_W_COL_B) }
+            if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_COL_B) } else if constexpr (NBX > 4) { QS_NEST6(mB, QS_W_COL_B) } else { QS_NEST4(mB, QS_W_COL_B) }
 #undef QS_W_COL_A
 #undef QS_W_COL_R
 #undef QS_W_COL_B
@@ -105,7 +107,7 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
         // ---- candidates: rhs - dinv sum_{j != p} A_pj lambda_j; the warm start of the feet's normal rows is in already
         float res = rhs;
 #define QS_W_WARM(j) res = fmaf(Ap[IB + (j)], rl(lam, B0 + (j)), res);
-        if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_WARM) } else { QS_NEST6(mB, QS_W_WARM) }
+        if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_WARM) } else if constexpr (NBX > 4) { QS_NEST6(mB, QS_W_WARM) } else { QS_NEST4(mB, QS_W_WARM) }
 #undef QS_W_WARM
         // one row: every lane clamps its own candidate, the owner's change goes round
 #define QS_W_ROW(COEF, J)                                                                                              \
@@ -158,7 +160,7 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
                 if (it & 1) { QS_NEST18(mA, QS_W_FWD_A) }   // limit rows, then the payload rows, forwards; on even sweeps the same backwards
                 else { QS_NEST18(mA, QS_W_BWD_A) }
             }
-            if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_FWD_B) QS_NEST12(mB, QS_W_FWD_C) } else { QS_NEST6(mB, QS_W_FWD_B) QS_NEST6(mB, QS_W_FWD_C) }
+            if constexpr (NBX > 6) { QS_NEST12(mB, QS_W_FWD_B) QS_NEST12(mB, QS_W_FWD_C) } else if constexpr (NBX > 4) { QS_NEST6(mB, QS_W_FWD_B) QS_NEST6(mB, QS_W_FWD_C) } else { QS_NEST4(mB, QS_W_FWD_B) QS_NEST4(mB, QS_W_FWD_C) }
 #undef QS_W_FWD_A
 #undef QS_W_BWD_A
 #undef QS_W_FWD_B
@@ -288,11 +290,25 @@ template <bool CONE> struct RareSolver<LaneDev, CONE> {
             }
             QS_PHASE_G(41)
             // ---- Delassus column, candidates, sweeps (core<>, above).  A solve without limit / payload rows and with six contact points at most --
-            // every one of the benchmark's -- takes the instantiation with 18 coefficient registers instead of 72: the sweep loop of the large
-            // one re-read ~ 30 coefficients from AGPRs and SGPR-spill lanes at the head of every sweep
+            // every one of the benchmark's -- takes an instantiation with 18 (12: four contact points) coefficient registers instead of 72: the
+            // sweep loop of the large one re-read ~ 30 coefficients from AGPRs and SGPR-spill lanes at the head of every sweep
             int n_sweeps = 0;
-            if (mA == 0 && mB <= 6) core<0, 6>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+#ifdef QS_DBG_CORE4   // diagnostic: both small instantiations on the same rows, bitwise mismatches into the self-narrow counter (tools/diag/core4_differential.py)
+            if (mA == 0 && mB <= 4) {
+                float lam6 = lam; int ns6 = 0;
+                core<0, 6>(cfg, w, a, b, rhs, dinv, diag, lam6, lo, hi, grp, mA, mB, mu_e, track, thr, ns6);
+                core<0, 4>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+                const bool bad = alive && __builtin_bit_cast(int, lam) != __builtin_bit_cast(int, lam6);
+                const unsigned long long bm = __ballot(bad);
+                if ((bm != 0ull || ns6 != n_sweeps) && threadIdx.x == 0)
+                    atomicAdd(&reinterpret_cast<const QsDevCfg&>(cfg).counters[QS_DEVCTR_SELF_NARROW], 1ull + (ns6 != n_sweeps ? 1ull << 20 : 0ull) + ((unsigned long long)mB << 40));
+            } else if (mA == 0 && mB <= 6) core<0, 6>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
             else core<NA, NB>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+#else
+            if (mA == 0 && mB <= 4) core<0, 4>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+            else if (mA == 0 && mB <= 6) core<0, 6>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+            else core<NA, NB>(cfg, w, a, b, rhs, dinv, diag, lam, lo, hi, grp, mA, mB, mu_e, track, thr, n_sweeps);
+#endif
             QS_PHASE_G(43)
 #if defined(QS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
             if (threadIdx.x == 0) {   // all workgroups: solves, sweeps, live rows, live contact points (normals)
