@@ -213,3 +213,12 @@ def test_touching_any_source_makes_the_build_recompile(tmp_path):
         assert b.needs_build(str(out)), d
     assert b.needs_build(str(tmp_path / "missing.so"))
     assert len(b.fingerprint(str(out))) == 64
+
+
+def test_the_build_does_not_pass_split_spill_mode():
+    """Round 5: the first library with the many-rows solver's core<0, 4> came out of `-mllvm -split-spill-mode=size` miscompiled (caught by the
+    GPU parity gates); the option is out of the build and must not come back as a flag (the comment that says why may name it)."""
+    b, repo = _load_build_module()
+    text = open(os.path.join(repo, "quadruped-springs_amd", "build.py")).read()
+    assert '"-split-spill-mode' not in text and "'-split-spill-mode" not in text
+    assert "split-spill-mode" not in os.environ.get("QS_HIPCC_EXTRA", "")
