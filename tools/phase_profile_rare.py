@@ -38,6 +38,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--headline":
           f"{out[47] / max(out[0], 1):.1f} live rows, {out[30] / max(out[0], 1):.1f} contact points per solve")
     sys.exit(0)
 every = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+TQ = float(os.environ.get("QS_PP_TORQUE", "4"))     # peak-to-peak of the random joint torques (0: the robot lies still -- no joint reaches its stop, the solves take the small instantiations)
 env = QuadrupedVecEnv(num_envs=n, auto_reset=False, task_env="NO_TASK", observation_space_mode="ENCODER", enable_springs=True, enable_action_filter=False,
                       isRLGymInterface=False, motor_control_mode="TORQUE", env_randomizer_mode="NONE", noise=False)
 env.reset_tensor()
@@ -49,13 +50,13 @@ s[idx, 13:25] = torch.tensor(np.tile([0.0, 1.2, -2.4], 4), dtype=torch.float32, 
 env.set_state(s)
 g = torch.Generator(device="cuda").manual_seed(0)
 for _ in range(20):
-    env.step_tensor((torch.rand((n, 12), generator=g, device="cuda") - 0.5) * 4)
+    env.step_tensor((torch.rand((n, 12), generator=g, device="cuda") - 0.5) * TQ)
 out = (C.c_uint64 * 48)()
 env.lib.qs_debug_phases(out, 1)
 c0 = env.counter("limit_path_substeps")
 steps = 50
 for _ in range(steps):
-    env.step_tensor((torch.rand((n, 12), generator=g, device="cuda") - 0.5) * 4)
+    env.step_tensor((torch.rand((n, 12), generator=g, device="cuda") - 0.5) * TQ)
 env.lib.qs_debug_phases(out, 0)
 print(f"workgroup 0 (environment 0 on its side, one robot in {every}), {steps} env steps x 10 substeps; many-rows wave-substeps per step: {(env.counter('limit_path_substeps') - c0) / steps:.0f}")
 tot = sum(out[k] for k in NAMES)
