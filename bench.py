@@ -245,6 +245,13 @@ def running_fingerprint():
     """(source fingerprint, reason it cannot be trusted or None): the tree this process's libqs_hip.so was built from.  Another
     library through QS_LIB_PATH, or a library older than its sources, belongs to no fingerprint."""
     b = _build_module()
+    try:      # since round 6 the library says itself which sources it was compiled from (qs_version(), build.py's -DQS_SOURCE_SHA)
+        from qs_amd import lib as _l
+        sha = _l.source_sha()
+        if sha:
+            return sha, None
+    except Exception:  # noqa: BLE001  (no device library in this process: the stand-in test mode)
+        pass
     if os.environ.get("QS_LIB_PATH"):
         return None, "QS_LIB_PATH names another library than the tree's"
     if b.needs_build():

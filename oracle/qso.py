@@ -92,6 +92,17 @@ class Oracle:
         w = np.ascontiguousarray(w, self.real).reshape(self.n, 4)
         self._check(self.lib.qso_set_warm(self.h, self._p(w)))
 
+    def snapshot(self):
+        """every environment's whole record (state, parameters, task / filter / wrapper state, counters, outputs) as bytes: restore() puts
+        it back, so that a test can ask "what would the step give from THIS state" without disturbing the run (tests/yardstick.py)"""
+        self.lib.qso_snapshot_size.restype = C.c_size_t
+        buf = C.create_string_buffer(self.lib.qso_snapshot_size(self.h))
+        self._check(self.lib.qso_snapshot(self.h, buf))
+        return buf
+
+    def restore(self, buf):
+        self._check(self.lib.qso_restore(self.h, buf))
+
     _INFO_DIM = {0: 4, 1: 4, 2: 12, 3: 12, 4: 48, 5: 1, 6: 24, 7: 4, 8: 12, 10: 4}
 
     def get_info(self, which):

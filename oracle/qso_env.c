@@ -877,6 +877,10 @@ int qso_set_warm(qso_handle* h, const real* w) {
     return 0;
 }
 
+size_t qso_snapshot_size(qso_handle* h) { return (size_t)h->cfg.n_envs * sizeof(qso_env); }
+int qso_snapshot(qso_handle* h, void* buf) { if (!buf) FAIL("null buffer"); memcpy(buf, h->env, qso_snapshot_size(h)); return 0; }
+int qso_restore(qso_handle* h, const void* buf) { if (!buf) FAIL("null buffer"); memcpy(h->env, buf, qso_snapshot_size(h)); return 0; }
+
 static void pack_params(const qso_env* e, real* o) {
     o[0] = e->mu;
     for (int k = 0; k < 3; k++) { o[1 + k] = e->k[k]; o[4 + k] = e->b[k]; o[7 + k] = e->rest[k]; o[10 + k] = e->kp[k]; o[13 + k] = e->kd[k]; o[17 + k] = e->m_leg[k]; o[21 + k] = e->r_pay[k]; }

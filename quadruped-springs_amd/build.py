@@ -98,7 +98,7 @@ def build(force=False, verbose=False):
              "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
              "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
              "-mllvm", "-greedy-regclass-priority-trumps-globalness=1"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
-            os.environ.get("QS_HIPCC_EXTRA", "").split() + ["-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
+            os.environ.get("QS_HIPCC_EXTRA", "").split() + ['-DQS_SOURCE_SHA="' + source_fingerprint() + '"', "-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
         if verbose:
             c.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(c))

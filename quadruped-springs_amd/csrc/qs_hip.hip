@@ -685,7 +685,12 @@ static int n_waves(int n) { return (n + QS_ENVS_PER_WAVE - 1) / QS_ENVS_PER_WAVE
 extern "C" {
 
 const char* qs_last_error(void) { return g_err; }
-const char* qs_version(void) { return "qs_amd 0.5 (gfx950, quad-per-env; ABI " QS_STR(QS_ABI_VERSION) ")"; }
+// build.py passes the fingerprint of the source tree the library is compiled from (every file under csrc/, the public header, the build
+// script with its flags): a binary says itself which sources it is, and the parity gate (tools/gate.sh) records what it validated
+#ifndef QS_SOURCE_SHA
+#define QS_SOURCE_SHA "unknown"
+#endif
+const char* qs_version(void) { return "qs_amd 0.6 (gfx950, quad-per-env; ABI " QS_STR(QS_ABI_VERSION) "; source " QS_SOURCE_SHA ")"; }
 int qs_abi_version(void) { return QS_ABI_VERSION; }
 
 static int create_impl(const qs_config* cfg, int device, qs_handle* h);

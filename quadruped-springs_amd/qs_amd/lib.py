@@ -100,6 +100,14 @@ def load():
     return lib
 
 
+def source_sha(lib=None):
+    """The fingerprint of the source tree the loaded library says it was compiled from (build.py's source_fingerprint(), passed to the
+    compiler as QS_SOURCE_SHA and returned inside qs_version()); None for a library that does not say (round 5 or earlier)."""
+    import re
+    m = re.search(r"source ([0-9a-f]{64})", (lib or load()).qs_version().decode())
+    return m.group(1) if m else None
+
+
 def check(rc):
     if rc != 0:
         raise RuntimeError("qs_amd: " + load().qs_last_error().decode())

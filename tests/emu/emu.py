@@ -50,6 +50,11 @@ class Emu:
         self.lib.qse_get_obs(self.h, self._p(obs))
         return obs
 
+    def get_term_obs(self):
+        obs = np.zeros((self.n, self.o), np.float32)
+        self.lib.qse_get_term_obs(self.h, self._p(obs))
+        return obs
+
     def step(self, actions):
         a = np.ascontiguousarray(actions, np.float32).reshape(self.n, self.d)
         obs = np.zeros((self.n, self.o), np.float32)

@@ -90,6 +90,12 @@ int qse_get_obs(void* h, float* obs) {
     for (int i = 0; i < e->cfg.n_envs; i++) memcpy(obs + (size_t)i * e->cfg.obs_dim, &e->obs[(size_t)i * QS_MAX_OBS], e->cfg.obs_dim * sizeof(float));
     return 0;
 }
+// infos[i]["terminal_observation"] of the last episode each environment finished (auto_reset)
+int qse_get_term_obs(void* h, float* obs) {
+    Emu* e = (Emu*)h;
+    for (int i = 0; i < e->cfg.n_envs; i++) memcpy(obs + (size_t)i * e->cfg.obs_dim, &e->term_obs[(size_t)i * QS_MAX_OBS], e->cfg.obs_dim * sizeof(float));
+    return 0;
+}
 int qse_step(void* h, const float* actions, float* obs, float* rew, uint8_t* done, uint8_t* trunc) {
     Emu* e = (Emu*)h;
     const int d = e->cfg.action_dim;

@@ -314,3 +314,88 @@ def test_demo_tasks_and_rsi(golden, name):
             np.testing.assert_allclose(e.get_state()[0][13:25], g[f"{name}_state"][t][13:25], atol=2e-2, err_msg=f"q step {t}")
             e.set_state(g[f"{name}_state"][t][None])     # float32 vs the float64 run: re-seat the rigid-body state
         assert dn[0]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(wrapper="LANDING"),
+    dict(action_space_mode="DEFAULT", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT", friction_model="pyramid"),
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="GROUND_RANDOMIZER", seed=4, self_collision=False),
+    dict(time_step=0.002, action_repeat=5, friction_model="cone", solver_residual_threshold=1e-7),
+], ids=["default", "landing_wrapper", "pyramid_12", "cpg_backflip", "dt2_cone"])
+def test_impact_steps_stay_inside_the_oracles_own_spread(kw):
+    """CPU twin of tests/test_gpu_parity.py::test_env_step_parity_resynced (the same driver, tests/yardstick.py, with the host lane
+    emulation as the device): hops, then robots thrown at the floor.  Env steps in which a trunk corner / hip / thigh / knee hit the ground
+    (the many-rows solve; body_contacts=True is the default) are held to `strict tolerance + 5 x |oracle float32 - oracle float64|` per
+    group of like quantities, every other step strictly; and over the impact steps the kernel arithmetic's distance to the float64 oracle
+    is distributed like the float32 oracle's own."""
+    import yardstick as Y
+    cfg, meta = build_config(n_envs=16, auto_reset=False, noise=False, **dict(dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                             enable_springs=True, enable_action_filter=True, env_randomizer_mode="NONE"), **kw))
+    assert cfg.body_contacts == 1
+    o, o32, e = Oracle(cfg), Oracle(cfg, "f32"), Emu(cfg)
+    o.reset(); o32.reset(); e.reset()
+    rec = Y.resynced_parity(o, o32, Y.EmuDevice(e), cfg, meta["layout"], steps=60, thrown_steps=60)
+    assert rec["impact_env_steps"] >= 30, rec
+    for name, _, _, tol in Y.STATE_GROUPS:
+        dev, own = Y.percentiles(rec["impact_dev"][name]), Y.percentiles(rec["impact_own"][name])
+        assert dev[1] <= tol + 2 * own[1] and dev[2] <= tol + 2 * own[2], f"{name}: |emulation - oracle64| p50 / p90 / p99 {dev} against the oracle's own {own}"
+
+
+def test_the_yardstick_is_tight_enough_to_catch_a_miscompiled_library():
+    """The bound the impact rows are held to must not be so wide that a wrong kernel passes it: round 5's fixed 0.5 m/s / 2 rad/s let the
+    1e-2 deviations of its miscompiled library through on those rows.  The bound now is `strict tolerance + 5 x the oracle's own float32 /
+    float64 spread` of that very step: over thrown robots its 90th percentile is under 1e-2 rad/s in the joint rates and 2e-3 m/s in the
+    base velocity (200 x tighter than round 5's), and a device whose joint rates are off by 2e-2 rad/s -- a hundredth of the old bound, a
+    tenth of the effect the body_contacts default exists for -- fails on the first impact row."""
+    import yardstick as Y
+    cfg, meta = build_config(n_envs=16, auto_reset=False, noise=False, task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC",
+                             enable_springs=True, enable_action_filter=True, env_randomizer_mode="NONE")
+    o, o32, e = Oracle(cfg), Oracle(cfg, "f32"), Emu(cfg)
+    o.reset(); o32.reset(); e.reset()
+    rec = Y.resynced_parity(o, o32, Y.EmuDevice(e), cfg, meta["layout"], steps=0, thrown_steps=60)
+    assert Y.TOL_QD + Y.FACTOR * Y.percentiles(rec["impact_own"]["qd"])[1] < 1e-2
+    assert Y.TOL_BASE_V + Y.FACTOR * Y.percentiles(rec["impact_own"]["base_velocity"])[1] < 2e-3
+
+    class Off(Y.EmuDevice):          # wrong on the rows of the many-rows solve only: the strict rows cannot be what catches it
+        def __init__(self, emu, oracle):
+            super().__init__(emu); self.o = oracle
+
+        def get_state(self):
+            s = self.e.get_state().copy()
+            s[self.o.get_info(5)[:, 0] > 0, 25:] += 2e-2
+            return s
+
+    o.reset(); o32.reset(); e.reset()
+    with pytest.raises(AssertionError, match="environments with a link on the ground"):
+        Y.resynced_parity(o, o32, Off(e, o), cfg, meta["layout"], steps=0, thrown_steps=60)
+
+
+def test_terminal_observations_of_fall_ended_episodes():
+    """CPU twin of tests/test_gpu_parity.py::test_terminal_observations_of_fall_ended_episodes_at_the_headline_size (the same driver with the
+    host lane emulation running free as the device): 64 environments, 40 falls."""
+    import yardstick as Y
+    kw = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
+              env_randomizer_mode="GROUND_RANDOMIZER", noise=False, seed=7)
+    cfg, meta = build_config(n_envs=64, auto_reset=True, **kw)
+    e = Emu(cfg); e.reset()
+    rec = Y.terminal_observation_parity(Y.FreeEmu(e), 64, [(0, 32), (32, 32)], lambda b, k, prec: Oracle(build_config(n_envs=k, auto_reset=True, env_id_offset=b, **kw)[0], prec),
+                                        meta["layout"], cfg.action_dim, target=40, max_steps=250)
+    assert rec["fall_ended_episodes"] >= 40 and rec["ended_on_the_device_only"] + rec["ended_in_the_oracle_only"] <= 1, rec
+    Y.assert_inside_own_spread(rec)
+
+
+@pytest.mark.parametrize("name", ["jump_in_place", "cpg_backflip"])
+def test_oracle_sampled_parity_of_a_free_running_device(name):
+    """CPU twin of tests/test_gpu_parity.py::test_full_size_oracle_sampled (the same driver, tests/yardstick.py::oracle_sampled_parity, with
+    the host lane emulation running free): every running environment within `strict tolerance + 5 x the oracle's own float32 / float64
+    spread` per group of quantities, switching env-steps counted by cause."""
+    import yardstick as Y
+    kw = dict(jump_in_place=dict(env_randomizer_mode="GROUND_RANDOMIZER"),
+              cpg_backflip=dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="TEST_RANDOMIZER"))[name]
+    kw = dict(dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True), **kw, seed=7, noise=False)
+    cfg, meta = build_config(n_envs=32, auto_reset=True, **kw)
+    e, o, p = Emu(cfg), Oracle(cfg), Oracle(cfg, "f32")
+    e.reset(); o.reset(); p.reset()
+    out = Y.oracle_sampled_parity(Y.FreeEmu(e), 32, [(0, 32)], [o], [p], meta["layout"], cfg.action_dim, steps=60, rng=np.random.default_rng(5))
+    assert out["strict"] + out["switching"] > 1500 and sum(out["switching_by_cause"].values()) == out["switching"], out

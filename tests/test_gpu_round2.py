@@ -500,12 +500,40 @@ def test_random_configurations_against_the_oracle(torch_cuda):
     """tools/fuzz_parity.py: random combinations of task, sensor bundle, action space, motor mode, randomizer, wrapper, friction model,
     early exit, springs, filter, time step, info block, payload model and mass rule -- reset and six re-seated steps each against the
     float32 oracle (1014 configurations ran clean when the round closed; here 60 draws, about 40 of them valid)."""
+    ran, bad = _fuzz().run(60, 7, verbose=False)
+    assert ran >= 25 and not bad, bad[:2]
+
+
+def _fuzz():
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
-    ran, bad = fuzz.run(60, 7, verbose=False)
-    assert ran >= 25 and not bad, bad[:2]
+    return fuzz
+
+
+@pytest.mark.parametrize("step_kernel", ["1", "2"], ids=["k_step", "k_step_dense"])
+def test_fuzz_fallen_robots_against_the_oracle(torch_cuda, monkeypatch, step_kernel):
+    """tools/fuzz_parity.py's `fallen` mode inside the driver-run gate (it is the mode that caught round 5's miscompiled
+    library -- 55 of 500 configurations off -- and it ran from a builder's script only): NO_TASK with the links' contact response on, two
+    thirds of the robots thrown onto trunk / hips / thighs / calves in random attitudes with random joint angles under raw torques x 4:
+    every kind of row of the many-rows solve (support points, joint stops, the soft payload's six), both friction models, both residual
+    thresholds -- reset and six re-seated steps each against the float32 oracle, tolerance + 5 x the oracle's own float64 / float32 spread.
+    160 draws with each step kernel forced (QS_STEP_VARIANT is read by qs_create)."""
+    monkeypatch.setenv("QS_STEP_VARIANT", step_kernel)
+    ran, bad = _fuzz().run(160, 600 + int(step_kernel), verbose=False, fallen=True)
+    assert ran >= 150 and not bad, (ran, bad[:2])
+
+
+@pytest.mark.parametrize("step_kernel", ["1", "2"], ids=["k_step", "k_step_dense"])
+def test_fuzz_lookahead_resets_bitwise(torch_cuda, monkeypatch, step_kernel):
+    """tools/fuzz_parity.py's `lookahead` mode inside the driver-run gate: random configurations with auto-reset, one handle with K look-ahead
+    reset states per environment against one that settles every reset in place, rough actions, every output of every step BITWISE (two
+    handles of the SAME library: a kernel that depends on its wave-mates -- what a miscompiled spill does -- shows here; 30 of 232 did in
+    round 5).  190 draws (about 150 valid) with each step kernel forced."""
+    monkeypatch.setenv("QS_STEP_VARIANT", step_kernel)
+    ran, bad = _fuzz().run_lookahead(190, 700 + int(step_kernel), verbose=False)
+    assert ran >= 120 and not bad, (ran, bad[:2])
 
 
 @pytest.mark.parametrize("variant", [dict(), dict(friction_model="pyramid"), dict(payload="soft", env_randomizer_mode="MASS_RANDOMIZER", seed=3),

@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol():
     assert set(lib.EXPORTS) == declared
 
 
+def test_the_library_says_which_sources_it_was_built_from():
+    """build.py compiles the fingerprint of the source tree into the library (-DQS_SOURCE_SHA), qs_version() returns it: a profile, a
+    bench line and the parity gate's record (profiles/validated_libraries.jsonl) name the binary by what it was compiled from."""
+    import importlib.util
+    from qs_amd import lib
+    spec = importlib.util.spec_from_file_location("qs_build", os.path.join(REPO, "quadruped-springs_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    assert lib.source_sha() == b.source_fingerprint()
+
+
 def test_config_struct_layout_matches_header():
     """Compile a tiny C program that prints sizeof/offsetof of qs_config and compare with the ctypes mirror."""
     import subprocess
