@@ -927,10 +927,17 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
     // `last`: the contact classification is READ after this substep (the last one of an env step: gym_env.py:241-245); the link-link tests of
     // the self-collision rule only run then -- they decide nothing about the motion (round 4: with cfg.body_contacts they ran in every
     // substep, 11 k cycles each for a robot lying on folded legs)
-    static QS_FN bool substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true, float* blk = nullptr, float* scratch_row = nullptr,
+    // Returns (HOT builds; the full build always 0): 0 = done; 1 = this wave needs a rare path IN this substep: nothing has been written,
+    // the env step goes on in the full build from this substep; 2 = done, and the wave will need the rare path in the NEXT substep (a link in
+    // its contact range whose rows cannot act yet but will by then, predicted from this substep's closing speeds): the caller hands over at
+    // the substep boundary instead of letting the next substep run into its vote (round 6: that vote sits behind the substep's dynamics --
+    // 10 k cycles of a 16 k substep, thrown away on the path of the wave every launch waits for).  A wrong guess costs time only: results
+    // do not depend on where the switch happens (Env::step).
+    static QS_FN int substep(const qs_config& cfg, const Par& Pr, State& s, const V* tau, Out& o, bool detect = true, float* blk = nullptr, float* scratch_row = nullptr,
                               bool last = true) {
         using namespace go1;
-        if (HOT && !SOFT && cfg.payload_soft) return true;   // this build holds no payload rows
+        if (HOT && !SOFT && cfg.payload_soft) return 1;   // this build holds no payload rows
+        bool hand_over_next = false;
         const bool soft = (!HOT || SOFT) && cfg.payload_soft && blk != nullptr;
         Model P;
         {   // opaque copies keep the compiler from hoisting the 24 leg constants out of the substep loop (where they would
@@ -1117,7 +1124,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
             M c3 = qand(qlt(mc + T::template xorl<3>(ml), V(MARGIN)), qlt(nc + T::template xorl<3>(nl), V(MARGIN)));   // diagonal
             M ctr = qand(qand(qlt(mc, V(TRUNK_HALF[1] + MARGIN)), qgt(qmax(p3.z, rf.z) + 0.02f, V(-TRUNK_HALF[2] - MARGIN))), qlt(nc, V(TRUNK_HALF[0] + MARGIN)));
             if (__builtin_expect(T::any(qor(qor(cy1, cx2), qor(c3, ctr))), 0)) {
-                if (HOT) return true;
+                if (HOT) return 1;
                 T::count_self_narrow(cfg);
                 LegGeom lg;
                 lg.p1 = p1; lg.ct = p2 + Z2 * V(LINK_BOX_Z); lg.X2 = X2; lg.Y = Y; lg.Z2 = Z2; lg.cc = p3 + Z3 * V(LINK_BOX_Z); lg.X3 = X3; lg.Z3 = Z3; lg.rf = rf;
@@ -1141,7 +1148,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
         // Nothing to solve when no foot of the wave's 16 environments is within contact range and no joint sits at a stop:
         // every row would be inactive (rhs = lambda = 0), i.e. delta v = 0 exactly.  Flight phases of a whole wave skip the
         // rows, the Delassus columns and the sweeps.
-        if (HOT && __builtin_expect(T::any(any_lim), 0)) return true;
+        if (HOT && __builtin_expect(T::any(any_lim), 0)) return 1;
         if (HOT && __builtin_expect(T::any(any_extra), 0)) {
             // A non-foot link is inside its contact range.  The full build gives a support point rows only once its normal row can act on the
             // predicted velocities (cfg.support_margin, below); while every point in range is still approaching, its result IS the common-path
@@ -1177,7 +1184,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
             const V hc_[5] = {h_trunk, h_hip, h_th_hi, h_th_lo, h_cf_hi};
             const float thr_[5] = {THR_TRUNK, THR_HIP, THR_THIGH, THR_THIGH, THR_CALF};
             const int dep_[5] = {0, 1, 2, 2, 3};   // joints of the leg that move the point
-            M can_act = qlt(one, zero);
+            M can_act = qlt(one, zero), can_next = qlt(one, zero);
 #pragma unroll
             for (int i = 0; i < 5; i++) {
                 const V3v pt = pc_[i];
@@ -1188,8 +1195,11 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                          dot(Rz, e1) * qp_[0] + dot(Rz, e2) * qp_[1] + dot(Rz, e3) * qp_[2];
                 V pen_x = hc_[i] + cfg.contact_slop;
                 can_act = qor(can_act, qand(qlt(hc_[i], V(thr_[i])), qor(qle(pen_x, zero), qgt((-reln) - pen_x * inv_dt_, V(-cfg.support_margin)))));
+                // the same predicate one substep on, at this substep's closing speed: the gap has shrunk by reln dt
+                can_next = qor(can_next, qand(qlt(hc_[i] + reln * dt, V(thr_[i])), qgt((-2.0f) * reln - pen_x * inv_dt_, V(-cfg.support_margin))));
             }
-            if (T::any(can_act)) return true;
+            if (T::any(can_act)) return 1;
+            hand_over_next = T::any(can_next);
         }
         // ---- v* = v + dt a (world frame for the base; classical acceleration of the origin = a_lin + w x v).  The first write to `s` of the
         // substep: a HOT build's wave that gives up (above) hands the state back as it came, and the env step goes on in the full build from
@@ -1480,7 +1490,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
         for (int j = 0; j < 3; j++) s.q[j] = s.q[j] + dt * s.qd[j];
         QS_PHASE(12)
         QS_PHASE_END
-        return false;
+        return HOT && hand_over_next ? 2 : 0;
     }
 };
 

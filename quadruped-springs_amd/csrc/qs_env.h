@@ -486,6 +486,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
     // the full build: the wave that every launch waits for paid up to two steps' time.  Continuing inside the same function -- the full
     // build's substep loop behind the hot one -- was tried first: the values live across both loops put ~30 scratch instructions into the
     // hot loop, 112.1 -> 102.5 M env-steps/s.)
+    enum { RESUME_AT_BOUNDARY = 0x100 };
     enum { ST_CMD = 0, ST_KP = 12, ST_KD = 15, ST_W = 18, ST_CPGP = 22, ST_CPGR = 28, ST_CPGTH = 32 };
     static QS_FN void stash_state(float* rec, const typename S::State& s) {
         T::st(rec, R_POS, s.pos.x); T::st(rec, R_POS + 1, s.pos.y); T::st(rec, R_POS + 2, s.pos.z);
@@ -674,19 +675,28 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
             }
         }
         static_assert(!LEAN || HOT, "the lean loop keeps its parameters in the observation row, which the full build's many-rows solve borrows");
+        // resume_k: the substep a handed-over step goes on at; + RESUME_AT_BOUNDARY when the common-path build finished the substep before
+        // and handed over between two substeps (the Hopf oscillators have not ticked for this one yet)
+        const bool resume_ticked = !(resume_k & RESUME_AT_BOUNDARY);
+        resume_k &= RESUME_AT_BOUNDARY - 1;
         int k = RESUME ? resume_k : 0;
         bool gave_up = false;   // (HOT builds, wave-uniform) substep k needs a rare path; `s` is as that substep found it
+        bool at_boundary = false;   // ... and that was seen coming one substep ahead: `s` is as substep k - 1 left it, nothing of substep k has run
         for (; k < n_sub; k++) {  // gym_env.py:236-237, 207-216
             V tau[3];
-            if (cpg && !(RESUME && k == resume_k)) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate (a resumed substep's tick has happened)
+            if (cpg && !(RESUME && k == resume_k && resume_ticked)) cpg_command(cfg, cpg_p, cpg_r, cpg_th, cmd);  // the oscillators tick at the physics rate (the tick of a substep that gave up half-way has happened)
             QS_PHASE_SUB_BEGIN
             if (LEAN) load_par_lean(rec, obs, P);
             S::actuate(cfg, P, s, cmd, o, tau, settle_n > 0);
-            if (__builtin_expect(S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts, blk, obs, k == n_sub - 1), 0)) { gave_up = true; break; }
+            const int rc = S::substep(cfg, P, s, tau, o, k == n_sub - 1 || cfg.body_contacts, blk, obs, k == n_sub - 1);
+            if (__builtin_expect(rc == 1, 0)) { gave_up = true; break; }
             QS_PHASE_SUB(k)
             if (__builtin_expect(any_trace, 0)) {
                 if (trace) write_trace(trace + k * QS_TRACE_DIM, (float)((double)(f2i(rec[R_SIM_STEP]) + k + 1) * cfg.dt), s, o);
             }
+            // (round 6) the next substep is going to need the rare path: hand over HERE, at the substep boundary, instead of running its
+            // dynamics up to the vote for nothing
+            if (HOT && __builtin_expect(rc == 2, 0) && k + 1 < n_sub) { k++; gave_up = true; at_boundary = true; break; }
         }
         // (Tried instead, round 4: the state checkpointed into the LDS record after every substep -- eleven LDS stores -- so that the hand-over
         // needs nothing kept: ~70 register moves fewer per substep in the ISA and 0.9 % SLOWER on the GPU, 109.5 against 110.5 M; the state
@@ -694,7 +704,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
         if (HOT && __builtin_expect(gave_up, 0)) {   // hand over to the full build: the state of this moment (the rest of the stash is in place)
             stash_state(rec, s);
             if (cpg) { T::st_leg(obs, ST_CMD, 3, cmd[0]); T::st_leg(obs, ST_CMD + 1, 3, cmd[1]); T::st_leg(obs, ST_CMD + 2, 3, cmd[2]); T::st_leg(obs, ST_CPGR, 1, cpg_r); T::st_leg(obs, ST_CPGTH, 1, cpg_th); }
-            StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.resume = k;
+            StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.resume = k | (at_boundary ? (int)RESUME_AT_BOUNDARY : 0);
             return z;
         }
         if (settle_n > 0) { store_state(rec, s, o); StepOut z; z.reward = V(0.0f); z.done = V(0.0f); z.trunc = V(0.0f); z.resume = -1; return z; }
