@@ -603,7 +603,12 @@ void qso_physics_substep(const qso_config* cfg, qso_env* e, const real* tau, rea
             for (int k = 0; k < 3; k++) cand[4][k] = C.ow[ic][k] - s3 * CALF_HALF[0] * X3[k] - sgy * CALF_HALF[1] * Y[k];
         }
         for (int i = 0; i < 5; i++) ch[i] = cand[i][2] < cthr[i] ? cand[i][2] : (real)1e9;
-        for (int slot = 0; slot < 2; slot++) {
+        /* how many: a leg carries at most three contact points -- its foot and two support points, or, with the foot off the ground, three
+           support points (round 6; rounds 2-5: two whatever the foot did.  A robot on its back rests on trunk corner + both ends of each
+           thigh box: with two of the three the choice flipped from substep to substep, the robot crept at 7 mm/s and lay 1-2 mm off where
+           four points per primitive (mode 1) put it; with three: 3e-7 m, at rest.  Mode 3 keeps the old cap for the comparison) */
+        const int n_slots = (e->manifold_mode == 3 || e->foot_contact[L]) ? 2 : 3;
+        for (int slot = 0; slot < n_slots; slot++) {
             int bi = 0;
             for (int i = 1; i < 5; i++) if (ch[i] < ch[bi]) bi = i;
             if (!(ch[bi] < (real)1e8)) break;
@@ -788,7 +793,7 @@ int qso_phys_step(qso_handle* h, int env, const real* tau) {
 }
 int qso_phys_set_gravity(qso_handle* h, real g) { h->gravity = g; return 0; }
 int qso_phys_set_manifold(qso_handle* h, int mode) {
-    if (mode < 0 || mode > 2) return -1;
+    if (mode < 0 || mode > 3) return -1;
     for (int i = 0; i < h->cfg.n_envs; i++) h->env[i].manifold_mode = mode;
     return 0;
 }

@@ -692,10 +692,11 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
     // what comes after it, in the quad layout again: delta v = H^-1 J^T lambda from the impulses lam[12] of the lane's rows (and the block's
     // plam[6]):  dv_b = L^-T sum_i w_i lam_i ;  dqd = sum_own u_r lam_r - (B K)^T dv_b.
     static QS_FN void integrate_rare(const qs_config& cfg, State& s, Out& o, const Row* xr, const V* lam, const V* Sm, const V* Ld, const V (*BK)[6], const V* R,
-                                     PayRows* pay, const V* plam) {
+                                     PayRows* pay, const V* plam, V foot_act) {
         const float dt = (float)cfg.dt;
-        o.foot_force = lam[0] * qrcp(dt);
-        s.warm = lam[0];
+        // (foot_act: slot 0 holds the FOOT's rows -- with the foot off the ground it may hold the leg's lowest support point, round 6)
+        o.foot_force = lam[0] * qrcp(dt) * foot_act;
+        s.warm = lam[0] * foot_act;
         V z[6], x[3];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -1339,12 +1340,22 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                 pc[2] = p2 - toff; pc[3] = p3 - toff;
                 pc[4] = p3 - X3 * (sg3 * CALF_HALF[0]) - Y * (sga * CALF_HALF[1]);
                 const float depth[5] = {0.0f, 1.0f, 2.0f, 2.0f, 3.0f};   // joints of the leg that move the point
+                // A leg carries at most three contact points: its foot and two support points -- or, with the foot off the ground, THREE support
+                // points (round 6; rounds 2-5: two whatever the foot did.  A robot on its back rests on trunk corner + both ends of each thigh
+                // box: with two of the three the choice flipped from substep to substep, the robot crept at 7 mm/s and lay 1-2 mm off where four
+                // points per primitive put it; with three it lies within 3e-7 m of that, at rest).  Pass 0 gives the lowest
+                // candidate of such a leg the FOOT's row slot, which is empty there (an inactive contact's rows are all zero): the leg's points
+                // stay lowest-first in Bullet's sweep order, the row layout, the lanes of the many-rows solve and its instantiations stay as they
+                // are.  Legs whose foot touches sit pass 0 out.
+                const M foot_off = qnot(act_m);
 #pragma unroll
-                for (int slot = 0; slot < 2; slot++) {
-                    V best = hh[0], bi = zero;
+                for (int pass = 0; pass < 3; pass++) {
+                    const int slot = pass - 1;   // -1: the foot's slot (rows 0 .. 2 of xr), 0 / 1: rows 3 .. 5 / 6 .. 8
+                    const M elig = pass == 0 ? foot_off : qlt(zero, one);
+                    V best = qsel(elig, hh[0], bigh), bi = zero;
 #pragma unroll
-                    for (int i = 1; i < 5; i++) { M m = qlt(hh[i], best); best = qsel(m, hh[i], best); bi = qsel(m, V((float)i), bi); }
-                    if (!T::any(qlt(best, V(1e8f)))) break;   // nobody in the wave has a (second) support point: the slot's rows stay empty
+                    for (int i = 1; i < 5; i++) { M m = qand(elig, qlt(hh[i], best)); best = qsel(m, hh[i], best); bi = qsel(m, V((float)i), bi); }
+                    if (!T::any(qlt(best, V(1e8f)))) { if (pass == 0) continue; else break; }   // nobody in the wave has a point for this slot: its rows stay empty
                     bi = qsel(qlt(best, V(1e8f)), bi, V(4.0f));   // empty slot: any point that the joints move (an all-zero Jacobian has no 1 / diag)
                     V3v pt = pc[0]; V dep = V(depth[0]);
 #pragma unroll
@@ -1354,7 +1365,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                         dep = qsel(m, V(depth[i]), dep);
                     }
 #pragma unroll
-                    for (int i = 0; i < 5; i++) hh[i] = qsel(qand(qgt(bi, V(i - 0.5f)), qlt(bi, V(i + 0.5f))), bigh, hh[i]);   // taken
+                    for (int i = 0; i < 5; i++) hh[i] = qsel(qand(qlt(best, V(1e8f)), qand(qgt(bi, V(i - 0.5f)), qlt(bi, V(i + 0.5f)))), bigh, hh[i]);   // taken
                     V dist_x = qsel(qlt(best, V(1e8f)), best, zero);
                     V f1 = qflag(qgt(dep, V(0.5f))), f2 = qflag(qgt(dep, V(1.5f))), f3 = qflag(qgt(dep, V(2.5f)));
                     V3v e1 = cross(ax1, pt - p1) * f1, e2 = cross(Y, pt - p2) * f2, e3 = cross(Y, pt - p3) * f3;
@@ -1382,13 +1393,32 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
 #endif
                     extra_live = qor(extra_live, live);
 #if defined(QS_PROBE_WARM) && defined(__HIP_DEVICE_COMPILE__)
-                    probe_live[slot] = live;
+                    probe_live[pass == 0 ? 0 : slot] = pass == 0 ? probe_live[0] : live;
 #endif
                     if (!T::any(live)) continue;               // nobody's point in this slot can act: no rows
                     V act_x = qflag(live);
-                    QS_CONTACT_ROW_AT(xr[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
-                    QS_CONTACT_ROW_AT(xr[4 + 3 * slot], (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
-                    QS_CONTACT_ROW_AT(xr[5 + 3 * slot], Rx, false, pt, e1, e2, e3, dist_x, act_x)
+                    if (pass == 0) {
+                        // into the foot's slot of the legs that have such a point (their foot is off the ground: its rows there are all zero); the
+                        // other legs keep what the slot holds
+                        Row t0_, t1_, t2_;
+                        QS_CONTACT_ROW_AT(t0_, Rz, true, pt, e1, e2, e3, dist_x, act_x)
+                        QS_CONTACT_ROW_AT(t1_, (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
+                        QS_CONTACT_ROW_AT(t2_, Rx, false, pt, e1, e2, e3, dist_x, act_x)
+                        const Row* tt_[3] = {&t0_, &t1_, &t2_};
+#pragma unroll
+                        for (int r = 0; r < 3; r++) {
+                            Row& d_ = xr[r]; const Row& a_ = *tt_[r];
+#pragma unroll
+                            for (int i = 0; i < 6; i++) d_.w[i] = qsel(live, a_.w[i], d_.w[i]);
+#pragma unroll
+                            for (int i = 0; i < 3; i++) { d_.jq[i] = qsel(live, a_.jq[i], d_.jq[i]); d_.u[i] = qsel(live, a_.u[i], d_.u[i]); }
+                            d_.rhs = qsel(live, a_.rhs, d_.rhs); d_.dinv = qsel(live, a_.dinv, d_.dinv); d_.diag = qsel(live, a_.diag, d_.diag); d_.act = qsel(live, a_.act, d_.act);
+                        }
+                    } else {
+                        QS_CONTACT_ROW_AT(xr[3 + 3 * slot], Rz, true, pt, e1, e2, e3, dist_x, act_x)
+                        QS_CONTACT_ROW_AT(xr[4 + 3 * slot], (mk3<V>(-Ry.x, -Ry.y, -Ry.z)), false, pt, e1, e2, e3, dist_x, act_x)
+                        QS_CONTACT_ROW_AT(xr[5 + 3 * slot], Rx, false, pt, e1, e2, e3, dist_x, act_x)
+                    }
                 }
             }
             rare_mine = qgt(T::quad_sum(qflag(qor(any_lim, extra_live))), V(0.5f));
@@ -1421,7 +1451,7 @@ template <class T, bool CONE = false, bool HOT = false, bool SOFT = false> struc
                 V lam12[12], plam[6];
                 if (soft) pay_r = pay_c;   // (the rows; the results in it are overwritten)
                 RareSolver<T, CONE>::solve(cfg, Pr.mu, xr, soft ? &pay_r : nullptr, rare_mine, s.warm * cfg.warmstart * rows[0].act, T::wave_scratch(scratch_row), lam12, plam);
-                integrate_rare(cfg, s_r, o_r, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam);
+                integrate_rare(cfg, s_r, o_r, xr, lam12, Sm, Ld, BK, R, soft ? &pay_r : nullptr, plam, active);
 #if defined(QS_PROBE_LAZY) && defined(__HIP_DEVICE_COMPILE__)
                 {   // probe[0] environment-substeps with a support point in range, [1] of them with every such row at zero impulse and no joint
                     // at its stop, [2 + 2 m] environments the rule at margin m would have sent to the many-rows solve, [3 + 2 m] environments in

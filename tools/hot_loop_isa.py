@@ -35,7 +35,7 @@ for name in sys.argv[2:]:
                 loops.append((labels[t], i))
     loops.sort(key=lambda x: x[0] - x[1])
     print(name, "instructions:", sum(isinstr(l) for l in f))
-    for a, b in [x for x in loops if x[1] - x[0] > 2500][:16]:
+    for a, b in [x for x in loops if x[1] - x[0] > 2500][:int(__import__("os").environ.get("QS_LOOPS", "16"))]:
         body = f[a:b + 1]
         cnt = lambda pred: sum(1 for l in body if pred(l))
         print(f"  lines {a}-{b}: {cnt(isinstr)} instr, scratch {cnt(lambda l: 'scratch_' in l)}, accvgpr {cnt(lambda l: 'v_accvgpr' in l)}, "
