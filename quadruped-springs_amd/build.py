@@ -81,10 +81,10 @@ def build(force=False, verbose=False):
     # (round 4: ROCm 7.2's "AMDGPU Rewrite AGPR-Copy-MFMA" pass, which only has work under -amdgpu-mfma-vgpr-form, segfaults on some
     # register allocations of the step kernels -- eliminateSpillsOfReassignedVGPRs --: seen on k_step<false, false> for two harmless
     # variations of the many-rows solver's source.  The build retries without the flag, loudly; QS_MFMA_VGPR_FORM=0 leaves it out at once.)
-    # -greedy-regclass-priority-trumps-globalness=1 (end of round 4): which live ranges LLVM's greedy register allocator colours first.  Same
-    # instructions' arithmetic, same results bit for bit (the front end has fixed every FMA); the substep loop keeps fewer copies in flight:
-    # about +1 % at N = 8192 under the cone (gpurun_out/r04zm, r04zn; twelve allocator / scheduler options were tried, the others lost or
-    # changed nothing).
+    # NOT -greedy-regclass-priority-trumps-globalness=1 any more (end of round 4: about +1 % at N = 8192; round 6, A/B'd again on the final source,
+    # three runs each on one box: 69.88 / 69.78 / 69.80 against 69.56 / 69.44 / 69.49 M with the links' response on, 110.07 / 109.85 / 109.95
+    # against 110.39 / 110.35 / 110.40 M without -- +0.5 % on one figure, -0.4 % on the other: inside what two boxes differ by.  It was the other
+    # half of the flag pair under which round 5's library came out miscompiled; one knob fewer at the edge of the register allocator).
     # NOT -split-spill-mode=size any more (round 4 had it next to the knob above, +0.3 %): round 5's source with the <0, 4> instantiation of the
     # many-rows solver's core came out of it MISCOMPILED -- 17 of 120 fallen-robot fuzz configurations off by 1e-2, the kernel depending on
     # its wave-mates -- while the same source without that option, without the knob above, or with two more instantiations passed, and a
@@ -96,8 +96,7 @@ def build(force=False, verbose=False):
     def command(with_form):
         c = [hipcc(), "--offload-arch=" + os.environ.get("QS_OFFLOAD_ARCH", "gfx950"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
              "-ffinite-math-only", "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on",
-             "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-             "-mllvm", "-greedy-regclass-priority-trumps-globalness=1"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
+             "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if with_form else []) + \
             os.environ.get("QS_HIPCC_EXTRA", "").split() + ['-DQS_SOURCE_SHA="' + source_fingerprint() + '"', "-I" + os.path.join(REPO, "include"), "-o", os.environ.get("QS_BUILD_OUT") or OUT, SRC, SRC_NORM]
         if verbose:
             c.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -28,7 +28,7 @@ def fuzz_counts(path):
     return dict(ran=bool(m), configurations=int(m.group(1)) if m else 0, deviated=int(m.group(2)) if m else None)
 
 
-def main(out, mode="full"):
+def main(out, mode="full", jsonl_dir=None):
     import importlib.util
     from qs_amd import lib
     spec = importlib.util.spec_from_file_location("qs_build", os.path.join(REPO, "quadruped-springs_amd", "build.py"))
@@ -48,7 +48,7 @@ def main(out, mode="full"):
     rec["deviated"] = sum((v["deviated"] or 0) for v in rec["fuzz"].values()) + rec["pytest_gpu"].get("failed", 0) + rec["pytest_gpu_dense_kernel"].get("failed", 0)
     rec["accepted"] = bool(tests_ok and fuzz_ok and rec["soak"]["ok"] and rec["source_sha256"] == rec["tree_sha256"])
     line = json.dumps(rec)
-    for path in (os.path.join(out, "verdict.json"), os.path.join(REPO, "gpurun_out", "validated_libraries.jsonl")):
+    for path in (os.path.join(out, "verdict.json"), os.path.join(jsonl_dir or os.path.join(REPO, "gpurun_out"), "validated_libraries.jsonl")):
         with open(path, "a" if path.endswith(".jsonl") else "w") as f:
             f.write(line + "\n")
     print("GATE", "ACCEPTED" if rec["accepted"] else "REFUSED", line)

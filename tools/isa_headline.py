@@ -11,7 +11,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-fno-slp-vectorize", "-ffinite-math-only",
          "-fno-signed-zeros", "-fno-trapping-math", "-ffp-contract=on", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-         "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 args = sys.argv[1:]
 dense = "--dense" in args
 if dense:
