@@ -249,7 +249,7 @@ def test_gate_record_reads_a_gate_run(tmp_path, capsys):
     out = tmp_path / "run"
     os.makedirs(out)
     for f in ("pytest_default.log", "pytest_dense.log"):
-        (out / f).write_text("....\n153 passed, 237 deselected in 350.00s (0:05:50)\n")
+        (out / f).write_text("....\n153 passed, 237 deselected in 350.00s (0:05:50)\nRCCL version : 2.26.6\nLibrccl path : /x/librccl.so\n")   # (the banner of the one-rank RCCL test comes last)
     for k in ("plain", "fallen", "lookahead", "fallen_dense"):
         (out / f"fuzz_{k}.log").write_text("case 0 ...\n250 configurations ran, 0 deviated\n")
     (out / "soak.log").write_text("step 300000: 63 M env-steps/s\nok\n")

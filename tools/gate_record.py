@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.join(REPO, "quadruped-springs_amd"))
 
 
 def pytest_counts(path):
-    try:
-        tail = open(path).read().strip().splitlines()[-1]
+    try:      # pytest's summary line (not the log's last line: the one-rank RCCL test prints its banner behind it)
+        tail = [l for l in open(path).read().splitlines() if re.search(r"\d+ (passed|failed|error)", l)][-1]
     except (OSError, IndexError):
         return dict(ran=False)
     g = lambda w: int(m.group(1)) if (m := re.search(rf"(\d+) {w}", tail)) else 0
