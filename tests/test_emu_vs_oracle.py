@@ -318,11 +318,10 @@ def test_demo_tasks_and_rsi(golden, name):
 
 @pytest.mark.parametrize("kw", [
     dict(),
-    dict(wrapper="LANDING"),
-    dict(action_space_mode="DEFAULT", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT", friction_model="pyramid"),
-    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="GROUND_RANDOMIZER", seed=4, self_collision=False),
-    dict(time_step=0.002, action_repeat=5, friction_model="cone", solver_residual_threshold=1e-7),
-], ids=["default", "landing_wrapper", "pyramid_12", "cpg_backflip", "dt2_cone"])
+    dict(action_space_mode="DEFAULT", task_env="JUMPING_FORWARD", observation_space_mode="PPO_BASIC_CONTACT", friction_model="pyramid", wrapper="LANDING"),
+    dict(task_env="BACKFLIP", observation_space_mode="PPO_BACKFLIP", action_space_mode="CPG", env_randomizer_mode="GROUND_RANDOMIZER", seed=4, self_collision=False,
+         time_step=0.002, action_repeat=5, solver_residual_threshold=1e-7),
+], ids=["default", "pyramid_12_landing_wrapper", "cpg_backflip_dt2"])
 def test_impact_steps_stay_inside_the_oracles_own_spread(kw):
     """CPU twin of tests/test_gpu_parity.py::test_env_step_parity_resynced (the same driver, tests/yardstick.py, with the host lane
     emulation as the device): hops, then robots thrown at the floor.  Env steps in which a trunk corner / hip / thigh / knee hit the ground
@@ -373,15 +372,15 @@ def test_the_yardstick_is_tight_enough_to_catch_a_miscompiled_library():
 
 def test_terminal_observations_of_fall_ended_episodes():
     """CPU twin of tests/test_gpu_parity.py::test_terminal_observations_of_fall_ended_episodes_at_the_headline_size (the same driver with the
-    host lane emulation running free as the device): 64 environments, 40 falls."""
+    host lane emulation running free as the device): 48 environments in two blocks, 24 falls."""
     import yardstick as Y
     kw = dict(task_env="JUMPING_IN_PLACE", observation_space_mode="PPO_BASIC", enable_springs=True, enable_action_filter=True,
               env_randomizer_mode="GROUND_RANDOMIZER", noise=False, seed=7)
-    cfg, meta = build_config(n_envs=64, auto_reset=True, **kw)
+    cfg, meta = build_config(n_envs=48, auto_reset=True, **kw)
     e = Emu(cfg); e.reset()
-    rec = Y.terminal_observation_parity(Y.FreeEmu(e), 64, [(0, 32), (32, 32)], lambda b, k, prec: Oracle(build_config(n_envs=k, auto_reset=True, env_id_offset=b, **kw)[0], prec),
-                                        meta["layout"], cfg.action_dim, target=40, max_steps=250)
-    assert rec["fall_ended_episodes"] >= 40 and rec["ended_on_the_device_only"] + rec["ended_in_the_oracle_only"] <= 1, rec
+    rec = Y.terminal_observation_parity(Y.FreeEmu(e), 48, [(0, 16), (16, 32)], lambda b, k, prec: Oracle(build_config(n_envs=k, auto_reset=True, env_id_offset=b, **kw)[0], prec),
+                                        meta["layout"], cfg.action_dim, target=24, max_steps=250)
+    assert rec["fall_ended_episodes"] >= 24 and rec["ended_on_the_device_only"] + rec["ended_in_the_oracle_only"] <= 1, rec
     Y.assert_inside_own_spread(rec)
 
 
