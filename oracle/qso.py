@@ -177,7 +177,8 @@ class Oracle:
         self.lib.qso_phys_set_gravity(self.h, self._creal(g))
 
     def set_manifold(self, mode):
-        """0: two support points per leg (default, what the kernels build); 1: up to four points per collision primitive (experiment)."""
+        """0: foot + two support points per leg, three with the foot off the ground (default, what the kernels build); 1: up to four points per
+        collision primitive (experiment); 2: mode 0 with warm-started support points; 3: two support points whatever the foot does (rounds 2 - 5)."""
         self._check(self.lib.qso_phys_set_manifold(self.h, int(mode)))
 
     def crba_rnea(self, env):

@@ -58,7 +58,7 @@ typedef struct {
        link -1 base / plane, 0 trunk, 2/6/10/14 hips, 3/7/11/15 thighs, 4/8/12/16 calves, 5/9/13/17 feet) */
     struct { int body_a, body_b, link_a, link_b; real dist, force; } contacts[QSO_MAX_CONTACTS];
     int n_contacts;
-    int manifold_mode;   /* qso_phys_set_manifold: 0 = up to two support points per leg (what the kernels build); 1 = experiment: up to four
+    int manifold_mode;   /* qso_phys_set_manifold: 0 = foot + two support points per leg, three without the foot (what the kernels build); 3 = two whatever the foot does (rounds 2 - 5); 1 = experiment: up to four
                           * points per collision primitive, as Bullet's persistent manifolds can hold; 2 = experiment: mode 0 with
                           * the support points' normal rows warm-started like the feet's (x cfg.warmstart) while the same candidate stays selected */
     real warm_sup[4][5]; /* mode 2: last normal impulse of leg L's candidate i (0 once it is not selected) */
