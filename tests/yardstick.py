@@ -55,9 +55,9 @@ def perturbed_states(s, rng, scale=1e-6):
 
 
 class Yardstick:
-    """Outputs of one oracle step as a dict of [n, k] arrays, their grouped spread between two evaluations, and the bound a device may use.
-
-    `fields`: name -> (groups, getter(oracle, step_result) -> [n, k]); the state and the observation are always there."""
+    """Outputs of one step as a dict of [n, k] arrays (collect), their grouped spread between two evaluations (spread), and what leaves the bound
+    `tolerance + 5 x spread` (excess).  `fields`: name -> (groups, width); state, observation and reward are always there, `extra` adds
+    single-group fields: name -> (width, tolerance)."""
 
     def __init__(self, layout, extra=None):
         self.og = obs_groups(layout)
@@ -128,8 +128,10 @@ def what_if(o64, snap, states, action, ys, base, base_done, trials, rng, warm=No
 
 
 def lowest_point(s):
-    """[n]: height of the robot's lowest surface point above the plane, conservatively (go1.urdf: trunk box corners; hip cylinders, thigh
-    ends, knees and feet as spheres of their primitive's largest half thickness), for states [n, 37]"""
+    """[n]: height of the robot's lowest surface point above the plane, conservatively, for states [n, 37].  Geometry of go1.urdf
+    (tests/golden/urdf_tables.npz: hip joints at (+-0.1881, +-0.04675, 0), thigh joints 0.08 outwards, links 0.213 long, trunk box half
+    extents 0.1881 x 0.04675 x 0.057): trunk box corners; hip cylinders (radius 0.046), thigh ends, knees (boxes up to 0.0245 thick) and
+    feet (radius 0.02) as spheres."""
     from scipy.spatial.transform import Rotation as Rot
     n = len(s)
     R = Rot.from_quat(s[:, 3:7]).as_matrix()
