@@ -260,3 +260,16 @@ def test_gate_record_reads_a_gate_run(tmp_path, capsys):
     assert g.main(str(out), "quick", jsonl_dir=str(tmp_path)) == 1
     assert not json.loads(open(tmp_path / "validated_libraries.jsonl").read().splitlines()[-1])["accepted"]
     capsys.readouterr()
+
+
+def test_design_md_stays_a_design():
+    """DESIGN.md is the CURRENT design -- at most 400 lines, prose within 160 columns (a table row is one line by
+    definition) -- and the history lives in EXPERIMENTS.md, which it points to."""
+    text = open(os.path.join(REPO, "DESIGN.md")).read()
+    lines = text.split("\n")
+    assert len(lines) <= 400, len(lines)
+    long = [(i + 1, len(l)) for i, l in enumerate(lines) if len(l) > 160 and not l.startswith("|")]
+    assert not long, long
+    assert "EXPERIMENTS.md" in text and os.path.exists(os.path.join(REPO, "EXPERIMENTS.md"))
+    for section in ("## 1.", "## 2.", "## 3.", "## 4.", "### 4a.", "## 5.", "## 6.", "## 7.", "## 8.", "## 9.", "## 10."):
+        assert section in text, section
